@@ -1,0 +1,75 @@
+// Shared device/host helpers for the gfx950 kernels of libdct_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dct.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define DCT_WAVE 64
+
+template <typename T> struct dct_type_of;
+template <> struct dct_type_of<float> { static constexpr int id = DCT_F32; };
+template <> struct dct_type_of<bf16_t> { static constexpr int id = DCT_BF16; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// Device-side copy of a dct_view (kernel argument).
+struct View {
+  char* ptr;
+  int n, h, w, c;
+  long long sn, sh, sw;
+};
+static inline View to_view(const dct_view* v) {
+  View r;
+  r.ptr = (char*)v->ptr; r.n = v->n; r.h = v->h; r.w = v->w; r.c = v->c;
+  r.sn = v->sn; r.sh = v->sh; r.sw = v->sw;
+  return r;
+}
+static inline bool view_ok(const dct_view* v) {
+  return v && v->ptr && v->n > 0 && v->h > 0 && v->w > 0 && v->c > 0 && v->sw >= v->c;
+}
+
+// wave-level sum (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// block-level sum for blockDim.x == 256; result valid in thread 0 (and broadcast through smem[0])
+__device__ __forceinline__ float block_sum_256(float v, float* smem4) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem4[w] = v;
+  __syncthreads();
+  return smem4[0] + smem4[1] + smem4[2] + smem4[3];
+}
+
+// ---- profiling hooks (prof.cpp) -------------------------------------------------------------
+void dct_prof_begin(int cls, hipStream_t s);
+void dct_prof_end(int cls, hipStream_t s);
+extern int g_dct_prof_on;
+
+#define DCT_LAUNCH(cls, kernel, grid, block, shmem, stream, ...)                       \
+  do {                                                                                 \
+    if (g_dct_prof_on) dct_prof_begin((cls), (stream));                                \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);               \
+    if (g_dct_prof_on) dct_prof_end((cls), (stream));                                  \
+  } while (0)
+
+static inline int dct_check_launch() {
+  return hipGetLastError() == hipSuccess ? DCT_OK : DCT_ERR_LAUNCH;
+}
+
+static inline unsigned div_up(long long a, long long b) { return (unsigned)((a + b - 1) / b); }

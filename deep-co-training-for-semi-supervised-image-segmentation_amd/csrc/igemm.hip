@@ -1,0 +1,364 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (K1/K2/K3 forward + data gradients).
+//
+//   D[channel][pixel] = sum_{tap,ci} Wt[channel][tap][ci] * X[pixel shifted by tap][ci]
+//
+// The MFMA A operand is the weight tile and the B operand the pixel tile, so an accumulator
+// register quad holds 4 consecutive output channels of ONE pixel: with NHWC output the
+// epilogue stores 8 B (bf16) / 16 B (f32) per lane per quad and 32 lanes x 2 halves cover
+// a contiguous 64 B / 128 B channel run of each pixel.
+//
+// Tile: BN channels x BM pixels x 64 bytes of K per step, 256 threads = 4 waves, each wave
+// 64 channels x (BM / WAVES_M) pixels of 32x32 MFMA tiles.  Global->register->LDS staging
+// with the next K-step's global loads in flight during the current step's MFMAs (one
+// barrier per step, two LDS buffers).  LDS rows are 64 B of data on an 80 B pitch, which
+// makes the ds_read_b128 fragment reads bank-conflict free (20*i mod 64 distinct for any
+// 16 rows distinct mod 16).
+//
+// bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  f32: v_mfma_f32_32x32x2_f32 -- exact
+// fp32 FMA chains, used by the parity path.
+#include "dct_common.h"
+
+namespace {
+
+struct IgemmParams {
+  const char* x; const char* w; const float* bias; const char* mask; char* y;
+  float* partial;
+  int M, N, Cin, R, S;
+  int Ho, Wo, Hi, Wi;
+  int stride, dil, pad_h, pad_w;
+  long long xsN, xsH, xsW;
+  long long ysN, ysH, ysW;
+  long long msN, msH, msW;
+  int relu, scatter, accumulate, mask_channels;
+  float mask_scale;
+  int kiters, kiters_per_split, cin_iters;
+  int cout;  // real Cout (N/4 in scatter mode)
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  static constexpr int KSTEP = 16;
+  __device__ static __forceinline__ void run(const char* a_row, const char* b_row, int half, f32x16& acc, int kk) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_row + kk * 32 + half * 16);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(b_row + kk * 32 + half * 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+};
+template <> struct Mfma<float> {
+  static constexpr int KSTEP = 2;
+  __device__ static __forceinline__ void run(const char* a_row, const char* b_row, int half, f32x16& acc, int kk) {
+    const float a = *reinterpret_cast<const float*>(a_row + (kk * 2 + half) * 4);
+    const float b = *reinterpret_cast<const float*>(b_row + (kk * 2 + half) * 4);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+};
+
+// Epilogue for 4 consecutive channels [c, c+4) of pixel (n, oy, ox).
+template <typename T>
+__device__ __forceinline__ void epilogue_store4(const IgemmParams& p, int n, int oy, int ox, int c, float v[4]) {
+  int co = c;
+  if (p.scatter) {
+    const int ab = c / p.cout;
+    co = c - ab * p.cout;
+    oy = 2 * oy + (ab >> 1);
+    ox = 2 * ox + (ab & 1);
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += p.bias[co + i];
+  }
+  if (p.relu) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  if (p.mask && co < p.mask_channels) {
+    const T* mp = reinterpret_cast<const T*>(p.mask) + (n * p.msN + oy * p.msH + ox * p.msW + co);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = to_f32(mp[i]) > 0.f ? v[i] * p.mask_scale : 0.f;
+  }
+  T* yp = reinterpret_cast<T*>(p.y) + (n * p.ysN + oy * p.ysH + ox * p.ysW + co);
+  if (p.accumulate) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += to_f32(yp[i]);
+  }
+  if constexpr (sizeof(T) == 2) {
+    bf16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x4*>(yp) = o;
+  } else {
+    f32x4 o = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(yp) = o;
+  }
+}
+
+template <typename T, int BN, int BM>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+  constexpr int EPV = 16 / sizeof(T);     // elements per 16-byte vector
+  constexpr int BK = 64 / sizeof(T);      // K elements per step (64 B rows)
+  constexpr int ROWB = 80;                // LDS row pitch
+  constexpr int WAVES_N = BN / 64;
+  constexpr int WAVES_M = 4 / WAVES_N;
+  constexpr int WM = BM / WAVES_M;
+  constexpr int TM = WM / 32;
+  constexpr int TN = 2;
+  constexpr int PA = BN / 64;             // staging passes (64 rows per pass)
+  constexpr int PB = BM / 64;
+  constexpr int BUF = (BN + BM) * ROWB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / WAVES_M, wm = wave % WAVES_M;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int chunk = tid & 3, srow = tid >> 2;
+  const long long Ktot = (long long)p.R * p.S * p.Cin;
+
+  // per-thread staging rows of the pixel tile
+  long long bbase[PB];
+  int biy0[PB], bix0[PB];
+#pragma unroll
+  for (int pp = 0; pp < PB; ++pp) {
+    const int m = m0 + srow + 64 * pp;
+    if (m < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int n = m / hw, rem = m - n * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      bbase[pp] = n * p.xsN;
+      biy0[pp] = oy * p.stride - p.pad_h;
+      bix0[pp] = ox * p.stride - p.pad_w;
+    } else {
+      bbase[pp] = 0; biy0[pp] = -(1 << 28); bix0[pp] = -(1 << 28);
+    }
+  }
+  const T* wbase[PA];
+#pragma unroll
+  for (int pp = 0; pp < PA; ++pp)
+    wbase[pp] = reinterpret_cast<const T*>(p.w) + (long long)(n0 + srow + 64 * pp) * Ktot + chunk * EPV;
+
+  const int kbeg = blockIdx.z * p.kiters_per_split;
+  const int kend = min(p.kiters, kbeg + p.kiters_per_split);
+
+  // running (r, s, c-iter) for the NEXT tile to load
+  int tap = kbeg / p.cin_iters;
+  int cit = kbeg - tap * p.cin_iters;
+  int r = tap / p.S, s = tap - r * p.S;
+
+  uint4 ra[PA], rb[PB];
+  auto load_tile = [&]() {
+    const int c0 = cit * BK;
+    const long long woff = (long long)(r * p.S + s) * p.Cin + c0;
+#pragma unroll
+    for (int pp = 0; pp < PA; ++pp) ra[pp] = *reinterpret_cast<const uint4*>(wbase[pp] + woff);
+#pragma unroll
+    for (int pp = 0; pp < PB; ++pp) {
+      const int iy = biy0[pp] + r * p.dil, ix = bix0[pp] + s * p.dil;
+      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
+        const T* xp = reinterpret_cast<const T*>(p.x) + (bbase[pp] + iy * p.xsH + ix * p.xsW + c0 + chunk * EPV);
+        rb[pp] = *reinterpret_cast<const uint4*>(xp);
+      } else {
+        rb[pp] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    if (++cit == p.cin_iters) { cit = 0; if (++s == p.S) { s = 0; ++r; } }
+  };
+  auto store_tile = [&](char* buf) {
+#pragma unroll
+    for (int pp = 0; pp < PA; ++pp)
+      *reinterpret_cast<uint4*>(buf + (srow + 64 * pp) * ROWB + chunk * 16) = ra[pp];
+#pragma unroll
+    for (int pp = 0; pp < PB; ++pp)
+      *reinterpret_cast<uint4*>(buf + (BN + srow + 64 * pp) * ROWB + chunk * 16) = rb[pp];
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (kbeg < kend) {
+    load_tile();
+    store_tile(smem);
+  }
+  __syncthreads();
+  int cur = 0;
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int it = kbeg; it < kend; ++it) {
+    const bool more = it + 1 < kend;
+    if (more) load_tile();
+    const char* A = smem + cur * BUF;
+    const char* B = A + BN * ROWB;
+#pragma unroll
+    for (int kk = 0; kk < BK / Mfma<T>::KSTEP; ++kk) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const char* arow = A + (wn * 64 + i * 32 + l31) * ROWB;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const char* brow = B + (wm * WM + j * 32 + l31) * ROWB;
+          Mfma<T>::run(arow, brow, half, acc[i][j], kk);
+        }
+      }
+    }
+    if (more) store_tile(smem + (cur ^ 1) * BUF);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wm * WM + j * 32 + l31;
+    if (m >= p.M) continue;
+    const int hw = p.Ho * p.Wo;
+    const int n = m / hw, rem = m - n * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = n0 + wn * 64 + i * 32 + 8 * q + 4 * half;
+        float v[4] = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        if (p.partial) {
+          float* pp = p.partial + ((long long)blockIdx.z * p.M + m) * p.N + c;
+          *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          epilogue_store4<T>(p, n, oy, ox, c, v);
+        }
+      }
+    }
+  }
+}
+
+// Sum split-K partial slabs and apply the epilogue.  One thread per (pixel, 4 channels).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmParams p, int splits) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int nq = p.N / 4;
+  if (idx >= (long long)p.M * nq) return;
+  const int m = (int)(idx / nq), c = (int)(idx - (long long)m * nq) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < splits; ++z) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p.partial + ((long long)z * p.M + m) * p.N + c);
+    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+  }
+  const int hw = p.Ho * p.Wo;
+  const int n = m / hw, rem = m - n * hw;
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  IgemmParams q = p;
+  q.partial = nullptr;
+  epilogue_store4<T>(q, n, oy, ox, c, v);
+}
+
+struct Plan {
+  int bn, bm, splits, kiters, kiters_per_split;
+  long long tiles;
+};
+
+static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int M, int N, Plan& pl) {
+  const int bk = dtype == DCT_BF16 ? 32 : 16;
+  if (x->c % bk != 0) return false;
+  if (N % 64 != 0) return false;
+  pl.bn = (N % 128 == 0) ? 128 : 64;
+  pl.bm = 128;
+  pl.kiters = d->R * d->S * (x->c / bk);
+  pl.tiles = (long long)div_up(M, pl.bm) * (N / pl.bn);
+  int splits = 1;
+  if (pl.tiles < 384) {
+    splits = (int)((768 + pl.tiles - 1) / pl.tiles);
+    if (splits > 16) splits = 16;
+    // keep at least 4 K-steps per split
+    while (splits > 1 && pl.kiters / splits < 4) --splits;
+  }
+  pl.kiters_per_split = (pl.kiters + splits - 1) / splits;
+  pl.splits = (pl.kiters + pl.kiters_per_split - 1) / pl.kiters_per_split;
+  return true;
+}
+
+template <typename T>
+static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
+  dim3 grid(div_up(p.M, pl.bm), p.N / pl.bn, pl.splits);
+  if (pl.bn == 128) {
+    DCT_LAUNCH(DCT_PROF_IGEMM, (igemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, p);
+  } else {
+    DCT_LAUNCH(DCT_PROF_IGEMM, (igemm_kernel<T, 64, 128>), grid, dim3(256), 0, st, p);
+  }
+  if (pl.splits > 1) {
+    const long long work = (long long)p.M * (p.N / 4);
+    DCT_LAUNCH(DCT_PROF_IGEMM, (splitk_epilogue_kernel<T>), dim3(div_up(work, 256)), dim3(256), 0, st, p, pl.splits);
+  }
+  return dct_check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype) {
+  if (!x || !y || !d) return 0;
+  const int Ho = d->scatter2x2 ? y->h / 2 : y->h, Wo = d->scatter2x2 ? y->w / 2 : y->w;
+  const int M = y->n * Ho * Wo;
+  const int N = d->scatter2x2 ? 4 * y->c : y->c;
+  Plan pl;
+  if (!make_plan(x, y, d, dtype, M, N, pl)) return 0;
+  return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* bias, const dct_view* mask,
+                          const dct_view* y, const dct_conv_desc* d, int dtype,
+                          void* workspace, size_t workspace_bytes, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(y) || !w_packed || !d) return DCT_ERR_BAD_ARG;
+  if (dtype != DCT_F32 && dtype != DCT_BF16) return DCT_ERR_BAD_ARG;
+  if (d->R < 1 || d->S < 1 || d->stride < 1 || d->dil < 1) return DCT_ERR_BAD_ARG;
+  if (x->n != y->n) return DCT_ERR_BAD_ARG;
+  IgemmParams p;
+  p.scatter = d->scatter2x2 ? 1 : 0;
+  if (p.scatter && (y->h % 2 || y->w % 2 || d->R != 1 || d->S != 1)) return DCT_ERR_BAD_ARG;
+  p.Ho = p.scatter ? y->h / 2 : y->h;
+  p.Wo = p.scatter ? y->w / 2 : y->w;
+  p.Hi = x->h; p.Wi = x->w;
+  // the output extent must be reachable: (Ho-1)*stride + (R-1)*dil - 2*pad < Hi is NOT required
+  // (out-of-range taps read zero), but shapes must match the conv arithmetic
+  {
+    const int eh = (x->h + 2 * d->pad_h - d->dil * (d->R - 1) - 1) / d->stride + 1;
+    const int ew = (x->w + 2 * d->pad_w - d->dil * (d->S - 1) - 1) / d->stride + 1;
+    if (eh != p.Ho || ew != p.Wo) return DCT_ERR_BAD_ARG;
+  }
+  p.M = y->n * p.Ho * p.Wo;
+  p.cout = y->c;
+  p.N = p.scatter ? 4 * y->c : y->c;
+  p.Cin = x->c; p.R = d->R; p.S = d->S;
+  p.stride = d->stride; p.dil = d->dil; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+  const int esz = dtype == DCT_BF16 ? 2 : 4;
+  const int epv = 16 / esz;
+  // 16-byte vector access requirements
+  if (((uintptr_t)x->ptr & 15) || ((uintptr_t)w_packed & 15) || (x->sw % epv) || (x->sh % epv) || (x->sn % epv)) return DCT_ERR_UNSUPPORTED;
+  if (((uintptr_t)y->ptr & (4 * esz - 1)) || (y->sw % 4) || (y->sh % 4) || (y->sn % 4) || (y->c % 4)) return DCT_ERR_UNSUPPORTED;
+  Plan pl;
+  if (!make_plan(x, y, d, dtype, p.M, p.N, pl)) return DCT_ERR_UNSUPPORTED;
+  if ((long long)p.M * p.N > (1ll << 40)) return DCT_ERR_UNSUPPORTED;
+  p.x = (const char*)x->ptr; p.w = (const char*)w_packed; p.bias = bias; p.y = (char*)y->ptr;
+  p.xsN = x->sn; p.xsH = x->sh; p.xsW = x->sw;
+  p.ysN = y->sn; p.ysH = y->sh; p.ysW = y->sw;
+  p.mask = nullptr; p.msN = p.msH = p.msW = 0;
+  p.mask_channels = 0; p.mask_scale = 1.f;
+  if (mask) {
+    if (!view_ok(mask) || mask->n != y->n || mask->h != y->h || mask->w != y->w) return DCT_ERR_BAD_ARG;
+    if (((uintptr_t)mask->ptr & (4 * esz - 1)) || (mask->sw % 4) || (mask->sh % 4) || (mask->sn % 4)) return DCT_ERR_UNSUPPORTED;
+    p.mask = (const char*)mask->ptr; p.msN = mask->sn; p.msH = mask->sh; p.msW = mask->sw;
+    p.mask_channels = d->mask_channels > 0 ? d->mask_channels : y->c;
+    if (p.mask_channels % 4) return DCT_ERR_UNSUPPORTED;
+    p.mask_scale = d->mask_scale;
+  }
+  p.relu = d->relu; p.accumulate = d->accumulate;
+  p.kiters = pl.kiters; p.kiters_per_split = pl.kiters_per_split;
+  p.cin_iters = x->c / (dtype == DCT_BF16 ? 32 : 16);
+  p.partial = nullptr;
+  if (pl.splits > 1) {
+    const size_t need = (size_t)pl.splits * p.M * p.N * sizeof(float);
+    if (!workspace || workspace_bytes < need) return DCT_ERR_WORKSPACE;
+    p.partial = (float*)workspace;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == DCT_BF16 ? launch<bf16_t>(p, pl, st) : launch<float>(p, pl, st);
+}

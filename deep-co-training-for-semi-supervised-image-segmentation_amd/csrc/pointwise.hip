@@ -1,0 +1,721 @@
+// HBM-bound kernels around the conv stack: weight repack, Cin=1 stem conv (fwd/dgrad/wgrad),
+// classifier head, 2x2 max-pool, bilinear resize (align_corners), dropout, ReLU backward, cast.
+// All operate on NHWC views with 16-byte (bf16x8 / f32x4) accesses along the channel axis.
+#include "dct_common.h"
+
+namespace {
+
+// ---- vector helpers: VEC channels as floats -------------------------------------------------
+template <typename T, int VEC> struct VecIO;
+template <> struct VecIO<bf16_t, 8> {
+  __device__ static void load(const bf16_t* p, float* v) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+  }
+  __device__ static void store(bf16_t* p, const float* v) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+template <> struct VecIO<float, 4> {
+  __device__ static void load(const float* p, float* v) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  __device__ static void store(float* p, const float* v) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+};
+template <typename T> struct VecIO<T, 1> {
+  __device__ static void load(const T* p, float* v) { v[0] = to_f32(*p); }
+  __device__ static void store(T* p, const float* v) { *p = from_f32<T>(v[0]); }
+};
+template <typename T> struct VecOf { static constexpr int value = 16 / sizeof(T); };
+
+struct PixIdx { int n, y, x, cv; bool ok; };
+// idx -> (pixel of a [n,h,w] grid, channel-vector cv)
+__device__ __forceinline__ PixIdx decode(long long idx, int n, int h, int w, int cvecs) {
+  PixIdx r;
+  const long long total = (long long)n * h * w * cvecs;
+  r.ok = idx < total;
+  if (!r.ok) { r.n = r.y = r.x = r.cv = 0; return r; }
+  r.cv = (int)(idx % cvecs);
+  long long pix = idx / cvecs;
+  r.x = (int)(pix % w); pix /= w;
+  r.y = (int)(pix % h);
+  r.n = (int)(pix / h);
+  return r;
+}
+__device__ __forceinline__ long long voff(const View& v, int n, int y, int x) {
+  return n * v.sn + y * v.sh + x * v.sw;
+}
+
+// ---- weight repack -------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const float* src, T* dst, int P, int Tt, int Q, int transpose, int flip) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)P * Tt * Q;
+  if (i >= total) return;
+  if (!transpose) { dst[i] = from_f32<T>(src[i]); return; }
+  // dst index i = (q, t', p)
+  const int p = (int)(i % P);
+  long long r = i / P;
+  const int t2 = (int)(r % Tt);
+  const int q = (int)(r / Tt);
+  const int t = flip ? Tt - 1 - t2 : t2;
+  dst[i] = from_f32<T>(src[((long long)p * Tt + t) * Q + q]);
+}
+
+// ---- Cin = 1 stem --------------------------------------------------------------------------
+struct StemGeom { int R, S, stride, dil, pad_h, pad_w, relu, cout; };
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(View x, const float* w, const float* bias, View y, StemGeom g) {
+  extern __shared__ float sw[];  // [cout][R*S] then bias[cout]
+  const int taps = g.R * g.S;
+  for (int i = threadIdx.x; i < g.cout * taps; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < g.cout; i += 256) sw[g.cout * taps + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int cvecs = (g.cout + VEC - 1) / VEC;
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, y.n, y.h, y.w, cvecs);
+  if (!id.ok) return;
+  float xin[25];
+  const float* xp = reinterpret_cast<const float*>(x.ptr);
+  for (int r = 0; r < g.R; ++r)
+    for (int s = 0; s < g.S; ++s) {
+      const int iy = id.y * g.stride + r * g.dil - g.pad_h, ix = id.x * g.stride + s * g.dil - g.pad_w;
+      xin[r * g.S + s] = ((unsigned)iy < (unsigned)x.h && (unsigned)ix < (unsigned)x.w) ? xp[voff(x, id.n, iy, ix)] : 0.f;
+    }
+  float out[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int c = id.cv * VEC + i;
+    float a = 0.f;
+    if (c < g.cout) {
+      for (int t = 0; t < taps; ++t) a = fmaf(xin[t], sw[c * taps + t], a);
+      a += sw[g.cout * taps + c];
+      if (g.relu) a = fmaxf(a, 0.f);
+    }
+    out[i] = a;
+  }
+  T* yp = reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, id.x) + id.cv * VEC;
+  if (id.cv * VEC + VEC <= g.cout) VecIO<T, VEC>::store(yp, out);
+  else
+    for (int i = 0; i < VEC && id.cv * VEC + i < g.cout; ++i) yp[i] = from_f32<T>(out[i]);
+}
+
+// dx[n,iy,ix] = sum_{co,r,s} dy[n,oy,ox,co] * w[co][r][s]  with oy*stride + r*dil - pad = iy.
+// One thread per (input pixel, VEC-channel slice); the cout/VEC slices of a pixel sit in adjacent
+// lanes and are summed with xor-shuffles (cout/VEC is a power of two <= 64).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void stem_dgrad_kernel(View dy, const float* w, View dx, StemGeom g) {
+  extern __shared__ float sw[];
+  const int taps = g.R * g.S;
+  for (int i = threadIdx.x; i < g.cout * taps; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int cvecs = g.cout / VEC;
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, dx.n, dx.h, dx.w, cvecs);
+  float a = 0.f;
+  if (id.ok) {
+    for (int r = 0; r < g.R; ++r) {
+      const int ty = id.y + g.pad_h - r * g.dil;
+      if (ty < 0 || ty % g.stride) continue;
+      const int oy = ty / g.stride;
+      if (oy >= dy.h) continue;
+      for (int s = 0; s < g.S; ++s) {
+        const int tx = id.x + g.pad_w - s * g.dil;
+        if (tx < 0 || tx % g.stride) continue;
+        const int ox = tx / g.stride;
+        if (ox >= dy.w) continue;
+        float v[VEC];
+        VecIO<T, VEC>::load(reinterpret_cast<const T*>(dy.ptr) + voff(dy, id.n, oy, ox) + id.cv * VEC, v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a = fmaf(v[i], sw[(id.cv * VEC + i) * taps + r * g.S + s], a);
+      }
+    }
+  }
+  for (int off = 1; off < cvecs; off <<= 1) a += __shfl_xor(a, off, 64);
+  if (id.ok && id.cv == 0) reinterpret_cast<float*>(dx.ptr)[voff(dx, id.n, id.y, id.x)] = a;
+}
+
+// partial[blk][co][taps+1]: dw taps then db.  Threads: co = tid % cout, sub = tid / cout.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(View x, View dy, float* partial, StemGeom g, int pix_per_block) {
+  __shared__ float red[256 * 10];
+  const int taps = g.R * g.S;  // <= 9
+  const int co = threadIdx.x % g.cout, sub = threadIdx.x / g.cout, subs = 256 / g.cout;
+  const long long P = (long long)dy.n * dy.h * dy.w;
+  const long long pbeg = (long long)blockIdx.x * pix_per_block, pend = min(P, pbeg + pix_per_block);
+  float acc[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = 0.f;
+  const float* xp = reinterpret_cast<const float*>(x.ptr);
+  for (long long pix = pbeg + sub; pix < pend; pix += subs) {
+    const int hw = dy.h * dy.w;
+    const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+    const int oy = rem / dy.w, ox = rem - oy * dy.w;
+    const float d = to_f32(reinterpret_cast<const T*>(dy.ptr)[voff(dy, n, oy, ox) + co]);
+    for (int r = 0; r < g.R; ++r)
+      for (int s = 0; s < g.S; ++s) {
+        const int iy = oy * g.stride + r * g.dil - g.pad_h, ix = ox * g.stride + s * g.dil - g.pad_w;
+        const float xv = ((unsigned)iy < (unsigned)x.h && (unsigned)ix < (unsigned)x.w) ? xp[voff(x, n, iy, ix)] : 0.f;
+        acc[r * g.S + s] = fmaf(d, xv, acc[r * g.S + s]);
+      }
+    acc[9] += d;
+  }
+#pragma unroll
+  for (int t = 0; t < 10; ++t) red[t * 256 + threadIdx.x] = acc[t];
+  __syncthreads();
+  if (sub == 0) {
+    for (int t = 0; t < 10; ++t) {
+      float s = 0.f;
+      for (int k = 0; k < subs; ++k) s += red[t * 256 + k * g.cout + co];
+      if (t < taps) partial[((long long)blockIdx.x * g.cout + co) * (taps + 1) + t] = s;
+      else if (t == 9) partial[((long long)blockIdx.x * g.cout + co) * (taps + 1) + taps] = s;
+    }
+  }
+}
+__global__ void stem_wgrad_reduce_kernel(const float* partial, float* dw, float* db, int cout, int taps, int blocks, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cout * (taps + 1)) return;
+  const int co = i / (taps + 1), t = i % (taps + 1);
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += partial[(long long)b * cout * (taps + 1) + i];
+  if (t < taps) { if (dw) dw[co * taps + t] = (accumulate ? dw[co * taps + t] : 0.f) + s; }
+  else if (db) db[co] = (accumulate ? db[co] : 0.f) + s;
+}
+
+// ---- classifier head -----------------------------------------------------------------------
+// y[pix][co] = sum_ci x[pix][ci]*w[co][ci] + b[co];  thread per pixel, cout <= 8
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void head_fwd_kernel(View x, const float* w, const float* bias, View y) {
+  extern __shared__ float sw[];  // [cout][cin] + bias
+  const int cin = x.c, cout = y.c;
+  for (int i = threadIdx.x; i < cout * cin; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < cout; i += 256) sw[cout * cin + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, x.n, x.h, x.w, 1);
+  if (!id.ok) return;
+  float acc[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+  const T* xp = reinterpret_cast<const T*>(x.ptr) + voff(x, id.n, id.y, id.x);
+  for (int c0 = 0; c0 < cin; c0 += VEC) {
+    float v[VEC];
+    VecIO<T, VEC>::load(xp + c0, v);
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < cout)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[o] = fmaf(v[i], sw[o * cin + c0 + i], acc[o]);
+  }
+  float* yp = reinterpret_cast<float*>(y.ptr) + voff(y, id.n, id.y, id.x);
+  for (int o = 0; o < cout; ++o) yp[o] = acc[o] + sw[cout * cin + o];
+}
+// dx[pix][ci] = sum_co dy[pix][co]*w[co][ci]  (* x>0 when relu_mask); thread per (pixel, VEC slice)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void head_dx_kernel(View x, View dy, const float* w, View dx, int relu_mask) {
+  extern __shared__ float sw[];
+  const int cin = x.c, cout = dy.c;
+  for (int i = threadIdx.x; i < cout * cin; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, x.n, x.h, x.w, cin / VEC);
+  if (!id.ok) return;
+  const float* dp = reinterpret_cast<const float*>(dy.ptr) + voff(dy, id.n, id.y, id.x);
+  float out[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) out[i] = 0.f;
+  for (int o = 0; o < cout; ++o) {
+    const float d = dp[o];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = fmaf(d, sw[o * cin + id.cv * VEC + i], out[i]);
+  }
+  if (relu_mask) {
+    float xv[VEC];
+    VecIO<T, VEC>::load(reinterpret_cast<const T*>(x.ptr) + voff(x, id.n, id.y, id.x) + id.cv * VEC, xv);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = xv[i] > 0.f ? out[i] : 0.f;
+  }
+  VecIO<T, VEC>::store(reinterpret_cast<T*>(dx.ptr) + voff(dx, id.n, id.y, id.x) + id.cv * VEC, out);
+}
+// partial[blk][co][cin+1]; threads: ci = tid % cin, sub = tid / cin  (cin divides 256)
+template <typename T>
+__global__ __launch_bounds__(256) void head_dw_kernel(View x, View dy, float* partial, int pix_per_block) {
+  __shared__ float red[256];
+  const int cin = x.c, cout = dy.c;
+  const int ci = threadIdx.x % cin, sub = threadIdx.x / cin, subs = 256 / cin;
+  const long long P = (long long)x.n * x.h * x.w;
+  const long long pbeg = (long long)blockIdx.x * pix_per_block, pend = min(P, pbeg + pix_per_block);
+  float acc[8], accb[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) { acc[o] = 0.f; accb[o] = 0.f; }
+  for (long long pix = pbeg + sub; pix < pend; pix += subs) {
+    const int hw = x.h * x.w;
+    const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+    const int yy = rem / x.w, xx = rem - yy * x.w;
+    const float xv = to_f32(reinterpret_cast<const T*>(x.ptr)[voff(x, n, yy, xx) + ci]);
+    const float* dp = reinterpret_cast<const float*>(dy.ptr) + voff(dy, n, yy, xx);
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < cout) { const float d = dp[o]; acc[o] = fmaf(d, xv, acc[o]); accb[o] += d; }
+  }
+  for (int o = 0; o < cout; ++o) {
+    red[threadIdx.x] = acc[o];
+    __syncthreads();
+    if (sub == 0) {
+      float s = 0.f;
+      for (int k = 0; k < subs; ++k) s += red[k * cin + ci];
+      partial[((long long)blockIdx.x * cout + o) * (cin + 1) + ci] = s;
+    }
+    __syncthreads();
+    red[threadIdx.x] = accb[o];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int k = 0; k < subs; ++k) s += red[k * cin];  // ci == 0 column holds every pixel once
+      partial[((long long)blockIdx.x * cout + o) * (cin + 1) + cin] = s;
+    }
+    __syncthreads();
+  }
+}
+__global__ void head_dw_reduce_kernel(const float* partial, float* dw, float* db, int cout, int cin, int blocks, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cout * (cin + 1)) return;
+  const int o = i / (cin + 1), c = i % (cin + 1);
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += partial[(long long)b * cout * (cin + 1) + i];
+  if (c < cin) { if (dw) dw[o * cin + c] = (accumulate ? dw[o * cin + c] : 0.f) + s; }
+  else if (db) db[o] = (accumulate ? db[o] : 0.f) + s;
+}
+
+// ---- max pool 2x2 s2 ceil ------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(View x, View y) {
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, y.n, y.h, y.w, y.c / VEC);
+  if (!id.ok) return;
+  float m[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) m[i] = -INFINITY;
+  for (int dy = 0; dy < 2; ++dy)
+    for (int dx = 0; dx < 2; ++dx) {
+      const int iy = 2 * id.y + dy, ix = 2 * id.x + dx;
+      if (iy < x.h && ix < x.w) {
+        float v[VEC];
+        VecIO<T, VEC>::load(reinterpret_cast<const T*>(x.ptr) + voff(x, id.n, iy, ix) + id.cv * VEC, v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) m[i] = v[i] > m[i] ? v[i] : m[i];
+      }
+    }
+  VecIO<T, VEC>::store(reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, id.x) + id.cv * VEC, m);
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(View x, View dy, View dx, int relu_mask, float scale) {
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, x.n, x.h, x.w, x.c / VEC);
+  if (!id.ok) return;
+  const int py = id.y >> 1, px = id.x >> 1;
+  const int me = (id.y & 1) * 2 + (id.x & 1);
+  float best[VEC];
+  int arg[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { best[i] = -INFINITY; arg[i] = -1; }
+  float mine[VEC];
+  for (int k = 0; k < 4; ++k) {
+    const int iy = 2 * py + (k >> 1), ix = 2 * px + (k & 1);
+    if (iy < x.h && ix < x.w) {
+      float v[VEC];
+      VecIO<T, VEC>::load(reinterpret_cast<const T*>(x.ptr) + voff(x, id.n, iy, ix) + id.cv * VEC, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        if (v[i] > best[i]) { best[i] = v[i]; arg[i] = k; }   // strict '>' : first max wins
+        if (k == me) mine[i] = v[i];
+      }
+    }
+  }
+  float g[VEC], out[VEC];
+  VecIO<T, VEC>::load(reinterpret_cast<const T*>(dy.ptr) + voff(dy, id.n, py, px) + id.cv * VEC, g);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    float o = arg[i] == me ? g[i] : 0.f;
+    if (relu_mask) o = mine[i] > 0.f ? o * scale : 0.f;
+    out[i] = o;
+  }
+  VecIO<T, VEC>::store(reinterpret_cast<T*>(dx.ptr) + voff(dx, id.n, id.y, id.x) + id.cv * VEC, out);
+}
+
+// ---- bilinear, align_corners = True ---------------------------------------------------------
+struct Lerp { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lerp lerp_of(int j, float scale, int in_size) {
+  // torch: real = scale * j; i0 = min(floor(real), in-1); lambda1 = clamp(real - i0, 0, 1)
+  const float real = scale * (float)j;
+  Lerp r;
+  r.i0 = min((int)floorf(real), in_size - 1);
+  r.i1 = min(r.i0 + 1, in_size - 1);
+  r.w1 = fminf(fmaxf(real - (float)r.i0, 0.f), 1.f);
+  r.w0 = 1.f - r.w1;
+  return r;
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(View x, View y, float sh, float sw) {
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, y.n, y.h, y.w, y.c / VEC);
+  if (!id.ok) return;
+  const Lerp ly = lerp_of(id.y, sh, x.h), lx = lerp_of(id.x, sw, x.w);
+  const T* xp = reinterpret_cast<const T*>(x.ptr) + id.cv * VEC;
+  float a[VEC], b[VEC], c[VEC], d[VEC], out[VEC];
+  VecIO<T, VEC>::load(xp + voff(x, id.n, ly.i0, lx.i0), a);
+  VecIO<T, VEC>::load(xp + voff(x, id.n, ly.i0, lx.i1), b);
+  VecIO<T, VEC>::load(xp + voff(x, id.n, ly.i1, lx.i0), c);
+  VecIO<T, VEC>::load(xp + voff(x, id.n, ly.i1, lx.i1), d);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i)
+    out[i] = ly.w0 * (lx.w0 * a[i] + lx.w1 * b[i]) + ly.w1 * (lx.w0 * c[i] + lx.w1 * d[i]);
+  VecIO<T, VEC>::store(reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, id.x) + id.cv * VEC, out);
+}
+// gather backward: thread per (source pixel, VEC slice); candidate destination rows/cols are a
+// slightly widened analytic range and each is tested with the forward's exact index arithmetic.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(View dy, View dx, float sh, float sw, int accumulate) {
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, dx.n, dx.h, dx.w, dx.c / VEC);
+  if (!id.ok) return;
+  auto range = [](int i, float scale, int out_size, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }
+    lo = max(0, (int)floorf((float)(i - 1) / scale) - 1);
+    hi = min(out_size - 1, (int)ceilf((float)(i + 1) / scale) + 1);
+  };
+  int jlo, jhi, klo, khi;
+  range(id.y, sh, dy.h, jlo, jhi);
+  range(id.x, sw, dy.w, klo, khi);
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  for (int j = jlo; j <= jhi; ++j) {
+    const Lerp ly = lerp_of(j, sh, dx.h);
+    const float wy = (ly.i0 == id.y ? ly.w0 : 0.f) + (ly.i1 == id.y ? ly.w1 : 0.f);
+    if (ly.i0 != id.y && ly.i1 != id.y) continue;
+    for (int k = klo; k <= khi; ++k) {
+      const Lerp lx = lerp_of(k, sw, dx.w);
+      if (lx.i0 != id.x && lx.i1 != id.x) continue;
+      const float wx = (lx.i0 == id.x ? lx.w0 : 0.f) + (lx.i1 == id.x ? lx.w1 : 0.f);
+      float g[VEC];
+      VecIO<T, VEC>::load(reinterpret_cast<const T*>(dy.ptr) + voff(dy, id.n, j, k) + id.cv * VEC, g);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(g[i], wy * wx, acc[i]);
+    }
+  }
+  T* op = reinterpret_cast<T*>(dx.ptr) + voff(dx, id.n, id.y, id.x) + id.cv * VEC;
+  if (accumulate) {
+    float old[VEC];
+    VecIO<T, VEC>::load(op, old);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] += old[i];
+  }
+  VecIO<T, VEC>::store(op, acc);
+}
+
+// ---- dropout (Philox4x32-10) ---------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned long long ctr, unsigned out[4]) {
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// thread per 4 consecutive channels of a pixel
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(View x, View y, unsigned char* mask_out, const unsigned char* mask_in,
+                                                       float p, unsigned long long seed, unsigned long long offset) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const PixIdx id = decode(idx, x.n, x.h, x.w, x.c / 4);
+  if (!id.ok) return;
+  const float scale = 1.f / (1.f - p);
+  bool keep[4];
+  const long long dense = (((long long)id.n * x.h + id.y) * x.w + id.x) * x.c + id.cv * 4;
+  if (mask_in) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) keep[i] = mask_in[dense + i] != 0;
+  } else {
+    unsigned r[4];
+    philox4x32_10(seed, offset + (unsigned long long)idx, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) keep[i] = (float)(r[i] >> 8) * (1.0f / 16777216.0f) >= p;
+  }
+  const T* xp = reinterpret_cast<const T*>(x.ptr) + voff(x, id.n, id.y, id.x) + id.cv * 4;
+  T* yp = reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, id.x) + id.cv * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    yp[i] = from_f32<T>(keep[i] ? to_f32(xp[i]) * scale : 0.f);
+    if (mask_out) mask_out[dense + i] = keep[i] ? 1 : 0;
+  }
+}
+
+// ---- relu backward / cast --------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(View g, View a, View y, float scale) {
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, y.n, y.h, y.w, y.c / VEC);
+  if (!id.ok) return;
+  float gv[VEC], av[VEC];
+  VecIO<T, VEC>::load(reinterpret_cast<const T*>(g.ptr) + voff(g, id.n, id.y, id.x) + id.cv * VEC, gv);
+  VecIO<T, VEC>::load(reinterpret_cast<const T*>(a.ptr) + voff(a, id.n, id.y, id.x) + id.cv * VEC, av);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) gv[i] = av[i] > 0.f ? gv[i] * scale : 0.f;
+  VecIO<T, VEC>::store(reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, id.x) + id.cv * VEC, gv);
+}
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(View x, View y) {
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, y.n, y.h, y.w, y.c);
+  if (!id.ok) return;
+  reinterpret_cast<TO*>(y.ptr)[voff(y, id.n, id.y, id.x) + id.cv] =
+      from_f32<TO>(to_f32(reinterpret_cast<const TI*>(x.ptr)[voff(x, id.n, id.y, id.x) + id.cv]));
+}
+
+static inline bool same_nhw(const dct_view* a, const dct_view* b) { return a->n == b->n && a->h == b->h && a->w == b->w; }
+static inline bool vec_ok(const dct_view* v, int vec, int esz) {
+  return v->c % vec == 0 && v->sw % vec == 0 && v->sh % vec == 0 && v->sn % vec == 0 && ((uintptr_t)v->ptr % (vec * esz)) == 0;
+}
+static inline StemGeom stem_geom(const dct_conv_desc* d, int cout) {
+  StemGeom g; g.R = d->R; g.S = d->S; g.stride = d->stride; g.dil = d->dil; g.pad_h = d->pad_h; g.pad_w = d->pad_w;
+  g.relu = d->relu; g.cout = cout; return g;
+}
+static inline int pix_blocks(long long P, int& ppb, int target_ppb, int max_blocks) {
+  long long blocks = (P + target_ppb - 1) / target_ppb;
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks < 1) blocks = 1;
+  ppb = (int)((P + blocks - 1) / blocks);
+  return (int)((P + ppb - 1) / ppb);
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                          \
+  do {                                                  \
+    if ((dtype) == DCT_BF16) { using T = bf16_t; constexpr int VEC = 8; (void)VEC; __VA_ARGS__; } \
+    else { using T = float; constexpr int VEC = 4; (void)VEC; __VA_ARGS__; }                    \
+  } while (0)
+
+extern "C" int dct_pack_weight(const float* src, void* dst, int P, int T_, int Q, int transpose, int flip_taps,
+                               int dtype, dct_stream stream) {
+  if (!src || !dst || P < 1 || T_ < 1 || Q < 1) return DCT_ERR_BAD_ARG;
+  const long long total = (long long)P * T_ * Q;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, pack_kernel<bf16_t>, dim3(div_up(total, 256)), dim3(256), 0, st, src, (bf16_t*)dst, P, T_, Q, transpose, flip_taps);
+  else if (dtype == DCT_F32) DCT_LAUNCH(DCT_PROF_POINTWISE, pack_kernel<float>, dim3(div_up(total, 256)), dim3(256), 0, st, src, (float*)dst, P, T_, Q, transpose, flip_taps);
+  else return DCT_ERR_BAD_ARG;
+  return dct_check_launch();
+}
+
+extern "C" int dct_conv_cin1_fwd(const dct_view* x, const float* w, const float* bias, const dct_view* y,
+                                 const dct_conv_desc* d, int dtype, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(y) || !w || !d || x->c != 1 || x->n != y->n) return DCT_ERR_BAD_ARG;
+  if (d->R * d->S > 25 || y->c > 512) return DCT_ERR_UNSUPPORTED;
+  const StemGeom g = stem_geom(d, y->c);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t sh = (size_t)(y->c * d->R * d->S + y->c) * sizeof(float);
+  DISPATCH_T(dtype, {
+    if (!vec_ok(y, 1, sizeof(T)) || (y->sw % VEC) || (y->sh % VEC) || (y->sn % VEC) || ((uintptr_t)y->ptr % 16)) return DCT_ERR_UNSUPPORTED;
+    const long long total = (long long)y->n * y->h * y->w * ((y->c + VEC - 1) / VEC);
+    DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_fwd_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), g);
+  });
+  return dct_check_launch();
+}
+
+extern "C" int dct_conv_cin1_dgrad(const dct_view* dy, const float* w, const dct_view* dx,
+                                   const dct_conv_desc* d, int dtype, dct_stream stream) {
+  if (!view_ok(dy) || !view_ok(dx) || !w || !d || dx->c != 1 || dx->n != dy->n) return DCT_ERR_BAD_ARG;
+  const StemGeom g = stem_geom(d, dy->c);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t sh = (size_t)(dy->c * d->R * d->S) * sizeof(float);
+  DISPATCH_T(dtype, {
+    const int cv = dy->c / VEC;
+    if (dy->c % VEC || cv > 64 || (cv & (cv - 1)) || !vec_ok(dy, VEC, sizeof(T))) return DCT_ERR_UNSUPPORTED;
+    const long long total = (long long)dx->n * dx->h * dx->w * cv;
+    DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_dgrad_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), sh, st, to_view(dy), w, to_view(dx), g);
+  });
+  return dct_check_launch();
+}
+
+extern "C" size_t dct_conv_cin1_wgrad_workspace_bytes(const dct_view* dy, const dct_conv_desc* d) {
+  if (!dy || !d) return 0;
+  int ppb;
+  const int blocks = pix_blocks((long long)dy->n * dy->h * dy->w, ppb, 1024, 2048);
+  return (size_t)blocks * dy->c * (d->R * d->S + 1) * sizeof(float);
+}
+extern "C" int dct_conv_cin1_wgrad(const dct_view* x, const dct_view* dy, float* dw, float* db,
+                                   const dct_conv_desc* d, int accumulate, int dtype,
+                                   void* workspace, size_t workspace_bytes, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(dy) || !d || x->c != 1 || x->n != dy->n) return DCT_ERR_BAD_ARG;
+  if (d->R * d->S > 9 || dy->c > 256 || 256 % dy->c) return DCT_ERR_UNSUPPORTED;
+  int ppb;
+  const int blocks = pix_blocks((long long)dy->n * dy->h * dy->w, ppb, 1024, 2048);
+  const int taps = d->R * d->S;
+  if (!workspace || workspace_bytes < (size_t)blocks * dy->c * (taps + 1) * sizeof(float)) return DCT_ERR_WORKSPACE;
+  const StemGeom g = stem_geom(d, dy->c);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, {
+    DCT_LAUNCH(DCT_PROF_POINTWISE, stem_wgrad_kernel<T>, dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
+  });
+  DCT_LAUNCH(DCT_PROF_POINTWISE, stem_wgrad_reduce_kernel, dim3(div_up(dy->c * (taps + 1), 256)), dim3(256), 0, st,
+             (const float*)workspace, dw, db, dy->c, taps, blocks, accumulate);
+  return dct_check_launch();
+}
+
+extern "C" int dct_conv1x1_head_fwd(const dct_view* x, const float* w, const float* bias, const dct_view* y,
+                                    int dtype, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(y) || !w || !same_nhw(x, y)) return DCT_ERR_BAD_ARG;
+  if (y->c > 8 || x->c > 1024) return DCT_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t sh = (size_t)(y->c * x->c + y->c) * sizeof(float);
+  DISPATCH_T(dtype, {
+    if (!vec_ok(x, VEC, sizeof(T))) return DCT_ERR_UNSUPPORTED;
+    const long long total = (long long)x->n * x->h * x->w;
+    DCT_LAUNCH(DCT_PROF_POINTWISE, (head_fwd_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y));
+  });
+  return dct_check_launch();
+}
+
+extern "C" size_t dct_conv1x1_head_bwd_workspace_bytes(const dct_view* x, int cout) {
+  if (!x) return 0;
+  int ppb;
+  const int blocks = pix_blocks((long long)x->n * x->h * x->w, ppb, 1024, 1024);
+  return (size_t)blocks * cout * (x->c + 1) * sizeof(float);
+}
+extern "C" int dct_conv1x1_head_bwd(const dct_view* x, const dct_view* dy, const float* w, const dct_view* dx,
+                                    float* dw, float* db, int relu_mask, int accumulate, int dtype,
+                                    void* workspace, size_t workspace_bytes, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(dy) || !w || !same_nhw(x, dy)) return DCT_ERR_BAD_ARG;
+  if (dy->c > 8 || x->c > 256 || 256 % x->c) return DCT_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t sh = (size_t)(dy->c * x->c) * sizeof(float);
+  if (dx) {
+    if (!view_ok(dx) || !same_nhw(x, dx) || dx->c != x->c) return DCT_ERR_BAD_ARG;
+    DISPATCH_T(dtype, {
+      if (!vec_ok(x, VEC, sizeof(T)) || !vec_ok(dx, VEC, sizeof(T))) return DCT_ERR_UNSUPPORTED;
+      const long long total = (long long)x->n * x->h * x->w * (x->c / VEC);
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (head_dx_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), sh, st, to_view(x), to_view(dy), w, to_view(dx), relu_mask);
+    });
+  }
+  if (dw || db) {
+    int ppb;
+    const int blocks = pix_blocks((long long)x->n * x->h * x->w, ppb, 1024, 1024);
+    if (!workspace || workspace_bytes < (size_t)blocks * dy->c * (x->c + 1) * sizeof(float)) return DCT_ERR_WORKSPACE;
+    DISPATCH_T(dtype, {
+      DCT_LAUNCH(DCT_PROF_POINTWISE, head_dw_kernel<T>, dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, ppb);
+    });
+    DCT_LAUNCH(DCT_PROF_POINTWISE, head_dw_reduce_kernel, dim3(div_up(dy->c * (x->c + 1), 256)), dim3(256), 0, st,
+               (const float*)workspace, dw, db, dy->c, x->c, blocks, accumulate);
+  }
+  return dct_check_launch();
+}
+
+extern "C" int dct_maxpool2x2_fwd(const dct_view* x, const dct_view* y, int dtype, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(y) || x->n != y->n || x->c != y->c) return DCT_ERR_BAD_ARG;
+  if (y->h != (x->h + 1) / 2 || y->w != (x->w + 1) / 2) return DCT_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, {
+    if (!vec_ok(x, VEC, sizeof(T)) || !vec_ok(y, VEC, sizeof(T))) return DCT_ERR_UNSUPPORTED;
+    const long long total = (long long)y->n * y->h * y->w * (y->c / VEC);
+    DCT_LAUNCH(DCT_PROF_POINTWISE, (maxpool_fwd_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), 0, st, to_view(x), to_view(y));
+  });
+  return dct_check_launch();
+}
+extern "C" int dct_maxpool2x2_bwd(const dct_view* x, const dct_view* dy, const dct_view* dx, int relu_mask,
+                                  float scale, int dtype, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(dy) || !view_ok(dx) || !same_nhw(x, dx) || x->c != dx->c || x->c != dy->c || x->n != dy->n) return DCT_ERR_BAD_ARG;
+  if (dy->h != (x->h + 1) / 2 || dy->w != (x->w + 1) / 2) return DCT_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, {
+    if (!vec_ok(x, VEC, sizeof(T)) || !vec_ok(dy, VEC, sizeof(T)) || !vec_ok(dx, VEC, sizeof(T))) return DCT_ERR_UNSUPPORTED;
+    const long long total = (long long)x->n * x->h * x->w * (x->c / VEC);
+    DCT_LAUNCH(DCT_PROF_POINTWISE, (maxpool_bwd_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), 0, st, to_view(x), to_view(dy), to_view(dx), relu_mask, scale);
+  });
+  return dct_check_launch();
+}
+
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+extern "C" int dct_bilinear_fwd(const dct_view* x, const dct_view* y, int dtype_in, int dtype_out, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(y) || x->n != y->n || x->c != y->c) return DCT_ERR_BAD_ARG;
+  if (dtype_in != dtype_out) return DCT_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const float sh = ac_scale(x->h, y->h), sw = ac_scale(x->w, y->w);
+  DISPATCH_T(dtype_in, {
+    const long long px = (long long)y->n * y->h * y->w;
+    if (vec_ok(x, VEC, sizeof(T)) && vec_ok(y, VEC, sizeof(T)))
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (bilinear_fwd_kernel<T, VEC>), dim3(div_up(px * (y->c / VEC), 256)), dim3(256), 0, st, to_view(x), to_view(y), sh, sw);
+    else
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (bilinear_fwd_kernel<T, 1>), dim3(div_up(px * y->c, 256)), dim3(256), 0, st, to_view(x), to_view(y), sh, sw);
+  });
+  return dct_check_launch();
+}
+extern "C" int dct_bilinear_bwd(const dct_view* dy, const dct_view* dx, int dtype_dy, int dtype_dx, int accumulate,
+                                dct_stream stream) {
+  if (!view_ok(dy) || !view_ok(dx) || dx->n != dy->n || dx->c != dy->c) return DCT_ERR_BAD_ARG;
+  if (dtype_dy != dtype_dx) return DCT_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const float sh = ac_scale(dx->h, dy->h), sw = ac_scale(dx->w, dy->w);
+  DISPATCH_T(dtype_dy, {
+    const long long px = (long long)dx->n * dx->h * dx->w;
+    if (vec_ok(dx, VEC, sizeof(T)) && vec_ok(dy, VEC, sizeof(T)))
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (bilinear_bwd_kernel<T, VEC>), dim3(div_up(px * (dx->c / VEC), 256)), dim3(256), 0, st, to_view(dy), to_view(dx), sh, sw, accumulate);
+    else
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (bilinear_bwd_kernel<T, 1>), dim3(div_up(px * dx->c, 256)), dim3(256), 0, st, to_view(dy), to_view(dx), sh, sw, accumulate);
+  });
+  return dct_check_launch();
+}
+
+static int dropout_impl(const dct_view* x, const dct_view* y, uint8_t* mask_out, const uint8_t* mask_in, float p,
+                        uint64_t seed, uint64_t offset, int dtype, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(y) || !same_nhw(x, y) || x->c != y->c || p < 0.f || p >= 1.f) return DCT_ERR_BAD_ARG;
+  if (x->c % 4) return DCT_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)x->n * x->h * x->w * (x->c / 4);
+  DISPATCH_T(dtype, {
+    DCT_LAUNCH(DCT_PROF_POINTWISE, dropout_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, to_view(x), to_view(y),
+               (unsigned char*)mask_out, (const unsigned char*)mask_in, p, (unsigned long long)seed, (unsigned long long)offset);
+  });
+  return dct_check_launch();
+}
+extern "C" int dct_dropout_fwd(const dct_view* x, const dct_view* y, uint8_t* mask_out, float p,
+                               uint64_t seed, uint64_t offset, int dtype, dct_stream stream) {
+  return dropout_impl(x, y, mask_out, nullptr, p, seed, offset, dtype, stream);
+}
+extern "C" int dct_dropout_apply(const dct_view* x, const dct_view* y, const uint8_t* mask, float p, int dtype,
+                                 dct_stream stream) {
+  if (!mask) return DCT_ERR_BAD_ARG;
+  return dropout_impl(x, y, nullptr, mask, p, 0, 0, dtype, stream);
+}
+
+extern "C" int dct_relu_bwd(const dct_view* g, const dct_view* a, const dct_view* y, float scale, int dtype,
+                            dct_stream stream) {
+  if (!view_ok(g) || !view_ok(a) || !view_ok(y) || !same_nhw(g, y) || !same_nhw(a, y) || g->c != y->c || a->c != y->c) return DCT_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, {
+    if (!vec_ok(g, VEC, sizeof(T)) || !vec_ok(a, VEC, sizeof(T)) || !vec_ok(y, VEC, sizeof(T))) return DCT_ERR_UNSUPPORTED;
+    const long long total = (long long)y->n * y->h * y->w * (y->c / VEC);
+    DCT_LAUNCH(DCT_PROF_POINTWISE, (relu_bwd_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), 0, st, to_view(g), to_view(a), to_view(y), scale);
+  });
+  return dct_check_launch();
+}
+
+extern "C" int dct_cast(const dct_view* x, const dct_view* y, int dtype_in, int dtype_out, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(y) || !same_nhw(x, y) || x->c != y->c) return DCT_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)y->n * y->h * y->w * y->c;
+  const dim3 grid(div_up(total, 256)), blk(256);
+  if (dtype_in == DCT_F32 && dtype_out == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, (cast_kernel<float, bf16_t>), grid, blk, 0, st, to_view(x), to_view(y));
+  else if (dtype_in == DCT_BF16 && dtype_out == DCT_F32) DCT_LAUNCH(DCT_PROF_POINTWISE, (cast_kernel<bf16_t, float>), grid, blk, 0, st, to_view(x), to_view(y));
+  else if (dtype_in == DCT_F32 && dtype_out == DCT_F32) DCT_LAUNCH(DCT_PROF_POINTWISE, (cast_kernel<float, float>), grid, blk, 0, st, to_view(x), to_view(y));
+  else if (dtype_in == DCT_BF16 && dtype_out == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, (cast_kernel<bf16_t, bf16_t>), grid, blk, 0, st, to_view(x), to_view(y));
+  else return DCT_ERR_BAD_ARG;
+  return dct_check_launch();
+}

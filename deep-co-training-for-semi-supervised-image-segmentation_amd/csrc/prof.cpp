@@ -1,0 +1,71 @@
+// Optional per-kernel-class timing (bench.py's roofline leg) + version/status strings.
+// The only global state in the library: an opt-in event log guarded by a mutex.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
+#include "dct_common.h"
+
+int g_dct_prof_on = 0;
+
+namespace {
+struct Rec { int cls; hipEvent_t a, b; };
+std::mutex g_mu;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+thread_local hipEvent_t t_pending = nullptr;
+
+hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+void dct_prof_begin(int, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  t_pending = get_event();
+  (void)hipEventRecord(t_pending, s);
+}
+void dct_prof_end(int cls, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Rec r;
+  r.cls = cls; r.a = t_pending; r.b = get_event();
+  (void)hipEventRecord(r.b, s);
+  g_recs.push_back(r);
+  t_pending = nullptr;
+}
+
+extern "C" int dct_prof_enable(int on) { g_dct_prof_on = on ? 1 : 0; return DCT_OK; }
+
+extern "C" int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset) {
+  if (!ms_per_class || !launches_per_class) return DCT_ERR_BAD_ARG;
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < DCT_PROF_NCLASS; ++i) { ms_per_class[i] = 0.0; launches_per_class[i] = 0; }
+  for (const Rec& r : g_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.cls >= 0 && r.cls < DCT_PROF_NCLASS) {
+      ms_per_class[r.cls] += ms;
+      launches_per_class[r.cls] += 1;
+    }
+  }
+  if (reset) {
+    for (const Rec& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_recs.clear();
+  }
+  return DCT_OK;
+}
+
+extern "C" int dct_version(void) { return 100; }
+
+extern "C" const char* dct_status_string(int status) {
+  switch (status) {
+    case DCT_OK: return "ok";
+    case DCT_ERR_BAD_ARG: return "bad argument";
+    case DCT_ERR_UNSUPPORTED: return "unsupported shape/dtype/alignment";
+    case DCT_ERR_LAUNCH: return "kernel launch failed";
+    case DCT_ERR_WORKSPACE: return "workspace missing or too small";
+    default: return "unknown status";
+  }
+}

@@ -1,0 +1,359 @@
+// Weight-gradient GEMM on MFMA for gfx950:
+//
+//   dW[p][tap][q] (+)= sum_m P[m][p] * Q[pixel(m)*stride + tap*dil - pad][q]
+//
+// The reduction runs over pixels, which is the SLOW axis of both NHWC operands, so both MFMA
+// operands need a transposed fragment: bf16 tiles are staged [pixel][channel] exactly as they
+// sit in HBM (coalesced 16-B loads, ds_write_b128) and read back with ds_read_b64_tr_b16, the
+// gfx950 transposing LDS read (4 pixels x 16 channels per 16-lane group, column-major into
+// the lanes).  The LDS pitch is row bytes + 64 so the four rows a 32-lane half touches land in
+// different 64-B quarters of the 256-B bank row (conflict-free).  f32 (parity path) uses
+// v_mfma_f32_32x32x2_f32, whose one-element-per-lane operands need no transpose.
+//
+// Work split: one block = (p tile, tap, q tile, pixel chunk).  Pixel chunks are the split-K;
+// block ids are decoded so that all (tap, tile) blocks of one chunk carry the same id mod 8,
+// i.e. share an XCD and re-read the same pixels from that XCD's L2 (speed only).  Partial
+// tiles go to a workspace and are summed in fixed order by a second kernel: deterministic,
+// and "+=" into an existing gradient is folded into that pass.
+#include "dct_common.h"
+
+namespace {
+
+struct WgradParams {
+  const char* P; const char* Q; float* out;
+  int M, Cp, Cq, R, S;
+  int Hp, Wp, Hq, Wq;
+  int stride, dil, pad_h, pad_w;
+  long long psN, psH, psW, qsN, qsH, qsW;
+  int chunks, pix_per_chunk, ptiles, qtiles;
+};
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int cbase, int kk, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = g >> 1;
+  const char* a0 = tile + (kk * 16 + 8 * h + q) * pitch + (cbase + 16 * (g & 1) + 4 * pp) * 2;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + 4 * pitch));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+template <typename T, int BP, int BQ>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  constexpr int ES = sizeof(T);
+  constexpr int EPV = 16 / ES;
+  constexpr int BKP = (ES == 2) ? 32 : 16;         // pixels per step
+  constexpr int PITCH_P = BP * ES + 64, PITCH_Q = BQ * ES + 64;
+  constexpr int CPR_P = BP / EPV, CPR_Q = BQ / EPV;  // 16-B chunks per row
+  constexpr int RPP_P = 256 / CPR_P, RPP_Q = 256 / CPR_Q;  // rows per pass
+  constexpr int NP_P = (BKP + RPP_P - 1) / RPP_P, NP_Q = (BKP + RPP_Q - 1) / RPP_Q;
+  constexpr int TP = BP / 64, TQ = BQ / 64;
+  constexpr int BUF = BKP * (PITCH_P + PITCH_Q);
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp = wave >> 1, wq = wave & 1;
+
+  // block decode (XCD-affine chunks)
+  const int tiles_per_chunk = p.ptiles * p.R * p.S * p.qtiles;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int chunk = (slot / tiles_per_chunk) * 8 + xcd;
+  if (chunk >= p.chunks) return;
+  int tile = slot % tiles_per_chunk;
+  const int qt = tile % p.qtiles; tile /= p.qtiles;
+  const int tap = tile % (p.R * p.S);
+  const int pt = tile / (p.R * p.S);
+  const int tr = tap / p.S, ts = tap - tr * p.S;
+  const int p0 = pt * BP, q0 = qt * BQ;
+
+  const int mbeg = chunk * p.pix_per_chunk;
+  const int mend = min(p.M, mbeg + p.pix_per_chunk);
+
+  const int rowP = tid / CPR_P, chP = tid % CPR_P;
+  const int rowQ = tid / CPR_Q, chQ = tid % CPR_Q;
+  const int hwp = p.Hp * p.Wp;
+
+  uint4 rp[NP_P], rq[NP_Q];
+  auto load_tile = [&](int mit) {
+#pragma unroll
+    for (int pp = 0; pp < NP_P; ++pp) {
+      const int row = rowP + pp * RPP_P;
+      const int m = mit + row;
+      if (row < BKP && m < mend) {
+        const int n = m / hwp, rem = m - n * hwp;
+        const int y = rem / p.Wp, x = rem - y * p.Wp;
+        const T* src = reinterpret_cast<const T*>(p.P) + (n * p.psN + y * p.psH + x * p.psW + p0 + chP * EPV);
+        rp[pp] = *reinterpret_cast<const uint4*>(src);
+      } else {
+        rp[pp] = make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int pp = 0; pp < NP_Q; ++pp) {
+      const int row = rowQ + pp * RPP_Q;
+      const int m = mit + row;
+      bool ok = row < BKP && m < mend;
+      int n = 0, iy = 0, ix = 0;
+      if (ok) {
+        n = m / hwp;
+        const int rem = m - n * hwp;
+        const int y = rem / p.Wp, x = rem - y * p.Wp;
+        iy = y * p.stride + tr * p.dil - p.pad_h;
+        ix = x * p.stride + ts * p.dil - p.pad_w;
+        ok = (unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq;
+      }
+      if (ok) {
+        const T* src = reinterpret_cast<const T*>(p.Q) + (n * p.qsN + iy * p.qsH + ix * p.qsW + q0 + chQ * EPV);
+        rq[pp] = *reinterpret_cast<const uint4*>(src);
+      } else {
+        rq[pp] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_tile = [&](char* buf) {
+#pragma unroll
+    for (int pp = 0; pp < NP_P; ++pp) {
+      const int row = rowP + pp * RPP_P;
+      if (row < BKP) *reinterpret_cast<uint4*>(buf + row * PITCH_P + chP * 16) = rp[pp];
+    }
+#pragma unroll
+    for (int pp = 0; pp < NP_Q; ++pp) {
+      const int row = rowQ + pp * RPP_Q;
+      if (row < BKP) *reinterpret_cast<uint4*>(buf + BKP * PITCH_P + row * PITCH_Q + chQ * 16) = rq[pp];
+    }
+  };
+
+  f32x16 acc[TP][TQ];
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (mbeg < mend) {
+    load_tile(mbeg);
+    store_tile(smem);
+  }
+  __syncthreads();
+  int cur = 0;
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int mit = mbeg; mit < mend; mit += BKP) {
+    const bool more = mit + BKP < mend;
+    if (more) load_tile(mit + BKP);
+    const char* Pt = smem + cur * BUF;
+    const char* Qt = Pt + BKP * PITCH_P;
+    if constexpr (ES == 2) {
+#pragma unroll
+      for (int kk = 0; kk < BKP / 16; ++kk) {
+        bf16x8 a[TP], b[TQ];
+#pragma unroll
+        for (int i = 0; i < TP; ++i) a[i] = tr_frag(Pt, PITCH_P, wp * (BP / 2) + i * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) b[j] = tr_frag(Qt, PITCH_Q, wq * (BQ / 2) + j * 32, kk, lane);
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+          for (int j = 0; j < TQ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BKP / 2; ++kk) {
+        float a[TP], b[TQ];
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+          a[i] = *reinterpret_cast<const float*>(Pt + (kk * 2 + half) * PITCH_P + (wp * (BP / 2) + i * 32 + l31) * 4);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+          b[j] = *reinterpret_cast<const float*>(Qt + (kk * 2 + half) * PITCH_Q + (wq * (BQ / 2) + j * 32 + l31) * 4);
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+          for (int j = 0; j < TQ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) store_tile(smem + (cur ^ 1) * BUF);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // store: out[chunk][p][tap][q]
+  const int taps = p.R * p.S;
+  float* base = p.out + (long long)chunk * p.Cp * taps * p.Cq;
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const int qc = q0 + wq * (BQ / 2) + j * 32 + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int pr = p0 + wp * (BP / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        base[((long long)pr * taps + tap) * p.Cq + qc] = acc[i][j][e];
+      }
+    }
+}
+
+// dw[i] (=|+=) sum_chunk partial[chunk][i]   (float4 per thread, fixed order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dw, long long n4,
+                                                           long long stride, int chunks, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = accumulate ? reinterpret_cast<const f32x4*>(dw)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < chunks; ++c) s += reinterpret_cast<const f32x4*>(partial + c * stride)[i];
+  reinterpret_cast<f32x4*>(dw)[i] = s;
+}
+
+struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles; };
+
+static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc* d, int dtype, WPlan& pl) {
+  if (p->c % 64 || q->c % 64) return false;
+  pl.bp = (p->c % 128 == 0) ? 128 : 64;
+  pl.bq = (q->c % 128 == 0) ? 128 : 64;
+  pl.ptiles = p->c / pl.bp; pl.qtiles = q->c / pl.bq;
+  const int bkp = dtype == DCT_BF16 ? 32 : 16;
+  const long long M = (long long)p->n * p->h * p->w;
+  const long long tiles = (long long)pl.ptiles * pl.qtiles * d->R * d->S;
+  long long chunks = (1536 + tiles - 1) / tiles;          // aim for ~1.5k blocks
+  const long long max_by_pix = (M + 8 * bkp - 1) / (8 * bkp);  // >= 8 K-steps per chunk
+  if (chunks > max_by_pix) chunks = max_by_pix;
+  // bound the partial-sum workspace to 192 MiB
+  const long long per_chunk = (long long)p->c * q->c * d->R * d->S * 4;
+  while (chunks > 1 && chunks * per_chunk > (192ll << 20)) --chunks;
+  if (chunks < 1) chunks = 1;
+  long long ppc = (M + chunks - 1) / chunks;
+  ppc = (ppc + bkp - 1) / bkp * bkp;
+  pl.ppc = (int)ppc;
+  pl.chunks = (int)((M + ppc - 1) / ppc);
+  return true;
+}
+
+template <typename T>
+static void launch_w(const WgradParams& wp, const WPlan& pl, hipStream_t st) {
+  const int tiles = pl.ptiles * pl.qtiles * wp.R * wp.S;
+  const unsigned grid = (unsigned)(((pl.chunks + 7) / 8) * 8 * tiles);
+  if (pl.bp == 128 && pl.bq == 128) DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad_kernel<T, 128, 128>), dim3(grid), dim3(256), 0, st, wp);
+  else if (pl.bp == 128) DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad_kernel<T, 128, 64>), dim3(grid), dim3(256), 0, st, wp);
+  else if (pl.bq == 128) DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad_kernel<T, 64, 128>), dim3(grid), dim3(256), 0, st, wp);
+  else DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad_kernel<T, 64, 64>), dim3(grid), dim3(256), 0, st, wp);
+}
+
+}  // namespace
+
+extern "C" size_t dct_conv2d_wgrad_workspace_bytes(const dct_view* p, const dct_view* q, const dct_conv_desc* d, int dtype) {
+  if (!p || !q || !d) return 0;
+  WPlan pl;
+  if (!make_wplan(p, q, d, dtype, pl)) return 0;
+  return (size_t)pl.chunks * p->c * q->c * d->R * d->S * sizeof(float);
+}
+
+extern "C" int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw, const dct_conv_desc* d, int dtype,
+                                void* workspace, size_t workspace_bytes, dct_stream stream) {
+  if (!view_ok(p) || !view_ok(q) || !dw || !d) return DCT_ERR_BAD_ARG;
+  if (dtype != DCT_F32 && dtype != DCT_BF16) return DCT_ERR_BAD_ARG;
+  if (p->n != q->n) return DCT_ERR_BAD_ARG;
+  {
+    const int eh = (q->h + 2 * d->pad_h - d->dil * (d->R - 1) - 1) / d->stride + 1;
+    const int ew = (q->w + 2 * d->pad_w - d->dil * (d->S - 1) - 1) / d->stride + 1;
+    if (eh != p->h || ew != p->w) return DCT_ERR_BAD_ARG;
+  }
+  const int esz = dtype == DCT_BF16 ? 2 : 4, epv = 16 / esz;
+  if (((uintptr_t)p->ptr & 15) || ((uintptr_t)q->ptr & 15) || (p->sw % epv) || (p->sh % epv) || (p->sn % epv) ||
+      (q->sw % epv) || (q->sh % epv) || (q->sn % epv) || ((uintptr_t)dw & 15))
+    return DCT_ERR_UNSUPPORTED;
+  WPlan pl;
+  if (!make_wplan(p, q, d, dtype, pl)) return DCT_ERR_UNSUPPORTED;
+  const size_t need = (size_t)pl.chunks * p->c * q->c * d->R * d->S * sizeof(float);
+  if (!workspace || workspace_bytes < need) return DCT_ERR_WORKSPACE;
+  WgradParams wp;
+  wp.P = (const char*)p->ptr; wp.Q = (const char*)q->ptr; wp.out = (float*)workspace;
+  wp.M = p->n * p->h * p->w; wp.Cp = p->c; wp.Cq = q->c; wp.R = d->R; wp.S = d->S;
+  wp.Hp = p->h; wp.Wp = p->w; wp.Hq = q->h; wp.Wq = q->w;
+  wp.stride = d->stride; wp.dil = d->dil; wp.pad_h = d->pad_h; wp.pad_w = d->pad_w;
+  wp.psN = p->sn; wp.psH = p->sh; wp.psW = p->sw; wp.qsN = q->sn; wp.qsH = q->sh; wp.qsW = q->sw;
+  wp.chunks = pl.chunks; wp.pix_per_chunk = pl.ppc; wp.ptiles = pl.ptiles; wp.qtiles = pl.qtiles;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DCT_BF16) launch_w<bf16_t>(wp, pl, st); else launch_w<float>(wp, pl, st);
+  const long long n = (long long)p->c * q->c * d->R * d->S;
+  DCT_LAUNCH(DCT_PROF_WGRAD, wgrad_reduce_kernel, dim3(div_up(n / 4, 256)), dim3(256), 0, st,
+             (const float*)workspace, dw, n / 4, n, pl.chunks, d->accumulate);
+  return dct_check_launch();
+}
+
+// ------------------------------------------------------------------------------- bias grad
+namespace {
+// partial[blk][c] = sum over the block's pixel range of dy[pix][c]; then a fixed-order reduce.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_partial_kernel(View dy, float* partial, int pix_per_block) {
+  const long long P = (long long)dy.n * dy.h * dy.w;
+  const long long pbeg = (long long)blockIdx.x * pix_per_block;
+  const long long pend = min(P, pbeg + pix_per_block);
+  const int C = dy.c;
+  // layout: threads span channels first (coalesced), then pixel sub-rows
+  const int lanes_c = C < 256 ? C : 256;
+  const int rows = 256 / lanes_c;
+  const int tc = threadIdx.x % lanes_c, trow = threadIdx.x / lanes_c;
+  __shared__ float red[256];
+  for (int c0 = 0; c0 < C; c0 += lanes_c) {
+    float s = 0.f;
+    if (trow < rows) {
+      for (long long pix = pbeg + trow; pix < pend; pix += rows) {
+        const int hw = dy.h * dy.w;
+        const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+        const int y = rem / dy.w, x = rem - y * dy.w;
+        s += to_f32(reinterpret_cast<const T*>(dy.ptr)[n * dy.sn + y * dy.sh + x * dy.sw + c0 + tc]);
+      }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (trow == 0) {
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += red[r * lanes_c + tc];
+      partial[(long long)blockIdx.x * C + c0 + tc] = t;
+    }
+    __syncthreads();
+  }
+}
+__global__ void bias_reduce_kernel(const float* partial, float* db, int C, int blocks, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = accumulate ? db[c] : 0.f;
+  for (int b = 0; b < blocks; ++b) s += partial[(long long)b * C + c];
+  db[c] = s;
+}
+static int bias_blocks(const dct_view* dy, int& ppb) {
+  const long long P = (long long)dy->n * dy->h * dy->w;
+  long long blocks = (P + 511) / 512;
+  if (blocks > 1024) blocks = 1024;
+  ppb = (int)((P + blocks - 1) / blocks);
+  return (int)((P + ppb - 1) / ppb);
+}
+}  // namespace
+
+extern "C" size_t dct_bias_grad_workspace_bytes(const dct_view* dy) {
+  if (!dy) return 0;
+  int ppb;
+  return (size_t)bias_blocks(dy, ppb) * dy->c * sizeof(float);
+}
+
+extern "C" int dct_bias_grad(const dct_view* dy, float* db, int accumulate, int dtype,
+                             void* workspace, size_t workspace_bytes, dct_stream stream) {
+  if (!view_ok(dy) || !db) return DCT_ERR_BAD_ARG;
+  if (dy->c > 256 && dy->c % 256) return DCT_ERR_UNSUPPORTED;
+  if (dy->c < 256 && 256 % dy->c) return DCT_ERR_UNSUPPORTED;
+  int ppb;
+  const int blocks = bias_blocks(dy, ppb);
+  if (!workspace || workspace_bytes < (size_t)blocks * dy->c * sizeof(float)) return DCT_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  View v = to_view(dy);
+  if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, bias_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, v, (float*)workspace, ppb);
+  else DCT_LAUNCH(DCT_PROF_POINTWISE, bias_partial_kernel<float>, dim3(blocks), dim3(256), 0, st, v, (float*)workspace, ppb);
+  DCT_LAUNCH(DCT_PROF_POINTWISE, bias_reduce_kernel, dim3(div_up(dy->c, 256)), dim3(256), 0, st,
+             (const float*)workspace, db, dy->c, blocks, accumulate);
+  return dct_check_launch();
+}

@@ -1,0 +1,275 @@
+"""Functional wrappers over the C ABI (one per kernel family), operating on physical-NHWC
+torch tensors that only provide device memory and the stream.  Used by the networks
+(arch/), the loss modules, the optimizer and the parity tests.  HIP only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import BF16, DTYPE_OF, F32, call, conv_desc, ptr, stream, view
+
+
+def _ws(nbytes: int, device) -> Optional[torch.Tensor]:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return DTYPE_OF[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"dct_amd: unsupported dtype {t.dtype}")
+
+
+# ------------------------------------------------------------------------------ conv family
+def conv2d(x, w_packed, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=False, mask=None,
+           mask_channels=0, mask_scale=1.0, accumulate=False, scatter2x2=False):
+    """y (NHWC view, written in place) = epilogue(conv(x, w_packed)); see include/dct.h dct_conv2d."""
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu, scatter2x2, accumulate, mask_channels, mask_scale)
+    vx, vy = view(x), view(y)
+    lib = _lib.load()
+    dt = _dt(x)
+    need = lib.dct_conv2d_workspace_bytes(C.byref(vx), C.byref(vy), C.byref(d), dt)
+    ws = _ws(need, x.device)
+    vm = view(mask) if mask is not None else None
+    call("dct_conv2d", C.byref(vx), ptr(w_packed), ptr(bias), C.byref(vm) if vm is not None else None,
+         C.byref(vy), C.byref(d), dt, ptr(ws), ws.numel(), stream())
+    return y
+
+
+def conv2d_wgrad(p, q, dw, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, accumulate=False):
+    """dw[p.c][R][S][q.c] (fp32, dense) (+)= sum_m p[m] (x) q[shifted m]."""
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w, accumulate=accumulate)
+    vp, vq = view(p), view(q)
+    lib = _lib.load()
+    dt = _dt(p)
+    need = lib.dct_conv2d_wgrad_workspace_bytes(C.byref(vp), C.byref(vq), C.byref(d), dt)
+    if need == 0:
+        raise RuntimeError("dct_amd: conv2d_wgrad unsupported shape")
+    ws = _ws(need, p.device)
+    call("dct_conv2d_wgrad", C.byref(vp), C.byref(vq), ptr(dw), C.byref(d), dt, ptr(ws), ws.numel(), stream())
+    return dw
+
+
+def bias_grad(dy, db, accumulate=False):
+    vd = view(dy)
+    need = _lib.load().dct_bias_grad_workspace_bytes(C.byref(vd))
+    ws = _ws(need, dy.device)
+    call("dct_bias_grad", C.byref(vd), ptr(db), int(accumulate), _dt(dy), ptr(ws), ws.numel(), stream())
+    return db
+
+
+def pack_weight(src_f32, dst, P, T, Q, transpose=False, flip_taps=False):
+    call("dct_pack_weight", ptr(src_f32), ptr(dst), P, T, Q, int(transpose), int(flip_taps), _dt(dst), stream())
+    return dst
+
+
+def conv_cin1_fwd(x, w, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=False):
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu)
+    vx, vy = view(x), view(y)
+    call("dct_conv_cin1_fwd", C.byref(vx), ptr(w), ptr(bias), C.byref(vy), C.byref(d), _dt(y), stream())
+    return y
+
+
+def conv_cin1_dgrad(dy, w, dx, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0):
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w)
+    vdy, vdx = view(dy), view(dx)
+    call("dct_conv_cin1_dgrad", C.byref(vdy), ptr(w), C.byref(vdx), C.byref(d), _dt(dy), stream())
+    return dx
+
+
+def conv_cin1_wgrad(x, dy, dw, db, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, accumulate=False):
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w)
+    vx, vdy = view(x), view(dy)
+    need = _lib.load().dct_conv_cin1_wgrad_workspace_bytes(C.byref(vdy), C.byref(d))
+    ws = _ws(need, x.device)
+    call("dct_conv_cin1_wgrad", C.byref(vx), C.byref(vdy), ptr(dw), ptr(db), C.byref(d), int(accumulate), _dt(dy),
+         ptr(ws), ws.numel(), stream())
+
+
+def head_fwd(x, w, bias, y):
+    vx, vy = view(x), view(y)
+    call("dct_conv1x1_head_fwd", C.byref(vx), ptr(w), ptr(bias), C.byref(vy), _dt(x), stream())
+    return y
+
+
+def head_bwd(x, dy, w, dx, dw, db, relu_mask=True, accumulate=False):
+    vx, vdy = view(x), view(dy)
+    vdx = view(dx) if dx is not None else None
+    need = _lib.load().dct_conv1x1_head_bwd_workspace_bytes(C.byref(vx), dy.shape[3])
+    ws = _ws(need, x.device)
+    call("dct_conv1x1_head_bwd", C.byref(vx), C.byref(vdy), ptr(w), C.byref(vdx) if vdx is not None else None,
+         ptr(dw), ptr(db), int(relu_mask), int(accumulate), _dt(x), ptr(ws), ws.numel(), stream())
+
+
+# ------------------------------------------------------------------------------ pointwise
+def maxpool_fwd(x, y):
+    vx, vy = view(x), view(y)
+    call("dct_maxpool2x2_fwd", C.byref(vx), C.byref(vy), _dt(x), stream())
+    return y
+
+
+def maxpool_bwd(x, dy, dx, relu_mask=False, scale=1.0):
+    vx, vdy, vdx = view(x), view(dy), view(dx)
+    call("dct_maxpool2x2_bwd", C.byref(vx), C.byref(vdy), C.byref(vdx), int(relu_mask), float(scale), _dt(x), stream())
+    return dx
+
+
+def bilinear_fwd(x, y):
+    vx, vy = view(x), view(y)
+    call("dct_bilinear_fwd", C.byref(vx), C.byref(vy), _dt(x), _dt(y), stream())
+    return y
+
+
+def bilinear_bwd(dy, dx, accumulate=False):
+    vdy, vdx = view(dy), view(dx)
+    call("dct_bilinear_bwd", C.byref(vdy), C.byref(vdx), _dt(dy), _dt(dx), int(accumulate), stream())
+    return dx
+
+
+def dropout_fwd(x, y, p, seed, offset, mask_out=None):
+    vx, vy = view(x), view(y)
+    call("dct_dropout_fwd", C.byref(vx), C.byref(vy), ptr(mask_out), float(p), int(seed), int(offset), _dt(x), stream())
+    return y
+
+
+def dropout_apply(x, y, mask_u8, p):
+    vx, vy = view(x), view(y)
+    call("dct_dropout_apply", C.byref(vx), C.byref(vy), ptr(mask_u8), float(p), _dt(x), stream())
+    return y
+
+
+def relu_bwd(g, a, y, scale=1.0):
+    vg, va, vy = view(g), view(a), view(y)
+    call("dct_relu_bwd", C.byref(vg), C.byref(va), C.byref(vy), float(scale), _dt(g), stream())
+    return y
+
+
+def cast(x, y):
+    vx, vy = view(x), view(y)
+    call("dct_cast", C.byref(vx), C.byref(vy), _dt(x), _dt(y), stream())
+    return y
+
+
+# ------------------------------------------------------------------------------ losses etc.
+def _loss_ws(device):
+    return torch.empty(_lib.load().dct_loss_workspace_bytes(0), dtype=torch.uint8, device=device)
+
+
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    arr = (C.c_void_p * len(ts))(*[ptr(t) for t in ts])
+    return arr
+
+
+def ce_fwd(logits_pc, targets, C_, ignore_index=255):
+    """logits_pc: fp32 [P, C] dense; targets int64 [P].  Returns device tensor [2] = (mean loss, count)."""
+    out = torch.empty(2, dtype=torch.float32, device=logits_pc.device)
+    ws = _loss_ws(logits_pc.device)
+    call("dct_ce_fwd", ptr(logits_pc), ptr(targets), logits_pc.numel() // C_, C_, int(ignore_index), ptr(out),
+         ptr(ws), ws.numel(), stream())
+    return out
+
+
+def ce_bwd(logits_pc, targets, C_, count, dlogits, gscale=None, gmul=1.0, ignore_index=255, accumulate=False):
+    call("dct_ce_bwd", ptr(logits_pc), ptr(targets), logits_pc.numel() // C_, C_, int(ignore_index), ptr(count),
+         ptr(gscale), float(gmul), ptr(dlogits), int(accumulate), stream())
+    return dlogits
+
+
+def softmax_fwd(logits_pc, C_):
+    probs = torch.empty_like(logits_pc)
+    call("dct_softmax_fwd", ptr(logits_pc), ptr(probs), logits_pc.numel() // C_, C_, stream())
+    return probs
+
+
+def softmax_bwd(probs, dprobs, C_, dlogits=None, accumulate=False):
+    if dlogits is None:
+        dlogits = torch.empty_like(probs)
+    call("dct_softmax_bwd", ptr(probs), ptr(dprobs), ptr(dlogits), probs.numel() // C_, C_, int(accumulate), stream())
+    return dlogits
+
+
+def entropy_fwd(probs, C_):
+    out = torch.empty(probs.numel() // C_, dtype=torch.float32, device=probs.device)
+    call("dct_entropy_fwd", ptr(probs), ptr(out), probs.numel() // C_, C_, stream())
+    return out
+
+
+def jsd_map_fwd(probs: List[torch.Tensor], C_):
+    P = probs[0].numel() // C_
+    out = torch.empty(P, dtype=torch.float32, device=probs[0].device)
+    call("dct_jsd_map_fwd", _ptr_array(probs), len(probs), ptr(out), P, C_, stream())
+    return out
+
+
+def jsd_map_bwd(probs: List[torch.Tensor], dmap, C_):
+    outs = [torch.empty_like(p) for p in probs]
+    call("dct_jsd_map_bwd", _ptr_array(probs), len(probs), ptr(dmap), _ptr_array(outs), probs[0].numel() // C_, C_, stream())
+    return outs
+
+
+def kl_map_fwd(p, y, C_, eps=1e-10):
+    out = torch.empty(p.numel() // C_, dtype=torch.float32, device=p.device)
+    call("dct_kl_map_fwd", ptr(p), ptr(y), ptr(out), p.numel() // C_, C_, float(eps), stream())
+    return out
+
+
+def kl_map_bwd(p, y, dmap, C_, eps=1e-10):
+    dp = torch.empty_like(p)
+    call("dct_kl_map_bwd", ptr(p), ptr(y), ptr(dmap), ptr(dp), p.numel() // C_, C_, float(eps), stream())
+    return dp
+
+
+def jsd_logits_fwd(logits: List[torch.Tensor], C_):
+    out = torch.empty(1, dtype=torch.float32, device=logits[0].device)
+    ws = _loss_ws(out.device)
+    call("dct_jsd_logits_fwd", _ptr_array(logits), len(logits), logits[0].numel() // C_, C_, ptr(out), ptr(ws), ws.numel(), stream())
+    return out
+
+
+def jsd_logits_bwd(logits: List[torch.Tensor], C_, dlogits: List[torch.Tensor], gscale=None, gmul=1.0, accumulate=False):
+    call("dct_jsd_logits_bwd", _ptr_array(logits), len(logits), logits[0].numel() // C_, C_, ptr(gscale), float(gmul),
+         _ptr_array(dlogits), int(accumulate), stream())
+    return dlogits
+
+
+def kl_logits_fwd(p_logits, y_logits, C_, eps=1e-10):
+    out = torch.empty(1, dtype=torch.float32, device=p_logits.device)
+    ws = _loss_ws(out.device)
+    call("dct_kl_logits_fwd", ptr(p_logits), ptr(y_logits), p_logits.numel() // C_, C_, float(eps), ptr(out), ptr(ws), ws.numel(), stream())
+    return out
+
+
+def kl_logits_bwd(p_logits, y_logits, C_, dp, gscale=None, gmul=1.0, eps=1e-10, accumulate=False):
+    call("dct_kl_logits_bwd", ptr(p_logits), ptr(y_logits), p_logits.numel() // C_, C_, float(eps), ptr(gscale), float(gmul),
+         ptr(dp), int(accumulate), stream())
+    return dp
+
+
+def argmax(x_pc, C_):
+    out = torch.empty(x_pc.numel() // C_, dtype=torch.int64, device=x_pc.device)
+    call("dct_argmax", ptr(x_pc), ptr(out), x_pc.numel() // C_, C_, stream())
+    return out
+
+
+def fgsm_step(x, g, eps, want_noise=True):
+    xa = torch.empty_like(x)
+    noise = torch.empty_like(x) if want_noise else None
+    call("dct_fgsm_step", ptr(x), ptr(g), float(eps), ptr(xa), ptr(noise), x.numel(), stream())
+    return xa, noise
+
+
+def adam_flat(p, g, m, v, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, bf16_shadow=None):
+    call("dct_adam_flat", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(step_size), float(bc2_sqrt), float(beta1),
+         float(beta2), float(eps), float(weight_decay), ptr(bf16_shadow), stream())
+
+
+def dice_counts(logits_bpc, gt_bp, B, C_):
+    """logits [B, pix, C] fp32 dense, gt [B, pix] int64 -> (inter, psum, gsum) int32 [B, C]."""
+    dev = logits_bpc.device
+    cnt = torch.zeros(3, B, C_, dtype=torch.int32, device=dev)
+    ppi = logits_bpc.numel() // (B * C_)
+    call("dct_dice_counts", ptr(logits_bpc), ptr(gt_bp), B, ppi, C_, ptr(cnt[0]), ptr(cnt[1]), ptr(cnt[2]), stream())
+    return cnt[0], cnt[1], cnt[2]

@@ -1,0 +1,221 @@
+/* dct.h -- C ABI of the MI355X-native co-training step library (libdct_hip.so).
+ *
+ * Drop-in boundary: the reference has no FFI; its hot path is Python calling
+ * third-party ATen ops.  This header declares one entry point per ATen op family the step
+ * invokes; each comment cites the reference call site it replaces.
+ * The Python host (package `dct_amd`) binds these with ctypes and puts them under the
+ * reference's own object API (CoTrainer / Segmentator / loss modules / FSGMGenerator).
+ *
+ * Conventions
+ *   - device pointers only; the library never allocates or frees device memory; workspaces are
+ *     caller-provided (size from the matching *_workspace_bytes);
+ *   - tensors are NHWC *views*: channel stride 1, element strides for n/h/w (so channel slices
+ *     of a concat buffer and interior windows of padded buffers are plain views);
+ *   - every launch goes to the hipStream_t passed in (void* here: no HIP headers needed);
+ *   - return 0 on success, negative dct_status on failure; no exceptions cross the ABI;
+ *   - no global mutable state: re-entrant from any thread.
+ */
+#ifndef DCT_H_
+#define DCT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum dct_status {
+  DCT_OK = 0,
+  DCT_ERR_BAD_ARG = -1,      /* null pointer, negative size, inconsistent shapes */
+  DCT_ERR_UNSUPPORTED = -2,  /* shape/dtype outside what the kernels are built for */
+  DCT_ERR_LAUNCH = -3,       /* hipGetLastError() != hipSuccess after a launch */
+  DCT_ERR_WORKSPACE = -4     /* workspace too small */
+} dct_status;
+
+typedef enum dct_dtype { DCT_F32 = 0, DCT_BF16 = 1 } dct_dtype;
+
+/* NHWC strided view; strides in ELEMENTS of the view's dtype; channel stride is 1. */
+typedef struct dct_view {
+  void* ptr;
+  int32_t n, h, w, c;
+  int64_t sn, sh, sw;
+} dct_view;
+
+typedef void* dct_stream; /* hipStream_t */
+
+int dct_version(void);
+const char* dct_status_string(int status);
+
+/* ---- K1/K2/K3: convolutions as implicit GEMM on MFMA -----------------------------------
+ * Replaces F.conv2d / F.conv_transpose2d behind nn.Conv2d / nn.ConvTranspose2d
+ * (arch/network.py:120-223, arch/enet.py:21-122) and their autograd backward.
+ *
+ * y[n,oy,ox,co] = epi( sum_{r,s,ci} x[n, oy*stride + r*dil - pad_h, ox*stride + s*dil - pad_w, ci]
+ *                                   * w[co][r][s][ci] )
+ * w is K-major packed: [Cout][R][S][Cin] in `dtype`.  Out-of-range taps read zero.
+ * epi: +bias[co] (fp32, nullable) -> relu (flag) -> * (mask[n,oy,ox,co] > 0 ? mask_scale : 0) for
+ *      co < mask_channels (mask nullable; ReLU / dropout backward fused) -> (+= old y if accumulate).
+ * scatter2x2 != 0: the N dimension is (a,b,co) = 4*Cout and element (pixel, (a,b,co)) is stored at
+ *      y[n, 2*oy+a, 2*ox+b, co]  (ConvTranspose2d k=2 s=2 forward, network.py:126,169).
+ * With dgrad-packed weights ([Cin][flipped taps][Cout]) and pad = k-1 the same entry computes
+ * the input gradient of a stride-1 conv; with R=S=2, stride 2 it computes ConvTranspose2d's.
+ * Cin must be a multiple of 32 (bf16) / 16 (f32); Cout (or 4*Cout) a multiple of 64.
+ */
+typedef struct dct_conv_desc {
+  int32_t R, S, stride, dil, pad_h, pad_w;
+  int32_t relu;
+  int32_t scatter2x2;
+  int32_t accumulate;
+  int32_t mask_channels;
+  float mask_scale;
+} dct_conv_desc;
+
+size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype);
+int dct_conv2d(const dct_view* x, const void* w_packed, const float* bias, const dct_view* mask,
+               const dct_view* y, const dct_conv_desc* d, int dtype,
+               void* workspace, size_t workspace_bytes, dct_stream stream);
+
+/* Weight gradient: dw[p][r][s][q] (+)= sum_m P[m][p] * Q[pixel(m)*stride + (r,s)*dil - pad][q]
+ * (fp32 output, K-major like the packed weights).  Conv2d: P = dy, Q = x.  ConvTranspose2d k2 s2:
+ * P = x, Q = dy, R=S=2, stride 2.   Replaces the weight half of conv backward (autograd of
+ * cotraining_totalloss.py:247). */
+size_t dct_conv2d_wgrad_workspace_bytes(const dct_view* p, const dct_view* q, const dct_conv_desc* d, int dtype);
+int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw, const dct_conv_desc* d, int dtype,
+                     void* workspace, size_t workspace_bytes, dct_stream stream);
+
+/* db[c] (+)= sum over pixels of dy[.., c]  (bias half of conv backward). */
+int dct_bias_grad(const dct_view* dy, float* db, int accumulate, int dtype,
+                  void* workspace, size_t workspace_bytes, dct_stream stream);
+size_t dct_bias_grad_workspace_bytes(const dct_view* dy);
+
+/* Repack fp32 master weights [P][T][Q] (T taps) into dst[Q][T'][P] (tap order reversed when
+ * flip_taps) or, when transpose == 0, a straight cast copy; dst dtype = `dtype`. */
+int dct_pack_weight(const float* src, void* dst, int P, int T, int Q, int transpose, int flip_taps,
+                    int dtype, dct_stream stream);
+
+/* First layer, Cin = 1 (network.py:159 dec1 conv; enet.py:21 initial conv): direct conv.
+ * x is fp32 [N,H,W,1]; w fp32 [Cout][R][S]; y in `dtype`. */
+int dct_conv_cin1_fwd(const dct_view* x, const float* w, const float* bias, const dct_view* y,
+                      const dct_conv_desc* d, int dtype, dct_stream stream);
+/* dx (fp32) = full correlation of dy with w  (the d/dx FGSM needs: AEGenerator.py:27-28). */
+int dct_conv_cin1_dgrad(const dct_view* dy, const float* w, const dct_view* dx,
+                        const dct_conv_desc* d, int dtype, dct_stream stream);
+size_t dct_conv_cin1_wgrad_workspace_bytes(const dct_view* dy, const dct_conv_desc* d);
+int dct_conv_cin1_wgrad(const dct_view* x, const dct_view* dy, float* dw, float* db,
+                        const dct_conv_desc* d, int accumulate, int dtype,
+                        void* workspace, size_t workspace_bytes, dct_stream stream);
+
+/* Classifier head: 1x1 conv to a few classes (network.py:223 `final`), Cout <= 8.
+ * x in `dtype` [.., Cin]; w fp32 [Cout][Cin]; y fp32 [.., Cout]. */
+int dct_conv1x1_head_fwd(const dct_view* x, const float* w, const float* bias, const dct_view* y,
+                         int dtype, dct_stream stream);
+size_t dct_conv1x1_head_bwd_workspace_bytes(const dct_view* x, int cout);
+/* dx (dtype, optional) = dy*W masked by (x>0) when relu_mask; dw,db (fp32, optional) (+)=. */
+int dct_conv1x1_head_bwd(const dct_view* x, const dct_view* dy, const float* w, const dct_view* dx,
+                         float* dw, float* db, int relu_mask, int accumulate, int dtype,
+                         void* workspace, size_t workspace_bytes, dct_stream stream);
+
+/* ---- K4: max pooling 2x2 stride 2 (ceil mode) ------------------------------------------
+ * Replaces nn.MaxPool2d(2, stride=2, ceil_mode=True) (network.py:166).  y.h = ceil(x.h/2).
+ * bwd: dx = dy routed to the first max in scan order, then * (x > 0 ? scale : 0) when relu_mask
+ * (fuses the ReLU / dropout backward that precedes the pool). */
+int dct_maxpool2x2_fwd(const dct_view* x, const dct_view* y, int dtype, dct_stream stream);
+int dct_maxpool2x2_bwd(const dct_view* x, const dct_view* dy, const dct_view* dx, int relu_mask,
+                       float scale, int dtype, dct_stream stream);
+
+/* ---- K5: bilinear resize, align_corners=True -------------------------------------------
+ * Replaces F.upsample_bilinear (network.py:232-240).  Any in/out size.  y may be a channel
+ * slice of a concat buffer.  in/out dtypes given separately (the final resize reads/writes f32).
+ * bwd is a gather (deterministic): dx[src] (+)= sum of dy[dst]*weight. */
+int dct_bilinear_fwd(const dct_view* x, const dct_view* y, int dtype_in, int dtype_out, dct_stream stream);
+int dct_bilinear_bwd(const dct_view* dy, const dct_view* dx, int dtype_dy, int dtype_dx, int accumulate,
+                     dct_stream stream);
+
+/* ---- K9: dropout ------------------------------------------------------------------------
+ * Replaces nn.Dropout(.5) (network.py:165,210).  Philox4x32-10 keyed by (seed, offset + element
+ * index); y = keep ? x/(1-p) : 0.  mask_out (uint8, nullable, dense NHWC) receives the keep mask. */
+int dct_dropout_fwd(const dct_view* x, const dct_view* y, uint8_t* mask_out, float p,
+                    uint64_t seed, uint64_t offset, int dtype, dct_stream stream);
+/* y = x * (mask_u8 ? 1/(1-p) : 0) with a caller-supplied dense mask (parity replay). */
+int dct_dropout_apply(const dct_view* x, const dct_view* y, const uint8_t* mask, float p, int dtype,
+                      dct_stream stream);
+
+/* ---- K7: elementwise -------------------------------------------------------------------- */
+/* y = g * (a > 0 ? scale : 0)   (ReLU backward where it cannot be fused). */
+int dct_relu_bwd(const dct_view* g, const dct_view* a, const dct_view* y, float scale, int dtype,
+                 dct_stream stream);
+int dct_cast(const dct_view* x, const dct_view* y, int dtype_in, int dtype_out, dct_stream stream);
+
+/* ---- K10: pixel-wise losses on fp32 NHWC logits [P pixels][C], 2 <= C <= 8 ----------------
+ * CE     : loss/loss.py:12-25   (log_softmax + NLL, mean over targets != ignore_index)
+ * softmax: models/segmentators.py:50
+ * JSD    : loss/loss.py:183-196 + :70-84 ; fused from logits of S <= 4 models; *mean* over pixels
+ * KL     : loss/loss.py:110-134 ; KL(y || p), y detached, mean over pixels
+ * All reductions are two-stage and deterministic.  Scalars are written to device memory;
+ * nothing synchronises with the host.
+ */
+size_t dct_loss_workspace_bytes(int64_t pixels);
+/* out[0] = mean CE, out[1] = number of counted pixels.  targets int64. */
+int dct_ce_fwd(const float* logits, const int64_t* targets, int64_t pixels, int C, int ignore_index,
+               float* out2, void* workspace, size_t workspace_bytes, dct_stream stream);
+/* dlogits (=|+=) gscale[0] * gmul * (softmax - onehot) / count ; gscale is a device scalar (nullable=1) */
+int dct_ce_bwd(const float* logits, const int64_t* targets, int64_t pixels, int C, int ignore_index,
+               const float* count, const float* gscale, float gmul, float* dlogits, int accumulate,
+               dct_stream stream);
+int dct_softmax_fwd(const float* logits, float* probs, int64_t pixels, int C, dct_stream stream);
+/* dlogits (=|+=) p * (dprobs - sum_c dprobs*p) */
+int dct_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, int64_t pixels, int C,
+                    int accumulate, dct_stream stream);
+/* map[pix] = -sum_c p*log(p+1e-16) */
+int dct_entropy_fwd(const float* probs, float* map, int64_t pixels, int C, dct_stream stream);
+/* probs-in variants keep the reference module API (JSD_2D()(list_of_probs) -> [B,H,W] map). */
+int dct_jsd_map_fwd(const float* const* probs, int S, float* map, int64_t pixels, int C, dct_stream stream);
+int dct_jsd_map_bwd(const float* const* probs, int S, const float* dmap, float* const* dprobs,
+                    int64_t pixels, int C, dct_stream stream);
+int dct_kl_map_fwd(const float* p, const float* y, float* map, int64_t pixels, int C, float eps,
+                   dct_stream stream);
+int dct_kl_map_bwd(const float* p, const float* y, const float* dmap, float* dp, int64_t pixels,
+                   int C, float eps, dct_stream stream);
+/* fused-from-logits fast path used by the step: out[0] = mean JSD over pixels */
+int dct_jsd_logits_fwd(const float* const* logits, int S, int64_t pixels, int C, float* out1,
+                       void* workspace, size_t workspace_bytes, dct_stream stream);
+int dct_jsd_logits_bwd(const float* const* logits, int S, int64_t pixels, int C, const float* gscale,
+                       float gmul, float* const* dlogits, int accumulate, dct_stream stream);
+/* out[0] = mean_pix sum_c y*(log(y+eps)-log(p+eps)), p = softmax(p_logits), y = softmax(y_logits) */
+int dct_kl_logits_fwd(const float* p_logits, const float* y_logits, int64_t pixels, int C, float eps,
+                      float* out1, void* workspace, size_t workspace_bytes, dct_stream stream);
+int dct_kl_logits_bwd(const float* p_logits, const float* y_logits, int64_t pixels, int C, float eps,
+                      const float* gscale, float gmul, float* dp_logits, int accumulate, dct_stream stream);
+/* cls[pix] = argmax_c x[pix][c] (first max), int64  (AEGenerator.py:25 pseudo-labels; Dice one-hot) */
+int dct_argmax(const float* x, int64_t* cls, int64_t pixels, int C, dct_stream stream);
+
+/* ---- K11: FGSM tail  x_adv = x + eps*sign(g), noise = eps*sign(g) (AEGenerator.py:35-51) ---- */
+int dct_fgsm_step(const float* x, const float* g, float eps, float* x_adv, float* noise, int64_t n,
+                  dct_stream stream);
+
+/* ---- K12: Adam over one flat fp32 buffer (torch.optim.Adam, segmentators.py:41; step :248) --
+ * g' = g + wd*p; m = m + (g'-m)*(1-b1); v = v*b2 + (1-b2)*g'^2;
+ * p -= step_size * m / (sqrt(v)/bc2_sqrt + eps)     (host passes step_size = lr/bc1, bc2_sqrt)
+ * bf16_shadow (nullable): also writes the updated p rounded to bf16 at the same index. */
+int dct_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float step_size,
+                  float bc2_sqrt, float beta1, float beta2, float eps, float weight_decay,
+                  void* bf16_shadow, dct_stream stream);
+
+/* ---- Dice accumulation on device (metrics/dice_meter.py:12-83) ----------------------------
+ * inter[b][c], psum[b][c], gsum[b][c] (int32, zeroed by caller) from logits argmax vs gt. */
+int dct_dice_counts(const float* logits, const int64_t* gt, int B, int64_t pixels_per_image, int C,
+                    int32_t* inter, int32_t* psum, int32_t* gsum, dct_stream stream);
+
+/* ---- per-kernel-class timing (bench.py roofline leg) --------------------------------------
+ * When enabled every launch made through this library is bracketed by hipEvents on its stream;
+ * dct_prof_read synchronises and returns accumulated milliseconds and launch counts per class. */
+enum { DCT_PROF_IGEMM = 0, DCT_PROF_WGRAD = 1, DCT_PROF_POINTWISE = 2, DCT_PROF_LOSS = 3,
+       DCT_PROF_ADAM = 4, DCT_PROF_OTHER = 5, DCT_PROF_NCLASS = 6 };
+int dct_prof_enable(int on);
+int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCT_H_ */

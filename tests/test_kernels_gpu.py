@@ -1,0 +1,449 @@
+"""Per-kernel parity: every C-ABI entry point (through dct_amd.hip_ops) against a plain
+PyTorch fp32 CPU computation of the same op, and against the oracle for the losses.
+fp32 mode is the parity path (tight tolerance); bf16 mode is compared against the same
+math on bf16-rounded inputs (tolerance = bf16 output rounding + accumulation order)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+
+DTYPES = [torch.float32, torch.bfloat16]
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from dct_amd import hip_ops
+    return hip_ops
+
+
+def q(t, dtype):
+    """round to the kernel's storage dtype, back to fp32 (the reference sees what the kernel sees)"""
+    return t.to(dtype).float()
+
+
+def to_dev(t_nchw, dtype):
+    return t_nchw.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def to_cpu(t_nhwc):
+    return t_nhwc.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, ref, dtype, what, rtol32=2e-4, rtol16=2e-2):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    scale = ref.abs().max().item() + 1e-30
+    rtol = rtol32 if dtype == torch.float32 else rtol16
+    err = (got - ref).abs()
+    tol = rtol * scale + rtol * ref.abs()
+    bad = err > tol
+    if bad.any() or not torch.isfinite(got).all():
+        idx = np.unravel_index(int(err.argmax()), err.shape)
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} off; max err {err.max().item():.3e} at {idx} "
+                             f"(got {got[idx].item():.6f} ref {ref[idx].item():.6f}); ref scale {scale:.3e}; "
+                             f"finite={bool(torch.isfinite(got).all())}")
+
+
+def kmajor(w_oihw, dtype):
+    return w_oihw.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+# ------------------------------------------------------------------------------------ conv2d
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,pad,stride,dil", [
+    (2, 64, 20, 18, 128, 3, 0, 1, 1),     # valid 3x3, BN=128
+    (2, 64, 20, 18, 64, 3, 0, 1, 1),      # BN=64 variant
+    (1, 128, 13, 11, 64, 3, 2, 1, 1),     # full (dgrad-form) padding
+    (1, 512, 8, 8, 256, 3, 0, 1, 1),      # tiny M, long K -> split-K path
+    (2, 64, 16, 16, 64, 1, 0, 1, 1),      # 1x1
+    (2, 128, 20, 18, 64, 2, 0, 2, 1),     # 2x2 stride 2 (convT dgrad form)
+    (1, 64, 24, 24, 64, 3, 2, 1, 2),      # dilated
+    (3, 64, 131, 7, 128, 3, 1, 1, 1),     # M not a tile multiple, pad 1
+])
+def test_conv2d_fwd(ops, dtype, B, Cin, H, W, Cout, k, pad, stride, dil):
+    g = torch.Generator().manual_seed(1)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = q(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dil))
+    y = torch.empty(B, ref.shape[2], ref.shape[3], Cout, dtype=dtype, device=DEV)
+    ops.conv2d(to_dev(x, dtype), kmajor(w, dtype), b.to(DEV), y, R=k, S=k, stride=stride, dil=dil, pad_h=pad, pad_w=pad, relu=True)
+    close(to_cpu(y), ref, dtype, "conv2d fwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_epilogue_mask_accumulate_views(ops, dtype):
+    g = torch.Generator().manual_seed(2)
+    B, Cin, H, W, Cout = 2, 64, 12, 10, 128
+    xbig = q(torch.randn(B, Cin + 64, H, W, generator=g), dtype)       # x is a channel slice of a wider buffer
+    x = xbig[:, 64:]
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / 24, dtype)
+    maskt = q(torch.randn(B, Cout, H - 2, W - 2, generator=g), dtype)
+    old = q(torch.randn(B, Cout + 64, H - 2, W - 2, generator=g), dtype)  # y is a channel slice too
+    conv = F.conv2d(x, w)
+    masked = conv.clone()
+    masked[:, :64] = torch.where(maskt[:, :64] > 0, conv[:, :64] * 2.0, torch.zeros(()))
+    ref = old.clone()
+    ref[:, :Cout] += masked
+    xd = to_dev(xbig, dtype)
+    yd = to_dev(old, dtype)
+    ops.conv2d(xd[..., 64:], kmajor(w, dtype), None, yd[..., :Cout], mask=to_dev(maskt, dtype), mask_channels=64,
+               mask_scale=2.0, accumulate=True)
+    close(to_cpu(yd), ref, dtype, "conv2d mask/accumulate/views")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 128, 10, 9, 64), (1, 1024, 9, 9, 512)])
+def test_convT2x2_fwd_scatter(ops, dtype, B, Cin, H, W, Cout):
+    g = torch.Generator().manual_seed(3)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = q(torch.randn(Cin, Cout, 2, 2, generator=g) / math.sqrt(Cin), dtype)   # torch ConvTranspose2d layout
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv_transpose2d(x, w, b, stride=2))
+    wp = w.permute(2, 3, 1, 0).reshape(4 * Cout, Cin).contiguous().to(dtype).to(DEV)    # [(a,b,co)][ci]
+    y = torch.empty(B, 2 * H, 2 * W, Cout, dtype=dtype, device=DEV)
+    ops.conv2d(to_dev(x, dtype), wp, b.to(DEV), y, R=1, S=1, relu=True, scatter2x2=True)
+    close(to_cpu(y), ref, dtype, "convT scatter fwd")
+
+
+# ------------------------------------------------------------------------------------ wgrad
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [
+    (2, 64, 20, 18, 128, 0), (2, 64, 20, 18, 64, 0), (1, 128, 14, 14, 128, 0),
+    (2, 128, 60, 60, 64, 0),      # many pixel chunks
+    (1, 64, 12, 12, 64, 1),       # padded conv
+])
+def test_conv2d_wgrad(ops, dtype, B, Cin, H, W, Cout, pad):
+    g = torch.Generator().manual_seed(4)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype).requires_grad_(False)
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    y = F.conv2d(x, w, padding=pad)
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    (ref,) = torch.autograd.grad(y, w, dy)
+    old = torch.randn(Cout, 3, 3, Cin, generator=g)
+    dw = old.clone().to(DEV)
+    ops.conv2d_wgrad(to_dev(dy, dtype), to_dev(x, dtype), dw, pad_h=pad, pad_w=pad, accumulate=True)
+    close(dw.cpu() - old, ref.permute(0, 2, 3, 1), dtype, "wgrad accumulate", rtol32=3e-4)
+    dw2 = torch.full_like(dw, float("nan"))
+    ops.conv2d_wgrad(to_dev(dy, dtype), to_dev(x, dtype), dw2, pad_h=pad, pad_w=pad, accumulate=False)
+    close(dw2.cpu(), ref.permute(0, 2, 3, 1), dtype, "wgrad overwrite", rtol32=3e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_convT_wgrad_and_dgrad(ops, dtype):
+    g = torch.Generator().manual_seed(5)
+    B, Cin, H, W, Cout = 2, 128, 10, 9, 64
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype).requires_grad_(True)
+    w = q(torch.randn(Cin, Cout, 2, 2, generator=g) / 16, dtype).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, stride=2)
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    rx, rw = torch.autograd.grad(y, [x, w], dy)
+    # wgrad: P = x, Q = dy, taps 2x2 stride 2 -> [ci][a][b][co]
+    dw = torch.empty(Cin, 2, 2, Cout, device=DEV)
+    ops.conv2d_wgrad(to_dev(x.detach(), dtype), to_dev(dy, dtype), dw, R=2, S=2, stride=2)
+    close(dw.cpu(), rw.permute(0, 2, 3, 1), dtype, "convT wgrad", rtol32=3e-4)
+    # dgrad: 2x2 stride-2 conv of dy with weights [ci][a][b][co]
+    wd = w.detach().permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+    dx = torch.empty(B, H, W, Cin, dtype=dtype, device=DEV)
+    ops.conv2d(to_dev(dy, dtype), wd, None, dx, R=2, S=2, stride=2)
+    close(to_cpu(dx), rx, dtype, "convT dgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_dgrad_via_packed_weights(ops, dtype):
+    g = torch.Generator().manual_seed(6)
+    B, Cin, H, W, Cout = 2, 64, 14, 12, 128
+    x = torch.zeros(B, Cin, H, W, requires_grad=True)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / 24, dtype)
+    y = F.conv2d(x, w)
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    (ref,) = torch.autograd.grad(y, x, dy)
+    master = w.permute(0, 2, 3, 1).contiguous().to(DEV)                # fp32 [co][r][s][ci]
+    wd = torch.empty(Cin, 3, 3, Cout, dtype=dtype, device=DEV)
+    ops.pack_weight(master, wd, Cout, 9, Cin, transpose=True, flip_taps=True)
+    dx = torch.empty(B, H, W, Cin, dtype=dtype, device=DEV)
+    ops.conv2d(to_dev(dy, dtype), wd, None, dx, pad_h=2, pad_w=2)
+    close(to_cpu(dx), ref, dtype, "conv dgrad")
+    wf = torch.empty(Cout, 3, 3, Cin, dtype=dtype, device=DEV)
+    ops.pack_weight(master, wf, Cout, 9, Cin)
+    assert torch.equal(wf.float().cpu(), w.permute(0, 2, 3, 1).contiguous())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [64, 128, 512])
+def test_bias_grad(ops, dtype, C):
+    g = torch.Generator().manual_seed(7)
+    dy = q(torch.randn(3, C, 33, 17, generator=g), dtype)
+    old = torch.randn(C, generator=g)
+    db = old.clone().to(DEV)
+    ops.bias_grad(to_dev(dy, dtype), db, accumulate=True)
+    close(db.cpu(), old + dy.sum((0, 2, 3)), dtype, "bias grad", rtol16=2e-4)
+
+
+# ------------------------------------------------------------------------------------ stem / head
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stem_cin1(ops, dtype):
+    g = torch.Generator().manual_seed(8)
+    B, H, W, Cout = 2, 30, 26, 64
+    x = torch.rand(B, 1, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Cout, 1, 3, 3, generator=g) / 3).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    y = F.conv2d(x, w, b)
+    yr = F.relu(y)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    yd = torch.empty(B, H - 2, W - 2, Cout, dtype=dtype, device=DEV)
+    ops.conv_cin1_fwd(xd, w.detach().reshape(Cout, 9).contiguous().to(DEV), b.detach().to(DEV), yd, relu=True)
+    close(to_cpu(yd), yr, dtype, "stem fwd", rtol16=8e-3)
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    rx, rw, rb = torch.autograd.grad(y, [x, w, b], dy)
+    dx = torch.empty(B, H, W, 1, device=DEV)
+    ops.conv_cin1_dgrad(to_dev(dy, dtype), w.detach().reshape(Cout, 9).contiguous().to(DEV), dx, pad_h=0, pad_w=0)
+    close(to_cpu(dx), rx, torch.float32, "stem dgrad")
+    dw = torch.zeros(Cout, 9, device=DEV)
+    db = torch.zeros(Cout, device=DEV)
+    ops.conv_cin1_wgrad(xd, to_dev(dy, dtype), dw, db)
+    close(dw.cpu(), rw.reshape(Cout, 9), torch.float32, "stem wgrad")
+    close(db.cpu(), rb, torch.float32, "stem bgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [2, 4])
+def test_head(ops, dtype, C):
+    g = torch.Generator().manual_seed(9)
+    B, Cin, H, W = 2, 64, 21, 19
+    x = q(F.relu(torch.randn(B, Cin, H, W, generator=g)), dtype).requires_grad_(True)
+    w = (torch.randn(C, Cin, 1, 1, generator=g) / 8).requires_grad_(True)
+    b = torch.randn(C, generator=g).requires_grad_(True)
+    y = F.conv2d(x, w, b)
+    yd = torch.empty(B, H, W, C, device=DEV)
+    wd = w.detach().reshape(C, Cin).contiguous().to(DEV)
+    ops.head_fwd(to_dev(x.detach(), dtype), wd, b.detach().to(DEV), yd)
+    close(to_cpu(yd), y, torch.float32, "head fwd")
+    dy = torch.randn(y.shape, generator=g)
+    rx, rw, rb = torch.autograd.grad(y, [x, w, b], dy)
+    rx = rx * (x.detach() > 0)
+    dx = torch.empty(B, H, W, Cin, dtype=dtype, device=DEV)
+    dw = torch.zeros(C, Cin, device=DEV)
+    db = torch.zeros(C, device=DEV)
+    ops.head_bwd(to_dev(x.detach(), dtype), dy.permute(0, 2, 3, 1).contiguous().to(DEV), wd, dx, dw, db, relu_mask=True)
+    close(to_cpu(dx), rx, dtype, "head dx", rtol16=8e-3)
+    close(dw.cpu(), rw.reshape(C, Cin), torch.float32, "head dw")
+    close(db.cpu(), rb, torch.float32, "head db")
+
+
+# ------------------------------------------------------------------------------------ pool / bilinear / dropout
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,W", [(12, 10), (57, 25), (29, 29)])
+def test_maxpool(ops, dtype, H, W):
+    g = torch.Generator().manual_seed(10)
+    x = q(F.relu(torch.randn(2, 64, H, W, generator=g)), dtype).requires_grad_(True)
+    y = F.max_pool2d(x, 2, stride=2, ceil_mode=True)
+    yd = torch.empty(2, y.shape[2], y.shape[3], 64, dtype=dtype, device=DEV)
+    xd = to_dev(x.detach(), dtype)
+    ops.maxpool_fwd(xd, yd)
+    assert torch.equal(to_cpu(yd), y.detach()), "maxpool fwd must be exact"
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    (rx,) = torch.autograd.grad(y, x, dy)
+    dx = torch.empty_like(xd)
+    ops.maxpool_bwd(xd, to_dev(dy, dtype), dx, relu_mask=False)
+    # ties only happen at 0 after ReLU; compare where x > 0, and check the relu-masked variant everywhere
+    pos = x.detach() > 0
+    assert torch.equal(to_cpu(dx)[pos], rx[pos])
+    ops.maxpool_bwd(xd, to_dev(dy, dtype), dx, relu_mask=True, scale=2.0)
+    close(to_cpu(dx), rx * pos * 2.0, dtype, "maxpool bwd masked", rtol16=1e-6, rtol32=1e-7)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,hin,win,hout,wout", [(64, 126, 126, 88, 88), (128, 13, 13, 18, 18), (4, 84, 84, 256, 256), (2, 17, 23, 40, 31), (64, 29, 29, 28, 28)])
+def test_bilinear(ops, dtype, C, hin, win, hout, wout):
+    if C < 8 and dtype == torch.bfloat16:
+        pytest.skip("classifier-sized resize runs in fp32")
+    g = torch.Generator().manual_seed(11)
+    x = q(torch.randn(2, C, hin, win, generator=g), dtype).requires_grad_(True)
+    y = F.interpolate(x, size=(hout, wout), mode="bilinear", align_corners=True)
+    big = torch.zeros(2, hout, wout, C + 8, dtype=dtype, device=DEV)      # write into a channel slice (concat)
+    ops.bilinear_fwd(to_dev(x.detach(), dtype), big[..., 8:])
+    close(to_cpu(big[..., 8:]), y, dtype, "bilinear fwd", rtol32=1e-5, rtol16=8e-3)
+    assert float(big[..., :8].abs().sum()) == 0.0
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    (rx,) = torch.autograd.grad(y, x, dy)
+    dx = torch.empty(2, hin, win, C, dtype=dtype, device=DEV)
+    ops.bilinear_bwd(to_dev(dy, dtype), dx)
+    close(to_cpu(dx), rx, dtype, "bilinear bwd", rtol32=1e-5, rtol16=8e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout(ops, dtype):
+    x = q(torch.rand(2, 512, 25, 25) + 0.5, dtype)
+    xd = to_dev(x, dtype)
+    yd = torch.empty_like(xd)
+    mask = torch.empty(xd.shape, dtype=torch.uint8, device=DEV)
+    ops.dropout_fwd(xd, yd, 0.5, seed=1234, offset=0, mask_out=mask)
+    keep = mask.float().mean().item()
+    assert abs(keep - 0.5) < 0.01, keep
+    ref = xd.float() * mask.float() * 2.0
+    close(yd.float(), ref, dtype, "dropout apply", rtol16=8e-3)
+    y2 = torch.empty_like(xd)
+    ops.dropout_fwd(xd, y2, 0.5, seed=1234, offset=0)
+    assert torch.equal(y2, yd), "same (seed, offset) must reproduce the mask"
+    ops.dropout_fwd(xd, y2, 0.5, seed=1234, offset=xd.numel())
+    assert not torch.equal(y2, yd)
+    y3 = torch.empty_like(xd)
+    ops.dropout_apply(xd, y3, mask, 0.5)
+    assert torch.equal(y3, yd)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_relu_bwd_and_cast(ops, dtype):
+    g = torch.Generator().manual_seed(12)
+    a = q(torch.randn(2, 64, 9, 7, generator=g), dtype)
+    gr = q(torch.randn(2, 64, 9, 7, generator=g), dtype)
+    out = torch.empty(2, 9, 7, 64, dtype=dtype, device=DEV)
+    ops.relu_bwd(to_dev(gr, dtype), to_dev(a, dtype), out, scale=1.0)
+    assert torch.equal(to_cpu(out), gr * (a > 0))
+    src = torch.randn(2, 5, 6, 16, device=DEV)
+    dst = torch.empty(2, 5, 6, 16, dtype=torch.bfloat16, device=DEV)
+    ops.cast(src, dst)
+    assert torch.equal(dst, src.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------ losses
+def _pc(t_nchw):
+    return t_nchw.permute(0, 2, 3, 1).contiguous().reshape(-1, t_nchw.shape[1]).to(DEV)
+
+
+def _back(t_pc, like):
+    B, C, H, W = like.shape
+    return t_pc.cpu().reshape(B, H, W, C).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("C", [2, 4, 3])
+def test_ce(ops, C):
+    g = torch.Generator().manual_seed(13)
+    x = (torch.randn(3, C, 17, 19, generator=g) * 3).requires_grad_(True)
+    t = torch.randint(0, C, (3, 17, 19), generator=g)
+    t[0, :3] = 255
+    ref = oracle.cross_entropy_2d(x, t)
+    (rg,) = torch.autograd.grad(ref, x)
+    xd, td = _pc(x.detach()), t.reshape(-1).to(DEV)
+    out = ops.ce_fwd(xd, td, C)
+    np.testing.assert_allclose(out[0].item(), ref.item(), rtol=2e-6)
+    assert out[1].item() == (t != 255).sum().item()
+    gs = torch.tensor([0.5], device=DEV)
+    d = torch.empty_like(xd)
+    ops.ce_bwd(xd, td, C, out[1:2], d, gscale=gs, gmul=2.0)
+    np.testing.assert_allclose(_back(d, x).numpy(), rg.numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_losses_match_golden(ops, golden):
+    """the reference's own numbers (tests/golden/g1_losses.npz) through the HIP kernels"""
+    g1 = golden("g1_losses")
+    torch.manual_seed(int(g1["seed"]))
+    a, b, c = (torch.randn(2, 4, 8, 8) for _ in range(3))
+    t = torch.randint(0, 4, (2, 8, 8))
+    ad, bd, cd = _pc(a), _pc(b), _pc(c)
+    np.testing.assert_allclose(ops.ce_fwd(ad, t.reshape(-1).to(DEV), 4)[0].item(), g1["ce"], rtol=2e-6)
+    np.testing.assert_allclose(ops.jsd_logits_fwd([ad, bd], 4).item(), g1["jsd2_map"].mean(), rtol=1e-5)
+    np.testing.assert_allclose(ops.jsd_logits_fwd([ad, bd, cd], 4).item(), g1["jsd3_map"].mean(), rtol=1e-5)
+    np.testing.assert_allclose(ops.kl_logits_fwd(ad, bd, 4).item(), g1["kl"], rtol=1e-5)
+    pa, pb = ops.softmax_fwd(ad, 4), ops.softmax_fwd(bd, 4)
+    np.testing.assert_allclose(ops.jsd_map_fwd([pa, pb], 4).cpu().reshape(2, 8, 8).numpy(), g1["jsd2_map"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(ops.kl_map_fwd(pa, pb, 4).cpu().reshape(2, 8, 8).numpy(), g1["kl_map"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(ops.entropy_fwd(pa, 4).cpu().reshape(2, 8, 8).numpy(), g1["entropy_a"], rtol=1e-5, atol=1e-7)
+    da, db_ = torch.zeros_like(ad), torch.zeros_like(bd)
+    ops.jsd_logits_bwd([ad, bd], 4, [da, db_])
+    np.testing.assert_allclose(_back(da, a).numpy(), g1["jsd2_grad_a"], rtol=2e-4, atol=1e-9)
+    np.testing.assert_allclose(_back(db_, a).numpy(), g1["jsd2_grad_b"], rtol=2e-4, atol=1e-9)
+    dk = torch.zeros_like(ad)
+    ops.kl_logits_bwd(ad, bd, 4, dk)
+    np.testing.assert_allclose(_back(dk, a).numpy(), g1["kl_grad_a"], rtol=2e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("S,C", [(2, 4), (3, 2), (4, 4)])
+def test_jsd_kl_vs_oracle(ops, S, C):
+    g = torch.Generator().manual_seed(14)
+    ls = [(torch.randn(2, C, 33, 31, generator=g) * 2).requires_grad_(True) for _ in range(S)]
+    probs = [oracle.softmax_channels(l) for l in ls]
+    jm = oracle.jsd_2d(probs)
+    j = jm.mean()
+    gr = torch.autograd.grad(j, ls, retain_graph=True)
+    lds = [_pc(l.detach()) for l in ls]
+    np.testing.assert_allclose(ops.jsd_logits_fwd(lds, C).item(), j.item(), rtol=2e-5)
+    dls = [torch.randn_like(l) for l in lds]
+    olds = [d.clone() for d in dls]
+    gs = torch.tensor([0.25], device=DEV)
+    ops.jsd_logits_bwd(lds, C, dls, gscale=gs, gmul=4.0, accumulate=True)
+    for s in range(S):
+        np.testing.assert_allclose(_back(dls[s] - olds[s], ls[0]).numpy(), gr[s].numpy(), rtol=3e-4, atol=2e-9)
+    # module-API variants (probs in, maps out)
+    pds = [ops.softmax_fwd(l, C) for l in lds]
+    np.testing.assert_allclose(_back(pds[0], ls[0]).numpy(), probs[0].detach().numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(ops.jsd_map_fwd(pds, C).cpu().numpy(), jm.detach().reshape(-1).numpy(), rtol=2e-4, atol=2e-7)
+    dmap = torch.randn(jm.shape, generator=g)
+    gp = torch.autograd.grad(jm, probs, dmap, retain_graph=True)
+    dps = ops.jsd_map_bwd(pds, dmap.reshape(-1).to(DEV), C)
+    for s in range(S):
+        np.testing.assert_allclose(_back(dps[s], ls[0]).numpy(), gp[s].numpy(), rtol=3e-4, atol=1e-6)
+    # softmax backward
+    (gl,) = torch.autograd.grad(probs[0], ls[0], gp[0], retain_graph=True)
+    np.testing.assert_allclose(_back(ops.softmax_bwd(pds[0], dps[0], C), ls[0]).numpy(), gl.numpy(), rtol=3e-4, atol=1e-6)
+    # KL
+    k = oracle.kl_divergence_2d(probs[0], probs[1].detach(), reduce=True)
+    (gk,) = torch.autograd.grad(k, ls[0], retain_graph=True)
+    np.testing.assert_allclose(ops.kl_logits_fwd(lds[0], lds[1], C).item(), k.item(), rtol=2e-5)
+    dk = torch.zeros_like(lds[0])
+    ops.kl_logits_bwd(lds[0], lds[1], C, dk)
+    np.testing.assert_allclose(_back(dk, ls[0]).numpy(), gk.numpy(), rtol=3e-4, atol=2e-9)
+    km = oracle.kl_divergence_2d(probs[0], probs[1].detach())
+    (gkp,) = torch.autograd.grad(km, probs[0], dmap)
+    np.testing.assert_allclose(_back(ops.kl_map_bwd(pds[0], pds[1], dmap.reshape(-1).to(DEV), C), ls[0]).numpy(), gkp.numpy(), rtol=3e-4, atol=1e-6)
+
+
+def test_argmax_fgsm_dice(ops):
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(3, 4, 16, 16, generator=g)
+    assert torch.equal(ops.argmax(_pc(x), 4).cpu().reshape(3, 16, 16), x.argmax(1))
+    img = torch.rand(1000, generator=g)
+    gr = torch.randn(1000, generator=g)
+    gr[::7] = 0
+    xa, nz = ops.fgsm_step(img.to(DEV), gr.to(DEV), 0.03)
+    assert torch.equal(nz.cpu(), 0.03 * gr.sign())
+    assert torch.equal(xa.cpu(), img + 0.03 * gr.sign())
+    gt = torch.randint(0, 4, (3, 1, 16, 16), generator=g)
+    inter, ps, gsm = ops.dice_counts(_pc(x).reshape(3, 256, 4), gt.reshape(3, 256).to(DEV), 3, 4)
+    d2 = (2 * inter.float() + 1e-8) / ((ps + gsm).float() + 1e-8)
+    np.testing.assert_allclose(d2.cpu().numpy(), oracle.dice_2d(x, gt).numpy(), rtol=1e-6)
+    d3 = (2 * inter.sum(0).float() + 1e-8) / ((ps.sum(0) + gsm.sum(0)).float() + 1e-8)
+    np.testing.assert_allclose(d3.cpu().numpy(), oracle.dice_3d(x, gt).numpy(), rtol=1e-6)
+
+
+def test_adam_flat(ops):
+    g = torch.Generator().manual_seed(16)
+    n = 100003
+    p = torch.randn(n, generator=g)
+    m = torch.zeros(n)
+    v = torch.zeros(n)
+    pd, md, vd = (t.clone().to(DEV) for t in (p, m, v))
+    shadow = torch.empty(n + 5, dtype=torch.bfloat16, device=DEV)[:n]
+    pt = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([pt], lr=1e-3, weight_decay=1e-4)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * 0.1
+        oracle.adam_reference_step(p, gr, m, v, step)
+        pt.grad = gr.clone()
+        opt.step()
+        bc1, bc2 = 1 - 0.9 ** step, 1 - 0.999 ** step
+        ops.adam_flat(pd, gr.to(DEV), md, vd, 1e-3 / bc1, math.sqrt(bc2), 0.9, 0.999, 1e-8, 1e-4, bf16_shadow=shadow)
+    np.testing.assert_allclose(p.numpy(), pt.detach().numpy(), rtol=1e-6, atol=1e-8)   # oracle adam == torch.optim.Adam
+    np.testing.assert_allclose(pd.cpu().numpy(), p.numpy(), rtol=2e-6, atol=2e-8)
+    np.testing.assert_allclose(md.cpu().numpy(), m.numpy(), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(vd.cpu().numpy(), v.numpy(), rtol=2e-6, atol=1e-12)
+    assert torch.equal(shadow.cpu(), pd.cpu().to(torch.bfloat16))
