@@ -1,0 +1,394 @@
+"""UNet of the reference (arch/network.py:115-130,153-171,196-240) as one HIP execution plan.
+
+Same parameters, same ``state_dict`` keys and logical shapes as the reference module, but
+the forward/backward are not a graph of ATen ops: ``forward`` runs a fixed sequence of
+hand-written gfx950 kernels over NHWC activations (include/dct.h), and a single
+``torch.autograd.Function`` node replays the matching backward sequence.
+
+Data layout in HBM
+  activations : NHWC, bf16 (default) or fp32 (parity mode); skip-concats are channel slices of
+                one buffer (the producer writes its slice, nothing is copied);
+  weights     : fp32 masters in one flat buffer, physically K-major ``[Cout][kh][kw][Cin]``
+                (``[Cin][a][b][Cout]`` for ConvTranspose2d) exposed as strided views with the
+                reference's logical shapes; per-step packs in the compute dtype for the forward
+                and the data-gradient GEMMs;
+  gradients   : weight/bias gradients are accumulated straight into the flat fp32 gradient
+                buffer that ``p.grad`` views alias (see arch/flat.py).
+
+No CPU path: inputs must be on the HIP device.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import hip_ops as K
+from .flat import FlatParams
+
+_WIDTHS = (64, 128, 256, 512)
+
+
+class _Slots(nn.Module):
+    def __init__(self, layers: Dict[int, nn.Module]):
+        super().__init__()
+        for idx, layer in layers.items():
+            self.add_module(str(idx), layer)
+
+    def at(self, idx: int) -> nn.Module:
+        return getattr(self, str(idx))
+
+
+class _Holder(nn.Module):
+    pass
+
+
+class _ConvP(nn.Module):
+    """Parameters of nn.Conv2d(cin, cout, k): logical [cout,cin,k,k], physical [cout][k][k][cin]."""
+    transposed = False
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.cin, self.cout, self.k = cin, cout, k
+        self.weight = nn.Parameter(torch.empty(cout, k, k, cin).permute(0, 3, 1, 2))
+        self.bias = nn.Parameter(torch.empty(cout))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # torch's nn.Conv2d default (kaiming_uniform a=sqrt(5)); the reference then applies
+        # weights_init (arch/__init__.py:60-65) on top, as get_arch() does here.
+        fan_in = self.weight.shape[1] * self.k * self.k
+        bound = 1.0 / fan_in ** 0.5
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            self.bias.uniform_(-bound, bound)
+
+
+class _ConvTP(_ConvP):
+    """Parameters of nn.ConvTranspose2d(cin, cout, 2, stride=2): logical [cin,cout,2,2],
+    physical [cin][a][b][cout]."""
+    transposed = True
+
+    def __init__(self, cin, cout):
+        nn.Module.__init__(self)
+        self.cin, self.cout, self.k = cin, cout, 2
+        self.weight = nn.Parameter(torch.empty(cin, 2, 2, cout).permute(0, 3, 1, 2))
+        self.bias = nn.Parameter(torch.empty(cout))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        fan_in = self.weight.shape[1] * 4  # torch uses weight.size(1) * receptive field
+        bound = 1.0 / fan_in ** 0.5
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            self.bias.uniform_(-bound, bound)
+
+
+class UNet(nn.Module):
+    """Drop-in for the reference ``UNet(in_channels=1, num_classes=2)`` (network.py:196).
+
+    ``compute_dtype``: torch.bfloat16 (MFMA bf16, fp32 accumulate) or torch.float32
+    (v_mfma_f32_32x32x2_f32; the parity mode).  ``dropout_p`` is the p of the two
+    ``nn.Dropout`` sites (network.py:165,210)."""
+
+    def __init__(self, in_channels: int = 1, num_classes: int = 2, compute_dtype=torch.bfloat16,
+                 dropout_p: float = 0.5):
+        super().__init__()
+        if in_channels != 1:
+            raise ValueError("dct_amd UNet: the hot path is single-channel slices (in_channels=1)")
+        if not 2 <= num_classes <= 8:
+            raise ValueError("dct_amd UNet: 2 <= num_classes <= 8")
+        self.num_classes = num_classes
+        self.compute_dtype = compute_dtype
+        self.dropout_p = float(dropout_p)
+        cin = in_channels
+        for lvl, width in enumerate(_WIDTHS, start=1):
+            blk = _Holder()
+            blk.down = _Slots({0: _ConvP(cin, width, 3), 2: _ConvP(width, width, 3)})
+            setattr(self, f"dec{lvl}", blk)
+            cin = width
+        self.center = _Slots({0: _ConvP(512, 1024, 3), 2: _ConvP(1024, 1024, 3), 5: _ConvTP(1024, 512)})
+        for lvl, (ci, feat, co) in {4: (1024, 512, 256), 3: (512, 256, 128), 2: (256, 128, 64)}.items():
+            blk = _Holder()
+            blk.up = _Slots({0: _ConvP(ci, feat, 3), 2: _ConvP(feat, feat, 3), 4: _ConvTP(feat, co)})
+            setattr(self, f"enc{lvl}", blk)
+        self.enc1 = _Slots({0: _ConvP(128, 64, 3), 2: _ConvP(64, 64, 3)})
+        self.final = _ConvP(64, num_classes, 1)
+
+        self._convs: List[_ConvP] = [m for m in self.modules() if isinstance(m, _ConvP)]
+        self.flat_params = FlatParams(list(self.parameters()))
+        self._pidx = {id(p): i for i, p in enumerate(self.flat_params.params)}
+        self._packs: Dict[int, dict] = {}
+        self._pack_key = None
+        self.external_dropout_masks: Optional[List[torch.Tensor]] = None  # parity replay hook
+        self.last_dropout_masks: Optional[List[torch.Tensor]] = None
+        self.record_dropout_masks = False
+        self._drop_calls = 0
+        self.dropout_seed = 0x5DEECE66D
+
+    # ------------------------------------------------------------------------------ weights
+    def mark_weights_updated(self):
+        self._pack_key = None
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._pack_key = None
+        return r
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._pack_key = None
+        return r
+
+    def _w(self, conv: _ConvP) -> torch.Tensor:
+        return self.flat_params.dense(self._pidx[id(conv.weight)])
+
+    def _gw(self, conv: _ConvP) -> torch.Tensor:
+        return self.flat_params.grad_dense(self._pidx[id(conv.weight)])
+
+    def _gb(self, conv: _ConvP) -> torch.Tensor:
+        return self.flat_params.grad_dense(self._pidx[id(conv.bias)])
+
+    def _ensure_packs(self):
+        """(Re)build compute-dtype weight packs when the fp32 masters changed."""
+        fp = self.flat_params
+        fp.ensure()
+        key = (fp.version, self.compute_dtype, tuple(p._version for p in fp.params))
+        if key == self._pack_key:
+            return
+        dt, dev = self.compute_dtype, fp.flat.device
+        for conv in self._convs:
+            if conv is self.final or conv is self.dec1.down.at(0):
+                continue  # stem and head read the fp32 masters directly
+            w = self._w(conv)
+            ent = self._packs.get(id(conv))
+            if ent is None or ent["dev"] != dev or ent["dt"] != dt:
+                ent = {"dev": dev, "dt": dt}
+                self._packs[id(conv)] = ent
+                n = w.numel()
+                if conv.transposed:
+                    ent["fwd"] = torch.empty(n, dtype=dt, device=dev)                    # [(a,b,co)][ci]
+                    ent["dgrad"] = w if dt == torch.float32 else torch.empty(n, dtype=dt, device=dev)  # [ci][a][b][co]
+                else:
+                    ent["fwd"] = w if dt == torch.float32 else torch.empty(n, dtype=dt, device=dev)    # [co][r][s][ci]
+                    ent["dgrad"] = torch.empty(n, dtype=dt, device=dev)                  # [ci][flip taps][co]
+            if conv.transposed:
+                K.pack_weight(w, ent["fwd"], conv.cin, 4, conv.cout, transpose=2)
+                if dt != torch.float32:
+                    K.pack_weight(w, ent["dgrad"], conv.cin, 4, conv.cout)
+                else:
+                    ent["dgrad"] = w
+            else:
+                taps = conv.k * conv.k
+                if dt != torch.float32:
+                    K.pack_weight(w, ent["fwd"], conv.cout, taps, conv.cin)
+                else:
+                    ent["fwd"] = w
+                K.pack_weight(w, ent["dgrad"], conv.cout, taps, conv.cin, transpose=1, flip_taps=True)
+        self._pack_key = key
+
+    # ------------------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("dct_amd UNet runs on the HIP device only (no CPU fallback)")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"expected [B,1,H,W], got {tuple(x.shape)}")
+        if min(x.shape[2], x.shape[3]) < 176:
+            # same failure the reference has (valid convs): SURVEY.md fact 3
+            raise RuntimeError("Kernel size can't be greater than actual input size (UNet needs H,W >= 176)")
+        self._ensure_packs()
+        params = self.flat_params.params
+        save = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _UNetFn.apply(self, save, x, *params)
+
+    # The plan itself ------------------------------------------------------------------------
+    def _run_forward(self, x: torch.Tensor, save: bool):
+        dt, dev = self.compute_dtype, x.device
+        B, _, H, W = x.shape
+        P = self._packs
+        A: Dict[str, torch.Tensor] = {}
+
+        def new(h, w, c, dtype=dt):
+            return torch.empty(B, h, w, c, dtype=dtype, device=dev)
+
+        def conv3(src, conv, dst):
+            K.conv2d(src, P[id(conv)]["fwd"], conv.bias, dst, relu=True)
+            return dst
+
+        xs = x.detach().to(torch.float32).reshape(B, H, W, 1)
+        if not xs.is_contiguous():
+            xs = xs.contiguous()
+        A["x"] = xs
+        training = self.training and self.dropout_p > 0
+        masks_out = [] if self.record_dropout_masks else None
+
+        def dropout(src, which):
+            if self.external_dropout_masks is not None:
+                dst = torch.empty_like(src)
+                K.dropout_apply(src, dst, self.external_dropout_masks[which], self.dropout_p)
+                return dst
+            if not training:
+                return src
+            dst = torch.empty_like(src)
+            m = torch.empty(src.shape, dtype=torch.uint8, device=dev) if masks_out is not None else None
+            self._drop_calls += 1
+            K.dropout_fwd(src, dst, self.dropout_p, self.dropout_seed, self._drop_calls << 40, mask_out=m)
+            if masks_out is not None:
+                masks_out.append(m)
+            return dst
+
+        # encoder ("dec" in the reference's naming)
+        h, w = H, W
+        src = xs
+        for lvl, width in enumerate(_WIDTHS, start=1):
+            blk = getattr(self, f"dec{lvl}").down
+            a = new(h - 2, w - 2, width)
+            if lvl == 1:
+                c0 = blk.at(0)
+                K.conv_cin1_fwd(xs, self._w(c0), c0.bias, a, relu=True)
+            else:
+                conv3(src, blk.at(0), a)
+            d = conv3(a, blk.at(2), new(h - 4, w - 4, width))
+            dd = dropout(d, 0) if lvl == 4 else d
+            h, w = (h - 4 + 1) // 2, (w - 4 + 1) // 2
+            p = K.maxpool_fwd(dd, new(h, w, width))
+            A[f"a{lvl}"], A[f"d{lvl}"], A[f"p{lvl}"] = a, dd, p
+            src = p
+        # center
+        c = self.center
+        c1 = conv3(src, c.at(0), new(h - 2, w - 2, 1024))
+        c2 = conv3(c1, c.at(2), new(h - 4, w - 4, 1024))
+        c2d = dropout(c2, 1)
+        h, w = 2 * (h - 4), 2 * (w - 4)
+        cat = new(h, w, 1024)
+        K.conv2d(c2d, P[id(c.at(5))]["fwd"], c.at(5).bias, cat[..., :512], R=1, S=1, relu=True, scatter2x2=True)
+        K.bilinear_fwd(A["p4"], cat[..., 512:])
+        A["c1"], A["c2"], A["cat4"] = c1, c2d, cat
+        # decoder ("enc")
+        for lvl, feat, co in ((4, 512, 256), (3, 256, 128), (2, 128, 64)):
+            u = getattr(self, f"enc{lvl}").up
+            ea = conv3(cat, u.at(0), new(h - 2, w - 2, feat))
+            eb = conv3(ea, u.at(2), new(h - 4, w - 4, feat))
+            h, w = 2 * (h - 4), 2 * (w - 4)
+            cat = new(h, w, 2 * co)
+            K.conv2d(eb, P[id(u.at(4))]["fwd"], u.at(4).bias, cat[..., :co], R=1, S=1, relu=True, scatter2x2=True)
+            K.bilinear_fwd(A[f"p{lvl - 1}"], cat[..., co:])
+            A[f"e{lvl}a"], A[f"e{lvl}b"], A[f"cat{lvl - 1}"] = ea, eb, cat
+        e1a = conv3(cat, self.enc1.at(0), new(h - 2, w - 2, 64))
+        e1b = conv3(e1a, self.enc1.at(2), new(h - 4, w - 4, 64))
+        f = K.head_fwd(e1b, self._w(self.final), self.final.bias, new(h - 4, w - 4, self.num_classes, torch.float32))
+        logits = K.bilinear_fwd(f, new(H, W, self.num_classes, torch.float32))
+        A["e1a"], A["e1b"] = e1a, e1b
+        A["fshape"] = (h - 4, w - 4)
+        if masks_out is not None:
+            self.last_dropout_masks = masks_out
+        drop_scale = 1.0 / (1.0 - self.dropout_p) if (training or self.external_dropout_masks is not None) else 1.0
+        A["drop_scale"] = drop_scale
+        return logits, (A if save else None)
+
+    def _run_backward(self, A, dlogits: torch.Tensor, need_dx: bool, need_dw: bool):
+        """dlogits: fp32 NHWC [B,H,W,C].  Accumulates parameter grads in place; returns dx or None."""
+        dt, dev = self.compute_dtype, dlogits.device
+        B = dlogits.shape[0]
+        P = self._packs
+        C = self.num_classes
+        ds = A["drop_scale"]
+
+        def new_like(t, c=None):
+            return torch.empty(t.shape[:3] + ((c,) if c else t.shape[3:]), dtype=dt, device=dev)
+
+        def conv_bwd(conv, x_in, dy, dx_out, mask=None, mask_channels=0, mask_scale=1.0, accumulate=False):
+            """dy: grad wrt the conv's pre-activation output (already ReLU-masked)."""
+            if need_dw:
+                K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=True)
+                K.bias_grad(dy, self._gb(conv), accumulate=True)
+            if dx_out is not None:
+                K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, pad_h=2, pad_w=2, mask=mask,
+                         mask_channels=mask_channels, mask_scale=mask_scale, accumulate=accumulate)
+            return dx_out
+
+        def convT_bwd(conv, x_in, dy, dx_out, mask, mask_scale=1.0):
+            if need_dw:
+                K.conv2d_wgrad(x_in, dy, self._gw(conv), R=2, S=2, stride=2, accumulate=True)
+                K.bias_grad(dy, self._gb(conv), accumulate=True)
+            K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, R=2, S=2, stride=2, mask=mask, mask_scale=mask_scale)
+            return dx_out
+
+        fh, fw = A["fshape"]
+        df = K.bilinear_bwd(dlogits, torch.empty(B, fh, fw, C, dtype=torch.float32, device=dev))
+        e1b, e1a = A["e1b"], A["e1a"]
+        de1b = new_like(e1b)
+        K.head_bwd(e1b, df, self._w(self.final), de1b,
+                   self._gw(self.final) if need_dw else None, self._gb(self.final) if need_dw else None,
+                   relu_mask=True, accumulate=True)
+        de1a = conv_bwd(self.enc1.at(2), e1a, de1b, new_like(e1a), mask=e1a)
+        cat = A["cat1"]
+        dcat = conv_bwd(self.enc1.at(0), cat, de1a, new_like(cat), mask=cat, mask_channels=64)
+        dp: Dict[int, torch.Tensor] = {}
+        for lvl, co in ((2, 64), (3, 128), (4, 256)):
+            u = getattr(self, f"enc{lvl}").up
+            ea, eb = A[f"e{lvl}a"], A[f"e{lvl}b"]
+            p = A[f"p{lvl - 1}"]
+            dp[lvl - 1] = K.bilinear_bwd(dcat[..., co:], new_like(p))
+            deb = convT_bwd(u.at(4), eb, dcat[..., :co], new_like(eb), mask=eb)
+            dea = conv_bwd(u.at(2), ea, deb, new_like(ea), mask=ea)
+            cat = A[f"cat{lvl}"]
+            dcat = conv_bwd(u.at(0), cat, dea, new_like(cat), mask=cat, mask_channels=2 * co)
+        # center (cat4: 512 convT channels + 512 skip channels)
+        c = self.center
+        p4 = A["p4"]
+        dp[4] = K.bilinear_bwd(dcat[..., 512:], new_like(p4))
+        c2d, c1 = A["c2"], A["c1"]
+        dc2 = convT_bwd(c.at(5), c2d, dcat[..., :512], new_like(c2d), mask=c2d, mask_scale=ds)
+        dc1 = conv_bwd(c.at(2), c1, dc2, new_like(c1), mask=c1)
+        conv_bwd(c.at(0), p4, dc1, dp[4], accumulate=True)
+        # encoder
+        dx = None
+        for lvl in (4, 3, 2, 1):
+            blk = getattr(self, f"dec{lvl}").down
+            a, d = A[f"a{lvl}"], A[f"d{lvl}"]
+            dd = K.maxpool_bwd(d, dp[lvl], new_like(d), relu_mask=True, scale=ds if lvl == 4 else 1.0)
+            da = conv_bwd(blk.at(2), a, dd, new_like(a), mask=a)
+            if lvl > 1:
+                conv_bwd(blk.at(0), A[f"p{lvl - 1}"], da, dp[lvl - 1], accumulate=True)
+            else:
+                c0 = blk.at(0)
+                if need_dw:
+                    K.conv_cin1_wgrad(A["x"], da, self._gw(c0), self._gb(c0), accumulate=True)
+                if need_dx:
+                    dx = K.conv_cin1_dgrad(da, self._w(c0), torch.empty_like(A["x"]), pad_h=0, pad_w=0)
+        return dx
+
+
+class _UNetFn(torch.autograd.Function):
+    """One autograd node for the whole network.  Parameter gradients are accumulated directly
+    into the net's flat gradient buffer (``p.grad`` views), so ``backward`` returns None for
+    them; only d/dx (FGSM, AEGenerator.py:27-28) is returned as a tensor."""
+
+    @staticmethod
+    def forward(ctx, net: UNet, save: bool, x: torch.Tensor, *params):
+        need_dw = any(p.requires_grad for p in params)
+        logits, acts = net._run_forward(x, save)
+        ctx.net, ctx.acts, ctx.need_dw = net, acts, need_dw
+        ctx.set_materialize_grads(False)
+        # logical NCHW view of the physical NHWC logits (channels_last strides)
+        return logits.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        net: UNet = ctx.net
+        n_params = len(net.flat_params.params)
+        if g is None or ctx.acts is None:
+            return (None, None, None) + (None,) * n_params
+        dl = g.permute(0, 2, 3, 1)
+        if dl.dtype != torch.float32 or not dl.is_contiguous():
+            dl = dl.to(torch.float32).contiguous()
+        need_dx = ctx.needs_input_grad[2]
+        need_dw = ctx.need_dw and any(ctx.needs_input_grad[3:])
+        if need_dw:
+            net.flat_params.ensure_grads()
+        dx = net._run_backward(ctx.acts, dl, need_dx, need_dw)
+        ctx.acts = None
+        gx = dx.reshape(dx.shape[0], 1, dx.shape[1], dx.shape[2]) if dx is not None else None
+        return (None, None, gx) + (None,) * n_params

@@ -60,11 +60,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* src, T* dst, int
   const long long total = (long long)P * Tt * Q;
   if (i >= total) return;
   if (!transpose) { dst[i] = from_f32<T>(src[i]); return; }
-  // dst index i = (q, t', p)
   const int p = (int)(i % P);
   long long r = i / P;
-  const int t2 = (int)(r % Tt);
-  const int q = (int)(r / Tt);
+  int t2, q;
+  if (transpose == 1) { t2 = (int)(r % Tt); q = (int)(r / Tt); }   // dst index i = (q, t', p)
+  else { q = (int)(r % Q); t2 = (int)(r / Q); }                    // transpose == 2: dst index i = (t', q, p)
   const int t = flip ? Tt - 1 - t2 : t2;
   dst[i] = from_f32<T>(src[((long long)p * Tt + t) * Q + q]);
 }

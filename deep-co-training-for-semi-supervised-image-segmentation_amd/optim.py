@@ -1,0 +1,100 @@
+"""Fused Adam over flat parameter buffers (K12): drop-in for ``torch.optim.Adam`` as the
+reference constructs it (models/segmentators.py:37-43; config/ACDC_config_cotraing.yaml:5-8).
+
+Same hyper-parameters, same update rule (L2 weight decay folded into the gradient, bias
+correction as torch 2.x), same ``state_dict`` layout (per-parameter ``step`` / ``exp_avg`` /
+``exp_avg_sq``) -- but ONE kernel launch per network instead of hundreds of tiny ones.
+"""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import torch
+
+from . import hip_ops
+from .arch.flat import FlatParams
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, flat: FlatParams = None,
+                 on_step=None):
+        if flat is None:
+            raise ValueError("FusedAdam needs the network's FlatParams (use net.flat_params)")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        plist = [p for g in self.param_groups for p in g["params"]]
+        assert len(self.param_groups) == 1 and len(plist) == len(flat.params) and all(a is b for a, b in zip(plist, flat.params)), \
+            "FusedAdam covers exactly one network's parameters, in order"
+        self.flat = flat
+        self._m = None
+        self._v = None
+        self._steps = 0
+        self._flat_version = -1
+        self._on_step = on_step
+
+    def _state_views(self):
+        f = self.flat
+        for p, off in zip(f.params, f.offsets):
+            st = self.state[p]
+            st["exp_avg"] = self._m.as_strided(p.shape, p.stride(), off)
+            st["exp_avg_sq"] = self._v.as_strided(p.shape, p.stride(), off)
+            st["step"] = torch.tensor(float(self._steps))
+
+    def _ensure_state(self):
+        f = self.flat
+        f.ensure()
+        dev = f.flat.device
+        ok = self._m is not None and self._m.device == dev
+        if ok:
+            base_m = self._m.data_ptr()
+            for p, off in zip(f.params, f.offsets):
+                st = self.state.get(p)
+                if not st or "exp_avg" not in st or st["exp_avg"].data_ptr() != base_m + 4 * off:
+                    ok = False
+                    break
+        if ok:
+            return
+        # (re)build flat moment buffers, importing whatever per-parameter state exists
+        # (e.g. after load_state_dict of a reference checkpoint or after .to(device))
+        m = torch.zeros(f.total, dtype=torch.float32, device=dev)
+        v = torch.zeros(f.total, dtype=torch.float32, device=dev)
+        steps = self._steps
+        for p, off in zip(f.params, f.offsets):
+            st = self.state.get(p)
+            if st and "exp_avg" in st:
+                m.as_strided(p.shape, p.stride(), off).copy_(st["exp_avg"])
+                v.as_strided(p.shape, p.stride(), off).copy_(st["exp_avg_sq"])
+                steps = max(steps, int(float(st.get("step", 0))))
+        self._m, self._v, self._steps = m, v, steps
+        self._state_views()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self._ensure_state()
+        f = self.flat
+        if not f.grads_attached():
+            raise RuntimeError("FusedAdam.step(): gradients are not in the network's flat gradient buffer "
+                               "(backward of a dct_amd network attaches them)")
+        g = self.param_groups[0]
+        self._steps += 1
+        b1, b2 = g["betas"]
+        bc1 = 1.0 - b1 ** self._steps
+        bc2 = 1.0 - b2 ** self._steps
+        hip_ops.adam_flat(f.flat, f.gflat, self._m, self._v, g["lr"] / bc1, math.sqrt(bc2), b1, b2, g["eps"],
+                          g["weight_decay"])
+        for p in f.params:
+            self.state[p]["step"] = torch.tensor(float(self._steps))
+        if self._on_step is not None:
+            self._on_step()
+        return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._m = None  # force re-import of the loaded per-parameter moments
+
+    def state_dict(self):
+        if self._m is not None:
+            self._state_views()
+        return super().state_dict()

@@ -89,8 +89,10 @@ int dct_bias_grad(const dct_view* dy, float* db, int accumulate, int dtype,
                   void* workspace, size_t workspace_bytes, dct_stream stream);
 size_t dct_bias_grad_workspace_bytes(const dct_view* dy);
 
-/* Repack fp32 master weights [P][T][Q] (T taps) into dst[Q][T'][P] (tap order reversed when
- * flip_taps) or, when transpose == 0, a straight cast copy; dst dtype = `dtype`. */
+/* Repack fp32 master weights src[P][T][Q] (T taps) into `dtype`:
+ *   transpose == 0: straight cast copy;
+ *   transpose == 1: dst[Q][T'][P]  (conv dgrad pack; tap order reversed when flip_taps);
+ *   transpose == 2: dst[T'][Q][P]  (ConvTranspose2d forward pack for the scatter2x2 mode). */
 int dct_pack_weight(const float* src, void* dst, int P, int T, int Q, int transpose, int flip_taps,
                     int dtype, dct_stream stream);
 

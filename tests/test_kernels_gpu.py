@@ -382,7 +382,8 @@ def test_jsd_kl_vs_oracle(ops, S, C):
     gs = torch.tensor([0.25], device=DEV)
     ops.jsd_logits_bwd(lds, C, dls, gscale=gs, gmul=4.0, accumulate=True)
     for s in range(S):
-        np.testing.assert_allclose(_back(dls[s] - olds[s], ls[0]).numpy(), gr[s].numpy(), rtol=3e-4, atol=2e-9)
+        # (old + g) - old re-rounds at |old| ~ 1: allow one ulp of the accumulator
+        np.testing.assert_allclose(_back(dls[s] - olds[s], ls[0]).numpy(), gr[s].numpy(), rtol=3e-4, atol=5e-7)
     # module-API variants (probs in, maps out)
     pds = [ops.softmax_fwd(l, C) for l in lds]
     np.testing.assert_allclose(_back(pds[0], ls[0]).numpy(), probs[0].detach().numpy(), rtol=1e-5, atol=1e-8)
@@ -444,6 +445,6 @@ def test_adam_flat(ops):
         ops.adam_flat(pd, gr.to(DEV), md, vd, 1e-3 / bc1, math.sqrt(bc2), 0.9, 0.999, 1e-8, 1e-4, bf16_shadow=shadow)
     np.testing.assert_allclose(p.numpy(), pt.detach().numpy(), rtol=1e-6, atol=1e-8)   # oracle adam == torch.optim.Adam
     np.testing.assert_allclose(pd.cpu().numpy(), p.numpy(), rtol=2e-6, atol=2e-8)
-    np.testing.assert_allclose(md.cpu().numpy(), m.numpy(), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(md.cpu().numpy(), m.numpy(), rtol=2e-6, atol=1e-8)   # fma contraction: ~2 ulp
     np.testing.assert_allclose(vd.cpu().numpy(), v.numpy(), rtol=2e-6, atol=1e-12)
     assert torch.equal(shadow.cpu(), pd.cpu().to(torch.bfloat16))
