@@ -83,6 +83,7 @@ SIGNATURES = {
     "dct_softmax_fwd": (_i, [_P, _P, _i64, _i, _P]),
     "dct_softmax_bwd": (_i, [_P, _P, _P, _i64, _i, _i, _P]),
     "dct_entropy_fwd": (_i, [_P, _P, _i64, _i, _P]),
+    "dct_entropy_bwd": (_i, [_P, _P, _P, _i64, _i, _P]),
     "dct_jsd_map_fwd": (_i, [_P, _i, _P, _i64, _i, _P]),
     "dct_jsd_map_bwd": (_i, [_P, _i, _P, _P, _i64, _i, _P]),
     "dct_kl_map_fwd": (_i, [_P, _P, _P, _i64, _i, _f, _P]),
@@ -93,7 +94,7 @@ SIGNATURES = {
     "dct_kl_logits_bwd": (_i, [_P, _P, _i64, _i, _f, _P, _f, _P, _i, _P]),
     "dct_argmax": (_i, [_P, _P, _i64, _i, _P]),
     "dct_fgsm_step": (_i, [_P, _P, _f, _P, _P, _i64, _P]),
-    "dct_adam_flat": (_i, [_P, _P, _P, _P, _i64, _f, _f, _f, _f, _f, _f, _P, _P]),
+    "dct_adam_flat": (_i, [_P, _P, _P, _P, _i64, _f, _f, C.c_double, C.c_double, _f, _f, _P, _P]),
     "dct_dice_counts": (_i, [_P, _P, _i, _i64, _i, _P, _P, _P, _P]),
     "dct_prof_enable": (_i, [_i]),
     "dct_prof_read": (_i, [_P, _P, _i]),

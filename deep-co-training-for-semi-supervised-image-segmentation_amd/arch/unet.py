@@ -126,6 +126,7 @@ class UNet(nn.Module):
         self.record_dropout_masks = False
         self._drop_calls = 0
         self.dropout_seed = 0x5DEECE66D
+        self._debug: Optional[dict] = None   # tools/debug_unet_layers.py stashes backward intermediates here
 
     # ------------------------------------------------------------------------------ weights
     def mark_weights_updated(self):
@@ -333,6 +334,8 @@ class UNet(nn.Module):
             dp[lvl - 1] = K.bilinear_bwd(dcat[..., co:], new_like(p))
             deb = convT_bwd(u.at(4), eb, dcat[..., :co], new_like(eb), mask=eb)
             dea = conv_bwd(u.at(2), ea, deb, new_like(ea), mask=ea)
+            if self._debug is not None:
+                self._debug[f"de{lvl}b"], self._debug[f"de{lvl}a"], self._debug[f"dcat{lvl - 1}"] = deb, dea, dcat
             cat = A[f"cat{lvl}"]
             dcat = conv_bwd(u.at(0), cat, dea, new_like(cat), mask=cat, mask_channels=2 * co)
         # center (cat4: 512 convT channels + 512 skip channels)

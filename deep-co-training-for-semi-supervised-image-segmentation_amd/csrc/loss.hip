@@ -150,11 +150,22 @@ __global__ __launch_bounds__(256) void entropy_fwd_kernel(const float* probs, fl
   }
 }
 
-// ---- JSD ------------------------------------------------------------------------------------------
-struct PtrPack { const float* in[4]; float* out[4]; };
-
 // d/dp of  H(p) = -sum p log(p+eps):  -(log(p+eps) + p/(p+eps))
 __device__ __forceinline__ float dent(float p) { return -(logf(p + kEntEps) + p / (p + kEntEps)); }
+template <int C>
+__global__ __launch_bounds__(256) void entropy_bwd_kernel(const float* probs, const float* dmap, float* dprobs, long long P) {
+  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < P; pix += (long long)gridDim.x * 256) {
+    float p[C], d[C];
+    load_px<C>(probs, pix, p);
+    const float g = dmap[pix];
+#pragma unroll
+    for (int c = 0; c < C; ++c) d[c] = g * dent(p[c]);
+    store_px<C>(dprobs, pix, d, false);
+  }
+}
+
+// ---- JSD ------------------------------------------------------------------------------------------
+struct PtrPack { const float* in[4]; float* out[4]; };
 
 template <int C, bool FROM_LOGITS>
 __global__ __launch_bounds__(256) void jsd_fwd_kernel(PtrPack pk, int S, long long P, float* map, float* partial) {
@@ -351,15 +362,16 @@ __global__ __launch_bounds__(256) void fgsm_kernel(const float* x, const float* 
   }
 }
 
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float step_size, float bc2s, float b1, float b2, float eps, float wd) {
+// omb1/omb2 = 1-beta computed in double on the host, as torch does (float(1-0.999) != 1.f-0.999f)
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float step_size, float bc2s, float omb1, float b2, float omb2, float eps, float wd) {
   g = fmaf(wd, p, g);
-  m = m + (g - m) * (1.f - b1);                 // exp_avg.lerp_(grad, 1-b1)
-  v = v * b2 + (1.f - b2) * g * g;              // mul_(b2).addcmul_(g, g, 1-b2)
+  m = m + (g - m) * omb1;                       // exp_avg.lerp_(grad, 1-b1)
+  v = v * b2 + omb2 * g * g;                    // mul_(b2).addcmul_(g, g, 1-b2)
   const float denom = sqrtf(v) / bc2s + eps;
   p = p - step_size * (m / denom);
 }
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float step_size,
-                                                    float bc2s, float b1, float b2, float eps, float wd, bf16_t* shadow) {
+                                                    float bc2s, float omb1, float b2, float omb2, float eps, float wd, bf16_t* shadow) {
   const long long n4 = n / 4;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float pp = pv[k], mm = mv[k], v2 = vv[k];
-      adam1(pp, gv[k], mm, v2, step_size, bc2s, b1, b2, eps, wd);
+      adam1(pp, gv[k], mm, v2, step_size, bc2s, omb1, b2, omb2, eps, wd);
       pv[k] = pp; mv[k] = mm; vv[k] = v2;
     }
     reinterpret_cast<f32x4*>(p)[i] = pv; reinterpret_cast<f32x4*>(m)[i] = mv; reinterpret_cast<f32x4*>(v)[i] = vv;
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long long i = n4 * 4 + threadIdx.x;
     float pp = p[i], mm = m[i], v2 = v[i];
-    adam1(pp, g[i], mm, v2, step_size, bc2s, b1, b2, eps, wd);
+    adam1(pp, g[i], mm, v2, step_size, bc2s, omb1, b2, omb2, eps, wd);
     p[i] = pp; m[i] = mm; v[i] = v2;
     if (shadow) shadow[i] = (bf16_t)pp;
   }
@@ -449,6 +461,13 @@ extern "C" int dct_entropy_fwd(const float* probs, float* map, int64_t pixels, i
   if (!probs || !map || pixels < 1) return DCT_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, entropy_fwd_kernel<C>, dim3(wide_grid(pixels)), dim3(256), 0, st, probs, map, (long long)pixels));
+  return dct_check_launch();
+}
+
+extern "C" int dct_entropy_bwd(const float* probs, const float* dmap, float* dprobs, int64_t pixels, int C_, dct_stream stream) {
+  if (!probs || !dmap || !dprobs || pixels < 1) return DCT_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, entropy_bwd_kernel<C>, dim3(wide_grid(pixels)), dim3(256), 0, st, probs, dmap, dprobs, (long long)pixels));
   return dct_check_launch();
 }
 
@@ -554,12 +573,12 @@ extern "C" int dct_fgsm_step(const float* x, const float* g, float eps, float* x
 }
 
 extern "C" int dct_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float step_size,
-                             float bc2_sqrt, float beta1, float beta2, float eps, float weight_decay,
+                             float bc2_sqrt, double beta1, double beta2, float eps, float weight_decay,
                              void* bf16_shadow, dct_stream stream) {
   if (!p || !g || !m || !v || n < 1) return DCT_ERR_BAD_ARG;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return DCT_ERR_UNSUPPORTED;
   if (bf16_shadow && ((uintptr_t)bf16_shadow & 7)) return DCT_ERR_UNSUPPORTED;
   DCT_LAUNCH(DCT_PROF_ADAM, adam_kernel, dim3(wide_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
-             step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, (bf16_t*)bf16_shadow);
+             step_size, bc2_sqrt, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, (bf16_t*)bf16_shadow);
   return dct_check_launch();
 }

@@ -1,0 +1,119 @@
+"""Data-parallel gradient exchange for co-training: one process per GPU, RCCL over xGMI.
+
+The reference's only multi-GPU facility is single-process ``nn.DataParallel``
+(models/segmentators.py:34-36): batch split on dim 0, per-replica BatchNorm statistics,
+gradients summed onto device 0.  The MI355X-native equivalent here:
+
+  * every rank holds all S models and draws its own labeled / unlabeled mini-batches
+    (global batch = world x per-GPU batch; equal per-rank batch sizes make the gradient
+    *average* equal to the global-batch mean gradient);
+  * each model's gradients already live in ONE flat fp32 buffer (arch/flat.py), so the exchange
+    is one large all-reduce per model straight out of that buffer -- no bucket copies, and for
+    Enet-sized models no swarm of latency-bound tiny collectives.  xGMI is point-to-point
+    (7 links x ~153 GB/s per GPU): a ring all-reduce of UNet's 124 MB takes ~1.4 ms at 8 GPUs, so
+    model m's all-reduce is issued asynchronously right after model m's backward is enqueued
+    and overlaps the backward of model m+1 (``begin`` / ``finish``);
+  * BatchNorm buffers stay per-rank (what DataParallel replicas do); FGSM's input-gradient pass
+    produces no parameter gradients and therefore never touches the exchange.
+
+Networks without a flat buffer (injected modules in host-logic tests) are reduced through a
+temporary flattened copy of their gradients.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGradSync(object):
+    def __init__(self, segmentators, process_group=None, broadcast_weights: bool = True):
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("FlatGradSync needs an initialised torch.distributed process group")
+        self.segmentators = list(segmentators)
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self._pending: List = []
+        self._avg = dist.get_backend(process_group) == "nccl"   # RCCL supports ReduceOp.AVG; gloo does not
+        if broadcast_weights:
+            self.broadcast_weights()
+
+    # -- weights: rank 0's initialisation everywhere ---------------------------------------------
+    @torch.no_grad()
+    def broadcast_weights(self):
+        for seg in self.segmentators:
+            net = seg.torchnet
+            flat = getattr(net, "flat_params", None)
+            if flat is not None:
+                flat.ensure()
+                dist.broadcast(flat.flat, src=0, group=self.group)
+                if hasattr(net, "mark_weights_updated"):
+                    net.mark_weights_updated()
+            else:
+                for p in net.parameters():
+                    dist.broadcast(p.data, src=0, group=self.group)
+            for b in net.buffers():
+                if b.dtype.is_floating_point:
+                    dist.broadcast(b.data, src=0, group=self.group)
+
+    # -- gradients ---------------------------------------------------------------------------------
+    def _reduce_tensor(self, t: torch.Tensor, async_op: bool):
+        if self._avg:
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), t
+
+    def begin(self, model_index: int):
+        """Start the (asynchronous) all-reduce of one model's gradients."""
+        net = self.segmentators[model_index].torchnet
+        flat = getattr(net, "flat_params", None)
+        if flat is not None and flat.grads_attached():
+            work, scale = self._reduce_tensor(flat.gflat, True)
+            self._pending.append((work, scale, None, None))
+            return
+        params = [p for p in net.parameters() if p.grad is not None]
+        if not params:
+            return
+        buf = torch.cat([p.grad.reshape(-1) for p in params])
+        work, scale = self._reduce_tensor(buf, True)
+        self._pending.append((work, scale, buf, params))
+
+    @torch.no_grad()
+    def finish(self):
+        for work, scale, buf, params in self._pending:
+            work.wait()
+            if scale is not None:
+                scale.mul_(1.0 / self.world)
+            if buf is not None:
+                off = 0
+                for p in params:
+                    n = p.grad.numel()
+                    p.grad.copy_(buf[off:off + n].view_as(p.grad))
+                    off += n
+        self._pending = []
+
+    def all_reduce(self):
+        for i in range(len(self.segmentators)):
+            self.begin(i)
+        self.finish()
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and initialise the
+    process group: 'nccl' (= RCCL on ROCm) when a GPU is visible, else 'gloo'."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return rank, local, world
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world

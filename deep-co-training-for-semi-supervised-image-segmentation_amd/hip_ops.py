@@ -197,6 +197,12 @@ def entropy_fwd(probs, C_):
     return out
 
 
+def entropy_bwd(probs, dmap, C_):
+    out = torch.empty_like(probs)
+    call("dct_entropy_bwd", ptr(probs), ptr(dmap), ptr(out), probs.numel() // C_, C_, stream())
+    return out
+
+
 def jsd_map_fwd(probs: List[torch.Tensor], C_):
     P = probs[0].numel() // C_
     out = torch.empty(P, dtype=torch.float32, device=probs[0].device)

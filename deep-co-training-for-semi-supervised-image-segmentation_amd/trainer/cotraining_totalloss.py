@@ -1,0 +1,494 @@
+"""``CoTrainer``: N-model deep co-training with the reference's interface
+(/root/reference/generalframework/trainer/cotraining_totalloss.py:28-482).
+
+The per-step body the reference inlines in ``_train_loop`` (:203-248) is factored out as
+``_run_step``.  It has two implementations with identical observable behaviour:
+
+* the *fused* path (dct_amd HIP networks + the stock loss modules on a HIP device): network
+  forwards are single autograd nodes over hand-written kernels; every loss value and its
+  logit-gradient come from one fused kernel each (CE, JSD-from-logits, KL-from-logits), the loss
+  weights are folded into those kernels, and ``total.backward()`` becomes ONE
+  ``torch.autograd.backward(heads, dlogits)`` call -- same single backward through every graph;
+* the *generic* path (any nn.Module / any criterion callables): the reference's op sequence
+  through the public module APIs.  Host-logic tests drive it with injected CPU modules.
+
+Same op order as the reference: S supervised forwards, then S unlabeled forwards, then the
+FGSM block on the cached batches, then ``zero_grad`` (after the forwards), one backward,
+all optimizers step.  The numpy RNG is consumed once per step when ``train_adv``.
+"""
+from __future__ import annotations
+
+import os
+from operator import itemgetter
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import yaml
+from torch import Tensor, nn
+
+from .. import ModelMode
+from .. import scheduler
+from ..metrics import AverageValueMeter, DiceMeter
+from ..models import Segmentator
+from ..utils import iterator_, map_, dict_merge, tqdm_
+from ..utils.AEGenerator import FSGMGenerator
+from .trainer import Trainer
+
+
+def fix_seed(seed):
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+class _NullWriter(object):
+    def add_scalars(self, *a, **k):
+        pass
+
+
+def _make_writer(save_dir):
+    try:
+        from tensorboardX import SummaryWriter  # optional, as in the reference (:6)
+        return SummaryWriter(str(save_dir))
+    except Exception:
+        return _NullWriter()
+
+
+class CoTrainer(Trainer):
+
+    def __init__(self, segmentators: List[Segmentator],
+                 labeled_dataloaders: List,
+                 unlabeled_dataloader,
+                 val_dataloader,
+                 criterions: Dict[str, nn.Module],
+                 max_epoch: int = 100,
+                 save_dir: str = 'tmp',
+                 device: str = 'cpu',
+                 axises: List[int] = [1, 2, 3],
+                 checkpoint: Union[List[str], None] = None,
+                 metricname: str = 'metrics.csv',
+                 adv_scheduler_dict: dict = None,
+                 cot_scheduler_dict: dict = None,
+                 adv_training_dict: dict = {},
+                 use_tqdm: bool = True,
+                 whole_config=None,
+                 steps_per_epoch: int = 300,
+                 grad_sync=None) -> None:
+        self.max_epoch = max_epoch
+        self.segmentators = segmentators
+        self.labeled_dataloaders = labeled_dataloaders
+        self.unlabeled_dataloader = unlabeled_dataloader
+        self.val_dataloader = val_dataloader
+
+        # same contract checks as the reference (:54-64)
+        assert self.segmentators.__len__() == self.labeled_dataloaders.__len__()
+        assert self.segmentators.__len__() >= 1
+        assert set(map_(id, self.segmentators)).__len__() == self.segmentators.__len__()
+        assert set(map_(id, self.labeled_dataloaders)).__len__() == self.segmentators.__len__()
+        assert set(map_(lambda x: x.batch_size, self.labeled_dataloaders)).__len__() == 1
+        self.criterions = criterions
+        assert set(self.criterions.keys()) == {'jsd', 'sup', 'adv'}
+
+        self.save_dir = Path(save_dir)
+        self.save_dir.mkdir(parents=True, exist_ok=True)
+        self.writer = _make_writer(self.save_dir)
+        if whole_config:
+            with open(Path(self.save_dir, 'config.yml'), 'w') as outfile:
+                yaml.dump(whole_config, outfile, default_flow_style=False)
+
+        self.device = torch.device(device)
+        self.C = self.segmentators[0].arch_params['num_classes']
+        self.axises = axises
+        self.best_scores = np.zeros(self.segmentators.__len__())
+        self.start_epoch = 0
+        self.metricname = metricname
+        self.n_batch = steps_per_epoch      # the reference hard-codes 300 (:191)
+
+        self.cot_scheduler = getattr(scheduler, cot_scheduler_dict['name'])(
+            **{k: v for k, v in cot_scheduler_dict.items() if k != 'name'})
+        self.adv_scheduler = getattr(scheduler, adv_scheduler_dict['name'])(
+            **{k: v for k, v in adv_scheduler_dict.items() if k != 'name'})
+        self.adv_training_dict = adv_training_dict
+
+        if checkpoint is not None:
+            self._load_checkpoint(checkpoint)
+
+        self.to(self.device)
+        self.use_tqdm = use_tqdm and tqdm_ is not None
+        self.grad_sync = grad_sync          # dct_amd.ddp.FlatGradSync or None (single process)
+        self.last_step = None
+
+    def to(self, device: torch.device):
+        [segmentator.to(device) for segmentator in self.segmentators]
+        [criterion.to(device) for _, criterion in self.criterions.items() if hasattr(criterion, "to")]
+
+    # ------------------------------------------------------------------------------ epochs
+    def start_training(self, train_jsd=False, train_adv=False, save_train=False, save_val=False,
+                       augment_labeled_data=False, augment_unlabeled_data=False):
+        S = len(self.segmentators)
+        metrics = {k: torch.zeros(self.max_epoch, S, self.C, 2, dtype=torch.float)
+                   for k in ('train_dice', 'train_unlab_dice', 'val_dice', 'val_batch_dice')}
+        for epoch in range(self.start_epoch, self.max_epoch):
+            train_dice, train_unlab_dice = self._train_loop(
+                labeled_dataloaders=self.labeled_dataloaders, unlabeled_dataloader=self.unlabeled_dataloader,
+                epoch=epoch, mode=ModelMode.TRAIN, save=save_train, train_jsd=train_jsd, train_adv=train_adv,
+                augment_labeled_data=augment_labeled_data, augment_unlabeled_data=augment_unlabeled_data)
+            with torch.no_grad():
+                val_dice, val_batch_dice = self._eval_loop(val_dataloader=self.val_dataloader, epoch=epoch,
+                                                           mode=ModelMode.EVAL, save=save_val)
+            self.schedulerStep()
+            for k, v in (('train_dice', train_dice), ('train_unlab_dice', train_unlab_dice),
+                         ('val_dice', val_dice), ('val_batch_dice', val_batch_dice)):
+                assert metrics[k][epoch].shape == v.shape
+                metrics[k][epoch] = v
+            if self._is_main():
+                self._write_metrics(metrics)
+            current_metric = val_batch_dice[:, self.axises, 0].mean(1)
+            if self._is_main():
+                self.checkpoint(current_metric, epoch)
+
+    def _is_main(self) -> bool:
+        return self.grad_sync is None or self.grad_sync.rank == 0
+
+    def _write_metrics(self, metrics):
+        for k, v in metrics.items():
+            np.save(self.save_dir / f'{k}.npy', v.data.numpy())
+        try:
+            import pandas as pd
+        except Exception:
+            return
+        for s in range(self.segmentators.__len__()):
+            df = pd.DataFrame({
+                **{f"train_dice_{i}": metrics["train_dice"][:, s, i, 0] for i in self.axises},
+                **{f"train_unlab_dice_{i}": metrics["train_unlab_dice"][:, s, i, 0] for i in self.axises},
+                **{f"val_dice_{i}": metrics["val_dice"][:, s, i, 0] for i in self.axises},
+                **{f"val_batch_dice_{i}": metrics["val_batch_dice"][:, s, i, 0] for i in self.axises}})
+            df.to_csv(Path(self.save_dir, self.metricname.replace('.csv', f'_{s}.csv')), float_format="%.4f",
+                      index_label="epoch")
+
+    # ------------------------------------------------------------------------------ the step
+    def _fused_ok(self) -> bool:
+        from ..loss.loss import CrossEntropyLoss2d, JSD_2D
+        if self.device.type != 'cuda':
+            return False
+        if type(self.criterions['sup']) is not CrossEntropyLoss2d or type(self.criterions['jsd']) is not JSD_2D:
+            return False
+        return all(hasattr(s.torchnet, "flat_params") for s in self.segmentators) and len(self.segmentators) <= 4
+
+    def _draw_adv_choice(self) -> Tuple[int, int]:
+        S = len(self.segmentators)
+        try:
+            choice = sorted(np.random.choice(list(range(S)), 2, replace=False).tolist())
+        except Exception:
+            choice = sorted(np.random.choice(list(range(S)), 2, replace=True).tolist())
+        return choice[0], choice[1]
+
+    def _run_step(self, lab_batches: Sequence[Tuple[Tensor, Tensor]], unlab_batch: Optional[Tuple[Tensor, Tensor]],
+                  train_jsd: bool, train_adv: bool, adv_choice: Optional[Tuple[int, int]] = None) -> dict:
+        """One co-training step == reference lines :207-248.  Returns
+        dict(sup=[Tensor], jsd=Tensor|0, adv=Tensor|0, preds=[Tensor], unlab_probs=[Tensor])."""
+        if train_adv and adv_choice is None:
+            adv_choice = self._draw_adv_choice()
+        lab = [(img.to(self.device), gt.to(self.device)) for img, gt in lab_batches]
+        unl = None
+        if unlab_batch is not None and (train_jsd or train_adv):
+            unl = (unlab_batch[0].to(self.device), unlab_batch[1].to(self.device) if unlab_batch[1] is not None else None)
+        if self._fused_ok():
+            out = self._run_step_fused(lab, unl, train_jsd, train_adv, adv_choice)
+        else:
+            out = self._run_step_generic(lab, unl, train_jsd, train_adv, adv_choice)
+        self.last_step = out
+        return out
+
+    def _finish_step(self, backward_calls):
+        """zero_grad (after the forwards, :245) -> backward (:246-247) -> [gradient all-reduce] -> step (:248).
+        ``backward_calls``: list of (model index or None, callable).  With data parallelism each
+        model's all-reduce starts as soon as its backward is enqueued and overlaps the next one."""
+        map_(lambda x: x.optimizer.zero_grad(), self.segmentators)
+        for idx, call in backward_calls:
+            call()
+            if self.grad_sync is not None and idx is not None:
+                self.grad_sync.begin(idx)
+        if self.grad_sync is not None:
+            if any(idx is None for idx, _ in backward_calls):
+                self.grad_sync.all_reduce()
+            else:
+                self.grad_sync.finish()
+        map_(lambda x: x.optimizer.step(), self.segmentators)
+
+    def _run_step_generic(self, lab, unl, train_jsd, train_adv, adv_choice) -> dict:
+        S = len(self.segmentators)
+        supervisedLoss, jsdLoss, advLoss = 0, 0, 0
+        sup, preds, unlab_preds = [], [], []
+        for i in range(S):
+            img, gt = lab[i]
+            pred = self.segmentators[i].predict(img, logit=True)
+            sup_loss = self.criterions.get('sup')(pred, gt.squeeze(1))
+            sup.append(sup_loss.detach())
+            preds.append(pred.detach())
+            supervisedLoss = supervisedLoss + sup_loss
+        if train_jsd:
+            unlab_preds = map_(lambda x: x.predict(unl[0], logit=False), self.segmentators)
+            jsdLoss = self.criterions.get('jsd')(unlab_preds).mean()
+        if train_adv:
+            a, b = adv_choice
+            advLoss = self._adv_from_batches((self.segmentators[a], self.segmentators[b]), lab[b], unl[0],
+                                             **self.adv_training_dict)
+        totalLoss = supervisedLoss + self.cot_scheduler.value * jsdLoss + self.adv_scheduler.value * advLoss
+        self._finish_step([(None, totalLoss.backward)])
+        return dict(sup=sup, jsd=jsdLoss.detach() if train_jsd else 0, adv=advLoss.detach() if train_adv else 0,
+                    preds=preds, unlab_probs=[p.detach() for p in unlab_preds])
+
+    def _run_step_fused(self, lab, unl, train_jsd, train_adv, adv_choice) -> dict:
+        from .. import hip_ops as K
+        from ..loss.loss import _pc, _nchw
+        S, C = len(self.segmentators), self.C
+        ignore = self.criterions['sup'].ignore_index
+        lam_cot, lam_adv = float(self.cot_scheduler.value), float(self.adv_scheduler.value)
+        heads: List[List[Tensor]] = [[] for _ in range(S)]
+        grads: List[List[Tensor]] = [[] for _ in range(S)]
+        sup, preds = [], []
+        for i in range(S):                                                     # :208-218
+            img, gt = lab[i]
+            logits = self.segmentators[i].torchnet(img)
+            lp = _pc(logits.detach())
+            t = gt.reshape(-1)
+            out = K.ce_fwd(lp, t, C, ignore)
+            dl = K.ce_bwd(lp, t, C, out[1:2], torch.empty_like(lp), ignore_index=ignore)
+            heads[i].append(logits)
+            grads[i].append(_nchw(dl))
+            sup.append(out[0])
+            preds.append(logits.detach())
+        jsd, unlab_probs = 0, []
+        if train_jsd:                                                          # :219-227
+            ulogits = [s.torchnet(unl[0]) for s in self.segmentators]
+            lps = [_pc(l.detach()) for l in ulogits]
+            jsd = K.jsd_logits_fwd(lps, C)[0]
+            unlab_probs = [_nchw(K.softmax_fwd(lp, C)) for lp in lps]
+            if lam_cot != 0.0:
+                dls = K.jsd_logits_bwd(lps, C, [torch.empty_like(lp) for lp in lps], gmul=lam_cot)
+                for i in range(S):
+                    heads[i].append(ulogits[i])
+                    grads[i].append(_nchw(dls[i]))
+        adv = 0
+        if train_adv:                                                          # :233-244 -> :371-392
+            a, b = adv_choice
+            eps = float(self.adv_training_dict.get('eplision', 0.05))
+            img_b, gt_b = lab[b]
+            x = torch.cat((img_b, unl[0]), dim=0)
+            net_b = self.segmentators[b].torchnet
+            x_adv, noise, lp_real = self._fgsm_fused(net_b, x, gt_b, eps, ignore)
+            logits_adv = self.segmentators[a].torchnet(x_adv)
+            lp_adv = _pc(logits_adv.detach())
+            adv = K.kl_logits_fwd(lp_adv, lp_real, C)[0]
+            if lam_adv != 0.0:
+                da = K.kl_logits_bwd(lp_adv, lp_real, C, torch.empty_like(lp_adv), gmul=lam_adv)
+                heads[a].append(logits_adv)
+                grads[a].append(_nchw(da))
+        self._finish_step([(i, (lambda h=heads[i], g=grads[i]: torch.autograd.backward(h, g))) for i in range(S)])
+        return dict(sup=sup, jsd=jsd, adv=adv, preds=preds, unlab_probs=unlab_probs)
+
+    def _fgsm_fused(self, net, x, gt, eps, ignore):
+        """FSGMGenerator (AEGenerator.py:16-51) on the fused kernels: forward, pseudo-label the
+        unlabeled tail, CE, backward to the input only, x + eps*sign(g).  Returns the physical
+        NHWC logits of the clean pass (their softmax is the detached KL target)."""
+        from .. import hip_ops as K
+        from ..loss.loss import _pc, _nchw
+        C = self.C
+        x = x.detach().requires_grad_(True)
+        params = [p for p in net.parameters() if p.requires_grad]
+        for p in params:
+            p.requires_grad_(False)
+        try:
+            logits = net(x)
+        finally:
+            for p in params:
+                p.requires_grad_(True)
+        lp = _pc(logits.detach())
+        t = gt.reshape(-1)
+        if x.shape[0] > gt.shape[0]:
+            pseudo = K.argmax(lp, C)
+            t = torch.cat((t, pseudo[t.numel():]))
+        out = K.ce_fwd(lp, t, C, ignore)
+        dl = K.ce_bwd(lp, t, C, out[1:2], torch.empty_like(lp), ignore_index=ignore)
+        (gx,) = torch.autograd.grad(logits, x, _nchw(dl))
+        x_adv, noise = K.fgsm_step(x.detach().contiguous(), gx.contiguous(), eps)
+        return x_adv, noise, lp
+
+    # ------------------------------------------------------------------------------ loops
+    def _train_loop(self, labeled_dataloaders: List, unlabeled_dataloader, epoch: int, mode: ModelMode, save: bool,
+                    augment_labeled_data=False, augment_unlabeled_data=False, train_jsd=False, train_adv=False):
+        fix_seed(epoch)
+        S = len(self.segmentators)
+        diceMeters = [DiceMeter(report_axises=self.axises, method='2d', C=self.C) for _ in range(S)]
+        unlabdiceMeters = [DiceMeter(report_axises=self.axises, method='2d', C=self.C) for _ in range(S)]
+        suplossMeters = [AverageValueMeter() for _ in range(S)]
+        jsdlossMeter = AverageValueMeter()
+        advlossMeter = AverageValueMeter()
+
+        [segmentator.set_mode(mode) for segmentator in self.segmentators]
+        for l_dataloader in labeled_dataloaders:
+            l_dataloader.dataset.set_mode(ModelMode.TRAIN if augment_labeled_data else ModelMode.EVAL)
+        unlabeled_dataloader.dataset.training = ModelMode.TRAIN if augment_unlabeled_data else ModelMode.EVAL
+        assert self.segmentators[0].training
+
+        desc = f">>   Training   ({epoch})" if mode == ModelMode.TRAIN else f">> Validating   ({epoch})"
+        n_batch = self.n_batch
+        fake_labeled_iterators = [iterator_(x) for x in labeled_dataloaders]
+        fake_unlabeled_iterator = iterator_(unlabeled_dataloader)
+        self._iters = (fake_labeled_iterators, fake_unlabeled_iterator)
+        report_iterator = iterator_(['label', 'unlab'])
+        report_status = 'label'
+        n_batch_iter = tqdm_(range(n_batch)) if self.use_tqdm else range(n_batch)
+
+        for batch_num in n_batch_iter:
+            if batch_num % 30 == 0 and train_jsd and self.cot_scheduler.value > 0:
+                report_status = report_iterator.__next__()
+            lab_batches, paths = [], []
+            for it in fake_labeled_iterators:
+                [[img, gt], _, path] = it.__next__()
+                lab_batches.append((img, gt))
+                paths.append(path)
+            unlab_batch, unl_path = None, None
+            if train_jsd:
+                [[unlab_img, unlab_gt], _, unl_path] = fake_unlabeled_iterator.__next__()
+                unlab_batch = (unlab_img, unlab_gt)
+            elif train_adv:
+                [[unlab_img, unlab_gt], _, unl_path] = fake_unlabeled_iterator.__cache__()   # as :377 does
+                unlab_batch = (unlab_img, unlab_gt)
+            out = self._run_step(lab_batches, unlab_batch, train_jsd, train_adv)
+            for i in range(S):
+                diceMeters[i].add(out['preds'][i], lab_batches[i][1].to(self.device))
+                suplossMeters[i].add(out['sup'][i])
+                if save:
+                    self._save_images(out['preds'][i].max(1)[1], paths[i], 'train', epoch, str(i))
+            if train_jsd:
+                for i in range(S):
+                    unlabdiceMeters[i].add(out['unlab_probs'][i], unlab_batch[1].to(self.device))
+                    if save:
+                        self._save_images(out['unlab_probs'][i].max(1)[1], unl_path, 'unlab', epoch, str(i))
+                jsdlossMeter.add(out['jsd'])
+            if train_adv:
+                advlossMeter.add(out['adv'])
+            if self.use_tqdm and (batch_num % 10 == 0 or batch_num == n_batch - 1):
+                nice_dict = self._report_dict(diceMeters if report_status == 'label' else unlabdiceMeters)
+                n_batch_iter.set_postfix({f'{k}_{k_}': f'{v[k_]:.2f}' for k, v in nice_dict.items() for k_ in v.keys()})
+                n_batch_iter.set_description(report_status + ': ' + ','.join(
+                    [f'L{i}:{suplossMeters[i].value()[0]:.3f}' for i in range(S)]))
+
+        lab_dsc_dict = self._dsc_dict(diceMeters)
+        unlab_dsc_dict = self._dsc_dict(unlabdiceMeters)
+        self.upload_dicts('labeled dataset', lab_dsc_dict, epoch)
+        self.upload_dicts('unlabeled dataset', unlab_dsc_dict, epoch)
+        nice_dict = self._report_dict(diceMeters)
+        if self._is_main():
+            print(f"{desc} " + ', '.join([f'{k}_{k_}:{v[k_]:.2f}' for k, v in nice_dict.items() for k_ in v.keys()]))
+        self.train_loss_summary = dict(sup=[m.value()[0] for m in suplossMeters], jsd=jsdlossMeter.value()[0],
+                                       adv=advlossMeter.value()[0])
+        return torch.stack([torch.stack(diceMeters[i].value()[1], dim=1) for i in range(S)]).cpu(), torch.stack(
+            [torch.stack(unlabdiceMeters[i].value()[1], dim=1) for i in range(S)]).cpu()
+
+    def _dsc_dict(self, meters):
+        vals = [m.value() for m in meters]
+        return {f"S{i}": {f"DSC{n}": float(vals[i][1][0][n]) for n in self.axises} for i in range(len(meters))}
+
+    def _report_dict(self, meters):
+        d = self._dsc_dict(meters)
+        mean = {f"S{i}": {"DSC": float(meters[i].value()[0][0])} for i in range(len(meters))}
+        return dict_merge(d, mean, re=True)
+
+    def _eval_loop(self, val_dataloader, epoch: int, mode: ModelMode = ModelMode.EVAL, save: bool = False):
+        [segmentator.set_mode(mode) for segmentator in self.segmentators]
+        val_dataloader.dataset.set_mode(ModelMode.EVAL)
+        assert not self.segmentators[0].training
+        desc = f">> Validating   ({epoch})"
+        S = self.segmentators.__len__()
+        coefdiceMeters = [DiceMeter(report_axises=self.axises, method='2d', C=self.C) for _ in range(S)]
+        batchdiceMeters = [DiceMeter(report_axises=self.axises, method='3d', C=self.C) for _ in range(S)]
+        vallossMeters = [AverageValueMeter() for _ in range(S)]
+        val_iter = tqdm_(val_dataloader) if self.use_tqdm else val_dataloader
+        for batch_num, [(img, gt), _, path] in enumerate(val_iter):
+            img, gt = img.to(self.device), gt.to(self.device)
+            preds = map_(lambda x: x.predict(img, logit=True), self.segmentators)
+            loss = map_(lambda pred: self.criterions.get('sup')(pred, gt.squeeze(1)), preds)
+            for i in range(S):
+                coefdiceMeters[i].add(preds[i], gt)
+                batchdiceMeters[i].add(preds[i], gt)
+                vallossMeters[i].add(loss[i].detach())
+                if save:
+                    self._save_images(preds[i].max(1)[1], path, 'eval', epoch, str(i))
+        dsc_dict = self._dsc_dict(batchdiceMeters)
+        self.upload_dicts('val_data', dsc_dict, epoch)
+        nice_dict = self._report_dict(batchdiceMeters)
+        if self._is_main():
+            print(f"{desc} " + ', '.join([f'{k}_{k_}: {v[k_]:.2f}' for k, v in nice_dict.items() for k_ in v.keys()]))
+        return torch.stack([torch.stack(coefdiceMeters[i].value()[1], dim=1) for i in range(S)]).cpu(), torch.stack(
+            [torch.stack(batchdiceMeters[i].value()[1], dim=1) for i in range(S)]).cpu()
+
+    # ------------------------------------------------------------------------------ adversarial term
+    def _adv_from_batches(self, segmentators: Sequence[Segmentator], lab_b: Tuple[Tensor, Tensor], unl_img: Tensor,
+                          eplision: float = 0.05) -> Tensor:
+        """KL( a(x_adv) || b(x).detach() ) with x = cat(labeled batch of b, unlabeled batch), x_adv from
+        FGSM on b (:371-392,440-442)."""
+        assert segmentators.__len__() == 2, 'only implemented for 2 segmentators'
+        img_2, gt_2 = lab_b
+        fsgm = self._fsgm_cls(segmentators[1].torchnet, eplision=eplision)
+        img_adv, noise, real_preds = fsgm(torch.cat((img_2, unl_img), dim=0), gt=gt_2, criterion=self.criterions['sup'])
+        adv_preds = segmentators[0].predict(img_adv, logit=False)
+        kl = self._kl_cls(reduce=True)
+        adv_losses = [kl(adv_preds, real_preds.detach())]
+        return sum(adv_losses) / adv_losses.__len__()
+
+    _fsgm_cls = FSGMGenerator
+
+    @property
+    def _kl_cls(self):
+        from ..loss.loss import KL_Divergence_2D
+        return getattr(self, "_kl_override", None) or KL_Divergence_2D
+
+    def _FSGM_adv_training(self, segmentators: Sequence[Segmentator], lab_data_iterators: Sequence[iterator_],
+                           unlab_data_iterator: iterator_, eplision: float = 0.05):
+        """Reference signature (:371-374): re-uses THIS step's batches through ``__cache__``."""
+        assert segmentators.__len__() == 2, 'only implemented for 2 segmentators'
+        [[unl_img, _], _, _] = unlab_data_iterator.__cache__()
+        [[img_2, gt_2], _, _] = lab_data_iterators[1].__cache__()
+        return self._adv_from_batches(segmentators, (img_2.to(self.device), gt_2.to(self.device)),
+                                      unl_img.to(self.device), eplision)
+
+    # ------------------------------------------------------------------------------ misc
+    def _save_images(self, segs: Tensor, names, mode: str, it: int, seg_num=None):
+        from PIL import Image
+        for seg, name in zip(segs, names):
+            p = Path(self.save_dir, f"iter{it:03d}", mode, *( [seg_num] if seg_num is not None else []), name).with_suffix(".png")
+            p.parent.mkdir(parents=True, exist_ok=True)
+            Image.fromarray(seg.cpu().numpy().astype(np.uint8)).save(str(p))
+
+    def upload_dicts(self, name, dicts, epoch):
+        for k, v in dicts.items():
+            self.writer.add_scalars(name + '/' + k, v, epoch)
+
+    def schedulerStep(self):
+        for segmentator in self.segmentators:
+            segmentator.schedulerStep()
+        self.cot_scheduler.step()
+        self.adv_scheduler.step()
+
+    def _load_checkpoint(self, checkpoint):
+        paths = sorted(Path(checkpoint).glob('best_*.pth')) or sorted(Path(checkpoint).glob('last*.pth'))
+        for i, cp in enumerate(paths[:len(self.segmentators)]):
+            state_dict = torch.load(cp, map_location=torch.device('cpu'), weights_only=False)
+            self.segmentators[i].load_state_dict(state_dict['segmentator'])
+            self.best_scores[i] = state_dict['best_score']
+            print(f'>>>  {cp} has been loaded successfully. Best score {self.best_scores[i]:.3f} @ {state_dict["best_epoch"]}.')
+            self.segmentators[i].train()
+
+    def checkpoint(self, metric, epoch, filename='best.pth'):
+        assert isinstance(metric, Tensor)
+        assert metric.__len__() == self.segmentators.__len__()
+        for i, score in enumerate(metric):
+            self.best_score = self.best_scores[i]
+            self.segmentator = self.segmentators[i]
+            super().checkpoint(score, epoch, filename=f'best_{i}.pth')
+            self.best_scores[i] = self.best_score

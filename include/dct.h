@@ -171,6 +171,8 @@ int dct_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, int
                     int accumulate, dct_stream stream);
 /* map[pix] = -sum_c p*log(p+1e-16) */
 int dct_entropy_fwd(const float* probs, float* map, int64_t pixels, int C, dct_stream stream);
+/* dprobs[pix][c] = dmap[pix] * -(log(p+1e-16) + p/(p+1e-16)) */
+int dct_entropy_bwd(const float* probs, const float* dmap, float* dprobs, int64_t pixels, int C, dct_stream stream);
 /* probs-in variants keep the reference module API (JSD_2D()(list_of_probs) -> [B,H,W] map). */
 int dct_jsd_map_fwd(const float* const* probs, int S, float* map, int64_t pixels, int C, dct_stream stream);
 int dct_jsd_map_bwd(const float* const* probs, int S, const float* dmap, float* const* dprobs,
@@ -198,10 +200,11 @@ int dct_fgsm_step(const float* x, const float* g, float eps, float* x_adv, float
 
 /* ---- K12: Adam over one flat fp32 buffer (torch.optim.Adam, segmentators.py:41; step :248) --
  * g' = g + wd*p; m = m + (g'-m)*(1-b1); v = v*b2 + (1-b2)*g'^2;
- * p -= step_size * m / (sqrt(v)/bc2_sqrt + eps)     (host passes step_size = lr/bc1, bc2_sqrt)
+ * p -= step_size * m / (sqrt(v)/bc2_sqrt + eps)     (host passes step_size = lr/bc1, bc2_sqrt;
+ * betas are doubles so that 1-beta is formed in double and then rounded, as torch does)
  * bf16_shadow (nullable): also writes the updated p rounded to bf16 at the same index. */
 int dct_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float step_size,
-                  float bc2_sqrt, float beta1, float beta2, float eps, float weight_decay,
+                  float bc2_sqrt, double beta1, double beta2, float eps, float weight_decay,
                   void* bf16_shadow, dct_stream stream);
 
 /* ---- Dice accumulation on device (metrics/dice_meter.py:12-83) ----------------------------

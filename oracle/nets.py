@@ -103,12 +103,18 @@ class UNet(nn.Module):
             u = getattr(self, f"enc{lvl}").up
             h = torch.cat([h, _resize_bilinear(skips[lvl - 1], h.shape[2:])], 1)
             h = F.relu(u.at(0)(h))
+            if taps is not None:
+                taps[f"e{lvl}a"] = h
             h = F.relu(u.at(2)(h))
+            if taps is not None:
+                taps[f"e{lvl}b"] = h
             h = F.relu(u.at(4)(h))
             if taps is not None:
                 taps[f"enc{lvl}"] = h
         h = torch.cat([h, _resize_bilinear(skips[0], h.shape[2:])], 1)
         h = F.relu(self.enc1.at(0)(h))
+        if taps is not None:
+            taps["e1a"] = h
         h = F.relu(self.enc1.at(2)(h))
         if taps is not None:
             taps["enc1"] = h

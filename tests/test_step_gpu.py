@@ -1,0 +1,123 @@
+"""The co-training step on the GPU (fused HIP path behind CoTrainer._run_step/_train_loop) against
+golden vectors captured from the reference's own CoTrainer._train_loop (tests/golden/g5_step_unet_*)
+and against the CPU oracle.  fp32 mode carries the parity claim."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+from helpers import FakeLoader, batches, digest  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _seeded_state(C, seed):
+    torch.manual_seed(seed)
+    return oracle.build_net("unet", C, dropout_p=0.0).state_dict()
+
+
+def _trainer(tmp_path, g, dtype, n_steps, fused=True):
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    C, H, B = int(g["C"]), int(g["H"]), int(g["B"])
+    segs = []
+    for s in g["net_seeds"]:
+        seg = Segmentator({"name": "unet", "num_classes": C, "compute_dtype": dtype, "dropout_p": 0.0},
+                          {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                          {"name": "StepLR", "step_size": 90, "gamma": 0.1})
+        seg.torchnet.load_state_dict(_seeded_state(C, int(s)))
+        segs.append(seg)
+    lab = [FakeLoader(batches(int(s), n_steps, B, H, C), B) for s in g["lab_seeds"]]
+    unl = FakeLoader(batches(int(g["unl_seed"]), n_steps, B, H, C), B)
+    crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tr = CoTrainer(segmentators=segs, labeled_dataloaders=lab, unlabeled_dataloader=unl, val_dataloader=unl,
+                   criterions=crit, max_epoch=1, save_dir=str(tmp_path), device=DEV, axises=list(range(1, C)),
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": float(g["lam_cot"])},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": float(g["lam_adv"])},
+                   adv_training_dict={"eplision": float(g["eps"])}, use_tqdm=False, steps_per_epoch=n_steps)
+    if not fused:
+        tr._fused_ok = lambda: False
+    return tr, lab, unl
+
+
+@pytest.mark.parametrize("tag", ["g5_step_unet_jsd", "g5_step_unet_adv"])
+def test_train_loop_fp32_matches_reference_golden(golden, tmp_path, tag):
+    from dct_amd import ModelMode
+    g = golden(tag)
+    n, adv = int(g["n_steps"]), bool(int(g["train_adv"]))
+    tr, lab, unl = _trainer(tmp_path, g, torch.float32, n)
+    assert tr._fused_ok()
+    log = []
+    orig = tr._run_step
+
+    def rec(*a, **k):
+        out = orig(*a, **k)
+        log.append(out)
+        return out
+
+    tr._run_step = rec
+    np.random.seed(1234)
+    dice_lab, dice_unl = tr._train_loop(lab, unl, epoch=0, mode=ModelMode.TRAIN, save=False, train_jsd=True, train_adv=adv)
+    assert len(log) == n
+    for k in range(n):
+        # step 0 starts from identical weights: fp32 kernels vs ATen -> 1e-5; later steps inherit Adam's
+        # lr*sign(g)-like first updates (chaotic in the last bits of g) -> 2e-3
+        tol = 1e-5 if k == 0 else 2e-3
+        np.testing.assert_allclose([s.item() for s in log[k]["sup"]], g["sup"][k][:2], rtol=tol)
+        np.testing.assert_allclose(log[k]["jsd"].item(), g["jsd"][k], rtol=max(tol, 1e-4), atol=1e-8)
+        if adv:
+            # FGSM sign() flips where |grad_x| ~ 0 change x_adv by 2*eps on isolated pixels
+            np.testing.assert_allclose(log[k]["adv"].item(), g["adv"][k], rtol=2e-2, atol=1e-7)
+    # _train_loop's return value: per-class (mean, std) of the 2-D Dice, [S, C, 2]
+    assert dice_lab.shape == (2, int(g["C"]), 2)
+    np.testing.assert_allclose(dice_lab[..., 0].numpy(), g["dice_lab"][..., 0], atol=2e-3)
+    np.testing.assert_allclose(dice_unl[..., 0].numpy(), g["dice_unl"][..., 0], atol=2e-3)
+    for j, seg in enumerate(tr.segmentators):
+        names = list(g[f"m{j}_names"])
+        sd = seg.torchnet.state_dict()
+        df = np.stack([digest(sd[k]) for k in names])
+        for col in (1, 2, 3):   # abs-sum, l2, max-abs of every tensor after the last step
+            np.testing.assert_allclose(df[:, col], g[f"m{j}_digest_final"][:, col], rtol=2e-3, atol=1e-5)
+        st = seg.optimizer.state
+        ea = np.stack([digest(st[p]["exp_avg"]) for p in seg.torchnet.parameters()])
+        np.testing.assert_allclose(ea[:, 2], g[f"m{j}_exp_avg_digest"][:, 2], rtol=2e-2, atol=1e-9)
+
+
+def test_fused_and_generic_paths_agree(golden, tmp_path):
+    """same step through (a) the fused kernels + one autograd.backward and (b) the public module
+    APIs (Segmentator.predict, loss modules, FSGMGenerator, total.backward())"""
+    g = golden("g5_step_unet_adv")
+    outs = []
+    for fused in (True, False):
+        tr, lab, unl = _trainer(tmp_path, g, torch.float32, 1, fused=fused)
+        for s in tr.segmentators:
+            s.train()
+        lb = [lab[i][0][0] for i in range(2)]
+        out = tr._run_step([(lb[0][0], lb[0][1]), (lb[1][0], lb[1][1])], (unl[0][0][0], unl[0][0][1]), True, True, (0, 1))
+        w = [digest(torch.cat([p.detach().flatten() for p in s.torchnet.parameters()])) for s in tr.segmentators]
+        outs.append((out, w))
+    (a, wa), (b, wb) = outs
+    np.testing.assert_allclose([s.item() for s in a["sup"]], [s.item() for s in b["sup"]], rtol=1e-6)
+    np.testing.assert_allclose(a["jsd"].item(), b["jsd"].item(), rtol=1e-5)
+    np.testing.assert_allclose(a["adv"].item(), b["adv"].item(), rtol=1e-4)
+    for x, y in zip(wa, wb):
+        np.testing.assert_allclose(x[1:], y[1:], rtol=1e-5)
+
+
+def test_bf16_step_tracks_oracle(tmp_path, golden):
+    """bf16 compute (the benchmarked configuration): losses of the first step vs the fp32 oracle"""
+    g = golden("g5_step_unet_jsd")
+    tr, lab, unl = _trainer(tmp_path, g, torch.bfloat16, 1)
+    for s in tr.segmentators:
+        s.train()
+    lb = [lab[i][0][0] for i in range(2)]
+    out = tr._run_step([(lb[0][0], lb[0][1]), (lb[1][0], lb[1][1])], (unl[0][0][0], unl[0][0][1]), True, False)
+    # bf16 activations: logits carry ~2e-3 relative error -> losses within 1e-2
+    np.testing.assert_allclose([s.item() for s in out["sup"]], g["sup"][0][:2], rtol=1e-2)
+    np.testing.assert_allclose(out["jsd"].item(), g["jsd"][0], rtol=5e-2, atol=1e-6)
+    for s in tr.segmentators:
+        for p in s.torchnet.parameters():
+            assert torch.isfinite(p).all()
