@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Headline benchmark: co-train imgs/sec (lab+unlab), 2xUNet ACDC-shaped 256x256 slices
+(BASELINE.json configs[1]: CE + JSD consistency, bs 8+8 per GPU, bf16), synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (CoTrainer._run_step) over one batch: 2 supervised
+forwards + CE, 2 unlabeled forwards + JSD, one backward through all four graphs, gradient
+all-reduce (N>1), fused Adam on both models.  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line (contract in the task statement), including
+
+  roofline     : dominant conv kernel class -- algorithmic FLOPs / time in
+                 that class measured with HIP events around every launch on its stream
+  cpu_baseline : the CPU oracle's co-training step timed on this host's cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32_TFLOPS = 157.3
+
+CONFIGS = {
+    # name: arch, H, C, B_l, B_u, train_adv, S
+    "cfg2": dict(arch="unet", H=256, C=4, B_l=8, B_u=8, train_adv=False, S=2,
+                 desc="2xUNet co-training (CE + JSD), ACDC-shaped 256x256 C=4, bs 8+8 per GPU"),
+    "cfg3": dict(arch="unet", H=256, C=4, B_l=8, B_u=8, train_adv=True, S=2,
+                 desc="2xUNet co-training (CE + JSD + FGSM eps .03), 256x256 C=4, bs 8+8 per GPU"),
+}
+
+
+def unet_conv_flops(H: int, W: int, C: int):
+    """Forward conv+convT FLOPs (2*MAC) of one image through the reference UNet, split into the part
+    the MFMA implicit-GEMM kernels execute and the small stem/head layers.  256x256/C=4 -> 34.51 GF."""
+    gemm = 0.0
+    small = 0.0
+    h, w, cin = H, W, 1
+    skips = []
+    for lvl, width in enumerate((64, 128, 256, 512)):
+        f = 2.0 * (h - 2) * (w - 2) * 9 * cin * width
+        if lvl == 0:
+            small += f
+        else:
+            gemm += f
+        gemm += 2.0 * (h - 4) * (w - 4) * 9 * width * width
+        h, w, cin = (h - 4 + 1) // 2, (w - 4 + 1) // 2, width
+    gemm += 2.0 * (h - 2) * (w - 2) * 9 * 512 * 1024 + 2.0 * (h - 4) * (w - 4) * 9 * 1024 * 1024
+    gemm += 2.0 * (h - 4) * (w - 4) * 4 * 1024 * 512
+    h, w = 2 * (h - 4), 2 * (w - 4)
+    for ci, feat, co in ((1024, 512, 256), (512, 256, 128), (256, 128, 64)):
+        gemm += 2.0 * (h - 2) * (w - 2) * 9 * ci * feat + 2.0 * (h - 4) * (w - 4) * 9 * feat * feat
+        gemm += 2.0 * (h - 4) * (w - 4) * 4 * feat * co
+        h, w = 2 * (h - 4), 2 * (w - 4)
+    gemm += 2.0 * (h - 2) * (w - 2) * 9 * 128 * 64 + 2.0 * (h - 4) * (w - 4) * 9 * 64 * 64
+    small += 2.0 * (h - 4) * (w - 4) * 64 * C
+    return gemm, small
+
+
+def make_trainer(cfg, dtype, device, rank, world, grad_sync_factory, n_batches=4):
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    from helpers import FakeLoader
+    S, C, H = cfg["S"], cfg["C"], cfg["H"]
+    torch.manual_seed(1234)        # identical initial weights on every rank
+    segs = [Segmentator({"name": cfg["arch"], "num_classes": C, "compute_dtype": dtype},
+                        {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                        {"name": "StepLR", "step_size": 90, "gamma": 0.1}) for _ in range(S)]
+
+    def dev_batches(seed, B):
+        g = torch.Generator().manual_seed(seed)
+        out = []
+        for i in range(n_batches):
+            img = torch.rand(B, 1, H, H, generator=g).to(device)
+            gt = torch.randint(0, C, (B, 1, H, H), generator=g).to(device)
+            out.append([[img, gt], None, [f"r{rank}_{seed}_{i}_{j}" for j in range(B)]])
+        return out
+
+    base = 1234 + 1000 * rank      # reference default seed (config/ACDC_config_cotraing.yaml:79) + rank
+    lab = [FakeLoader(dev_batches(base + 1 + i, cfg["B_l"]), cfg["B_l"]) for i in range(S)]
+    unl = FakeLoader(dev_batches(base + 99, cfg["B_u"]), cfg["B_u"])
+    crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tr = CoTrainer(segs, lab, unl, unl, crit, max_epoch=1, save_dir=tempfile.mkdtemp(prefix="dct_bench_"),
+                   device=str(device), axises=list(range(1, C)),
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False)
+    for i, s in enumerate(segs):
+        s.train()
+        if hasattr(s.torchnet, "dropout_seed"):
+            s.torchnet.dropout_seed += 7919 * (rank * S + i)
+    if world > 1:
+        tr.grad_sync = grad_sync_factory(segs)
+    return tr, lab, unl
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """The oracle's step (fp32, ATen CPU kernels = what the reference executes) on a bounded sample."""
+    import oracle
+    S, C, H = cfg["S"], cfg["C"], cfg["H"]
+    B = 1
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    models = []
+    for s in range(S):
+        torch.manual_seed(100 + s)
+        models.append(oracle.OracleModel.make(oracle.build_net(cfg["arch"], C).train()))
+    g = torch.Generator().manual_seed(5)
+    lab = [(torch.rand(B, 1, H, H, generator=g), torch.randint(0, C, (B, 1, H, H), generator=g)) for _ in range(S)]
+    unl = torch.rand(B, 1, H, H, generator=g)
+
+    def step():
+        oracle.cotrain_step(models, lab, unl, True, cfg["train_adv"], lam_cot=0.5, lam_adv=0.05, eps=0.03)
+
+    step()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < seconds_budget * 0.5 and n < 12):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    imgs = S * B + B
+    return {"value": imgs / dt, "unit": "imgs/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32 restatement of the reference step) {S}x{cfg['arch']} {H}x{H} C={C}, "
+                      f"bs {B}+{B} ({imgs} imgs/step), {n} timed steps after 1 warm-up, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        from dct_amd import ddp
+        ddp.init_from_env("nccl")
+
+    from dct_amd import _lib
+    cfg = CONFIGS[args.config]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    def sync_factory(segs):
+        from dct_amd.ddp import FlatGradSync
+        return FlatGradSync(segs)
+
+    tr, lab, unl = make_trainer(cfg, dtype, device, rank, world, sync_factory)
+    S = cfg["S"]
+    nb = len(unl)
+
+    def one_step(i):
+        lb = [(lab[m][i % nb][0][0], lab[m][i % nb][0][1]) for m in range(S)]
+        ub = (unl[i % nb][0][0], unl[i % nb][0][1])
+        return tr._run_step(lb, ub, True, cfg["train_adv"], (0, 1) if cfg["train_adv"] else None)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    use_events = not args.no_kernel_events
+    if use_events:
+        _lib.prof_read(reset=True)
+        _lib.prof_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if use_events:
+        _lib.prof_enable(False)
+        prof = _lib.prof_read(reset=True)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = dict(sup=[float(s) for s in out["sup"]], jsd=float(out["jsd"]))
+    assert all(v == v for v in losses["sup"]) and losses["jsd"] == losses["jsd"], "NaN loss in the timed region"
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    imgs_per_step = S * cfg["B_l"] + cfg["B_u"]
+    value = imgs_per_step * world / (elapsed / args.steps)
+
+    result = {
+        "metric": "co-train imgs/sec/node (lab+unlab), 2xUNet ACDC 256x256",
+        "value": value, "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.config}: {cfg['desc']}", "imgs_per_step_per_gpu": imgs_per_step,
+                   "global_batch": f"{cfg['B_l'] * world}+{cfg['B_u'] * world}", "parallelism": f"dp{world}",
+                   "weights": "random init (xavier_normal), reference architecture"},
+        "losses_last_step": losses,
+    }
+    if rank == 0:
+        if prof is not None:
+            gemm_f, small_f = unet_conv_flops(cfg["H"], cfg["H"], cfg["C"])
+            passes = S * (cfg["B_l"] + cfg["B_u"])                      # image-passes with fwd+dgrad+wgrad
+            fgsm_imgs = (cfg["B_l"] + cfg["B_u"]) if cfg["train_adv"] else 0
+            # per step: igemm class runs fwd + dgrad (2F per image-pass); wgrad class runs F per image-pass;
+            # FGSM adds one fwd+dgrad pass on model b (no wgrad) and one full pass on model a
+            flops = {"igemm": (passes + 2 * fgsm_imgs) * 2 * gemm_f, "wgrad": (passes + fgsm_imgs) * gemm_f}
+            per = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps}
+                   for k, v in prof.items()}
+            dom = max(("igemm", "wgrad"), key=lambda k: per[k]["ms_per_step"])
+            ach = flops[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e12
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+            result["roofline"] = {
+                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "kernel": {"igemm": "igemm_kernel (conv fwd + data-grad implicit GEMM, incl. split-K epilogue)",
+                           "wgrad": "wgrad_kernel (weight-grad GEMM, incl. fixed-order reduce)"}[dom],
+                "algorithmic_flops_per_step": flops[dom], "kernel_ms_per_step": per[dom]["ms_per_step"],
+                "avg_launch_us": 1e3 * per[dom]["ms_per_step"] / max(per[dom]["launches_per_step"], 1),
+                "conv_stack": {"achieved": (flops["igemm"] + flops["wgrad"]) /
+                               ((per["igemm"]["ms_per_step"] + per["wgrad"]["ms_per_step"]) * 1e-3) / 1e12,
+                               "unit": "TFLOP/s"},
+                "per_class_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in per.items()},
+                "measured": "HIP events around every launch on the launch stream, inside the timed region",
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

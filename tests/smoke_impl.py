@@ -1,4 +1,6 @@
 """__graft_entry__.smoke(): one small co-training step on cuda:0, checked against the CPU oracle."""
+import os
+import sys
 import tempfile
 
 import numpy as np
@@ -10,6 +12,7 @@ def run_smoke():
     from dct_amd.loss import get_loss_fn
     from dct_amd.models import Segmentator
     from dct_amd.trainer import CoTrainer
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from helpers import FakeLoader, batches
     C, H, B = 4, 176, 1
     segs, omodels = [], []
