@@ -106,12 +106,26 @@ def make_trainer(cfg, dtype, device, rank, world, grad_sync_factory, n_batches=4
     return tr, lab, unl
 
 
+def host_cores() -> int:
+    """Cores this process may actually use: scheduler affinity capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host on the GPU boxes and oversubscribes ATen's pool)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(cfg, seconds_budget=25.0):
-    """The oracle's step (fp32, ATen CPU kernels = what the reference executes) on a bounded sample."""
+    """The oracle's step (fp32, ATen CPU kernels = what the reference executes) on a bounded sample:
+    bs 1+1, one warm-up step, then as many timed steps as fit the budget (at least one)."""
     import oracle
     S, C, H = cfg["S"], cfg["C"], cfg["H"]
     B = 1
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     torch.set_num_threads(threads)
     models = []
     for s in range(S):
@@ -124,16 +138,19 @@ def cpu_baseline(cfg, seconds_budget=25.0):
     def step():
         oracle.cotrain_step(models, lab, unl, True, cfg["train_adv"], lam_cot=0.5, lam_adv=0.05, eps=0.03)
 
+    t0 = time.perf_counter()
     step()  # warm-up
+    warm = time.perf_counter() - t0
     n, t0 = 0, time.perf_counter()
-    while n < 3 or (time.perf_counter() - t0 < seconds_budget * 0.5 and n < 12):
+    while n < 1 or (n < 8 and (time.perf_counter() - t0) + warm * 1.2 < seconds_budget - warm):
         step()
         n += 1
     dt = (time.perf_counter() - t0) / n
     imgs = S * B + B
     return {"value": imgs / dt, "unit": "imgs/sec", "cores": threads, "kind": "port",
             "sample": f"oracle (PyTorch-CPU fp32 restatement of the reference step) {S}x{cfg['arch']} {H}x{H} C={C}, "
-                      f"bs {B}+{B} ({imgs} imgs/step), {n} timed steps after 1 warm-up, {dt:.2f} s/step"}
+                      f"bs {B}+{B} ({imgs} imgs/step), {n} timed steps after 1 warm-up, {dt:.2f} s/step, "
+                      f"{threads} threads"}
 
 
 def main():

@@ -96,6 +96,7 @@ SIGNATURES = {
     "dct_fgsm_step": (_i, [_P, _P, _f, _P, _P, _i64, _P]),
     "dct_adam_flat": (_i, [_P, _P, _P, _P, _i64, _f, _f, C.c_double, C.c_double, _f, _f, _P, _P]),
     "dct_dice_counts": (_i, [_P, _P, _i, _i64, _i, _P, _P, _P, _P]),
+    "dct_tune_set": (_i, [_i, _i]),
     "dct_prof_enable": (_i, [_i]),
     "dct_prof_read": (_i, [_P, _P, _i]),
 }

@@ -92,6 +92,8 @@ class UNet(nn.Module):
     (v_mfma_f32_32x32x2_f32; the parity mode).  ``dropout_p`` is the p of the two
     ``nn.Dropout`` sites (network.py:165,210)."""
 
+    batch_independent = True   # no BatchNorm: samples of a batch never interact
+
     def __init__(self, in_channels: int = 1, num_classes: int = 2, compute_dtype=torch.bfloat16,
                  dropout_p: float = 0.5):
         super().__init__()

@@ -232,6 +232,144 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 main kernel ("v2"): K-step of 64 elements (128-B LDS rows), tiles staged straight from HBM
+// into LDS by global_load_lds_dwordx4 (no VGPR round trip), two LDS stages, one barrier per
+// K-step.  One wave-instruction fills 8 rows x 128 B; the LDS image is lane-linear, so the
+// bank-conflict swizzle is applied to the per-lane SOURCE chunk and again on the fragment read:
+// 16-B chunk c of row r lives at slot c ^ ((r >> 1) & 7), which makes every ds_read_b128 lane group
+// hit 16 distinct 16-B slots of the 256-B bank row.  Out-of-image taps (data-gradient halo) read a
+// 128-B zero page instead of branching around the DMA; rows past M are clamped to the last pixel
+// (their results are never stored).
+__device__ __attribute__((aligned(128))) const uint4 g_zero_page[8] = {};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BOUNDS>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmParams p) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int ROWB = 128;                 // bytes per LDS row = 64 bf16 of K
+  constexpr int BK = 64;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int RPP = NW * 8;               // rows staged per pass (8 per wave-instruction)
+  constexpr int PA = BN / RPP, PB = BM / RPP;
+  static_assert(BN % RPP == 0 && BM % RPP == 0 && TM >= 1 && TN >= 1, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / WAVES_M, wm = wave % WAVES_M;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int srow = wave * 8 + (lane >> 3);                 // staging row within a pass
+  const int schunk = (lane & 7) ^ ((srow >> 1) & 7);       // source chunk for this lane's LDS slot
+  const long long Ktot = (long long)p.R * p.S * p.Cin;
+
+  long long rowoff[PB];
+  int biy0[PB], bix0[PB];
+#pragma unroll
+  for (int pp = 0; pp < PB; ++pp) {
+    int m = m0 + srow + RPP * pp;
+    if (m >= p.M) m = p.M - 1;
+    const int hw = p.Ho * p.Wo;
+    const int n = m / hw, rem = m - n * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
+    rowoff[pp] = n * p.xsN + iy0 * p.xsH + ix0 * p.xsW + schunk * 8;
+    biy0[pp] = iy0; bix0[pp] = ix0;
+  }
+  const bf16_t* wrow = reinterpret_cast<const bf16_t*>(p.w) + (long long)(n0 + srow) * Ktot + schunk * 8;
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
+
+  const int kbeg = blockIdx.z * p.kiters_per_split;
+  const int kend = min(p.kiters, kbeg + p.kiters_per_split);
+  int tap = kbeg / p.cin_iters;
+  int cit = kbeg - tap * p.cin_iters;
+  int r = tap / p.S, s = tap - r * p.S;
+
+  auto stage = [&](char* buf) {
+    const int c0 = cit * BK;
+    const long long woff = (long long)(r * p.S + s) * p.Cin + c0;
+    char* la = buf + wave * 8 * ROWB;
+#pragma unroll
+    for (int pp = 0; pp < PA; ++pp)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wrow + (long long)pp * RPP * Ktot + woff), (lptr_t)(la + pp * RPP * ROWB), 16, 0, 0);
+    char* lb = buf + (BN + wave * 8) * ROWB;
+    const long long toff = (long long)(r * p.dil) * p.xsH + (long long)(s * p.dil) * p.xsW + c0;
+#pragma unroll
+    for (int pp = 0; pp < PB; ++pp) {
+      const char* src = reinterpret_cast<const char*>(xb + rowoff[pp] + toff);
+      if (BOUNDS) {
+        const int iy = biy0[pp] + r * p.dil, ix = bix0[pp] + s * p.dil;
+        if (!((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)) src = zero;
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lb + pp * RPP * ROWB), 16, 0, 0);
+    }
+    if (++cit == p.cin_iters) { cit = 0; if (++s == p.S) { s = 0; ++r; } }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (kbeg < kend) stage(smem);
+  __syncthreads();
+  int cur = 0;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int swz = (l31 >> 1) & 7;
+  for (int it = kbeg; it < kend; ++it) {
+    if (it + 1 < kend) stage(smem + (cur ^ 1) * STAGE);
+    const char* A = smem + cur * STAGE + (wn * WTN + l31) * ROWB;
+    const char* B = smem + cur * STAGE + (BN + wm * WTM + l31) * ROWB;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int coff = ((2 * kk + half) ^ swz) * 16;
+      bf16x8 a[TN], b[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) a[i] = *reinterpret_cast<const bf16x8*>(A + i * 32 * ROWB + coff);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) b[j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * ROWB + coff);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wm * WTM + j * 32 + l31;
+    if (m >= p.M) continue;
+    const int hw = p.Ho * p.Wo;
+    const int n = m / hw, rem = m - n * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = n0 + wn * WTN + i * 32 + 8 * q + 4 * half;
+        float v[4] = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        if (p.partial) {
+          float* pp = p.partial + ((long long)blockIdx.z * p.M + m) * p.N + c;
+          *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          epilogue_store4<bf16_t>(p, n, oy, ox, c, v);
+        }
+      }
+    }
+  }
+}
+
 // Sum split-K partial slabs and apply the epilogue.  One thread per (pixel, 4 channels).
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmParams p, int splits) {
@@ -253,34 +391,72 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmParams p, int
 }
 
 struct Plan {
-  int bn, bm, splits, kiters, kiters_per_split;
+  int bn, bm, splits, kiters, kiters_per_split, bk;
+  int v2;       // 1: igemm2_kernel (bf16, Cin % 64 == 0)
+  int bounds;   // v2: some tap can fall outside the input
   long long tiles;
 };
 
+int g_tune_igemm_v2 = 1;        // dct_tune_set(DCT_TUNE_IGEMM_V2, 0) forces the register-staged kernel
+int g_tune_igemm_split = -1;    // >= 1 forces the split-K factor
+
 static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int M, int N, Plan& pl) {
-  const int bk = dtype == DCT_BF16 ? 32 : 16;
-  if (x->c % bk != 0) return false;
+  const int bk0 = dtype == DCT_BF16 ? 32 : 16;
+  if (x->c % bk0 != 0) return false;
   if (N % 64 != 0) return false;
-  pl.bn = (N % 128 == 0) ? 128 : 64;
-  pl.bm = 128;
-  pl.kiters = d->R * d->S * (x->c / bk);
+  pl.v2 = (dtype == DCT_BF16 && x->c % 64 == 0 && g_tune_igemm_v2) ? 1 : 0;
+  if (pl.v2) {
+    pl.bk = 64;
+    if (N % 128 == 0) { pl.bn = 128; pl.bm = 128; } else { pl.bn = 64; pl.bm = 256; }
+    const int Ho = d->scatter2x2 ? y->h / 2 : y->h, Wo = d->scatter2x2 ? y->w / 2 : y->w;
+    const bool inside = d->pad_h == 0 && d->pad_w == 0 &&
+                        (Ho - 1) * d->stride + (d->R - 1) * d->dil < x->h &&
+                        (Wo - 1) * d->stride + (d->S - 1) * d->dil < x->w;
+    pl.bounds = inside ? 0 : 1;
+  } else {
+    pl.bk = bk0;
+    pl.bn = (N % 128 == 0) ? 128 : 64;
+    pl.bm = 128;
+    pl.bounds = 1;
+  }
+  pl.kiters = d->R * d->S * (x->c / pl.bk);
   pl.tiles = (long long)div_up(M, pl.bm) * (N / pl.bn);
   int splits = 1;
+  const int min_steps = pl.v2 ? 3 : 4;   // K-steps each split must keep
   if (pl.tiles < 384) {
     splits = (int)((768 + pl.tiles - 1) / pl.tiles);
     if (splits > 16) splits = 16;
-    // keep at least 4 K-steps per split
-    while (splits > 1 && pl.kiters / splits < 4) --splits;
+    while (splits > 1 && pl.kiters / splits < min_steps) --splits;
   }
+  if (g_tune_igemm_split >= 1) splits = g_tune_igemm_split;
+  if (splits > pl.kiters) splits = pl.kiters;
   pl.kiters_per_split = (pl.kiters + splits - 1) / splits;
   pl.splits = (pl.kiters + pl.kiters_per_split - 1) / pl.kiters_per_split;
   return true;
 }
 
+template <int BM, int BN, int WM, int WN, bool BOUNDS>
+static void launch_v2(const IgemmParams& p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+  static bool attr_set = false;   // idempotent one-time opt-in to > 64 KiB dynamic LDS
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, BOUNDS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm2_kernel<BM, BN, WM, WN, BOUNDS>), grid, dim3(WM * WN * 64), lds, st, p);
+}
+
 template <typename T>
 static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
   dim3 grid(div_up(p.M, pl.bm), p.N / pl.bn, pl.splits);
-  if (pl.bn == 128) {
+  if (pl.v2) {
+    if (pl.bn == 128) {
+      if (pl.bounds) launch_v2<128, 128, 2, 2, true>(p, grid, st); else launch_v2<128, 128, 2, 2, false>(p, grid, st);
+    } else {
+      if (pl.bounds) launch_v2<256, 64, 4, 1, true>(p, grid, st); else launch_v2<256, 64, 4, 1, false>(p, grid, st);
+    }
+  } else if (pl.bn == 128) {
     DCT_LAUNCH(DCT_PROF_IGEMM, (igemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, p);
   } else {
     DCT_LAUNCH(DCT_PROF_IGEMM, (igemm_kernel<T, 64, 128>), grid, dim3(256), 0, st, p);
@@ -352,7 +528,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   }
   p.relu = d->relu; p.accumulate = d->accumulate;
   p.kiters = pl.kiters; p.kiters_per_split = pl.kiters_per_split;
-  p.cin_iters = x->c / (dtype == DCT_BF16 ? 32 : 16);
+  p.cin_iters = x->c / pl.bk;
   p.partial = nullptr;
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * p.M * p.N * sizeof(float);
@@ -361,4 +537,12 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   }
   hipStream_t st = (hipStream_t)stream;
   return dtype == DCT_BF16 ? launch<bf16_t>(p, pl, st) : launch<float>(p, pl, st);
+}
+
+extern "C" int dct_tune_set(int knob, int value) {
+  switch (knob) {
+    case DCT_TUNE_IGEMM_V2: g_tune_igemm_v2 = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_SPLIT: g_tune_igemm_split = value; return DCT_OK;
+    default: return DCT_ERR_BAD_ARG;
+  }
 }

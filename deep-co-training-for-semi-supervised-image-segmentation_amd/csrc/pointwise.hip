@@ -141,53 +141,6 @@ __global__ __launch_bounds__(256) void stem_dgrad_kernel(View dy, const float* w
   if (id.ok && id.cv == 0) reinterpret_cast<float*>(dx.ptr)[voff(dx, id.n, id.y, id.x)] = a;
 }
 
-// partial[blk][co][taps+1]: dw taps then db.  Threads: co = tid % cout, sub = tid / cout.
-template <typename T>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(View x, View dy, float* partial, StemGeom g, int pix_per_block) {
-  __shared__ float red[256 * 10];
-  const int taps = g.R * g.S;  // <= 9
-  const int co = threadIdx.x % g.cout, sub = threadIdx.x / g.cout, subs = 256 / g.cout;
-  const long long P = (long long)dy.n * dy.h * dy.w;
-  const long long pbeg = (long long)blockIdx.x * pix_per_block, pend = min(P, pbeg + pix_per_block);
-  float acc[10];
-#pragma unroll
-  for (int t = 0; t < 10; ++t) acc[t] = 0.f;
-  const float* xp = reinterpret_cast<const float*>(x.ptr);
-  for (long long pix = pbeg + sub; pix < pend; pix += subs) {
-    const int hw = dy.h * dy.w;
-    const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
-    const int oy = rem / dy.w, ox = rem - oy * dy.w;
-    const float d = to_f32(reinterpret_cast<const T*>(dy.ptr)[voff(dy, n, oy, ox) + co]);
-    for (int r = 0; r < g.R; ++r)
-      for (int s = 0; s < g.S; ++s) {
-        const int iy = oy * g.stride + r * g.dil - g.pad_h, ix = ox * g.stride + s * g.dil - g.pad_w;
-        const float xv = ((unsigned)iy < (unsigned)x.h && (unsigned)ix < (unsigned)x.w) ? xp[voff(x, n, iy, ix)] : 0.f;
-        acc[r * g.S + s] = fmaf(d, xv, acc[r * g.S + s]);
-      }
-    acc[9] += d;
-  }
-#pragma unroll
-  for (int t = 0; t < 10; ++t) red[t * 256 + threadIdx.x] = acc[t];
-  __syncthreads();
-  if (sub == 0) {
-    for (int t = 0; t < 10; ++t) {
-      float s = 0.f;
-      for (int k = 0; k < subs; ++k) s += red[t * 256 + k * g.cout + co];
-      if (t < taps) partial[((long long)blockIdx.x * g.cout + co) * (taps + 1) + t] = s;
-      else if (t == 9) partial[((long long)blockIdx.x * g.cout + co) * (taps + 1) + taps] = s;
-    }
-  }
-}
-__global__ void stem_wgrad_reduce_kernel(const float* partial, float* dw, float* db, int cout, int taps, int blocks, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= cout * (taps + 1)) return;
-  const int co = i / (taps + 1), t = i % (taps + 1);
-  float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[(long long)b * cout * (taps + 1) + i];
-  if (t < taps) { if (dw) dw[co * taps + t] = (accumulate ? dw[co * taps + t] : 0.f) + s; }
-  else if (db) db[co] = (accumulate ? db[co] : 0.f) + s;
-}
-
 // ---- classifier head -----------------------------------------------------------------------
 // y[pix][co] = sum_ci x[pix][ci]*w[co][ci] + b[co];  thread per pixel, cout <= 8
 template <typename T, int VEC>
@@ -241,56 +194,6 @@ __global__ __launch_bounds__(256) void head_dx_kernel(View x, View dy, const flo
   }
   VecIO<T, VEC>::store(reinterpret_cast<T*>(dx.ptr) + voff(dx, id.n, id.y, id.x) + id.cv * VEC, out);
 }
-// partial[blk][co][cin+1]; threads: ci = tid % cin, sub = tid / cin  (cin divides 256)
-template <typename T>
-__global__ __launch_bounds__(256) void head_dw_kernel(View x, View dy, float* partial, int pix_per_block) {
-  __shared__ float red[256];
-  const int cin = x.c, cout = dy.c;
-  const int ci = threadIdx.x % cin, sub = threadIdx.x / cin, subs = 256 / cin;
-  const long long P = (long long)x.n * x.h * x.w;
-  const long long pbeg = (long long)blockIdx.x * pix_per_block, pend = min(P, pbeg + pix_per_block);
-  float acc[8], accb[8];
-#pragma unroll
-  for (int o = 0; o < 8; ++o) { acc[o] = 0.f; accb[o] = 0.f; }
-  for (long long pix = pbeg + sub; pix < pend; pix += subs) {
-    const int hw = x.h * x.w;
-    const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
-    const int yy = rem / x.w, xx = rem - yy * x.w;
-    const float xv = to_f32(reinterpret_cast<const T*>(x.ptr)[voff(x, n, yy, xx) + ci]);
-    const float* dp = reinterpret_cast<const float*>(dy.ptr) + voff(dy, n, yy, xx);
-#pragma unroll
-    for (int o = 0; o < 8; ++o)
-      if (o < cout) { const float d = dp[o]; acc[o] = fmaf(d, xv, acc[o]); accb[o] += d; }
-  }
-  for (int o = 0; o < cout; ++o) {
-    red[threadIdx.x] = acc[o];
-    __syncthreads();
-    if (sub == 0) {
-      float s = 0.f;
-      for (int k = 0; k < subs; ++k) s += red[k * cin + ci];
-      partial[((long long)blockIdx.x * cout + o) * (cin + 1) + ci] = s;
-    }
-    __syncthreads();
-    red[threadIdx.x] = accb[o];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float s = 0.f;
-      for (int k = 0; k < subs; ++k) s += red[k * cin];  // ci == 0 column holds every pixel once
-      partial[((long long)blockIdx.x * cout + o) * (cin + 1) + cin] = s;
-    }
-    __syncthreads();
-  }
-}
-__global__ void head_dw_reduce_kernel(const float* partial, float* dw, float* db, int cout, int cin, int blocks, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= cout * (cin + 1)) return;
-  const int o = i / (cin + 1), c = i % (cin + 1);
-  float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[(long long)b * cout * (cin + 1) + i];
-  if (c < cin) { if (dw) dw[o * cin + c] = (accumulate ? dw[o * cin + c] : 0.f) + s; }
-  else if (db) db[o] = (accumulate ? db[o] : 0.f) + s;
-}
-
 // ---- max pool 2x2 s2 ceil ------------------------------------------------------------------
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(View x, View y) {
@@ -544,31 +447,6 @@ extern "C" int dct_conv_cin1_dgrad(const dct_view* dy, const float* w, const dct
   return dct_check_launch();
 }
 
-extern "C" size_t dct_conv_cin1_wgrad_workspace_bytes(const dct_view* dy, const dct_conv_desc* d) {
-  if (!dy || !d) return 0;
-  int ppb;
-  const int blocks = pix_blocks((long long)dy->n * dy->h * dy->w, ppb, 1024, 2048);
-  return (size_t)blocks * dy->c * (d->R * d->S + 1) * sizeof(float);
-}
-extern "C" int dct_conv_cin1_wgrad(const dct_view* x, const dct_view* dy, float* dw, float* db,
-                                   const dct_conv_desc* d, int accumulate, int dtype,
-                                   void* workspace, size_t workspace_bytes, dct_stream stream) {
-  if (!view_ok(x) || !view_ok(dy) || !d || x->c != 1 || x->n != dy->n) return DCT_ERR_BAD_ARG;
-  if (d->R * d->S > 9 || dy->c > 256 || 256 % dy->c) return DCT_ERR_UNSUPPORTED;
-  int ppb;
-  const int blocks = pix_blocks((long long)dy->n * dy->h * dy->w, ppb, 1024, 2048);
-  const int taps = d->R * d->S;
-  if (!workspace || workspace_bytes < (size_t)blocks * dy->c * (taps + 1) * sizeof(float)) return DCT_ERR_WORKSPACE;
-  const StemGeom g = stem_geom(d, dy->c);
-  hipStream_t st = (hipStream_t)stream;
-  DISPATCH_T(dtype, {
-    DCT_LAUNCH(DCT_PROF_POINTWISE, stem_wgrad_kernel<T>, dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
-  });
-  DCT_LAUNCH(DCT_PROF_POINTWISE, stem_wgrad_reduce_kernel, dim3(div_up(dy->c * (taps + 1), 256)), dim3(256), 0, st,
-             (const float*)workspace, dw, db, dy->c, taps, blocks, accumulate);
-  return dct_check_launch();
-}
-
 extern "C" int dct_conv1x1_head_fwd(const dct_view* x, const float* w, const float* bias, const dct_view* y,
                                     int dtype, dct_stream stream) {
   if (!view_ok(x) || !view_ok(y) || !w || !same_nhw(x, y)) return DCT_ERR_BAD_ARG;
@@ -583,17 +461,14 @@ extern "C" int dct_conv1x1_head_fwd(const dct_view* x, const float* w, const flo
   return dct_check_launch();
 }
 
-extern "C" size_t dct_conv1x1_head_bwd_workspace_bytes(const dct_view* x, int cout) {
-  if (!x) return 0;
-  int ppb;
-  const int blocks = pix_blocks((long long)x->n * x->h * x->w, ppb, 1024, 1024);
-  return (size_t)blocks * cout * (x->c + 1) * sizeof(float);
-}
+int dct_head_dw_launch(const dct_view* x, const dct_view* dy, float* dw, float* db, int accumulate, int dtype,
+                       void* workspace, size_t workspace_bytes, hipStream_t st);  // reduce.hip
+
 extern "C" int dct_conv1x1_head_bwd(const dct_view* x, const dct_view* dy, const float* w, const dct_view* dx,
                                     float* dw, float* db, int relu_mask, int accumulate, int dtype,
                                     void* workspace, size_t workspace_bytes, dct_stream stream) {
   if (!view_ok(x) || !view_ok(dy) || !w || !same_nhw(x, dy)) return DCT_ERR_BAD_ARG;
-  if (dy->c > 8 || x->c > 256 || 256 % x->c) return DCT_ERR_UNSUPPORTED;
+  if (dy->c > 8) return DCT_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = (size_t)(dy->c * x->c) * sizeof(float);
   if (dx) {
@@ -605,14 +480,8 @@ extern "C" int dct_conv1x1_head_bwd(const dct_view* x, const dct_view* dy, const
     });
   }
   if (dw || db) {
-    int ppb;
-    const int blocks = pix_blocks((long long)x->n * x->h * x->w, ppb, 1024, 1024);
-    if (!workspace || workspace_bytes < (size_t)blocks * dy->c * (x->c + 1) * sizeof(float)) return DCT_ERR_WORKSPACE;
-    DISPATCH_T(dtype, {
-      DCT_LAUNCH(DCT_PROF_POINTWISE, head_dw_kernel<T>, dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, ppb);
-    });
-    DCT_LAUNCH(DCT_PROF_POINTWISE, head_dw_reduce_kernel, dim3(div_up(dy->c * (x->c + 1), 256)), dim3(256), 0, st,
-               (const float*)workspace, dw, db, dy->c, x->c, blocks, accumulate);
+    const int rc = dct_head_dw_launch(x, dy, dw, db, accumulate, dtype, workspace, workspace_bytes, st);
+    if (rc != DCT_OK) return rc;
   }
   return dct_check_launch();
 }

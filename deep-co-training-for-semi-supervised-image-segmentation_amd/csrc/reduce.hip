@@ -1,0 +1,371 @@
+// Reductions over pixels (HBM-bound): bias gradient, Cin=1 stem weight gradient, classifier-head
+// weight gradient.  All three stream a [pixels][C] activation once with 16-byte channel-vector
+// loads (a wave reads whole 128-B+ channel runs of consecutive pixels), keep per-thread partial
+// sums in registers, fold them across the block through shuffles/LDS and write one partial
+// row per block; a second tiny kernel sums the block partials in fixed order (deterministic,
+// "+=" into the existing gradient folded in).
+//
+// Thread layout: tid = row * CV + cv with CV = C / VEC channel vectors; `rows` = 256 / CV pixels
+// are in flight per block iteration.
+#include "dct_common.h"
+
+namespace {
+
+template <typename T> struct Vec;
+template <> struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+  }
+};
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  __device__ static __forceinline__ void load(const float* p, float* v) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+};
+
+// element offset of flat pixel index `pix` in an NHWC view
+__device__ __forceinline__ long long pix_off(const View& v, long long pix, int linear) {
+  if (linear) return pix * v.sw;
+  const int hw = v.h * v.w;
+  const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+  const int y = rem / v.w, x = rem - y * v.w;
+  return n * v.sn + y * v.sh + x * v.sw;
+}
+static inline int view_linear(const dct_view* v) {
+  return (v->sh == (long long)v->w * v->sw && v->sn == (long long)v->h * v->sh) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------- bias grad
+// partial[blk][c] = sum over the block's pixels of dy[pix][c]
+template <typename T>
+__global__ __launch_bounds__(256) void bias_partial_kernel(View dy, float* partial, int ppb, int linear) {
+  constexpr int VEC = Vec<T>::N;
+  __shared__ float red[256 * VEC];
+  const int C = dy.c;
+  const int CV = C / VEC;               // <= 256, divides 256
+  const int rows = 256 / CV;
+  const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
+  const long long P = (long long)dy.n * dy.h * dy.w;
+  const long long pbeg = (long long)blockIdx.x * ppb, pend = min(P, pbeg + ppb);
+  const T* base = reinterpret_cast<const T*>(dy.ptr) + cv * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  long long pix = pbeg + row;
+  for (; pix + 3 * rows < pend; pix += 4 * rows) {
+    float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+    Vec<T>::load(base + pix_off(dy, pix, linear), v0);
+    Vec<T>::load(base + pix_off(dy, pix + rows, linear), v1);
+    Vec<T>::load(base + pix_off(dy, pix + 2 * rows, linear), v2);
+    Vec<T>::load(base + pix_off(dy, pix + 3 * rows, linear), v3);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] += (v0[i] + v1[i]) + (v2[i] + v3[i]);
+  }
+  for (; pix < pend; pix += rows) {
+    float v0[VEC];
+    Vec<T>::load(base + pix_off(dy, pix, linear), v0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] += v0[i];
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) red[row * C + cv * VEC + i] = acc[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += red[r * C + c];
+    partial[(long long)blockIdx.x * C + c] = s;
+  }
+}
+
+// out[i] (=|+=) sum_b partial[b][i]; 64 outputs per block, 4 strided partial sums each
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, float* out, int n, int blocks, int accumulate) {
+  __shared__ float red[256];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float s = 0.f;
+  if (i < n)
+    for (int b = part; b < blocks; b += 4) s += partial[(long long)b * n + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && i < n) {
+    const float t = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    out[i] = accumulate ? out[i] + t : t;
+  }
+}
+
+static int bias_plan(const dct_view* dy, int vec, int& ppb) {
+  const long long P = (long long)dy->n * dy->h * dy->w;
+  const int rows = 256 / (dy->c / vec);
+  long long blocks = (P + 8ll * rows - 1) / (8ll * rows);   // >= 8 iterations per thread
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  ppb = (int)((P + blocks - 1) / blocks);
+  return (int)((P + ppb - 1) / ppb);
+}
+
+// ------------------------------------------------------------------------------- stem wgrad
+struct StemG { int R, S, stride, dil, pad_h, pad_w; };
+
+// partial[blk][co][taps+1] (taps of dw, then db).  x fp32 [N,H,W,1], dy T [N,Ho,Wo,Cout]
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_fast_kernel(View x, View dy, float* partial, StemG g, int ppb) {
+  constexpr int VEC = Vec<T>::N;
+  constexpr int NT = 10;                 // 9 taps + bias
+  __shared__ float red[4 * NT * 64];     // [wave][slot][C], C <= 64
+  const int C = dy.c, CV = C / VEC;      // power of two, C <= 64
+  const int rows = 256 / CV;
+  const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
+  const int taps = g.R * g.S;
+  const long long P = (long long)dy.n * dy.h * dy.w;
+  const long long pbeg = (long long)blockIdx.x * ppb, pend = min(P, pbeg + ppb);
+  const float* xp = reinterpret_cast<const float*>(x.ptr);
+  const T* dbase = reinterpret_cast<const T*>(dy.ptr) + cv * VEC;
+  float acc[NT][VEC];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
+  const int hw = dy.h * dy.w;
+  for (long long pix = pbeg + row; pix < pend; pix += rows) {
+    const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+    const int oy = rem / dy.w, ox = rem - oy * dy.w;
+    float d[VEC];
+    Vec<T>::load(dbase + n * dy.sn + oy * dy.sh + ox * dy.sw, d);
+    float xv[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int iy = oy * g.stride + r * g.dil - g.pad_h, ix = ox * g.stride + s * g.dil - g.pad_w;
+        const bool ok = r < g.R && s < g.S && (unsigned)iy < (unsigned)x.h && (unsigned)ix < (unsigned)x.w;
+        xv[r * 3 + s] = ok ? xp[n * x.sn + iy * x.sh + ix * x.sw] : 0.f;
+      }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[t][i] = fmaf(d[i], xv[t], acc[t][i]);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[9][i] += d[i];
+  }
+  // fold the rows that share a wave (lanes with equal cv are CV apart)
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float v = acc[t][i];
+      for (int off = CV; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+      acc[t][i] = v;
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < CV) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) red[(wave * NT + t) * C + lane * VEC + i] = acc[t][i];
+  }
+  __syncthreads();
+  // out index (co, t) with t in [0, taps]; tap t of a (R,S) kernel sits at slot (t / S) * 3 + t % S
+  for (int o = threadIdx.x; o < C * (taps + 1); o += 256) {
+    const int co = o / (taps + 1), t = o - co * (taps + 1);
+    const int slot = t < taps ? (t / g.S) * 3 + (t % g.S) : 9;
+    const float s = (red[(0 * NT + slot) * C + co] + red[(1 * NT + slot) * C + co]) +
+                    (red[(2 * NT + slot) * C + co] + red[(3 * NT + slot) * C + co]);
+    partial[(long long)blockIdx.x * C * (taps + 1) + o] = s;
+  }
+}
+
+// out: dw[co][taps], db[co] from reduced[co][taps+1]
+__global__ __launch_bounds__(256) void split_dw_db_kernel(const float* partial, float* dw, float* db, int cout, int inner, int blocks, int accumulate) {
+  __shared__ float red[256];
+  const int n = cout * (inner + 1);
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float s = 0.f;
+  if (i < n)
+    for (int b = part; b < blocks; b += 4) s += partial[(long long)b * n + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && i < n) {
+    const float t = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    const int co = i / (inner + 1), k = i - co * (inner + 1);
+    if (k < inner) { if (dw) dw[co * inner + k] = accumulate ? dw[co * inner + k] + t : t; }
+    else if (db) db[co] = accumulate ? db[co] + t : t;
+  }
+}
+
+// ------------------------------------------------------------------------------- head wgrad
+// partial[blk][co][cin+1]: x T [P][Cin], dy f32 [P][Cout <= 8]
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void head_dw_fast_kernel(View x, View dy, float* partial, int ppb, int lin_x, int lin_dy) {
+  constexpr int VEC = Vec<T>::N;
+  extern __shared__ float red[];         // [4 waves][COUT][C] + [4][COUT]
+  const int C = x.c, CV = C / VEC;       // CV <= 64, power of two
+  const int rows = 256 / CV;
+  const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
+  const long long P = (long long)x.n * x.h * x.w;
+  const long long pbeg = (long long)blockIdx.x * ppb, pend = min(P, pbeg + ppb);
+  const T* xb = reinterpret_cast<const T*>(x.ptr) + cv * VEC;
+  const float* db_ = reinterpret_cast<const float*>(dy.ptr);
+  float acc[COUT][VEC], accb[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    accb[o] = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[o][i] = 0.f;
+  }
+  for (long long pix = pbeg + row; pix < pend; pix += rows) {
+    float xv[VEC];
+    Vec<T>::load(xb + pix_off(x, pix, lin_x), xv);
+    const float* dp = db_ + pix_off(dy, pix, lin_dy);
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      const float d = dp[o];
+      accb[o] += d;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[o][i] = fmaf(d, xv[i], acc[o][i]);
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float v = acc[o][i];
+      for (int off = CV; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+      acc[o][i] = v;
+    }
+    float v = accb[o];
+    for (int off = CV; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    accb[o] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = CV >= 64 ? 1 : 4;       // CV == 64: a wave is one row; rows 0..3 are the 4 waves
+  float* redb = red + 4 * COUT * C;
+  if (lane < CV) {
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) red[(wave * COUT + o) * C + lane * VEC + i] = acc[o][i];
+      if (lane == 0) redb[wave * COUT + o] = accb[o];
+    }
+  }
+  (void)nw;
+  __syncthreads();
+  for (int i = threadIdx.x; i < COUT * (C + 1); i += 256) {
+    const int o = i / (C + 1), k = i - o * (C + 1);
+    float s;
+    if (k < C) s = (red[(0 * COUT + o) * C + k] + red[(1 * COUT + o) * C + k]) + (red[(2 * COUT + o) * C + k] + red[(3 * COUT + o) * C + k]);
+    else s = (redb[0 * COUT + o] + redb[1 * COUT + o]) + (redb[2 * COUT + o] + redb[3 * COUT + o]);
+    partial[(long long)blockIdx.x * COUT * (C + 1) + i] = s;
+  }
+}
+
+static int pix_plan(long long P, int rows, int iters, int max_blocks, int& ppb) {
+  long long blocks = (P + (long long)rows * iters - 1) / ((long long)rows * iters);
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks < 1) blocks = 1;
+  ppb = (int)((P + blocks - 1) / blocks);
+  return (int)((P + ppb - 1) / ppb);
+}
+
+static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" size_t dct_bias_grad_workspace_bytes(const dct_view* dy) {
+  if (!dy || dy->c < 1) return 0;
+  return (size_t)1024 * dy->c * sizeof(float);
+}
+
+extern "C" int dct_bias_grad(const dct_view* dy, float* db, int accumulate, int dtype,
+                             void* workspace, size_t workspace_bytes, dct_stream stream) {
+  if (!view_ok(dy) || !db) return DCT_ERR_BAD_ARG;
+  if (dtype != DCT_F32 && dtype != DCT_BF16) return DCT_ERR_BAD_ARG;
+  const int vec = dtype == DCT_BF16 ? 8 : 4, esz = dtype == DCT_BF16 ? 2 : 4;
+  if (dy->c % vec) return DCT_ERR_UNSUPPORTED;
+  const int cv = dy->c / vec;
+  if (cv > 256 || 256 % cv) return DCT_ERR_UNSUPPORTED;
+  if (((uintptr_t)dy->ptr % 16) || (dy->sw % vec) || (dy->sh % vec) || (dy->sn % vec)) return DCT_ERR_UNSUPPORTED;
+  (void)esz;
+  int ppb;
+  const int blocks = bias_plan(dy, vec, ppb);
+  if (!workspace || workspace_bytes < (size_t)blocks * dy->c * sizeof(float)) return DCT_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const View v = to_view(dy);
+  const int lin = view_linear(dy);
+  if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, bias_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, v, (float*)workspace, ppb, lin);
+  else DCT_LAUNCH(DCT_PROF_POINTWISE, bias_partial_kernel<float>, dim3(blocks), dim3(256), 0, st, v, (float*)workspace, ppb, lin);
+  DCT_LAUNCH(DCT_PROF_POINTWISE, partial_reduce_kernel, dim3(div_up(dy->c, 64)), dim3(256), 0, st,
+             (const float*)workspace, db, dy->c, blocks, accumulate);
+  return dct_check_launch();
+}
+
+extern "C" size_t dct_conv_cin1_wgrad_workspace_bytes(const dct_view* dy, const dct_conv_desc* d) {
+  if (!dy || !d) return 0;
+  return (size_t)1024 * dy->c * (d->R * d->S + 1) * sizeof(float);
+}
+
+extern "C" int dct_conv_cin1_wgrad(const dct_view* x, const dct_view* dy, float* dw, float* db,
+                                   const dct_conv_desc* d, int accumulate, int dtype,
+                                   void* workspace, size_t workspace_bytes, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(dy) || !d || x->c != 1 || x->n != dy->n) return DCT_ERR_BAD_ARG;
+  if (dtype != DCT_F32 && dtype != DCT_BF16) return DCT_ERR_BAD_ARG;
+  if (d->R < 1 || d->S < 1 || d->R > 3 || d->S > 3) return DCT_ERR_UNSUPPORTED;
+  const int vec = dtype == DCT_BF16 ? 8 : 4;
+  if (dy->c % vec) return DCT_ERR_UNSUPPORTED;
+  const int cv = dy->c / vec;
+  if (dy->c > 64 || !pow2(cv)) return DCT_ERR_UNSUPPORTED;
+  if (((uintptr_t)dy->ptr % 16) || (dy->sw % vec) || (dy->sh % vec) || (dy->sn % vec)) return DCT_ERR_UNSUPPORTED;
+  const int taps = d->R * d->S;
+  int ppb;
+  const int blocks = pix_plan((long long)dy->n * dy->h * dy->w, 256 / cv, 8, 1024, ppb);
+  if (!workspace || workspace_bytes < (size_t)blocks * dy->c * (taps + 1) * sizeof(float)) return DCT_ERR_WORKSPACE;
+  StemG g; g.R = d->R; g.S = d->S; g.stride = d->stride; g.dil = d->dil; g.pad_h = d->pad_h; g.pad_w = d->pad_w;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, stem_wgrad_fast_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
+  else DCT_LAUNCH(DCT_PROF_POINTWISE, stem_wgrad_fast_kernel<float>, dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
+  DCT_LAUNCH(DCT_PROF_POINTWISE, split_dw_db_kernel, dim3(div_up(dy->c * (taps + 1), 64)), dim3(256), 0, st,
+             (const float*)workspace, dw, db, dy->c, taps, blocks, accumulate);
+  return dct_check_launch();
+}
+
+extern "C" size_t dct_conv1x1_head_bwd_workspace_bytes(const dct_view* x, int cout) {
+  if (!x || cout < 1) return 0;
+  return (size_t)1024 * cout * (x->c + 1) * sizeof(float);
+}
+
+namespace {
+template <typename T>
+static void launch_head_dw(int cout, int blocks, size_t sh, hipStream_t st, const View& x, const View& dy, float* ws, int ppb, int lx, int ld) {
+  switch (cout) {
+#define CASE(N) case N: DCT_LAUNCH(DCT_PROF_POINTWISE, (head_dw_fast_kernel<T, N>), dim3(blocks), dim3(256), sh, st, x, dy, ws, ppb, lx, ld); break;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+  }
+}
+}  // namespace
+
+// dw/db half of the classifier head backward (dct_conv1x1_head_bwd in pointwise.hip calls this)
+int dct_head_dw_launch(const dct_view* x, const dct_view* dy, float* dw, float* db, int accumulate, int dtype,
+                       void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const int vec = dtype == DCT_BF16 ? 8 : 4;
+  if (x->c % vec) return DCT_ERR_UNSUPPORTED;
+  const int cv = x->c / vec;
+  if (cv > 64 || !pow2(cv) || dy->c < 1 || dy->c > 8) return DCT_ERR_UNSUPPORTED;
+  if (((uintptr_t)x->ptr % 16) || (x->sw % vec) || (x->sh % vec) || (x->sn % vec)) return DCT_ERR_UNSUPPORTED;
+  int ppb;
+  const int blocks = pix_plan((long long)x->n * x->h * x->w, 256 / cv, 8, 1024, ppb);
+  if (!workspace || workspace_bytes < (size_t)blocks * dy->c * (x->c + 1) * sizeof(float)) return DCT_ERR_WORKSPACE;
+  const size_t sh = (size_t)(4 * dy->c * x->c + 4 * dy->c) * sizeof(float);
+  if (sh > 64 * 1024) return DCT_ERR_UNSUPPORTED;
+  const View vx = to_view(x), vdy = to_view(dy);
+  const int lx = view_linear(x), ld = view_linear(dy);
+  if (dtype == DCT_BF16) launch_head_dw<bf16_t>(dy->c, blocks, sh, st, vx, vdy, (float*)workspace, ppb, lx, ld);
+  else launch_head_dw<float>(dy->c, blocks, sh, st, vx, vdy, (float*)workspace, ppb, lx, ld);
+  DCT_LAUNCH(DCT_PROF_POINTWISE, split_dw_db_kernel, dim3(div_up(dy->c * (x->c + 1), 64)), dim3(256), 0, st,
+             (const float*)workspace, dw, db, dy->c, x->c, blocks, accumulate);
+  return dct_check_launch();
+}

@@ -285,75 +285,3 @@ extern "C" int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw,
   return dct_check_launch();
 }
 
-// ------------------------------------------------------------------------------- bias grad
-namespace {
-// partial[blk][c] = sum over the block's pixel range of dy[pix][c]; then a fixed-order reduce.
-template <typename T>
-__global__ __launch_bounds__(256) void bias_partial_kernel(View dy, float* partial, int pix_per_block) {
-  const long long P = (long long)dy.n * dy.h * dy.w;
-  const long long pbeg = (long long)blockIdx.x * pix_per_block;
-  const long long pend = min(P, pbeg + pix_per_block);
-  const int C = dy.c;
-  // layout: threads span channels first (coalesced), then pixel sub-rows
-  const int lanes_c = C < 256 ? C : 256;
-  const int rows = 256 / lanes_c;
-  const int tc = threadIdx.x % lanes_c, trow = threadIdx.x / lanes_c;
-  __shared__ float red[256];
-  for (int c0 = 0; c0 < C; c0 += lanes_c) {
-    float s = 0.f;
-    if (trow < rows) {
-      for (long long pix = pbeg + trow; pix < pend; pix += rows) {
-        const int hw = dy.h * dy.w;
-        const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
-        const int y = rem / dy.w, x = rem - y * dy.w;
-        s += to_f32(reinterpret_cast<const T*>(dy.ptr)[n * dy.sn + y * dy.sh + x * dy.sw + c0 + tc]);
-      }
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (trow == 0) {
-      float t = 0.f;
-      for (int r = 0; r < rows; ++r) t += red[r * lanes_c + tc];
-      partial[(long long)blockIdx.x * C + c0 + tc] = t;
-    }
-    __syncthreads();
-  }
-}
-__global__ void bias_reduce_kernel(const float* partial, float* db, int C, int blocks, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = accumulate ? db[c] : 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[(long long)b * C + c];
-  db[c] = s;
-}
-static int bias_blocks(const dct_view* dy, int& ppb) {
-  const long long P = (long long)dy->n * dy->h * dy->w;
-  long long blocks = (P + 511) / 512;
-  if (blocks > 1024) blocks = 1024;
-  ppb = (int)((P + blocks - 1) / blocks);
-  return (int)((P + ppb - 1) / ppb);
-}
-}  // namespace
-
-extern "C" size_t dct_bias_grad_workspace_bytes(const dct_view* dy) {
-  if (!dy) return 0;
-  int ppb;
-  return (size_t)bias_blocks(dy, ppb) * dy->c * sizeof(float);
-}
-
-extern "C" int dct_bias_grad(const dct_view* dy, float* db, int accumulate, int dtype,
-                             void* workspace, size_t workspace_bytes, dct_stream stream) {
-  if (!view_ok(dy) || !db) return DCT_ERR_BAD_ARG;
-  if (dy->c > 256 && dy->c % 256) return DCT_ERR_UNSUPPORTED;
-  if (dy->c < 256 && 256 % dy->c) return DCT_ERR_UNSUPPORTED;
-  int ppb;
-  const int blocks = bias_blocks(dy, ppb);
-  if (!workspace || workspace_bytes < (size_t)blocks * dy->c * sizeof(float)) return DCT_ERR_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
-  View v = to_view(dy);
-  if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, bias_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, v, (float*)workspace, ppb);
-  else DCT_LAUNCH(DCT_PROF_POINTWISE, bias_partial_kernel<float>, dim3(blocks), dim3(256), 0, st, v, (float*)workspace, ppb);
-  DCT_LAUNCH(DCT_PROF_POINTWISE, bias_reduce_kernel, dim3(div_up(dy->c, 256)), dim3(256), 0, st,
-             (const float*)workspace, db, dy->c, blocks, accumulate);
-  return dct_check_launch();
-}

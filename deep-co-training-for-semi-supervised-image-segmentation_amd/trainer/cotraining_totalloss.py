@@ -118,6 +118,7 @@ class CoTrainer(Trainer):
         self.to(self.device)
         self.use_tqdm = use_tqdm and tqdm_ is not None
         self.grad_sync = grad_sync          # dct_amd.ddp.FlatGradSync or None (single process)
+        self.batch_lab_unlab = True         # one B_l+B_u pass per batch-independent net (see _run_step_fused)
         self.last_step = None
 
     def to(self, device: torch.device):
@@ -250,28 +251,62 @@ class CoTrainer(Trainer):
         heads: List[List[Tensor]] = [[] for _ in range(S)]
         grads: List[List[Tensor]] = [[] for _ in range(S)]
         sup, preds = [], []
+        # Networks whose samples do not interact (UNet: no BatchNorm) run the labeled and the
+        # unlabeled batch as ONE pass of B_l + B_u images: same per-pixel results, twice the GEMM
+        # rows per launch and half the launches.  Nets with batch statistics keep separate passes
+        # (three separate BN-statistics batches per model per step).
+        fuse = bool(train_jsd and unl is not None and self.batch_lab_unlab and
+                    all(getattr(s.torchnet, "batch_independent", False) and
+                        getattr(s.torchnet, "external_dropout_masks", None) is None for s in self.segmentators))
+        full_logits, full_dl = [], []
         for i in range(S):                                                     # :208-218
             img, gt = lab[i]
-            logits = self.segmentators[i].torchnet(img)
-            lp = _pc(logits.detach())
+            if fuse:
+                logits_all = self.segmentators[i].torchnet(torch.cat((img, unl[0]), dim=0))
+                lp_all = _pc(logits_all.detach())
+                dl_all = torch.empty_like(lp_all)
+                full_logits.append((logits_all, lp_all))
+                full_dl.append(dl_all)
+                B_l = img.shape[0]
+                logits, lp, dl_out = logits_all[:B_l], lp_all[:B_l], dl_all[:B_l]
+            else:
+                logits = self.segmentators[i].torchnet(img)
+                lp = _pc(logits.detach())
+                dl_out = torch.empty_like(lp)
             t = gt.reshape(-1)
             out = K.ce_fwd(lp, t, C, ignore)
-            dl = K.ce_bwd(lp, t, C, out[1:2], torch.empty_like(lp), ignore_index=ignore)
-            heads[i].append(logits)
-            grads[i].append(_nchw(dl))
+            K.ce_bwd(lp, t, C, out[1:2], dl_out, ignore_index=ignore)
+            if not fuse:
+                heads[i].append(logits)
+                grads[i].append(_nchw(dl_out))
             sup.append(out[0])
             preds.append(logits.detach())
         jsd, unlab_probs = 0, []
         if train_jsd:                                                          # :219-227
-            ulogits = [s.torchnet(unl[0]) for s in self.segmentators]
-            lps = [_pc(l.detach()) for l in ulogits]
+            if fuse:
+                B_l = lab[0][0].shape[0]
+                ulogits = [fl[0][B_l:] for fl in full_logits]
+                lps = [fl[1][B_l:] for fl in full_logits]
+                dl_outs = [d[B_l:] for d in full_dl]
+            else:
+                ulogits = [s.torchnet(unl[0]) for s in self.segmentators]
+                lps = [_pc(l.detach()) for l in ulogits]
+                dl_outs = [torch.empty_like(lp) for lp in lps]
             jsd = K.jsd_logits_fwd(lps, C)[0]
             unlab_probs = [_nchw(K.softmax_fwd(lp, C)) for lp in lps]
             if lam_cot != 0.0:
-                dls = K.jsd_logits_bwd(lps, C, [torch.empty_like(lp) for lp in lps], gmul=lam_cot)
-                for i in range(S):
-                    heads[i].append(ulogits[i])
-                    grads[i].append(_nchw(dls[i]))
+                K.jsd_logits_bwd(lps, C, dl_outs, gmul=lam_cot)
+                if not fuse:
+                    for i in range(S):
+                        heads[i].append(ulogits[i])
+                        grads[i].append(_nchw(dl_outs[i]))
+            elif fuse:
+                for d in dl_outs:
+                    d.zero_()
+        if fuse:
+            for i in range(S):
+                heads[i].append(full_logits[i][0])
+                grads[i].append(_nchw(full_dl[i]))
         adv = 0
         if train_adv:                                                          # :233-244 -> :371-392
             a, b = adv_choice

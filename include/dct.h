@@ -218,6 +218,11 @@ int dct_dice_counts(const float* logits, const int64_t* gt, int B, int64_t pixel
 enum { DCT_PROF_IGEMM = 0, DCT_PROF_WGRAD = 1, DCT_PROF_POINTWISE = 2, DCT_PROF_LOSS = 3,
        DCT_PROF_ADAM = 4, DCT_PROF_OTHER = 5, DCT_PROF_NCLASS = 6 };
 int dct_prof_enable(int on);
+/* Process-wide tuning / A-B knobs for benchmarking (never needed for correctness; defaults are the
+ * shipped configuration). */
+enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0: register-staged kernel */
+       DCT_TUNE_IGEMM_SPLIT = 1 }; /* >= 1: force the split-K factor; -1 (default): planner's choice */
+int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 
 #ifdef __cplusplus
