@@ -199,10 +199,6 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
-    use_events = not args.no_kernel_events
-    if use_events:
-        _lib.prof_read(reset=True)
-        _lib.prof_enable(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -214,10 +210,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # Roofline leg: the SAME K steps once more with every launch bracketed by HIP events on its
+    # stream (kept out of the timed region above: ~1200 event records per step would cost the
+    # step ~25 % and `value` must be the unperturbed rate).
     prof = None
+    use_events = not args.no_kernel_events and rank == 0
     if use_events:
+        _lib.prof_read(reset=True)
+        _lib.prof_enable(True)
+        for i in range(args.steps):
+            one_step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
         _lib.prof_enable(False)
         prof = _lib.prof_read(reset=True)
+    if world > 1:
+        dist.barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -262,7 +269,7 @@ def main():
                                ((per["igemm"]["ms_per_step"] + per["wgrad"]["ms_per_step"]) * 1e-3) / 1e12,
                                "unit": "TFLOP/s"},
                 "per_class_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in per.items()},
-                "measured": "HIP events around every launch on the launch stream, inside the timed region",
+                "measured": "HIP events around every launch on the launch stream, over the same K steps re-run right after the timed region",
             }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg)

@@ -539,10 +539,12 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   return dtype == DCT_BF16 ? launch<bf16_t>(p, pl, st) : launch<float>(p, pl, st);
 }
 
+int dct_tune_set_wgrad(int knob, int value);  // wgrad.hip
+
 extern "C" int dct_tune_set(int knob, int value) {
   switch (knob) {
     case DCT_TUNE_IGEMM_V2: g_tune_igemm_v2 = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT: g_tune_igemm_split = value; return DCT_OK;
-    default: return DCT_ERR_BAD_ARG;
+    default: return dct_tune_set_wgrad(knob, value);
   }
 }

@@ -82,26 +82,34 @@ __global__ __launch_bounds__(256) void bias_partial_kernel(View dy, float* parti
   }
 }
 
-// out[i] (=|+=) sum_b partial[b][i]; 64 outputs per block, 4 strided partial sums each
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, float* out, int n, int blocks, int accumulate) {
-  __shared__ float red[256];
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+// out[i] (=|+=) sum_b partial[b][i]; 16 outputs per block, 16 strided partial sums each, folded in
+// fixed order through LDS
+__device__ __forceinline__ float fold16(const float* partial, int i, int n, int blocks, float* red) {
+  const int part = threadIdx.x >> 4;
   float s = 0.f;
   if (i < n)
-    for (int b = part; b < blocks; b += 4) s += partial[(long long)b * n + i];
+    for (int b = part; b < blocks; b += 16) s += partial[(long long)b * n + i];
   red[threadIdx.x] = s;
   __syncthreads();
-  if (part == 0 && i < n) {
-    const float t = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
-    out[i] = accumulate ? out[i] + t : t;
+  float t = 0.f;
+  if (part == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k * 16 + threadIdx.x];
   }
+  return t;
+}
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, float* out, int n, int blocks, int accumulate) {
+  __shared__ float red[256];
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+  const float t = fold16(partial, i, n, blocks, red);
+  if (threadIdx.x < 16 && i < n) out[i] = accumulate ? out[i] + t : t;
 }
 
 static int bias_plan(const dct_view* dy, int vec, int& ppb) {
   const long long P = (long long)dy->n * dy->h * dy->w;
   const int rows = 256 / (dy->c / vec);
   long long blocks = (P + 8ll * rows - 1) / (8ll * rows);   // >= 8 iterations per thread
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
   ppb = (int)((P + blocks - 1) / blocks);
   return (int)((P + ppb - 1) / ppb);
@@ -178,18 +186,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_fast_kernel(View x, View dy, f
   }
 }
 
-// out: dw[co][taps], db[co] from reduced[co][taps+1]
+// out: dw[co][inner], db[co] from partial[blk][co][inner+1]
 __global__ __launch_bounds__(256) void split_dw_db_kernel(const float* partial, float* dw, float* db, int cout, int inner, int blocks, int accumulate) {
   __shared__ float red[256];
   const int n = cout * (inner + 1);
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  float s = 0.f;
-  if (i < n)
-    for (int b = part; b < blocks; b += 4) s += partial[(long long)b * n + i];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  if (part == 0 && i < n) {
-    const float t = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+  const float t = fold16(partial, i, n, blocks, red);
+  if (threadIdx.x < 16 && i < n) {
     const int co = i / (inner + 1), k = i - co * (inner + 1);
     if (k < inner) { if (dw) dw[co * inner + k] = accumulate ? dw[co * inner + k] + t : t; }
     else if (db) db[co] = accumulate ? db[co] + t : t;
@@ -298,7 +301,7 @@ extern "C" int dct_bias_grad(const dct_view* dy, float* db, int accumulate, int 
   const int lin = view_linear(dy);
   if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, bias_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, v, (float*)workspace, ppb, lin);
   else DCT_LAUNCH(DCT_PROF_POINTWISE, bias_partial_kernel<float>, dim3(blocks), dim3(256), 0, st, v, (float*)workspace, ppb, lin);
-  DCT_LAUNCH(DCT_PROF_POINTWISE, partial_reduce_kernel, dim3(div_up(dy->c, 64)), dim3(256), 0, st,
+  DCT_LAUNCH(DCT_PROF_POINTWISE, partial_reduce_kernel, dim3(div_up(dy->c, 16)), dim3(256), 0, st,
              (const float*)workspace, db, dy->c, blocks, accumulate);
   return dct_check_launch();
 }
@@ -327,7 +330,7 @@ extern "C" int dct_conv_cin1_wgrad(const dct_view* x, const dct_view* dy, float*
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, stem_wgrad_fast_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
   else DCT_LAUNCH(DCT_PROF_POINTWISE, stem_wgrad_fast_kernel<float>, dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
-  DCT_LAUNCH(DCT_PROF_POINTWISE, split_dw_db_kernel, dim3(div_up(dy->c * (taps + 1), 64)), dim3(256), 0, st,
+  DCT_LAUNCH(DCT_PROF_POINTWISE, split_dw_db_kernel, dim3(div_up(dy->c * (taps + 1), 16)), dim3(256), 0, st,
              (const float*)workspace, dw, db, dy->c, taps, blocks, accumulate);
   return dct_check_launch();
 }
@@ -365,7 +368,7 @@ int dct_head_dw_launch(const dct_view* x, const dct_view* dy, float* dw, float* 
   const int lx = view_linear(x), ld = view_linear(dy);
   if (dtype == DCT_BF16) launch_head_dw<bf16_t>(dy->c, blocks, sh, st, vx, vdy, (float*)workspace, ppb, lx, ld);
   else launch_head_dw<float>(dy->c, blocks, sh, st, vx, vdy, (float*)workspace, ppb, lx, ld);
-  DCT_LAUNCH(DCT_PROF_POINTWISE, split_dw_db_kernel, dim3(div_up(dy->c * (x->c + 1), 64)), dim3(256), 0, st,
+  DCT_LAUNCH(DCT_PROF_POINTWISE, split_dw_db_kernel, dim3(div_up(dy->c * (x->c + 1), 16)), dim3(256), 0, st,
              (const float*)workspace, dw, db, dy->c, x->c, blocks, accumulate);
   return dct_check_launch();
 }

@@ -30,6 +30,23 @@ struct WgradParams {
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
+// Block -> (pixel chunk, tile).  With >= 8 chunks all (tap, tile) blocks of one chunk carry the same
+// id mod 8 (they share an XCD and re-read the chunk's pixels from that XCD's L2); with fewer
+// chunks the tiles are simply dealt over all XCDs.
+__device__ __forceinline__ bool decode_block(const WgradParams& p, int& chunk, int& tile) {
+  const int tiles_per_chunk = p.ptiles * p.R * p.S * p.qtiles;
+  const int bid = blockIdx.x;
+  if (p.chunks >= 8) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    chunk = (slot / tiles_per_chunk) * 8 + xcd;
+    tile = slot % tiles_per_chunk;
+  } else {
+    chunk = bid / tiles_per_chunk;
+    tile = bid - chunk * tiles_per_chunk;
+  }
+  return chunk < p.chunks;
+}
+
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int cbase, int kk, int lane) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = g >> 1;
   const char* a0 = tile + (kk * 16 + 8 * h + q) * pitch + (cbase + 16 * (g & 1) + 4 * pp) * 2;
@@ -57,13 +74,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wp = wave >> 1, wq = wave & 1;
 
-  // block decode (XCD-affine chunks)
-  const int tiles_per_chunk = p.ptiles * p.R * p.S * p.qtiles;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int chunk = (slot / tiles_per_chunk) * 8 + xcd;
-  if (chunk >= p.chunks) return;
-  int tile = slot % tiles_per_chunk;
+  int chunk, tile;
+  if (!decode_block(p, chunk, tile)) return;
   const int qt = tile % p.qtiles; tile /= p.qtiles;
   const int tap = tile % (p.R * p.S);
   const int pt = tile / (p.R * p.S);
@@ -199,6 +211,184 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 main kernel ("v2"): 64 pixels per K-step, both tiles staged straight from HBM into LDS with
+// global_load_lds_dwordx4 (two stages, one barrier per step).  The LDS image is lane-linear
+// ([pixel][channel], one wave-instruction = 1 KiB of consecutive rows), so the conflict-avoiding
+// layout for the transposing reads is an XOR on the 64-B column group applied to the per-lane
+// SOURCE chunk and again on the read: the four pixel rows a 32-lane half reads then sit in four
+// different 64-B quarters of the 256-B bank row.  LDS row rho holds pixel 4*(rho % 16) + rho / 16 of the
+// step (the reduction is order-free), which gives every thread four CONSECUTIVE pixels: one
+// div-free decode (float reciprocal + fix-up) and three increments per step instead of eight
+// integer divisions.
+__device__ __attribute__((aligned(128))) const uint4 g_wzero_page[8] = {};
+typedef __attribute__((address_space(1))) const void* wg_gptr_t;
+typedef __attribute__((address_space(3))) void* wg_lptr_t;
+
+struct FastDiv { int d; float rcp; };
+__device__ __forceinline__ int fdiv(int m, const FastDiv& f, int& rem) {   // 0 <= m < 2^24
+  int q = (int)((float)m * f.rcp);
+  int r = m - q * f.d;
+  if (r < 0) { --q; r += f.d; }
+  else if (r >= f.d) { ++q; r -= f.d; }
+  rem = r;
+  return q;
+}
+
+struct Wgrad2Params {
+  WgradParams w;
+  FastDiv dhw, dw_;
+  int direct;      // chunks == 1: add straight into out (no partial slab)
+  int accumulate;
+};
+
+// Tile rows are RB bytes (128 or 256); a wave fills NI = RB / 64 ... see below.  A thread's LDS rows are
+// rho_i = RS * i + c (RS = 64 / NI), and LDS row rho holds pixel k = NI * (rho % RS) + rho / RS of the step,
+// so the thread's NI pixels are consecutive.  The 16-B chunk index is XORed with swz(rho) << 2.
+template <int RB> struct TileGeo {
+  static constexpr int CPR = RB / 16;          // chunks per row: 8 | 16
+  static constexpr int RPI = 64 / CPR;         // rows per wave-instruction: 8 | 4
+  static constexpr int NI = 64 / (4 * RPI);    // instructions per wave per stage: 2 | 4
+  static constexpr int RS = 64 / NI;           // row stride between a thread's instructions: 32 | 16
+  __device__ static __forceinline__ int swz(int rho) { return ((rho / RS) & (NI - 1)) << 2; }
+  __device__ static __forceinline__ int row_of(int k) { return RS * (k % NI) + k / NI; }
+};
+
+// transposed fragment: 16 pixels (k) x 32 channels starting at channel cbase
+template <int RB>
+__device__ __forceinline__ bf16x8 tr_frag2(const char* tile, int cbase, int kk, int lane) {
+  using G = TileGeo<RB>;
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = g >> 1;
+  const int colb = (cbase + 16 * (g & 1) + 4 * pp) * 2;          // byte column of this lane's 8 bytes
+  const int k0 = kk * 16 + 8 * h + q, k1 = k0 + 4;               // pixel index within the step
+  const int r0 = G::row_of(k0), r1 = G::row_of(k1);
+  const char* a0 = tile + r0 * RB + (colb ^ (G::swz(r0) << 4));
+  const char* a1 = tile + r1 * RB + (colb ^ (G::swz(r1) << 4));
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a1));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+template <int BP, int BQ>
+__global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
+  const WgradParams& p = pr.w;
+  constexpr int BKP = 64;
+  constexpr int RBP = BP * 2, RBQ = BQ * 2;                 // row bytes
+  using GP = TileGeo<RBP>;
+  using GQ = TileGeo<RBQ>;
+  constexpr int TP = BP / 64, TQ = BQ / 64;
+  constexpr int STAGE = BKP * (RBP + RBQ);
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp = wave >> 1, wq = wave & 1;
+
+  int chunk, tile;
+  if (!decode_block(p, chunk, tile)) return;
+  const int qt = tile % p.qtiles; tile /= p.qtiles;
+  const int tap = tile % (p.R * p.S);
+  const int pt = tile / (p.R * p.S);
+  const int tr = tap / p.S, ts = tap - tr * p.S;
+  const int p0 = pt * BP, q0 = qt * BQ;
+  const int mbeg = chunk * p.pix_per_chunk;
+  const int mend = min(p.M, mbeg + p.pix_per_chunk);
+
+  const bf16_t* Pb = reinterpret_cast<const bf16_t*>(p.P) + p0;
+  const bf16_t* Qb = reinterpret_cast<const bf16_t*>(p.Q) + q0;
+  const char* zero = reinterpret_cast<const char*>(g_wzero_page) + (lane & 7) * 16;
+  const int tyo = tr * p.dil - p.pad_h, txo = ts * p.dil - p.pad_w;
+  const int cP = wave * GP::RPI + lane / GP::CPR;            // this thread's row within a wave-instruction group
+  const int cQ = wave * GQ::RPI + lane / GQ::CPR;
+
+  auto stage = [&](char* buf, int mit) {
+    {   // ---- P rows: pixels mit + NI*cP + i
+      int m = mit + GP::NI * cP;
+      int rem, x;
+      int n = fdiv(min(m, p.M - 1), pr.dhw, rem);
+      int y = fdiv(rem, pr.dw_, x);
+#pragma unroll
+      for (int i = 0; i < GP::NI; ++i) {
+        const int rho = GP::RS * i + cP;
+        const int chunkc = (lane % GP::CPR) ^ GP::swz(rho);
+        const char* src = (m < mend)
+            ? reinterpret_cast<const char*>(Pb + (n * p.psN + y * p.psH + x * p.psW + chunkc * 8)) : zero;
+        __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(buf + (GP::RS * i + wave * GP::RPI) * RBP), 16, 0, 0);
+        ++m;
+        if (++x == p.Wp) { x = 0; if (++y == p.Hp) { y = 0; ++n; } }
+      }
+    }
+    {   // ---- Q rows: the same pixels shifted by the tap
+      int m = mit + GQ::NI * cQ;
+      int rem, x;
+      int n = fdiv(min(m, p.M - 1), pr.dhw, rem);
+      int y = fdiv(rem, pr.dw_, x);
+#pragma unroll
+      for (int i = 0; i < GQ::NI; ++i) {
+        const int rho = GQ::RS * i + cQ;
+        const int chunkc = (lane % GQ::CPR) ^ GQ::swz(rho);
+        const int iy = y * p.stride + tyo, ix = x * p.stride + txo;
+        const bool ok = m < mend && (unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq;
+        const char* src = ok
+            ? reinterpret_cast<const char*>(Qb + (n * p.qsN + iy * p.qsH + ix * p.qsW + chunkc * 8)) : zero;
+        __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(buf + BKP * RBP + (GQ::RS * i + wave * GQ::RPI) * RBQ), 16, 0, 0);
+        ++m;
+        if (++x == p.Wp) { x = 0; if (++y == p.Hp) { y = 0; ++n; } }
+      }
+    }
+  };
+
+  f32x16 acc[TP][TQ];
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (mbeg < mend) stage(smem, mbeg);
+  __syncthreads();
+  int cur = 0;
+  for (int mit = mbeg; mit < mend; mit += BKP) {
+    if (mit + BKP < mend) stage(smem + (cur ^ 1) * STAGE, mit + BKP);
+    const char* Pt = smem + cur * STAGE;
+    const char* Qt = Pt + BKP * RBP;
+#pragma unroll
+    for (int kk = 0; kk < BKP / 16; ++kk) {
+      bf16x8 a[TP], b[TQ];
+#pragma unroll
+      for (int i = 0; i < TP; ++i) a[i] = tr_frag2<RBP>(Pt, wp * (BP / 2) + i * 32, kk, lane);
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) b[j] = tr_frag2<RBQ>(Qt, wq * (BQ / 2) + j * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const int half = lane >> 5, l31 = lane & 31;
+  const int taps = p.R * p.S;
+  float* base = pr.direct ? p.out : p.out + (long long)chunk * p.Cp * taps * p.Cq;
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const int qc = q0 + wq * (BQ / 2) + j * 32 + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int prow = p0 + wp * (BP / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        float* dst = base + ((long long)prow * taps + tap) * p.Cq + qc;
+        if (pr.direct && pr.accumulate) *dst += acc[i][j][e]; else *dst = acc[i][j][e];
+      }
+    }
+}
+
 // dw[i] (=|+=) sum_chunk partial[chunk][i]   (float4 per thread, fixed order)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dw, long long n4,
                                                            long long stride, int chunks, int accumulate) {
@@ -209,38 +399,74 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
   reinterpret_cast<f32x4*>(dw)[i] = s;
 }
 
-struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles; };
+struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct; };
+
+int g_tune_wgrad_v2 = 1;       // dct_tune_set(DCT_TUNE_WGRAD_V2, 0): register-staged kernel
+int g_tune_wgrad_chunks = -1;  // >= 1 forces the number of pixel chunks
 
 static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc* d, int dtype, WPlan& pl) {
   if (p->c % 64 || q->c % 64) return false;
   pl.bp = (p->c % 128 == 0) ? 128 : 64;
   pl.bq = (q->c % 128 == 0) ? 128 : 64;
   pl.ptiles = p->c / pl.bp; pl.qtiles = q->c / pl.bq;
-  const int bkp = dtype == DCT_BF16 ? 32 : 16;
   const long long M = (long long)p->n * p->h * p->w;
+  pl.v2 = (dtype == DCT_BF16 && g_tune_wgrad_v2 && M < (1 << 24)) ? 1 : 0;
+  const int bkp = pl.v2 ? 64 : (dtype == DCT_BF16 ? 32 : 16);
   const long long tiles = (long long)pl.ptiles * pl.qtiles * d->R * d->S;
-  long long chunks = (1536 + tiles - 1) / tiles;          // aim for ~1.5k blocks
-  const long long max_by_pix = (M + 8 * bkp - 1) / (8 * bkp);  // >= 8 K-steps per chunk
-  if (chunks > max_by_pix) chunks = max_by_pix;
+  long long chunks;
+  if (pl.v2) {
+    chunks = tiles >= 400 ? 1 : (768 + tiles - 1) / tiles;
+    const long long max_by_pix = (M + 4 * bkp - 1) / (4 * bkp);      // >= 4 K-steps per chunk
+    if (chunks > max_by_pix) chunks = max_by_pix;
+  } else {
+    chunks = (1536 + tiles - 1) / tiles;                      // aim for ~1.5k blocks
+    const long long max_by_pix = (M + 8 * bkp - 1) / (8 * bkp);      // >= 8 K-steps per chunk
+    if (chunks > max_by_pix) chunks = max_by_pix;
+  }
   // bound the partial-sum workspace to 192 MiB
   const long long per_chunk = (long long)p->c * q->c * d->R * d->S * 4;
   while (chunks > 1 && chunks * per_chunk > (192ll << 20)) --chunks;
+  if (g_tune_wgrad_chunks >= 1) chunks = g_tune_wgrad_chunks;
   if (chunks < 1) chunks = 1;
   long long ppc = (M + chunks - 1) / chunks;
   ppc = (ppc + bkp - 1) / bkp * bkp;
   pl.ppc = (int)ppc;
   pl.chunks = (int)((M + ppc - 1) / ppc);
+  pl.direct = (pl.v2 && pl.chunks == 1) ? 1 : 0;
   return true;
+}
+
+static unsigned wgrid(const WPlan& pl, int taps) {
+  const int tiles = pl.ptiles * pl.qtiles * taps;
+  return (unsigned)((pl.chunks >= 8 ? ((pl.chunks + 7) / 8) * 8 : pl.chunks) * tiles);
 }
 
 template <typename T>
 static void launch_w(const WgradParams& wp, const WPlan& pl, hipStream_t st) {
-  const int tiles = pl.ptiles * pl.qtiles * wp.R * wp.S;
-  const unsigned grid = (unsigned)(((pl.chunks + 7) / 8) * 8 * tiles);
+  const unsigned grid = wgrid(pl, wp.R * wp.S);
   if (pl.bp == 128 && pl.bq == 128) DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad_kernel<T, 128, 128>), dim3(grid), dim3(256), 0, st, wp);
   else if (pl.bp == 128) DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad_kernel<T, 128, 64>), dim3(grid), dim3(256), 0, st, wp);
   else if (pl.bq == 128) DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad_kernel<T, 64, 128>), dim3(grid), dim3(256), 0, st, wp);
   else DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad_kernel<T, 64, 64>), dim3(grid), dim3(256), 0, st, wp);
+}
+
+template <int BP, int BQ>
+static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
+  constexpr size_t lds = 2 * 64 * (size_t)(BP + BQ) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<BP, BQ>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ>), dim3(grid), dim3(256), lds, st, pr);
+}
+static void launch_w2(const Wgrad2Params& pr, const WPlan& pl, hipStream_t st) {
+  const unsigned grid = wgrid(pl, pr.w.R * pr.w.S);
+  if (pl.bp == 128 && pl.bq == 128) launch_w2_t<128, 128>(pr, grid, st);
+  else if (pl.bp == 128) launch_w2_t<128, 64>(pr, grid, st);
+  else if (pl.bq == 128) launch_w2_t<64, 128>(pr, grid, st);
+  else launch_w2_t<64, 64>(pr, grid, st);
 }
 
 }  // namespace
@@ -249,7 +475,7 @@ extern "C" size_t dct_conv2d_wgrad_workspace_bytes(const dct_view* p, const dct_
   if (!p || !q || !d) return 0;
   WPlan pl;
   if (!make_wplan(p, q, d, dtype, pl)) return 0;
-  return (size_t)pl.chunks * p->c * q->c * d->R * d->S * sizeof(float);
+  return pl.direct ? 16 : (size_t)pl.chunks * p->c * q->c * d->R * d->S * sizeof(float);
 }
 
 extern "C" int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw, const dct_conv_desc* d, int dtype,
@@ -268,20 +494,35 @@ extern "C" int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw,
     return DCT_ERR_UNSUPPORTED;
   WPlan pl;
   if (!make_wplan(p, q, d, dtype, pl)) return DCT_ERR_UNSUPPORTED;
-  const size_t need = (size_t)pl.chunks * p->c * q->c * d->R * d->S * sizeof(float);
-  if (!workspace || workspace_bytes < need) return DCT_ERR_WORKSPACE;
+  const size_t need = pl.direct ? 0 : (size_t)pl.chunks * p->c * q->c * d->R * d->S * sizeof(float);
+  if (need && (!workspace || workspace_bytes < need)) return DCT_ERR_WORKSPACE;
   WgradParams wp;
-  wp.P = (const char*)p->ptr; wp.Q = (const char*)q->ptr; wp.out = (float*)workspace;
+  wp.P = (const char*)p->ptr; wp.Q = (const char*)q->ptr; wp.out = pl.direct ? dw : (float*)workspace;
   wp.M = p->n * p->h * p->w; wp.Cp = p->c; wp.Cq = q->c; wp.R = d->R; wp.S = d->S;
   wp.Hp = p->h; wp.Wp = p->w; wp.Hq = q->h; wp.Wq = q->w;
   wp.stride = d->stride; wp.dil = d->dil; wp.pad_h = d->pad_h; wp.pad_w = d->pad_w;
   wp.psN = p->sn; wp.psH = p->sh; wp.psW = p->sw; wp.qsN = q->sn; wp.qsH = q->sh; wp.qsW = q->sw;
   wp.chunks = pl.chunks; wp.pix_per_chunk = pl.ppc; wp.ptiles = pl.ptiles; wp.qtiles = pl.qtiles;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DCT_BF16) launch_w<bf16_t>(wp, pl, st); else launch_w<float>(wp, pl, st);
-  const long long n = (long long)p->c * q->c * d->R * d->S;
-  DCT_LAUNCH(DCT_PROF_WGRAD, wgrad_reduce_kernel, dim3(div_up(n / 4, 256)), dim3(256), 0, st,
-             (const float*)workspace, dw, n / 4, n, pl.chunks, d->accumulate);
+  if (pl.v2) {
+    Wgrad2Params pr;
+    pr.w = wp;
+    pr.dhw.d = p->h * p->w; pr.dhw.rcp = 1.0f / (float)pr.dhw.d;
+    pr.dw_.d = p->w; pr.dw_.rcp = 1.0f / (float)pr.dw_.d;
+    pr.direct = pl.direct; pr.accumulate = d->accumulate;
+    launch_w2(pr, pl, st);
+  } else if (dtype == DCT_BF16) launch_w<bf16_t>(wp, pl, st);
+  else launch_w<float>(wp, pl, st);
+  if (!pl.direct) {
+    const long long n = (long long)p->c * q->c * d->R * d->S;
+    DCT_LAUNCH(DCT_PROF_WGRAD, wgrad_reduce_kernel, dim3(div_up(n / 4, 256)), dim3(256), 0, st,
+               (const float*)workspace, dw, n / 4, n, pl.chunks, d->accumulate);
+  }
   return dct_check_launch();
 }
 
+int dct_tune_set_wgrad(int knob, int value) {
+  if (knob == DCT_TUNE_WGRAD_V2) { g_tune_wgrad_v2 = value; return DCT_OK; }
+  if (knob == DCT_TUNE_WGRAD_CHUNKS) { g_tune_wgrad_chunks = value; return DCT_OK; }
+  return DCT_ERR_BAD_ARG;
+}

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Per-layer micro-benchmark of the conv GEMM kernels on the UNet layer shapes of cfg2
+(256x256 input, batch B): forward, data-gradient and weight-gradient, TFLOP/s per layer and
+FLOP-weighted totals.  Knobs (dct_tune_set) let one process A/B kernel variants.
+
+    python tools/bench_conv.py [--batch 16] [--reps 20] [--what fwd,dgrad,wgrad] [--ab]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import dct_amd  # noqa: E402,F401
+from dct_amd import _lib, hip_ops as K  # noqa: E402
+
+DEV = "cuda:0"
+
+# (name, Cin, Hin, Cout) for the 3x3 valid convs; convT as (name, Cin, Hin, Cout) 2x2 s2
+CONVS = [("dec1b", 64, 254, 64), ("dec2a", 64, 126, 128), ("dec2b", 128, 124, 128), ("dec3a", 128, 61, 256),
+         ("dec3b", 256, 59, 256), ("dec4a", 256, 29, 512), ("dec4b", 512, 27, 512), ("cen_a", 512, 13, 1024),
+         ("cen_b", 1024, 11, 1024), ("enc4a", 1024, 18, 512), ("enc4b", 512, 16, 512), ("enc3a", 512, 28, 256),
+         ("enc3b", 256, 26, 256), ("enc2a", 256, 48, 128), ("enc2b", 128, 46, 128), ("enc1a", 128, 88, 64),
+         ("enc1b", 64, 86, 64)]
+CONVT = [("cenT", 1024, 9, 512), ("enc4T", 512, 14, 256), ("enc3T", 256, 24, 128), ("enc2T", 128, 44, 64)]
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e-3
+
+
+def run(B, reps, what, label):
+    dt = torch.bfloat16
+    rows = []
+    tot = {k: [0.0, 0.0] for k in ("fwd", "dgrad", "wgrad")}
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for name, cin, hin, cout in CONVS:
+        ho = hin - 2
+        x = torch.randn(B, hin, hin, cin, device=DEV, generator=g).to(dt)
+        w = (torch.randn(cout, 3, 3, cin, device=DEV, generator=g) / (3 * cin ** 0.5)).to(dt)
+        wd = (torch.randn(cin, 3, 3, cout, device=DEV, generator=g) / (3 * cout ** 0.5)).to(dt)
+        bias = torch.randn(cout, device=DEV, generator=g)
+        y = torch.empty(B, ho, ho, cout, device=DEV, dtype=dt)
+        dy = torch.randn(B, ho, ho, cout, device=DEV, generator=g).to(dt)
+        dx = torch.empty(B, hin, hin, cin, device=DEV, dtype=dt)
+        dw = torch.zeros(cout * 9 * cin, device=DEV)
+        fl = 2.0 * B * ho * ho * 9 * cin * cout
+        r = {"name": name, "flops": fl}
+        if "fwd" in what:
+            t = timeit(lambda: K.conv2d(x, w, bias, y, relu=True), reps)
+            r["fwd"] = t; tot["fwd"][0] += fl; tot["fwd"][1] += t
+        if "dgrad" in what:
+            t = timeit(lambda: K.conv2d(dy, wd, None, dx, pad_h=2, pad_w=2, mask=x), reps)
+            r["dgrad"] = t; tot["dgrad"][0] += fl; tot["dgrad"][1] += t
+        if "wgrad" in what:
+            t = timeit(lambda: K.conv2d_wgrad(dy, x, dw, accumulate=True), reps)
+            r["wgrad"] = t; tot["wgrad"][0] += fl; tot["wgrad"][1] += t
+        rows.append(r)
+    for name, cin, hin, cout in CONVT:
+        x = torch.randn(B, hin, hin, cin, device=DEV, generator=g).to(dt)
+        wf = (torch.randn(4 * cout, cin, device=DEV, generator=g) / cin ** 0.5).to(dt)
+        wd = (torch.randn(cin, 4 * cout, device=DEV, generator=g) / cout ** 0.5).to(dt)
+        bias = torch.randn(cout, device=DEV, generator=g)
+        y = torch.empty(B, 2 * hin, 2 * hin, cout, device=DEV, dtype=dt)
+        dy = torch.randn(B, 2 * hin, 2 * hin, cout, device=DEV, generator=g).to(dt)
+        dx = torch.empty(B, hin, hin, cin, device=DEV, dtype=dt)
+        dw = torch.zeros(cin * 4 * cout, device=DEV)
+        fl = 2.0 * B * hin * hin * 4 * cin * cout
+        r = {"name": name, "flops": fl}
+        if "fwd" in what:
+            t = timeit(lambda: K.conv2d(x, wf, bias, y, R=1, S=1, relu=True, scatter2x2=True), reps)
+            r["fwd"] = t; tot["fwd"][0] += fl; tot["fwd"][1] += t
+        if "dgrad" in what:
+            t = timeit(lambda: K.conv2d(dy, wd, None, dx, R=2, S=2, stride=2, mask=x), reps)
+            r["dgrad"] = t; tot["dgrad"][0] += fl; tot["dgrad"][1] += t
+        if "wgrad" in what:
+            t = timeit(lambda: K.conv2d_wgrad(x, dy, dw, R=2, S=2, stride=2, accumulate=True), reps)
+            r["wgrad"] = t; tot["wgrad"][0] += fl; tot["wgrad"][1] += t
+        rows.append(r)
+    print(f"--- {label}  (B={B}; us / TFLOP/s)")
+    for r in rows:
+        s = f"{r['name']:7s} {r['flops'] / 1e9:8.2f} GF"
+        for k in ("fwd", "dgrad", "wgrad"):
+            if k in r:
+                s += f" | {k} {r[k] * 1e6:8.1f} {r['flops'] / r[k] / 1e12:7.1f}"
+        print(s)
+    for k, (f, t) in tot.items():
+        if t > 0:
+            print(f"TOTAL {k}: {t * 1e3:.3f} ms, {f / t / 1e12:.1f} TFLOP/s")
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--what", default="fwd,dgrad,wgrad")
+    ap.add_argument("--ab", action="store_true", help="also run with the register-staged igemm kernel")
+    args = ap.parse_args()
+    what = args.what.split(",")
+    lib = _lib.load()
+    run(args.batch, args.reps, what, "default")
+    if args.ab:
+        lib.dct_tune_set(0, 0)
+        lib.dct_tune_set(2, 0)
+        run(args.batch, args.reps, what, "v1 kernels (register staged)")
+        lib.dct_tune_set(0, 1)
+        lib.dct_tune_set(2, 1)
+
+
+if __name__ == "__main__":
+    main()
