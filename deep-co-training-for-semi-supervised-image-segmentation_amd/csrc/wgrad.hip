@@ -29,6 +29,26 @@ struct WgradParams {
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+
+// The transposing LDS reads of the LDS-DMA kernels are issued through inline asm: with the builtin,
+// hipcc (ROCm 7.2) orders every ds_read_b64_tr_b16 behind ALL outstanding global_load_lds and puts an
+// s_waitcnt vmcnt(0) in front of the first read of each K-step, which serialises the prefetch of the
+// next stage with the compute of the current one.  The price is hand-placed lgkmcnt waits: a wait is
+// followed by empty asm statements that "touch" the destination registers, so no consumer can be
+// scheduled above it.
+__device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(lds_char_ptr)(p); }
+__device__ __forceinline__ void tr_issue(unsigned addr, bf16x4& dst) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <int N> __device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void touch(bf16x4& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ bf16x8 join(const bf16x4& lo, const bf16x4& hi) {
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
 
 // Block -> (pixel chunk, tile).  With >= 8 chunks all (tap, tile) blocks of one chunk carry the same
 // id mod 8 (they share an XCD and re-read the chunk's pixels from that XCD's L2); with fewer
@@ -296,47 +316,54 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
   const int mbeg = chunk * p.pix_per_chunk;
   const int mend = min(p.M, mbeg + p.pix_per_chunk);
 
-  const bf16_t* Pb = reinterpret_cast<const bf16_t*>(p.P) + p0;
-  const bf16_t* Qb = reinterpret_cast<const bf16_t*>(p.Q) + q0;
+  const char* Pb = p.P + (long long)p0 * 2;
+  const char* Qb = p.Q + (long long)q0 * 2;
   const char* zero = reinterpret_cast<const char*>(g_wzero_page) + (lane & 7) * 16;
   const int tyo = tr * p.dil - p.pad_h, txo = ts * p.dil - p.pad_w;
-  const int cP = wave * GP::RPI + lane / GP::CPR;            // this thread's row within a wave-instruction group
-  const int cQ = wave * GQ::RPI + lane / GQ::CPR;
+  // Staging addresses.  Wave w stages the 16 pixels [16w, 16w + 16) of a step (rows rho = RS*i + c hold
+  // pixel NI*c + i).  Per step, lane l decodes ONE pixel (16w + l % 16) into 32-bit element offsets of
+  // its dy / x rows (-1: contributes zero), and every lane then fetches the offsets of the pixels it
+  // stages with a lane permute -- instead of every lane decoding all of its rows.
+  const int cP = lane / GP::CPR, cQ = lane / GQ::CPR;          // row within a wave-instruction
+  int srcP[GP::NI], srcQ[GQ::NI];                                // permute source lanes (x4 for ds_bpermute)
+  int chP[GP::NI], chQ[GQ::NI];                                  // byte offset of this lane's (swizzled) chunk
+#pragma unroll
+  for (int i = 0; i < GP::NI; ++i) {
+    srcP[i] = (GP::NI * cP + i) * 4;
+    chP[i] = ((lane % GP::CPR) ^ GP::swz(GP::RS * i + wave * GP::RPI + cP)) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < GQ::NI; ++i) {
+    srcQ[i] = (GQ::NI * cQ + i) * 4;
+    chQ[i] = ((lane % GQ::CPR) ^ GQ::swz(GQ::RS * i + wave * GQ::RPI + cQ)) * 16;
+  }
+  const int psN = (int)p.psN, psH = (int)p.psH, psW = (int)p.psW;
+  const int qsN = (int)p.qsN, qsH = (int)p.qsH, qsW = (int)p.qsW;
 
   auto stage = [&](char* buf, int mit) {
-    {   // ---- P rows: pixels mit + NI*cP + i
-      int m = mit + GP::NI * cP;
+    const int m = mit + 16 * wave + (lane & 15);
+    int offP = -1, offQ = -1;
+    {
       int rem, x;
-      int n = fdiv(min(m, p.M - 1), pr.dhw, rem);
-      int y = fdiv(rem, pr.dw_, x);
-#pragma unroll
-      for (int i = 0; i < GP::NI; ++i) {
-        const int rho = GP::RS * i + cP;
-        const int chunkc = (lane % GP::CPR) ^ GP::swz(rho);
-        const char* src = (m < mend)
-            ? reinterpret_cast<const char*>(Pb + (n * p.psN + y * p.psH + x * p.psW + chunkc * 8)) : zero;
-        __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(buf + (GP::RS * i + wave * GP::RPI) * RBP), 16, 0, 0);
-        ++m;
-        if (++x == p.Wp) { x = 0; if (++y == p.Hp) { y = 0; ++n; } }
+      const int n = fdiv(min(m, p.M - 1), pr.dhw, rem);
+      const int y = fdiv(rem, pr.dw_, x);
+      const int iy = y * p.stride + tyo, ix = x * p.stride + txo;
+      if (m < mend) {
+        offP = n * psN + y * psH + x * psW;
+        if ((unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq) offQ = n * qsN + iy * qsH + ix * qsW;
       }
     }
-    {   // ---- Q rows: the same pixels shifted by the tap
-      int m = mit + GQ::NI * cQ;
-      int rem, x;
-      int n = fdiv(min(m, p.M - 1), pr.dhw, rem);
-      int y = fdiv(rem, pr.dw_, x);
 #pragma unroll
-      for (int i = 0; i < GQ::NI; ++i) {
-        const int rho = GQ::RS * i + cQ;
-        const int chunkc = (lane % GQ::CPR) ^ GQ::swz(rho);
-        const int iy = y * p.stride + tyo, ix = x * p.stride + txo;
-        const bool ok = m < mend && (unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq;
-        const char* src = ok
-            ? reinterpret_cast<const char*>(Qb + (n * p.qsN + iy * p.qsH + ix * p.qsW + chunkc * 8)) : zero;
-        __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(buf + BKP * RBP + (GQ::RS * i + wave * GQ::RPI) * RBQ), 16, 0, 0);
-        ++m;
-        if (++x == p.Wp) { x = 0; if (++y == p.Hp) { y = 0; ++n; } }
-      }
+    for (int i = 0; i < GP::NI; ++i) {
+      const int off = __builtin_amdgcn_ds_bpermute(srcP[i], offP);
+      const char* src = off >= 0 ? Pb + ((long long)off * 2 + chP[i]) : zero;
+      __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(buf + (GP::RS * i + wave * GP::RPI) * RBP), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < GQ::NI; ++i) {
+      const int off = __builtin_amdgcn_ds_bpermute(srcQ[i], offQ);
+      const char* src = off >= 0 ? Qb + ((long long)off * 2 + chQ[i]) : zero;
+      __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(buf + BKP * RBP + (GQ::RS * i + wave * GQ::RPI) * RBQ), 16, 0, 0);
     }
   };
 
@@ -351,17 +378,58 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
   if (mbeg < mend) stage(smem, mbeg);
   __syncthreads();
   int cur = 0;
+  // per-lane fragment bases: everything lane-dependent hoisted; kk and the +4 partner are constants
+  int pbase[TP], qbase[TQ];
+  {
+    const int g = lane >> 4, li = lane & 15, lq = li >> 2, lpp = li & 3, lh = g >> 1;
+    const int kq0 = 8 * lh + lq;
+    const int rp = GP::row_of(kq0), rq = GQ::row_of(kq0);
+#pragma unroll
+    for (int i = 0; i < TP; ++i) {
+      const int colb = (wp * (BP / 2) + i * 32 + 16 * (g & 1) + 4 * lpp) * 2;
+      pbase[i] = rp * RBP + (colb ^ (GP::swz(rp) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const int colb = (wq * (BQ / 2) + j * 32 + 16 * (g & 1) + 4 * lpp) * 2;
+      qbase[j] = BKP * RBP + rq * RBQ + (colb ^ (GQ::swz(rq) << 4));
+    }
+  }
+  constexpr int P_KK = (16 / GP::NI) * RBP, P_HI = (4 / GP::NI) * RBP;
+  constexpr int Q_KK = (16 / GQ::NI) * RBQ, Q_HI = (4 / GQ::NI) * RBQ;
+  constexpr int NRD = 2 * (TP + TQ);             // tr reads per 16-pixel sub-step
+  const unsigned smem_off = lds_off(smem);
   for (int mit = mbeg; mit < mend; mit += BKP) {
     if (mit + BKP < mend) stage(smem + (cur ^ 1) * STAGE, mit + BKP);
-    const char* Pt = smem + cur * STAGE;
-    const char* Qt = Pt + BKP * RBP;
+    const unsigned Pl = smem_off + cur * STAGE;
+    bf16x4 fa[2][TP][2], fb[2][TQ][2];           // [set][tile][lo/hi], sets alternate per sub-step
+    auto issue = [&](int set, int kk) {
+#pragma unroll
+      for (int i = 0; i < TP; ++i) {
+        tr_issue(Pl + pbase[i] + kk * P_KK, fa[set][i][0]);
+        tr_issue(Pl + pbase[i] + kk * P_KK + P_HI, fa[set][i][1]);
+      }
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) {
+        tr_issue(Pl + qbase[j] + kk * Q_KK, fb[set][j][0]);
+        tr_issue(Pl + qbase[j] + kk * Q_KK + Q_HI, fb[set][j][1]);
+      }
+    };
+    issue(0, 0);
 #pragma unroll
     for (int kk = 0; kk < BKP / 16; ++kk) {
+      const int set = kk & 1;
+      if (kk + 1 < BKP / 16) { issue(set ^ 1, kk + 1); lgkm_wait<NRD>(); } else { lgkm_wait<0>(); }
+#pragma unroll
+      for (int i = 0; i < TP; ++i) { touch(fa[set][i][0]); touch(fa[set][i][1]); }
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) { touch(fb[set][j][0]); touch(fb[set][j][1]); }
+      __builtin_amdgcn_sched_barrier(0);
       bf16x8 a[TP], b[TQ];
 #pragma unroll
-      for (int i = 0; i < TP; ++i) a[i] = tr_frag2<RBP>(Pt, wp * (BP / 2) + i * 32, kk, lane);
+      for (int i = 0; i < TP; ++i) a[i] = join(fa[set][i][0], fa[set][i][1]);
 #pragma unroll
-      for (int j = 0; j < TQ; ++j) b[j] = tr_frag2<RBQ>(Qt, wq * (BQ / 2) + j * 32, kk, lane);
+      for (int j = 0; j < TQ; ++j) b[j] = join(fb[set][j][0], fb[set][j][1]);
 #pragma unroll
       for (int i = 0; i < TP; ++i)
 #pragma unroll
@@ -399,18 +467,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
   reinterpret_cast<f32x4*>(dw)[i] = s;
 }
 
-struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct; };
+struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct, slabs; };
 
 int g_tune_wgrad_v2 = 1;       // dct_tune_set(DCT_TUNE_WGRAD_V2, 0): register-staged kernel
 int g_tune_wgrad_chunks = -1;  // >= 1 forces the number of pixel chunks
 
 static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc* d, int dtype, WPlan& pl) {
   if (p->c % 64 || q->c % 64) return false;
+  const long long M = (long long)p->n * p->h * p->w;
   pl.bp = (p->c % 128 == 0) ? 128 : 64;
   pl.bq = (q->c % 128 == 0) ? 128 : 64;
   pl.ptiles = p->c / pl.bp; pl.qtiles = q->c / pl.bq;
-  const long long M = (long long)p->n * p->h * p->w;
-  pl.v2 = (dtype == DCT_BF16 && g_tune_wgrad_v2 && M < (1 << 24)) ? 1 : 0;
+  const bool fits32 = (long long)p->n * p->sn < (1ll << 30) && (long long)q->n * q->sn < (1ll << 30);   // 32-bit element offsets
+  pl.v2 = (dtype == DCT_BF16 && g_tune_wgrad_v2 && M < (1 << 24) && fits32) ? 1 : 0;
   const int bkp = pl.v2 ? 64 : (dtype == DCT_BF16 ? 32 : 16);
   const long long tiles = (long long)pl.ptiles * pl.qtiles * d->R * d->S;
   long long chunks;
@@ -432,6 +501,7 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
   ppc = (ppc + bkp - 1) / bkp * bkp;
   pl.ppc = (int)ppc;
   pl.chunks = (int)((M + ppc - 1) / ppc);
+  pl.slabs = pl.chunks;
   pl.direct = (pl.v2 && pl.chunks == 1) ? 1 : 0;
   return true;
 }
@@ -475,7 +545,7 @@ extern "C" size_t dct_conv2d_wgrad_workspace_bytes(const dct_view* p, const dct_
   if (!p || !q || !d) return 0;
   WPlan pl;
   if (!make_wplan(p, q, d, dtype, pl)) return 0;
-  return pl.direct ? 16 : (size_t)pl.chunks * p->c * q->c * d->R * d->S * sizeof(float);
+  return pl.direct ? 16 : (size_t)pl.slabs * p->c * q->c * d->R * d->S * sizeof(float);
 }
 
 extern "C" int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw, const dct_conv_desc* d, int dtype,
@@ -494,7 +564,7 @@ extern "C" int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw,
     return DCT_ERR_UNSUPPORTED;
   WPlan pl;
   if (!make_wplan(p, q, d, dtype, pl)) return DCT_ERR_UNSUPPORTED;
-  const size_t need = pl.direct ? 0 : (size_t)pl.chunks * p->c * q->c * d->R * d->S * sizeof(float);
+  const size_t need = pl.direct ? 0 : (size_t)pl.slabs * p->c * q->c * d->R * d->S * sizeof(float);
   if (need && (!workspace || workspace_bytes < need)) return DCT_ERR_WORKSPACE;
   WgradParams wp;
   wp.P = (const char*)p->ptr; wp.Q = (const char*)q->ptr; wp.out = pl.direct ? dw : (float*)workspace;
@@ -516,7 +586,7 @@ extern "C" int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw,
   if (!pl.direct) {
     const long long n = (long long)p->c * q->c * d->R * d->S;
     DCT_LAUNCH(DCT_PROF_WGRAD, wgrad_reduce_kernel, dim3(div_up(n / 4, 256)), dim3(256), 0, st,
-               (const float*)workspace, dw, n / 4, n, pl.chunks, d->accumulate);
+               (const float*)workspace, dw, n / 4, n, pl.slabs, d->accumulate);
   }
   return dct_check_launch();
 }

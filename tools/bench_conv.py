@@ -41,12 +41,14 @@ def timeit(fn, reps):
     return a.elapsed_time(b) / reps * 1e-3
 
 
-def run(B, reps, what, label):
+def run(B, reps, what, label, only=None):
     dt = torch.bfloat16
     rows = []
     tot = {k: [0.0, 0.0] for k in ("fwd", "dgrad", "wgrad")}
     g = torch.Generator(device=DEV).manual_seed(0)
     for name, cin, hin, cout in CONVS:
+        if only and name not in only:
+            continue
         ho = hin - 2
         x = torch.randn(B, hin, hin, cin, device=DEV, generator=g).to(dt)
         w = (torch.randn(cout, 3, 3, cin, device=DEV, generator=g) / (3 * cin ** 0.5)).to(dt)
@@ -69,6 +71,8 @@ def run(B, reps, what, label):
             r["wgrad"] = t; tot["wgrad"][0] += fl; tot["wgrad"][1] += t
         rows.append(r)
     for name, cin, hin, cout in CONVT:
+        if only and name not in only:
+            continue
         x = torch.randn(B, hin, hin, cin, device=DEV, generator=g).to(dt)
         wf = (torch.randn(4 * cout, cin, device=DEV, generator=g) / cin ** 0.5).to(dt)
         wd = (torch.randn(cin, 4 * cout, device=DEV, generator=g) / cout ** 0.5).to(dt)
@@ -107,15 +111,17 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
+    ap.add_argument("--only", default="", help="comma-separated layer names")
     ap.add_argument("--ab", action="store_true", help="also run with the register-staged igemm kernel")
     args = ap.parse_args()
     what = args.what.split(",")
     lib = _lib.load()
-    run(args.batch, args.reps, what, "default")
+    only = set(args.only.split(",")) if args.only else None
+    run(args.batch, args.reps, what, "default", only)
     if args.ab:
         lib.dct_tune_set(0, 0)
         lib.dct_tune_set(2, 0)
-        run(args.batch, args.reps, what, "v1 kernels (register staged)")
+        run(args.batch, args.reps, what, "v1 kernels (register staged)", only)
         lib.dct_tune_set(0, 1)
         lib.dct_tune_set(2, 1)
 
