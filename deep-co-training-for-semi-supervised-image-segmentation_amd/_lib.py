@@ -31,6 +31,10 @@ class ConvDesc(C.Structure):
                 ("accumulate", C.c_int32), ("mask_channels", C.c_int32), ("mask_scale", C.c_float)]
 
 
+class EnetTf(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_void_p), ("mode", C.c_int32)]
+
+
 def conv_desc(R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=0, scatter2x2=0, accumulate=0,
               mask_channels=0, mask_scale=1.0) -> ConvDesc:
     return ConvDesc(R, S, stride, dil, pad_h, pad_w, int(relu), int(scatter2x2), int(accumulate),
@@ -50,6 +54,7 @@ _P = C.c_void_p
 _VP = C.POINTER(View)
 _DP = C.POINTER(ConvDesc)
 _i, _i64, _f, _sz, _u64 = C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
+_TP = C.POINTER(EnetTf)
 
 # name -> (restype, argtypes); mirrors include/dct.h one to one
 SIGNATURES = {
@@ -95,6 +100,15 @@ SIGNATURES = {
     "dct_argmax": (_i, [_P, _P, _i64, _i, _P]),
     "dct_fgsm_step": (_i, [_P, _P, _f, _P, _P, _i64, _P]),
     "dct_adam_flat": (_i, [_P, _P, _P, _P, _i64, _f, _f, C.c_double, C.c_double, _f, _f, _P, _P]),
+    "dct_enet_conv": (_i, [_VP, _P, _P, _TP, _VP, _DP, _i, _i, _i, _i, _VP, _VP, _i, _i, _P]),
+    "dct_enet_reduce_workspace_bytes": (_sz, [_i]),
+    "dct_enet_bn_fwd_stats": (_i, [_VP, _P, _P, _f, _f, _P, _P, _i, _P, _P, _P, _P, _i, _i, _P, _sz, _P]),
+    "dct_enet_bn_bwd": (_i, [_VP, _VP, _VP, _P, _P, _P, _i, _P, _P, _P, _P, _P, _P, _i, _VP, _i, _i, _P, _sz, _P]),
+    "dct_enet_channel_sum": (_i, [_VP, _P, _i, _i, _P, _sz, _P]),
+    "dct_enet_tail_fwd": (_i, [_VP, _TP, _VP, _VP, _TP, _P, _i, _i, _VP, _i, _i, _P]),
+    "dct_enet_tail_bwd": (_i, [_VP, _VP, _P, _i, _i, _i, _VP, _i, _i, _P]),
+    "dct_enet_wgrad_workspace_bytes": (_sz, [_VP, _VP, _DP]),
+    "dct_enet_wgrad": (_i, [_VP, _TP, _VP, _TP, _P, _DP, _i, _i, _P, _sz, _P]),
     "dct_dice_counts": (_i, [_P, _P, _i, _i64, _i, _P, _P, _P, _P]),
     "dct_tune_set": (_i, [_i, _i]),
     "dct_prof_enable": (_i, [_i]),

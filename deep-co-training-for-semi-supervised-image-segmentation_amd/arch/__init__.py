@@ -7,6 +7,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from .enet import Enet
 from .unet import UNet, _ConvP
 
 __all__ = ['weights_init', 'get_arch', 'ARCH_CALLABLES']
@@ -21,6 +22,7 @@ def _register_arch(arch, callable, alias=None):
 
 
 _register_arch('unet', UNet)
+_register_arch('enet', Enet)
 
 
 def weights_init(m):

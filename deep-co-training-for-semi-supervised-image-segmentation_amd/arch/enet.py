@@ -1,0 +1,464 @@
+"""Enet of the reference (arch/enet.py:8-243) as one HIP execution plan.
+
+Same parameters / buffers, ``state_dict`` keys and logical shapes as the reference module
+(``encoder.initial.*``, ``encoder.bottleneck_{1_0..3_8}.{block1x1_1,middle_block,block1x1_2}.*``,
+``decoder.layers.{0..5}.*``; ``enet.py:191-192`` registers the encoder blocks by name), but the
+forward/backward are fixed sequences of the fused Enet kernels of include/dct.h:
+
+  * a conv writes its RAW output once; its BatchNorm statistics come from one reduction pass and
+    the normalise + PReLU/ReLU is applied by whoever reads it next ("normalise on load");
+  * the bottleneck tail ``relu(main + ext)`` (enet.py:146-149) is one kernel that also does the
+    max-pool-with-indices / zero channel pad (down) or max-unpool (up) of the main branch;
+  * backward mirrors it: one BN/activation backward (reduce + apply) per conv, data gradient and
+    weight gradient through the same generic small-channel kernels.
+
+``Dropout2d`` is constructed by the reference (enet.py:122) but never applied in ``forward``, so
+Enet is deterministic in train mode apart from the BatchNorm batch statistics -- three separate
+statistics batches per model per step (labeled, unlabeled, adversarial), which is why the trainer
+never merges passes for this network (``batch_independent = False``).
+
+Data layout in HBM: activations NHWC in ``compute_dtype`` (bf16 default / fp32 parity mode); the
+pooling argmax codes are uint8 [N,h,w,C]; weights are the fp32 masters of the flat parameter
+buffer, physically K-major ``[Cout][kh][kw][Cin]`` (``[Cin][kh][kw][Cout]`` for transposed convs).
+No CPU path.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import hip_ops as K
+from ..hip_ops import Tf
+from .flat import FlatParams
+from .unet import _ConvP, _Slots
+
+_STAGE23 = [("regular", 1), ("dilated", 2), ("asym", 1), ("dilated", 4),
+            ("regular", 1), ("dilated", 8), ("asym", 1), ("dilated", 16)]
+
+
+class _EConv(_ConvP):
+    """nn.Conv2d(cin, cout, (kh, kw), stride, padding, dilation, bias) parameters, K-major storage."""
+    transposed = False
+
+    def __init__(self, cin, cout, kh, kw, stride=1, pad=(0, 0), dil=1, bias=True):
+        nn.Module.__init__(self)
+        self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
+        self.stride, self.pad, self.dil = stride, pad, dil
+        self.weight = nn.Parameter(torch.empty(cout, kh, kw, cin).permute(0, 3, 1, 2))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout))
+        else:
+            self.register_parameter("bias", None)
+        fan_in = cin * kh * kw
+        bound = 1.0 / fan_in ** 0.5
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if bias:
+                self.bias.uniform_(-bound, bound)
+
+    @property
+    def taps(self):
+        return self.kh * self.kw
+
+
+class _EConvT(_EConv):
+    """nn.ConvTranspose2d(cin, cout, k, stride=2, padding, output_padding): logical [cin,cout,k,k],
+    physical [cin][k][k][cout]."""
+    transposed = True
+
+    def __init__(self, cin, cout, k, stride=2, pad=0, out_pad=0, bias=True):
+        nn.Module.__init__(self)
+        self.cin, self.cout, self.kh, self.kw = cin, cout, k, k
+        self.stride, self.pad, self.dil, self.out_pad = stride, (pad, pad), 1, out_pad
+        self.weight = nn.Parameter(torch.empty(cin, k, k, cout).permute(0, 3, 1, 2))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout))
+        else:
+            self.register_parameter("bias", None)
+        bound = 1.0 / (cout * k * k) ** 0.5
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if bias:
+                self.bias.uniform_(-bound, bound)
+
+
+class _BN(nn.Module):
+    """nn.BatchNorm2d(c, eps=1e-3) parameters and buffers (enet.py:22,55,...)."""
+    is_dct_batchnorm = True
+
+    def __init__(self, c, eps=1e-3, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _PReLU(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.full((c,), 0.25))
+
+
+class _ReLU(nn.Module):
+    pass
+
+
+def _act(c, relu):
+    return _ReLU() if relu else _PReLU(c)
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, cout, kind="regular", dilation=1, relu=False):
+        super().__init__()
+        self.kind, self.cin, self.cout = kind, cin, cout
+        mid = cout // 4
+        k = 2 if kind == "down" else 1
+        self.block1x1_1 = _Slots({0: _EConv(cin, mid, k, k, stride=k, bias=False), 1: _BN(mid), 2: _act(mid, relu)})
+        if kind == "up":
+            self.conv_before_unpool = _Slots({0: _EConv(cin, cout, 1, 1, bias=False), 1: _BN(cout)})
+            core = _EConvT(mid, mid, 3, stride=2, pad=1, out_pad=1)
+        elif kind == "dilated":
+            core = _EConv(mid, mid, 3, 3, pad=(dilation, dilation), dil=dilation)
+        elif kind == "asym":
+            core = _Slots({0: _EConv(mid, mid, 5, 1, pad=(2, 0), bias=False), 1: _EConv(mid, mid, 1, 5, pad=(0, 2))})
+        else:
+            core = _EConv(mid, mid, 3, 3, pad=(1, 1))
+        self.middle_block = _Slots({0: core, 1: _BN(mid), 2: _act(mid, relu)})
+        self.block1x1_2 = _Slots({0: _EConv(mid, cout, 1, 1, bias=False), 1: _BN(cout), 2: _act(cout, relu)})
+
+
+class _Initial(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = _EConv(1, 13, 3, 3, stride=2, pad=(1, 1))
+        self.batch_norm = _BN(13)
+        self.prelu = _PReLU(13)
+
+
+class _Encoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.order: List[str] = []
+
+        def add(name, mod):
+            self.add_module(name, mod)
+            self.order.append(name)
+
+        add("initial", _Initial())
+        add("bottleneck_1_0", _Bottleneck(14, 64, "down"))
+        for i in range(1, 5):
+            add(f"bottleneck_1_{i}", _Bottleneck(64, 64))
+        add("bottleneck_2_0", _Bottleneck(64, 128, "down"))
+        for stage in (2, 3):
+            for i, (kind, dil) in enumerate(_STAGE23, start=1):
+                add(f"bottleneck_{stage}_{i}", _Bottleneck(128, 128, kind, dil))
+
+
+class _Decoder(nn.Module):
+    def __init__(self, num_classes):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            _Bottleneck(128, 64, "up", relu=True), _Bottleneck(64, 64, relu=True), _Bottleneck(64, 64, relu=True),
+            _Bottleneck(64, 14, "up", relu=True), _Bottleneck(14, 14, relu=True),
+            _EConvT(14, num_classes, 2, stride=2)])
+
+
+class _Rec(object):
+    """what one conv+BN(+act) unit leaves behind for its consumers and for the backward"""
+    __slots__ = ("raw", "tf", "mean", "invstd", "bn", "act", "conv", "src", "src_tf")
+
+
+class Enet(nn.Module):
+    """Drop-in for the reference ``Enet(num_classes)`` (enet.py:234-243)."""
+    batch_independent = False     # BatchNorm batch statistics couple the samples of a pass
+
+    def __init__(self, num_classes: int = 2, compute_dtype=torch.bfloat16):
+        super().__init__()
+        if not 2 <= num_classes <= 8:
+            raise ValueError("dct_amd Enet: 2 <= num_classes <= 8")
+        self.num_classes = num_classes
+        self.compute_dtype = compute_dtype
+        self.encoder = _Encoder()
+        self.decoder = _Decoder(num_classes)
+        self.flat_params = FlatParams(list(self.parameters()))
+        self._pidx = {id(p): i for i, p in enumerate(self.flat_params.params)}
+
+    @property
+    def _nbt(self):
+        return [m.num_batches_tracked for m in self.modules() if isinstance(m, _BN)]
+
+    def mark_weights_updated(self):
+        pass    # no packed copies: the kernels read the fp32 masters
+
+    # ------------------------------------------------------------------------------ helpers
+    def _w(self, p):
+        return self.flat_params.dense(self._pidx[id(p)])
+
+    def _g(self, p):
+        return self.flat_params.grad_dense(self._pidx[id(p)])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("dct_amd Enet runs on the HIP device only (no CPU fallback)")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"expected [B,1,H,W], got {tuple(x.shape)}")
+        if x.shape[2] % 8 or x.shape[3] % 8:
+            raise RuntimeError("Enet needs H and W divisible by 8 (three stride-2 stages, enet.py:26,132)")
+        self.flat_params.ensure()
+        params = self.flat_params.params
+        save = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _EnetFn.apply(self, save, x, *params)
+
+    # ------------------------------------------------------------------------------ forward plan
+    def _cba(self, src, src_tf, conv, bn, act, out_hw, save) -> _Rec:
+        """conv (+bias) -> raw; BatchNorm statistics -> consumer transform."""
+        dt, dev = self.compute_dtype, src.device
+        B = src.shape[0]
+        raw = torch.empty(B, out_hw[0], out_hw[1], conv.cout, dtype=torch.float32, device=dev)   # raw: always fp32
+        self._conv_fwd(src, src_tf, conv, raw)
+        rec = _Rec()
+        rec.raw, rec.conv, rec.bn, rec.act, rec.src, rec.src_tf = raw, conv, bn, act, src, src_tf
+        c = conv.cout
+        vec = torch.empty(4, c, dtype=torch.float32, device=dev)
+        K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                            self.training, vec[0], vec[1], vec[2], vec[3])
+        if isinstance(act, _PReLU):
+            rec.tf = Tf(vec[0], vec[1], self._w(act.weight), Tf.PRELU)
+        elif isinstance(act, _ReLU):
+            rec.tf = Tf(vec[0], vec[1], None, Tf.RELU)
+        else:
+            rec.tf = Tf(vec[0], vec[1], None, Tf.AFFINE)
+        rec.mean, rec.invstd = vec[2], vec[3]
+        return rec
+
+    def _conv_fwd(self, src, src_tf, conv, dst):
+        w = self._w(conv.weight)
+        b = self._w(conv.bias) if conv.bias is not None else None
+        t = conv.taps
+        if conv.transposed:
+            K.enet_conv(src, w, b, src_tf, dst, R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1],
+                        transposed=True, ws=(1, conv.cout, t * conv.cout))
+        else:
+            K.enet_conv(src, w, b, src_tf, dst, R=conv.kh, S=conv.kw, stride=conv.stride, dil=conv.dil, pad_h=conv.pad[0],
+                        pad_w=conv.pad[1], ws=(t * conv.cin, conv.cin, 1))
+
+    def _conv_dgrad(self, g, conv, dst, accumulate=False, resid=None):
+        """dst (+)= d(loss)/d(conv input) given g = d/d(conv output)."""
+        w = self._w(conv.weight)
+        t = conv.taps
+        rg, rm = resid if resid is not None else (None, None)
+        if conv.transposed:
+            K.enet_conv(g, w, None, None, dst, R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1],
+                        ws=(t * conv.cout, conv.cout, 1), accumulate=accumulate, resid_grad=rg, resid_mask=rm)
+        else:
+            K.enet_conv(g, w, None, None, dst, R=conv.kh, S=conv.kw, stride=conv.stride, dil=conv.dil, pad_h=conv.pad[0],
+                        pad_w=conv.pad[1], transposed=True, ws=(1, conv.cin, t * conv.cin), accumulate=accumulate,
+                        resid_grad=rg, resid_mask=rm)
+        return dst
+
+    def _conv_wgrad(self, g, conv, src, src_tf):
+        """dW (+ db) += for a conv whose input was src (read through src_tf) and output gradient is g."""
+        dw = self._g(conv.weight)
+        if conv.transposed:
+            K.enet_wgrad(src, src_tf, g, None, dw, R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1])
+        else:
+            K.enet_wgrad(g, None, src, src_tf, dw, R=conv.kh, S=conv.kw, stride=conv.stride, dil=conv.dil, pad_h=conv.pad[0],
+                         pad_w=conv.pad[1])
+        if conv.bias is not None:
+            K.enet_channel_sum(g, self._g(conv.bias))
+
+    def _bottleneck_fwd(self, blk: _Bottleneck, x, idx_in, save):
+        dt, dev = self.compute_dtype, x.device
+        B, h, w, _ = x.shape
+        st: Dict[str, object] = {"blk": blk, "x": x}
+        if blk.kind == "down":
+            oh, ow = h // 2, w // 2
+        elif blk.kind == "up":
+            oh, ow = 2 * h, 2 * w
+        else:
+            oh, ow = h, w
+        s1 = blk.block1x1_1
+        r1 = self._cba(x, None, s1.at(0), s1.at(1), s1.at(2), (oh, ow) if blk.kind == "down" else (h, w), save)
+        mb = blk.middle_block
+        core = mb.at(0)
+        if blk.kind == "asym":
+            c5, c15 = core.at(0), core.at(1)
+            mid_raw = torch.empty(B, oh, ow, c5.cout, dtype=torch.float32, device=dev)
+            self._conv_fwd(r1.raw, r1.tf, c5, mid_raw)
+            r2 = self._cba(mid_raw, None, c15, mb.at(1), mb.at(2), (oh, ow), save)
+            st["mid_raw"] = mid_raw
+        else:
+            r2 = self._cba(r1.raw, r1.tf, core, mb.at(1), mb.at(2), (oh, ow), save)
+        s3 = blk.block1x1_2
+        r3 = self._cba(r2.raw, r2.tf, s3.at(0), s3.at(1), s3.at(2), (oh, ow), save)
+        out = torch.empty(B, oh, ow, blk.cout, dtype=dt, device=dev)
+        idx_out = None
+        if blk.kind == "down":
+            idx_out = torch.empty(B, oh, ow, blk.cin, dtype=torch.uint8, device=dev)
+            K.enet_tail_fwd(r3.raw, r3.tf, x, None, None, idx_out, blk.cin, 1, out)
+        elif blk.kind == "up":
+            cb = blk.conv_before_unpool
+            rm = self._cba(x, None, cb.at(0), cb.at(1), None, (h, w), save)
+            K.enet_tail_fwd(r3.raw, r3.tf, None, rm.raw, rm.tf, idx_in, blk.cout, 2, out)
+            st["rm"], st["idx"] = rm, idx_in
+        else:
+            K.enet_tail_fwd(r3.raw, r3.tf, x, None, None, None, 0, 0, out)
+        if idx_out is not None:
+            st["idx"] = idx_out
+        st.update(r1=r1, r2=r2, r3=r3, out=out)
+        return out, idx_out, (st if save else None)
+
+    def _run_forward(self, x, save):
+        dt, dev = self.compute_dtype, x.device
+        B, _, H, W = x.shape
+        xs = x.detach().to(torch.float32).reshape(B, H, W, 1)
+        if not xs.is_contiguous():
+            xs = xs.contiguous()
+        ini = self.encoder.initial
+        r0 = self._cba(xs, None, ini.conv, ini.batch_norm, ini.prelu, (H // 2, W // 2), save)   # the image stays fp32
+        h = torch.empty(B, H // 2, W // 2, 14, dtype=dt, device=dev)
+        K.enet_tail_fwd(r0.raw, r0.tf, xs, None, None, None, 13, 3, h)
+        tape = [{"kind": "initial", "x": xs, "r0": r0, "out": h}] if save else None
+        stack = []
+        for name in self.encoder.order[1:]:
+            blk = getattr(self.encoder, name)
+            h, idx, st = self._bottleneck_fwd(blk, h, None, save)
+            if idx is not None:
+                stack.append(idx)
+            if save:
+                tape.append(st)
+        for blk in list(self.decoder.layers)[:5]:
+            idx = stack.pop() if blk.kind == "up" else None
+            h, _, st = self._bottleneck_fwd(blk, h, idx, save)
+            if save:
+                tape.append(st)
+        fin = self.decoder.layers[5]
+        logits = torch.empty(B, H, W, self.num_classes, dtype=torch.float32, device=dev)
+        self._conv_fwd(h, None, fin, logits)
+        if self.training:      # nn.BatchNorm2d bookkeeping, one multi-tensor launch for all 84 layers
+            torch._foreach_add_(self._nbt, 1)
+        if save:
+            tape.append({"kind": "final", "x": h, "training": self.training})
+        return logits, tape
+
+    # ------------------------------------------------------------------------------ backward plan
+    def _bn_bwd(self, rec: _Rec, g, g_mask, need_dw):
+        """grad wrt act(bn(raw)) -> grad wrt raw; accumulates dgamma / dbeta / dslope."""
+        dev = rec.raw.device
+        c = rec.raw.shape[3]
+        draw = torch.empty(rec.raw.shape, dtype=self.compute_dtype, device=dev)
+        scratch = torch.empty(2 * c, dtype=torch.float32, device=dev)
+        dg = self._g(rec.bn.weight) if need_dw else None
+        db = self._g(rec.bn.bias) if need_dw else None
+        ds = self._g(rec.act.weight) if (need_dw and isinstance(rec.act, _PReLU)) else None
+        if isinstance(rec.act, _PReLU) and ds is None:
+            ds = torch.zeros(c, dtype=torch.float32, device=dev)
+        if dg is None:
+            dg = torch.zeros(c, dtype=torch.float32, device=dev)
+            db = torch.zeros(c, dtype=torch.float32, device=dev)
+        K.enet_bn_bwd(rec.raw, g, g_mask, rec.tf, rec.mean, rec.invstd, dg, db, ds, scratch, draw, training=self._tape_training)
+        return draw
+
+    def _bottleneck_bwd(self, st, dout, need_dw, need_dx=True):
+        blk: _Bottleneck = st["blk"]
+        x, out = st["x"], st["out"]
+        r1, r2, r3 = st["r1"], st["r2"], st["r3"]
+        dt = self.compute_dtype
+        # ---- extension branch, last to first
+        d3 = self._bn_bwd(r3, dout, out, need_dw)
+        if need_dw:
+            self._conv_wgrad(d3, r3.conv, r2.raw, r2.tf)
+        g2 = self._conv_dgrad(d3, r3.conv, torch.empty(r2.raw.shape, dtype=dt, device=r2.raw.device))
+        d2 = self._bn_bwd(r2, g2, None, need_dw)
+        if blk.kind == "asym":
+            c5, c15 = blk.middle_block.at(0).at(0), blk.middle_block.at(0).at(1)
+            mid_raw = st["mid_raw"]
+            if need_dw:
+                self._conv_wgrad(d2, c15, mid_raw, None)
+            gmid = self._conv_dgrad(d2, c15, torch.empty(mid_raw.shape, dtype=dt, device=mid_raw.device))
+            if need_dw:
+                self._conv_wgrad(gmid, c5, r1.raw, r1.tf)
+            g1 = self._conv_dgrad(gmid, c5, torch.empty(r1.raw.shape, dtype=dt, device=r1.raw.device))
+        else:
+            if need_dw:
+                self._conv_wgrad(d2, r2.conv, r1.raw, r1.tf)
+            g1 = self._conv_dgrad(d2, r2.conv, torch.empty(r1.raw.shape, dtype=dt, device=r1.raw.device))
+        d1 = self._bn_bwd(r1, g1, None, need_dw)
+        if need_dw:
+            self._conv_wgrad(d1, r1.conv, x, None)
+        # ---- input gradient = extension branch + main branch
+        dx = torch.empty_like(x)
+        if blk.kind == "down":
+            K.enet_tail_bwd(dout, out, st["idx"], blk.cin, 1, dx)
+            self._conv_dgrad(d1, r1.conv, dx, accumulate=True)
+        elif blk.kind == "up":
+            rm: _Rec = st["rm"]
+            gm = K.enet_tail_bwd(dout, out, st["idx"], blk.cout, 2, torch.empty(rm.raw.shape, dtype=dt, device=rm.raw.device))
+            dm = self._bn_bwd(rm, gm, None, need_dw)
+            if need_dw:
+                self._conv_wgrad(dm, rm.conv, x, None)
+            self._conv_dgrad(dm, rm.conv, dx)
+            self._conv_dgrad(d1, r1.conv, dx, accumulate=True)
+        else:
+            self._conv_dgrad(d1, r1.conv, dx, resid=(dout, out))
+        return dx
+
+    def _run_backward(self, tape, dlogits, need_dx, need_dw):
+        dt, dev = self.compute_dtype, dlogits.device
+        fin = self.decoder.layers[5]
+        st = tape[-1]
+        self._tape_training = st["training"]
+        dl = dlogits if dt == torch.float32 else K.cast(dlogits, torch.empty(dlogits.shape, dtype=dt, device=dev))
+        if need_dw:
+            self._conv_wgrad(dl, fin, st["x"], None)
+        g = torch.empty_like(st["x"])
+        self._conv_dgrad(dl, fin, g)
+        for st in reversed(tape[1:-1]):
+            g = self._bottleneck_bwd(st, g, need_dw)
+        st = tape[0]
+        r0 = st["r0"]
+        d0 = self._bn_bwd(r0, g[..., :13], None, need_dw)
+        ini = self.encoder.initial
+        if need_dw:
+            self._conv_wgrad(d0, ini.conv, st["x"], None)
+        dx = None
+        if need_dx:
+            dx = torch.empty_like(st["x"])
+            self._conv_dgrad(d0, ini.conv, dx)
+            K.enet_tail_bwd(g, st["x"], None, 13, 3, dx, accumulate=True)
+        return dx
+
+
+class _EnetFn(torch.autograd.Function):
+    """One autograd node for the whole network (see arch/unet.py::_UNetFn)."""
+
+    @staticmethod
+    def forward(ctx, net: Enet, save: bool, x: torch.Tensor, *params):
+        need_dw = any(p.requires_grad for p in params)
+        logits, tape = net._run_forward(x, save)
+        ctx.net, ctx.tape, ctx.need_dw = net, tape, need_dw
+        ctx.set_materialize_grads(False)
+        return logits.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        net: Enet = ctx.net
+        n_params = len(net.flat_params.params)
+        if g is None or ctx.tape is None:
+            return (None, None, None) + (None,) * n_params
+        dl = g.permute(0, 2, 3, 1)
+        if dl.dtype != torch.float32 or not dl.is_contiguous():
+            dl = dl.to(torch.float32).contiguous()
+        need_dx = ctx.needs_input_grad[2]
+        need_dw = ctx.need_dw and any(ctx.needs_input_grad[3:])
+        if need_dw:
+            net.flat_params.ensure_grads()
+        dx = net._run_backward(ctx.tape, dl, need_dx, need_dw)
+        ctx.tape = None
+        gx = dx.reshape(dx.shape[0], 1, dx.shape[1], dx.shape[2]) if dx is not None else None
+        return (None, None, gx) + (None,) * n_params

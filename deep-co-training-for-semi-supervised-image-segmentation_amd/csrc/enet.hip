@@ -1,0 +1,645 @@
+// Enet kernels (K2/K3/K4/K6/K7/K8 of SURVEY.md 8a): arch/enet.py:8-243 of the reference.
+//
+// Enet's layers have 1..128 channels (internal widths 3, 16, 32): there is no dense contraction
+// worth an MFMA tile and the net is HBM/launch bound, so these are direct VALU
+// kernels built around FUSION rather than GEMM shape:
+//   * every conv reads its input through the producer's BatchNorm + PReLU/ReLU ("normalise on
+//     load": y = act(scale[c] * raw + shift[c])), so a normalised activation is never written;
+//   * one generic kernel covers conv / transposed conv / both data gradients (direct or
+//     "transposed" gather form, weights addressed through three strides), with optional bias,
+//     residual-gradient add and "+=" epilogue;
+//   * BatchNorm statistics and the three backward sums come from per-block partials (double
+//     accumulators) folded in fixed order by a one-block finalize kernel: deterministic;
+//   * the bottleneck tail relu(main + act(bn(raw))) also does the 2x2 max-pool-with-indices /
+//     max-unpool / zero-channel-pad of the down- and up-sampling bottlenecks.
+// Activations are NHWC in `dtype` (bf16 or f32); all per-channel vectors and the math are fp32.
+#include "dct_common.h"
+
+namespace {
+
+// Element access through a view whose storage is `T` or, when its bit of the call's f32 mask is set, fp32
+// (raw conv outputs stay fp32 in bf16 mode: BatchNorm subtracts their mean, which would cancel bf16's 8 bits).
+template <typename T> __device__ __forceinline__ float ldv(const View& v, long long off, int f32) {
+  return f32 ? reinterpret_cast<const float*>(v.ptr)[off] : to_f32(reinterpret_cast<const T*>(v.ptr)[off]);
+}
+template <typename T> __device__ __forceinline__ void stv(const View& v, long long off, int f32, float val) {
+  if (f32) reinterpret_cast<float*>(v.ptr)[off] = val; else reinterpret_cast<T*>(v.ptr)[off] = from_f32<T>(val);
+}
+__device__ __forceinline__ long long voff(const View& v, int n, int y, int x) { return n * v.sn + y * v.sh + x * v.sw; }
+
+struct Tf {            // input transform of the producer layer: act(scale*x + shift)
+  const float* scale; const float* shift; const float* slope;   // slope: PReLU weights (mode 2)
+  int mode;            // 0 none, 1 affine, 2 affine + PReLU, 3 affine + ReLU
+};
+__device__ __forceinline__ float tf_apply(const Tf& t, int c, float v) {
+  if (t.mode == 0) return v;
+  float z = fmaf(t.scale[c], v, t.shift[c]);
+  if (t.mode == 2) z = z > 0.f ? z : z * t.slope[c];
+  else if (t.mode == 3) z = fmaxf(z, 0.f);
+  return z;
+}
+static inline Tf to_tf(const dct_enet_tf* t) {
+  Tf r; r.scale = nullptr; r.shift = nullptr; r.slope = nullptr; r.mode = 0;
+  if (t) { r.scale = t->scale; r.shift = t->shift; r.slope = t->slope; r.mode = t->mode; }
+  return r;
+}
+
+struct ConvP {
+  View x, y, rg, rm;              // input, output, residual grad + its ReLU mask (optional)
+  const float* w; const float* bias;
+  Tf tf;
+  int R, S, stride, dil, pad_h, pad_w;
+  int transposed, accumulate, has_resid;
+  int ws_out, ws_tap, ws_in;      // weight strides (elements): W(o, tap, i)
+  int G;                          // output-channel groups of 8
+  int fm;                         // f32 mask: bit0 x, bit1 y, bit2 resid grad, bit3 resid mask
+};
+
+// One thread = one output pixel x 8 output channels.  Weights live in LDS as [tap][i][G*8].
+template <typename T>
+__global__ __launch_bounds__(256) void enet_conv_kernel(ConvP p) {
+  extern __shared__ float Ws[];
+  const int Cin = p.x.c, Cout = p.y.c, taps = p.R * p.S, CO = p.G * 8;
+  for (int e = threadIdx.x; e < taps * Cin * CO; e += 256) {
+    const int o = e % CO, i = (e / CO) % Cin, t = e / (CO * Cin);
+    Ws[e] = o < Cout ? p.w[(long long)o * p.ws_out + t * p.ws_tap + i * p.ws_in] : 0.f;
+  }
+  __syncthreads();
+  const int g = threadIdx.x % p.G;
+  const long long pix = (long long)blockIdx.x * (256 / p.G) + threadIdx.x / p.G;
+  const long long P = (long long)p.y.n * p.y.h * p.y.w;
+  if (pix >= P) return;
+  const int hw = p.y.h * p.y.w;
+  const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+  const int oy = rem / p.y.w, ox = rem - oy * p.y.w;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  const int xf = p.fm & 1;
+  for (int r = 0; r < p.R; ++r) {
+    int iy;
+    if (p.transposed) {
+      const int ty = oy + p.pad_h - r * p.dil;
+      if (ty < 0 || ty % p.stride) continue;
+      iy = ty / p.stride;
+    } else {
+      iy = oy * p.stride - p.pad_h + r * p.dil;
+    }
+    if ((unsigned)iy >= (unsigned)p.x.h) continue;
+    for (int s = 0; s < p.S; ++s) {
+      int ix;
+      if (p.transposed) {
+        const int tx = ox + p.pad_w - s * p.dil;
+        if (tx < 0 || tx % p.stride) continue;
+        ix = tx / p.stride;
+      } else {
+        ix = ox * p.stride - p.pad_w + s * p.dil;
+      }
+      if ((unsigned)ix >= (unsigned)p.x.w) continue;
+      const long long xo = voff(p.x, n, iy, ix);
+      const float* wt = Ws + (r * p.S + s) * Cin * CO + g * 8;
+      for (int i = 0; i < Cin; ++i) {
+        const float v = tf_apply(p.tf, i, ldv<T>(p.x, xo + i, xf));
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + i * CO);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(wt + i * CO + 4);
+        acc[0] = fmaf(v, w0[0], acc[0]); acc[1] = fmaf(v, w0[1], acc[1]);
+        acc[2] = fmaf(v, w0[2], acc[2]); acc[3] = fmaf(v, w0[3], acc[3]);
+        acc[4] = fmaf(v, w1[0], acc[4]); acc[5] = fmaf(v, w1[1], acc[5]);
+        acc[6] = fmaf(v, w1[2], acc[6]); acc[7] = fmaf(v, w1[3], acc[7]);
+      }
+    }
+  }
+  const long long yo = n * p.y.sn + oy * p.y.sh + ox * p.y.sw;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = g * 8 + k;
+    if (c >= Cout) break;
+    float v = acc[k];
+    if (p.bias) v += p.bias[c];
+    if (p.has_resid) {
+      if (ldv<T>(p.rm, voff(p.rm, n, oy, ox) + c, p.fm & 8) > 0.f) v += ldv<T>(p.rg, voff(p.rg, n, oy, ox) + c, p.fm & 4);
+    }
+    if (p.accumulate) v += ldv<T>(p.y, yo + c, p.fm & 2);
+    stv<T>(p.y, yo + c, p.fm & 2, v);
+  }
+}
+
+// ---- per-channel sums over pixels: partial[blk][c][k], k < NS, double accumulators -------------
+// kind 0: {sum x, sum x^2}                                  (BatchNorm statistics; bias grad uses k = 0)
+// kind 1: {sum dz, sum dz*xhat, sum g*z*[z<0]}              (BatchNorm / PReLU backward)
+struct RedP {
+  View x, g, m;                  // x: raw conv output; g: upstream grad; m: ReLU mask of g (optional)
+  const float* scale; const float* shift; const float* slope; const float* mean; const float* invstd;
+  int act;                       // activation after the BN: 0 none, 2 PReLU, 3 ReLU
+  int has_mask, kind, ppb;
+  int fm;                        // f32 mask: bit0 x (raw), bit1 g, bit2 g mask, bit3 draw
+};
+
+template <typename T>
+__device__ __forceinline__ float grad_in(const RedP& p, int n, int y, int x, int c) {
+  float g = ldv<T>(p.g, voff(p.g, n, y, x) + c, p.fm & 2);
+  if (p.has_mask) {
+    if (!(ldv<T>(p.m, voff(p.m, n, y, x) + c, p.fm & 4) > 0.f)) g = 0.f;
+  }
+  return g;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void enet_reduce_kernel(RedP p, double* partial) {
+  __shared__ double red[256 * 3];
+  const int C = p.x.c;
+  int CP = 1;
+  while (CP < C) CP <<= 1;                       // <= 128
+  const int rows = 256 / CP;
+  const int c = threadIdx.x % CP, row = threadIdx.x / CP;
+  const long long P = (long long)p.x.n * p.x.h * p.x.w;
+  const long long pbeg = (long long)blockIdx.x * p.ppb, pend = min(P, pbeg + p.ppb);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    const int hw = p.x.h * p.x.w;
+    float sc = 0.f, sh = 0.f, sl = 0.f, mu = 0.f, is = 0.f;
+    if (p.kind == 1) { sc = p.scale[c]; sh = p.shift[c]; mu = p.mean[c]; is = p.invstd[c]; if (p.act == 2) sl = p.slope[c]; }
+    for (long long pix = pbeg + row; pix < pend; pix += rows) {
+      const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+      const int y = rem / p.x.w, x = rem - y * p.x.w;
+      const float v = ldv<T>(p.x, voff(p.x, n, y, x) + c, p.fm & 1);
+      if (p.kind == 0) {
+        a0 += (double)v; a1 += (double)v * (double)v;
+      } else {
+        const float g = grad_in<T>(p, n, y, x, c);
+        const float z = fmaf(sc, v, sh);
+        float dz = g;
+        if (p.act == 2) { if (!(z > 0.f)) { dz = g * sl; a2 += (double)(g * z); } }
+        else if (p.act == 3) { if (!(z > 0.f)) dz = 0.f; }
+        const float xh = (v - mu) * is;
+        a0 += (double)dz; a1 += (double)dz * (double)xh;
+      }
+    }
+  }
+  red[threadIdx.x * 3 + 0] = a0; red[threadIdx.x * 3 + 1] = a1; red[threadIdx.x * 3 + 2] = a2;
+  __syncthreads();
+  if (row == 0 && c < C) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) { s0 += red[(r * CP + c) * 3]; s1 += red[(r * CP + c) * 3 + 1]; s2 += red[(r * CP + c) * 3 + 2]; }
+    double* o = partial + ((long long)blockIdx.x * C + c) * 3;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+  }
+}
+
+// BatchNorm forward finalize (one block): statistics -> scale/shift (+ running statistics)
+__global__ void enet_bn_finalize_kernel(const double* partial, int blocks, int C, double count,
+                                        const float* gamma, const float* beta, float eps, float momentum,
+                                        float* running_mean, float* running_var, int training,
+                                        float* scale, float* shift, float* save_mean, float* save_invstd) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < blocks; ++b) { s0 += partial[((long long)b * C + c) * 3]; s1 += partial[((long long)b * C + c) * 3 + 1]; }
+    const double m = s0 / count;
+    double v = s1 / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m; var = (float)v;
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  } else {
+    mean = running_mean[c]; var = running_var[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
+}
+
+// BatchNorm backward finalize: dgamma/dbeta/dslope (+=) and the two per-channel means the apply pass needs
+__global__ void enet_bn_bwd_finalize_kernel(const double* partial, int blocks, int C, double count, int training,
+                                            float* dgamma, float* dbeta, float* dslope, float* c1, float* c2) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < blocks; ++b) {
+    const double* q = partial + ((long long)b * C + c) * 3;
+    s0 += q[0]; s1 += q[1]; s2 += q[2];
+  }
+  if (dbeta) dbeta[c] += (float)s0;
+  if (dgamma) dgamma[c] += (float)s1;
+  if (dslope) dslope[c] += (float)s2;
+  // eval mode: mean / invstd are constants (running statistics), so no correction terms
+  c1[c] = training ? (float)(s0 / count) : 0.f;
+  c2[c] = training ? (float)(s1 / count) : 0.f;
+}
+
+// plain per-channel sum finalize (bias gradient): out[c] += sum_b partial[b][c][0]
+__global__ void enet_sum_finalize_kernel(const double* partial, int blocks, int C, float* out) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += partial[((long long)b * C + c) * 3];
+  out[c] += (float)s;
+}
+
+// draw = scale * (dz - c1 - xhat * c2)
+template <typename T>
+__global__ __launch_bounds__(256) void enet_bn_bwd_apply_kernel(RedP p, const float* c1, const float* c2, View out) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int C = p.x.c;
+  const long long total = (long long)p.x.n * p.x.h * p.x.w * C;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  long long pix = idx / C;
+  const int x = (int)(pix % p.x.w); pix /= p.x.w;
+  const int y = (int)(pix % p.x.h);
+  const int n = (int)(pix / p.x.h);
+  const float v = ldv<T>(p.x, voff(p.x, n, y, x) + c, p.fm & 1);
+  const float g = grad_in<T>(p, n, y, x, c);
+  const float z = fmaf(p.scale[c], v, p.shift[c]);
+  float dz = g;
+  if (p.act == 2) { if (!(z > 0.f)) dz = g * p.slope[c]; }
+  else if (p.act == 3) { if (!(z > 0.f)) dz = 0.f; }
+  const float xh = (v - p.mean[c]) * p.invstd[c];
+  const float r = p.scale[c] * (dz - c1[c] - xh * c2[c]);
+  stv<T>(out, voff(out, n, y, x) + c, p.fm & 8, r);
+}
+
+// ---- bottleneck tail --------------------------------------------------------------------------
+struct TailP {
+  View raw, main, out, rawm;      // raw: last conv output; main: x (regular) / pre-pool x (down) / image (initial)
+  Tf tf, tfm;                     // BN+act of raw; BN of rawm (up)
+  unsigned char* idx;             // [N, h, w, Cm] pooling argmax code (down: written, up: read), dense
+  int mode;                       // 0 regular, 1 down, 2 up, 3 initial
+  int Cm;                         // channels of the pooled main branch (down) / of idx
+  int fm;                         // f32 mask: bit0 raw, bit1 main, bit2 rawm, bit3 out
+};
+
+// first maximum of the 2x2 window in scan order (ATen's max_pool2d keeps the first; NaN wins)
+template <typename T>
+__device__ __forceinline__ float pool4(const View& v, int n, int oy, int ox, int c, int f32, int& code) {
+  float best = -INFINITY;
+  code = 0;
+  for (int k = 0; k < 4; ++k) {
+    const float t = ldv<T>(v, voff(v, n, 2 * oy + (k >> 1), 2 * ox + (k & 1)) + c, f32);
+    if (t > best || t != t) { best = t; code = k; }
+  }
+  return best;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void enet_tail_fwd_kernel(TailP p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int C = p.out.c;
+  const long long total = (long long)p.out.n * p.out.h * p.out.w * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  long long pix = i / C;
+  const int ox = (int)(pix % p.out.w); pix /= p.out.w;
+  const int oy = (int)(pix % p.out.h);
+  const int n = (int)(pix / p.out.h);
+  const long long oo = voff(p.out, n, oy, ox) + c;
+  int code;
+  if (p.mode == 3) {   // initial block: 13 conv channels through BN+PReLU, channel 13 = maxpool(image)
+    float r;
+    if (c < p.raw.c) r = tf_apply(p.tf, c, ldv<T>(p.raw, voff(p.raw, n, oy, ox) + c, p.fm & 1));
+    else r = pool4<T>(p.main, n, oy, ox, 0, p.fm & 2, code);
+    stv<T>(p.out, oo, p.fm & 8, r);
+    return;
+  }
+  const float ext = tf_apply(p.tf, c, ldv<T>(p.raw, voff(p.raw, n, oy, ox) + c, p.fm & 1));
+  float mainv = 0.f;
+  if (p.mode == 0) {
+    mainv = ldv<T>(p.main, voff(p.main, n, oy, ox) + c, p.fm & 2);
+  } else if (p.mode == 1) {
+    if (c < p.Cm) {
+      mainv = pool4<T>(p.main, n, oy, ox, c, p.fm & 2, code);
+      p.idx[(((long long)n * p.out.h + oy) * p.out.w + ox) * p.Cm + c] = (unsigned char)code;
+    }
+  } else {   // up: max_unpool of bn(rawm) at half resolution
+    const int sy = oy >> 1, sx = ox >> 1;
+    if (p.idx[(((long long)n * p.rawm.h + sy) * p.rawm.w + sx) * p.Cm + c] == (oy & 1) * 2 + (ox & 1))
+      mainv = tf_apply(p.tfm, c, ldv<T>(p.rawm, voff(p.rawm, n, sy, sx) + c, p.fm & 4));
+  }
+  stv<T>(p.out, oo, p.fm & 8, fmaxf(mainv + ext, 0.f));
+}
+
+// backward of the main branch of down / up / initial blocks
+struct TailBP {
+  View dout, out, dst;            // upstream grad, ReLU mask (mode 3: the input image), destination
+  const unsigned char* idx;
+  int mode;                       // 1 down: dst = dx at double resolution (zero where not argmax)
+                                  // 2 up:   dst = grad of bn(rawm) at half resolution (gather)
+                                  // 3 initial: dst [N,H,W,1] (+)= routed grad of channel Cm of dout (no mask)
+  int Cm, accumulate;
+  int fm;                         // f32 mask: bit0 dout, bit1 out, bit2 dst
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void enet_tail_bwd_kernel(TailBP p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int C = p.dst.c;
+  const long long total = (long long)p.dst.n * p.dst.h * p.dst.w * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  long long pix = i / C;
+  const int x = (int)(pix % p.dst.w); pix /= p.dst.w;
+  const int y = (int)(pix % p.dst.h);
+  const int n = (int)(pix / p.dst.h);
+  const long long dof = voff(p.dst, n, y, x) + c;
+  float g = 0.f;
+  if (p.mode == 1) {          // dst = x-resolution; (y, x) in the 2x2 window of (y/2, x/2)
+    const int oy = y >> 1, ox = x >> 1;
+    if (c < p.Cm && p.idx[(((long long)n * p.dout.h + oy) * p.dout.w + ox) * p.Cm + c] == (y & 1) * 2 + (x & 1)) {
+      if (ldv<T>(p.out, voff(p.out, n, oy, ox) + c, p.fm & 2) > 0.f) g = ldv<T>(p.dout, voff(p.dout, n, oy, ox) + c, p.fm & 1);
+    }
+  } else if (p.mode == 2) {   // dst = half resolution; pick the unpooled position
+    const int code = p.idx[(((long long)n * p.dst.h + y) * p.dst.w + x) * p.Cm + c];
+    const int oy = 2 * y + (code >> 1), ox = 2 * x + (code & 1);
+    if (ldv<T>(p.out, voff(p.out, n, oy, ox) + c, p.fm & 2) > 0.f) g = ldv<T>(p.dout, voff(p.dout, n, oy, ox) + c, p.fm & 1);
+  } else {                    // initial: p.out = the input image
+    const int oy = y >> 1, ox = x >> 1;
+    int code;
+    (void)pool4<T>(p.out, n, oy, ox, 0, p.fm & 2, code);
+    if (code == (y & 1) * 2 + (x & 1)) g = ldv<T>(p.dout, voff(p.dout, n, oy, ox) + p.Cm, p.fm & 1);
+  }
+  if (p.accumulate) g += ldv<T>(p.dst, dof, p.fm & 4);
+  stv<T>(p.dst, dof, p.fm & 4, g);
+}
+
+// ---- weight gradient: dW[o][tap][i] (physical index e, see ws_* strides of the forward) -------------
+// A pixel p = (n, ay, ax) of view A pairs with pixel (ay*stride - pad + r*dil, ...) of view B.
+// conv:  A = draw (Cout), B = layer input (Cin, transform tfb);   entry e = (o, tap, i) of [Cout][R][S][Cin]
+// convT: A = layer input (Cin, transform tfa), B = dy (Cout);      entry e = (i_A, tap, o_B) of [Cin][R][S][Cout]
+struct WgP {
+  View a, b;
+  Tf tfa, tfb;
+  int R, S, stride, dil, pad_h, pad_w;
+  int ppb;
+  int fm;                         // f32 mask: bit0 a, bit1 b
+};
+constexpr int WG_PB = 8;           // pixels staged per round
+constexpr int WG_MAXE = 40;        // entries per thread (E <= 10240)
+
+template <typename T>
+__global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, int E) {
+  extern __shared__ float sm[];
+  const int Ca = p.a.c, Cb = p.b.c, taps = p.R * p.S;
+  float* As = sm;                             // [WG_PB][Ca]
+  float* Bs = sm + WG_PB * Ca;                // [WG_PB][taps][Cb]
+  const long long P = (long long)p.a.n * p.a.h * p.a.w;
+  const long long pbeg = (long long)blockIdx.x * p.ppb, pend = min(P, pbeg + p.ppb);
+  float acc[WG_MAXE];
+#pragma unroll
+  for (int j = 0; j < WG_MAXE; ++j) acc[j] = 0.f;
+  const int hw = p.a.h * p.a.w;
+  const int kb = taps * Cb;
+  for (long long p0 = pbeg; p0 < pend; p0 += WG_PB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < WG_PB * Ca; e += 256) {
+      const int q = e / Ca, c = e - q * Ca;
+      const long long pix = p0 + q;
+      float v = 0.f;
+      if (pix < pend) {
+        const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+        const int y = rem / p.a.w, x = rem - y * p.a.w;
+        v = tf_apply(p.tfa, c, ldv<T>(p.a, voff(p.a, n, y, x) + c, p.fm & 1));
+      }
+      As[e] = v;
+    }
+    for (int e = threadIdx.x; e < WG_PB * kb; e += 256) {
+      const int q = e / kb, r2 = e - q * kb;
+      const int t = r2 / Cb, c = r2 - t * Cb;
+      const long long pix = p0 + q;
+      float v = 0.f;
+      if (pix < pend) {
+        const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
+        const int y = rem / p.a.w, x = rem - y * p.a.w;
+        const int by = y * p.stride - p.pad_h + (t / p.S) * p.dil, bx = x * p.stride - p.pad_w + (t % p.S) * p.dil;
+        if ((unsigned)by < (unsigned)p.b.h && (unsigned)bx < (unsigned)p.b.w)
+          v = tf_apply(p.tfb, c, ldv<T>(p.b, voff(p.b, n, by, bx) + c, p.fm & 2));
+      }
+      Bs[e] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WG_MAXE; ++j) {
+      const int e = j * 256 + threadIdx.x;
+      if (e < E) {
+        const int o = e / kb, k = e - o * kb;
+        float s = acc[j];
+#pragma unroll
+        for (int q = 0; q < WG_PB; ++q) s = fmaf(As[q * Ca + o], Bs[q * kb + k], s);
+        acc[j] = s;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < WG_MAXE; ++j) {
+    const int e = j * 256 + threadIdx.x;
+    if (e < E) partial[(long long)blockIdx.x * E + e] = acc[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void enet_wgrad_reduce_kernel(const float* partial, float* dw, int E, int blocks) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += partial[(long long)b * E + e];
+  dw[e] += s;
+}
+
+static inline bool ok_dtype(int d) { return d == DCT_F32 || d == DCT_BF16; }
+static inline int red_plan(long long P, int C, int& ppb) {
+  int CP = 1;
+  while (CP < C) CP <<= 1;
+  const int rows = 256 / CP;
+  long long blocks = (P + 16ll * rows - 1) / (16ll * rows);
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  ppb = (int)((P + blocks - 1) / blocks);
+  return (int)((P + ppb - 1) / ppb);
+}
+
+}  // namespace
+
+#define ENET_T(dtype, ...) do { if ((dtype) == DCT_BF16) { using T = bf16_t; __VA_ARGS__; } else { using T = float; __VA_ARGS__; } } while (0)
+
+extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
+                             const dct_view* y, const dct_conv_desc* d, int transposed,
+                             int ws_out, int ws_tap, int ws_in,
+                             const dct_view* resid_grad, const dct_view* resid_mask,
+                             int f32_mask, int dtype, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(y) || !w || !d || !ok_dtype(dtype) || x->n != y->n) return DCT_ERR_BAD_ARG;
+  if (d->R < 1 || d->S < 1 || d->stride < 1 || d->dil < 1) return DCT_ERR_BAD_ARG;
+  if (y->c > 128 || x->c > 128) return DCT_ERR_UNSUPPORTED;
+  ConvP p;
+  p.x = to_view(x); p.y = to_view(y);
+  p.w = w; p.bias = bias; p.tf = to_tf(tf);
+  p.R = d->R; p.S = d->S; p.stride = d->stride; p.dil = d->dil; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+  p.transposed = transposed ? 1 : 0; p.accumulate = d->accumulate ? 1 : 0;
+  p.ws_out = ws_out; p.ws_tap = ws_tap; p.ws_in = ws_in;
+  p.has_resid = 0;
+  p.rg = p.y; p.rm = p.y;
+  if (resid_grad) {
+    if (!view_ok(resid_grad) || !view_ok(resid_mask)) return DCT_ERR_BAD_ARG;
+    p.rg = to_view(resid_grad); p.rm = to_view(resid_mask); p.has_resid = 1;
+  }
+  int G = (y->c + 7) / 8;
+  int Gp = 1;
+  while (Gp < G) Gp <<= 1;                  // 1, 2, 4, 8, 16: divides 256
+  p.G = Gp;
+  p.fm = f32_mask;
+  const size_t lds = (size_t)d->R * d->S * x->c * Gp * 8 * sizeof(float);
+  if (lds > 64 * 1024) return DCT_ERR_UNSUPPORTED;
+  const long long P = (long long)y->n * y->h * y->w;
+  const unsigned grid = div_up(P, 256 / Gp);
+  hipStream_t st = (hipStream_t)stream;
+  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_conv_kernel<T>, dim3(grid), dim3(256), lds, st, p));
+  return dct_check_launch();
+}
+
+extern "C" size_t dct_enet_reduce_workspace_bytes(int channels) {
+  return (size_t)256 * (channels > 0 ? channels : 1) * 3 * sizeof(double);
+}
+
+static int enet_reduce_launch(const RedP& p0, int dtype, void* workspace, size_t workspace_bytes, hipStream_t st, int& blocks_out) {
+  RedP p = p0;
+  const long long P = (long long)p.x.n * p.x.h * p.x.w;
+  int ppb;
+  const int blocks = red_plan(P, p.x.c, ppb);
+  if (!workspace || workspace_bytes < (size_t)blocks * p.x.c * 3 * sizeof(double)) return DCT_ERR_WORKSPACE;
+  p.ppb = ppb;
+  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_reduce_kernel<T>, dim3(blocks), dim3(256), 0, st, p, (double*)workspace));
+  blocks_out = blocks;
+  return DCT_OK;
+}
+
+extern "C" int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, const float* beta, float eps, float momentum,
+                                     float* running_mean, float* running_var, int training,
+                                     float* scale, float* shift, float* save_mean, float* save_invstd,
+                                     int f32_mask, int dtype, void* workspace, size_t workspace_bytes, dct_stream stream) {
+  if (!view_ok(raw) || !gamma || !beta || !scale || !shift || !ok_dtype(dtype) || raw->c > 128) return DCT_ERR_BAD_ARG;
+  if (!training && (!running_mean || !running_var)) return DCT_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = 0;
+  if (training) {
+    RedP p; p.x = to_view(raw); p.g = p.x; p.m = p.x;
+    p.scale = p.shift = p.slope = p.mean = p.invstd = nullptr;
+    p.act = 0; p.has_mask = 0; p.kind = 0; p.ppb = 0; p.fm = f32_mask & 1;
+    const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
+    if (rc != DCT_OK) return rc;
+  }
+  const double count = (double)raw->n * raw->h * raw->w;
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_finalize_kernel, dim3(1), dim3(128), 0, st, (const double*)workspace, blocks, raw->c, count,
+             gamma, beta, eps, momentum, running_mean, running_var, training ? 1 : 0, scale, shift, save_mean, save_invstd);
+  return dct_check_launch();
+}
+
+extern "C" int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct_view* g_mask,
+                               const float* scale, const float* shift, const float* slope, int act,
+                               const float* mean, const float* invstd,
+                               float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
+                               const dct_view* draw, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
+                               dct_stream stream) {
+  if (!view_ok(raw) || !view_ok(g) || !view_ok(draw) || !scale || !shift || !mean || !invstd || !c1c2 || !ok_dtype(dtype))
+    return DCT_ERR_BAD_ARG;
+  if (raw->c > 128 || (act == 2 && !slope)) return DCT_ERR_BAD_ARG;
+  RedP p; p.x = to_view(raw); p.g = to_view(g); p.m = p.g;
+  p.has_mask = 0;
+  if (g_mask) { if (!view_ok(g_mask)) return DCT_ERR_BAD_ARG; p.m = to_view(g_mask); p.has_mask = 1; }
+  p.scale = scale; p.shift = shift; p.slope = slope; p.mean = mean; p.invstd = invstd;
+  p.act = act; p.kind = 1; p.ppb = 0; p.fm = f32_mask;
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = 0;
+  const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
+  if (rc != DCT_OK) return rc;
+  const double count = (double)raw->n * raw->h * raw->w;
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, st, (const double*)workspace, blocks, raw->c, count,
+             training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, c1c2 + raw->c);
+  const long long total = (long long)raw->n * raw->h * raw->w * raw->c;
+  const View vo = to_view(draw);
+  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_apply_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, p,
+                           (const float*)c1c2, (const float*)(c1c2 + raw->c), vo));
+  return dct_check_launch();
+}
+
+extern "C" int dct_enet_channel_sum(const dct_view* x, float* out, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
+                                    dct_stream stream) {
+  if (!view_ok(x) || !out || !ok_dtype(dtype) || x->c > 128) return DCT_ERR_BAD_ARG;
+  RedP p; p.x = to_view(x); p.g = p.x; p.m = p.x;
+  p.scale = p.shift = p.slope = p.mean = p.invstd = nullptr;
+  p.act = 0; p.has_mask = 0; p.kind = 0; p.ppb = 0; p.fm = f32_mask & 1;
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = 0;
+  const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
+  if (rc != DCT_OK) return rc;
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_sum_finalize_kernel, dim3(1), dim3(128), 0, st, (const double*)workspace, blocks, x->c, out);
+  return dct_check_launch();
+}
+
+extern "C" int dct_enet_tail_fwd(const dct_view* raw, const dct_enet_tf* tf, const dct_view* main_in,
+                                 const dct_view* rawm, const dct_enet_tf* tfm, uint8_t* idx, int idx_channels,
+                                 int mode, const dct_view* out, int f32_mask, int dtype, dct_stream stream) {
+  if (!view_ok(raw) || !view_ok(out) || !ok_dtype(dtype) || mode < 0 || mode > 3) return DCT_ERR_BAD_ARG;
+  TailP p;
+  p.raw = to_view(raw); p.out = to_view(out); p.main = p.raw; p.rawm = p.raw;
+  p.tf = to_tf(tf); p.tfm = to_tf(tfm); p.idx = idx; p.mode = mode; p.Cm = idx_channels; p.fm = f32_mask;
+  if (mode == 0 || mode == 1 || mode == 3) { if (!view_ok(main_in)) return DCT_ERR_BAD_ARG; p.main = to_view(main_in); }
+  if (mode == 1 && (!idx || main_in->h != 2 * out->h || main_in->w != 2 * out->w || idx_channels != main_in->c)) return DCT_ERR_BAD_ARG;
+  if (mode == 2) {
+    if (!view_ok(rawm) || !idx || rawm->h * 2 != out->h || rawm->w * 2 != out->w || idx_channels != out->c) return DCT_ERR_BAD_ARG;
+    p.rawm = to_view(rawm);
+  }
+  if (mode == 3 && (main_in->c != 1 || main_in->h != 2 * out->h || out->c != raw->c + 1)) return DCT_ERR_BAD_ARG;
+  const long long total = (long long)out->n * out->h * out->w * out->c;
+  hipStream_t st = (hipStream_t)stream;
+  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_tail_fwd_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, p));
+  return dct_check_launch();
+}
+
+extern "C" int dct_enet_tail_bwd(const dct_view* dout, const dct_view* out_mask, const uint8_t* idx, int idx_channels,
+                                 int mode, int accumulate, const dct_view* dst, int f32_mask, int dtype, dct_stream stream) {
+  if (!view_ok(dout) || !view_ok(out_mask) || !view_ok(dst) || !ok_dtype(dtype) || mode < 1 || mode > 3) return DCT_ERR_BAD_ARG;
+  if (mode != 3 && !idx) return DCT_ERR_BAD_ARG;
+  TailBP p;
+  p.dout = to_view(dout); p.out = to_view(out_mask); p.dst = to_view(dst);
+  p.idx = idx; p.mode = mode; p.Cm = idx_channels; p.accumulate = accumulate ? 1 : 0; p.fm = f32_mask;
+  const long long total = (long long)dst->n * dst->h * dst->w * dst->c;
+  hipStream_t st = (hipStream_t)stream;
+  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_tail_bwd_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, p));
+  return dct_check_launch();
+}
+
+extern "C" size_t dct_enet_wgrad_workspace_bytes(const dct_view* a, const dct_view* b, const dct_conv_desc* d) {
+  if (!a || !b || !d) return 0;
+  return (size_t)128 * a->c * d->R * d->S * b->c * sizeof(float);
+}
+
+extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const dct_view* b, const dct_enet_tf* tfb,
+                              float* dw, const dct_conv_desc* d, int f32_mask, int dtype,
+                              void* workspace, size_t workspace_bytes, dct_stream stream) {
+  if (!view_ok(a) || !view_ok(b) || !dw || !d || !ok_dtype(dtype) || a->n != b->n) return DCT_ERR_BAD_ARG;
+  const int E = a->c * d->R * d->S * b->c;
+  if (E > 256 * WG_MAXE) return DCT_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)WG_PB * (a->c + d->R * d->S * b->c) * sizeof(float);
+  if (lds > 64 * 1024) return DCT_ERR_UNSUPPORTED;
+  WgP p;
+  p.a = to_view(a); p.b = to_view(b); p.tfa = to_tf(tfa); p.tfb = to_tf(tfb);
+  p.R = d->R; p.S = d->S; p.stride = d->stride; p.dil = d->dil; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+  p.fm = f32_mask;
+  const long long P = (long long)a->n * a->h * a->w;
+  long long blocks = (P + 8 * WG_PB - 1) / (8 * WG_PB);
+  if (blocks > 128) blocks = 128;
+  if (blocks < 1) blocks = 1;
+  long long ppb = (P + blocks - 1) / blocks;
+  ppb = (ppb + WG_PB - 1) / WG_PB * WG_PB;
+  p.ppb = (int)ppb;
+  const int nb = (int)((P + ppb - 1) / ppb);
+  if (!workspace || workspace_bytes < (size_t)nb * E * sizeof(float)) return DCT_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_wgrad_kernel<T>, dim3(nb), dim3(256), lds, st, p, (float*)workspace, E));
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_wgrad_reduce_kernel, dim3(div_up(E, 256)), dim3(256), 0, st, (const float*)workspace, dw, E, nb);
+  return dct_check_launch();
+}

@@ -9,7 +9,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, DTYPE_OF, F32, call, conv_desc, ptr, stream, view
+from ._lib import BF16, DTYPE_OF, F32, EnetTf, call, conv_desc, ptr, stream, view
 
 
 def _ws(nbytes: int, device) -> Optional[torch.Tensor]:
@@ -279,3 +279,121 @@ def dice_counts(logits_bpc, gt_bp, B, C_):
     ppi = logits_bpc.numel() // (B * C_)
     call("dct_dice_counts", ptr(logits_bpc), ptr(gt_bp), B, ppi, C_, ptr(cnt[0]), ptr(cnt[1]), ptr(cnt[2]), stream())
     return cnt[0], cnt[1], cnt[2]
+
+
+# ------------------------------------------------------------------------------ Enet family
+class Tf(object):
+    """Producer transform act(scale*x + shift) applied by consumers on load (include/dct.h dct_enet_tf)."""
+    NONE, AFFINE, PRELU, RELU = 0, 1, 2, 3
+
+    def __init__(self, scale, shift, slope=None, mode=1):
+        self.scale, self.shift, self.slope, self.mode = scale, shift, slope, mode
+
+    def c(self):
+        return EnetTf(ptr(self.scale), ptr(self.shift), ptr(self.slope), int(self.mode))
+
+
+def _tfp(tf):
+    if tf is None:
+        return None, None
+    s = tf.c()
+    return s, C.byref(s)
+
+
+_red_ws = {}
+
+
+def _enet_ws(device, nbytes):
+    key = (str(device), "red")
+    t = _red_ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _red_ws[key] = t
+    return t
+
+
+def _mixed(*ts):
+    """(dtype code T, f32 mask) of a call whose view arguments are ``ts`` (None = absent): T is bf16 when any
+    view is bf16, and bit k of the mask marks view k as fp32 storage."""
+    any_bf16 = any(t is not None and t.dtype == torch.bfloat16 for t in ts)
+    mask = 0
+    for k, t in enumerate(ts):
+        if t is not None and t.dtype == torch.float32:
+            mask |= 1 << k
+        elif t is not None and t.dtype != torch.bfloat16:
+            raise RuntimeError(f"dct_amd: unsupported dtype {t.dtype}")
+    return (BF16 if any_bf16 else F32), mask
+
+
+def enet_conv(x, w, bias, tf, y, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, transposed=False, ws=(0, 0, 0),
+              resid_grad=None, resid_mask=None, accumulate=False):
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w, accumulate=accumulate)
+    vx, vy = view(x), view(y)
+    keep, tfp = _tfp(tf)
+    vrg = view(resid_grad) if resid_grad is not None else None
+    vrm = view(resid_mask) if resid_mask is not None else None
+    dt, fm = _mixed(x, y, resid_grad, resid_mask)
+    call("dct_enet_conv", C.byref(vx), ptr(w), ptr(bias), tfp, C.byref(vy), C.byref(d), int(transposed),
+         int(ws[0]), int(ws[1]), int(ws[2]), C.byref(vrg) if vrg is not None else None,
+         C.byref(vrm) if vrm is not None else None, fm, dt, stream())
+    return y
+
+
+def enet_bn_fwd_stats(raw, gamma, beta, eps, momentum, running_mean, running_var, training, scale, shift, mean, invstd,
+                      dtype_hint=None):
+    vr = view(raw)
+    ws = _enet_ws(raw.device, _lib.load().dct_enet_reduce_workspace_bytes(raw.shape[3]))
+    dt, fm = _mixed(raw)
+    call("dct_enet_bn_fwd_stats", C.byref(vr), ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(running_mean),
+         ptr(running_var), int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), fm, dt, ptr(ws), ws.numel(), stream())
+
+
+def enet_bn_bwd(raw, g, g_mask, tf, mean, invstd, dgamma, dbeta, dslope, c1c2, draw, training=True):
+    vr, vg, vd = view(raw), view(g), view(draw)
+    vm = view(g_mask) if g_mask is not None else None
+    ws = _enet_ws(raw.device, _lib.load().dct_enet_reduce_workspace_bytes(raw.shape[3]))
+    act = tf.mode if tf.mode in (2, 3) else 0
+    dt, fm = _mixed(raw, g, g_mask, draw)
+    call("dct_enet_bn_bwd", C.byref(vr), C.byref(vg), C.byref(vm) if vm is not None else None,
+         ptr(tf.scale), ptr(tf.shift), ptr(tf.slope), int(act), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(dslope),
+         ptr(c1c2), int(training), C.byref(vd), fm, dt, ptr(ws), ws.numel(), stream())
+    return draw
+
+
+def enet_channel_sum(x, out):
+    vx = view(x)
+    ws = _enet_ws(x.device, _lib.load().dct_enet_reduce_workspace_bytes(x.shape[3]))
+    dt, fm = _mixed(x)
+    call("dct_enet_channel_sum", C.byref(vx), ptr(out), fm, dt, ptr(ws), ws.numel(), stream())
+
+
+def enet_tail_fwd(raw, tf, main_in, rawm, tfm, idx, idx_channels, mode, out):
+    vr, vo = view(raw), view(out)
+    vmain = view(main_in) if main_in is not None else None
+    vrm = view(rawm) if rawm is not None else None
+    k1, tfp = _tfp(tf)
+    k2, tfmp = _tfp(tfm)
+    dt, fm = _mixed(raw, main_in, rawm, out)
+    call("dct_enet_tail_fwd", C.byref(vr), tfp, C.byref(vmain) if vmain is not None else None,
+         C.byref(vrm) if vrm is not None else None, tfmp, ptr(idx), int(idx_channels), int(mode), C.byref(vo), fm, dt, stream())
+    return out
+
+
+def enet_tail_bwd(dout, out_mask, idx, idx_channels, mode, dst, accumulate=False):
+    vd, vm, vdst = view(dout), view(out_mask), view(dst)
+    dt, fm = _mixed(dout, out_mask, dst)
+    call("dct_enet_tail_bwd", C.byref(vd), C.byref(vm), ptr(idx), int(idx_channels), int(mode), int(accumulate), C.byref(vdst),
+         fm, dt, stream())
+    return dst
+
+
+def enet_wgrad(a, tfa, b, tfb, dw, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0):
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w)
+    va, vb = view(a), view(b)
+    need = _lib.load().dct_enet_wgrad_workspace_bytes(C.byref(va), C.byref(vb), C.byref(d))
+    ws = _enet_ws(a.device, need)
+    k1, tfap = _tfp(tfa)
+    k2, tfbp = _tfp(tfb)
+    dt, fm = _mixed(a, b)
+    call("dct_enet_wgrad", C.byref(va), tfap, C.byref(vb), tfbp, ptr(dw), C.byref(d), fm, dt, ptr(ws), ws.numel(), stream())
+    return dw

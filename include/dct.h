@@ -207,6 +207,76 @@ int dct_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float
                   float bc2_sqrt, double beta1, double beta2, float eps, float weight_decay,
                   void* bf16_shadow, dct_stream stream);
 
+/* ---- K2/K3/K4/K6/K7/K8: Enet layers (arch/enet.py:8-243) -------------------------------------
+ * Enet's widths are 1..128 channels (internal 3/16/32): HBM- and launch-bound, so these are direct
+ * fused kernels, not GEMMs.  Every consumer reads its input through the producer's BatchNorm +
+ * activation ("normalise on load"): in = act(scale[c]*raw + shift[c]); mode 0 none, 1 affine,
+ * 2 affine+PReLU(slope[c]), 3 affine+ReLU.  All per-channel vectors are fp32 device arrays. */
+typedef struct dct_enet_tf {
+  const float* scale; const float* shift; const float* slope;
+  int32_t mode;
+} dct_enet_tf;
+
+/* Every Enet entry point takes `dtype` (the storage type T of the bf16/f32 activations) and an
+ * `f32_mask`: bit k set = the k-th dct_view argument of that call (in declaration order) is stored
+ * in fp32 regardless of `dtype`.  In bf16 mode the RAW conv outputs stay fp32 (BatchNorm subtracts
+ * their mean, which would cancel most of bf16's 8 mantissa bits); block outputs and gradients are T. */
+
+/* Generic small-channel convolution (<= 128 channels each side).  Replaces nn.Conv2d /
+ * nn.ConvTranspose2d of enet.py:21,52-109 and both of their data gradients:
+ *   direct:      y[oy,ox,o] = sum W(o,r,s,i) * in[oy*stride - pad + r*dil, ..., i]
+ *   transposed:  y[oy,ox,o] = sum W(o,r,s,i) * in[(oy + pad - r*dil)/stride, ..., i]   (where divisible)
+ * with W(o,r,s,i) = w[o*ws_out + (r*S+s)*ws_tap + i*ws_in] (fp32 master weights, any role).
+ * Epilogue: + bias[o] -> + resid_grad*[resid_mask > 0] (residual-branch gradient of a bottleneck)
+ * -> (+= y when d->accumulate).  f32_mask bits: 0 x, 1 y, 2 resid_grad, 3 resid_mask. */
+int dct_enet_conv(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
+                  const dct_view* y, const dct_conv_desc* d, int transposed,
+                  int ws_out, int ws_tap, int ws_in,
+                  const dct_view* resid_grad, const dct_view* resid_mask,
+                  int f32_mask, int dtype, dct_stream stream);
+
+size_t dct_enet_reduce_workspace_bytes(int channels);
+/* nn.BatchNorm2d(eps 1e-3, momentum 0.1) forward statistics of a raw conv output (enet.py:22,55-122):
+ * training: batch mean / biased var (double accumulation, fixed-order fold), running stats updated
+ * with the unbiased var; eval: running stats.  Writes scale = gamma*invstd, shift = beta - mean*scale
+ * (what consumers apply on load) and save_mean / save_invstd for the backward.  f32_mask bit 0: raw. */
+int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, int training,
+                          float* scale, float* shift, float* save_mean, float* save_invstd,
+                          int f32_mask, int dtype, void* workspace, size_t workspace_bytes, dct_stream stream);
+/* Backward of act(BN(raw)) given g = grad wrt the activation output (optionally gated by
+ * g_mask > 0, the ReLU of the bottleneck sum): dgamma/dbeta/dslope += ..., and
+ * draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) (training; eval mode: gamma*invstd*dz with the
+ * running statistics).  c1c2: 2*C floats of scratch.  f32_mask bits: 0 raw, 1 g, 2 g_mask, 3 draw. */
+int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct_view* g_mask,
+                    const float* scale, const float* shift, const float* slope, int act,
+                    const float* mean, const float* invstd,
+                    float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
+                    const dct_view* draw, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
+                    dct_stream stream);
+/* out[c] += sum over pixels of x[.., c]   (bias gradients).  f32_mask bit 0: x. */
+int dct_enet_channel_sum(const dct_view* x, float* out, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
+                         dct_stream stream);
+/* Bottleneck tail out = relu(main + act(bn(raw))) (enet.py:132-149), mode:
+ *   0 regular: main = main_in;   1 down: main = maxpool2x2(main_in) zero-padded to out.c channels,
+ *   argmax codes written to idx [N,h,w,idx_channels];   2 up: main = max_unpool(bn(rawm)) by idx;
+ *   3 initial block (enet.py:26-30): out = cat(prelu(bn(raw)), maxpool2x2(main_in = the image)).
+ * f32_mask bits: 0 raw, 1 main_in, 2 rawm, 3 out. */
+int dct_enet_tail_fwd(const dct_view* raw, const dct_enet_tf* tf, const dct_view* main_in,
+                      const dct_view* rawm, const dct_enet_tf* tfm, uint8_t* idx, int idx_channels,
+                      int mode, const dct_view* out, int f32_mask, int dtype, dct_stream stream);
+/* Main-branch gradient of those tails: 1 down -> dst = routed grad at double resolution;
+ * 2 up -> dst = grad of bn(rawm) (gather); 3 initial -> dst (image grad) (+)= pooled-channel grad
+ * (out_mask = the input image).  f32_mask bits: 0 dout, 1 out_mask, 2 dst. */
+int dct_enet_tail_bwd(const dct_view* dout, const dct_view* out_mask, const uint8_t* idx, int idx_channels,
+                      int mode, int accumulate, const dct_view* dst, int f32_mask, int dtype, dct_stream stream);
+/* dw[a.c][R][S][b.c] += sum_pixels tfa(a[p]) (x) tfb(b[p*stride - pad + tap*dil]).
+ * Conv2d: a = draw, b = layer input; ConvTranspose2d: a = layer input, b = dy.  f32_mask bits: 0 a, 1 b. */
+size_t dct_enet_wgrad_workspace_bytes(const dct_view* a, const dct_view* b, const dct_conv_desc* d);
+int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const dct_view* b, const dct_enet_tf* tfb,
+                   float* dw, const dct_conv_desc* d, int f32_mask, int dtype,
+                   void* workspace, size_t workspace_bytes, dct_stream stream);
+
 /* ---- Dice accumulation on device (metrics/dice_meter.py:12-83) ----------------------------
  * inter[b][c], psum[b][c], gsum[b][c] (int32, zeroed by caller) from logits argmax vs gt. */
 int dct_dice_counts(const float* logits, const int64_t* gt, int B, int64_t pixels_per_image, int C,

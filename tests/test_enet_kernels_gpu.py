@@ -1,0 +1,231 @@
+"""Per-kernel parity of the Enet C-ABI entry points (dct_enet_*) against plain PyTorch fp32 CPU math, in
+fp32 storage (parity path) and in the mixed bf16 mode (block outputs / gradients bf16, raw conv outputs
+fp32) -- the mixed mode is compared with the same math on bf16-rounded inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def K():
+    from dct_amd import hip_ops
+    return hip_ops
+
+
+def q(t, dt):
+    return t.to(dt).float()
+
+
+def nhwc(t, dt):
+    return t.permute(0, 2, 3, 1).contiguous().to(dt).to(DEV)
+
+
+def nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, ref, dt, what, r32=1e-4, r16=2e-2):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    rtol = r32 if dt == torch.float32 else r16
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs()
+    bad = err > rtol * scale + rtol * ref.abs()
+    assert not bad.any() and torch.isfinite(got).all(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max():.3e}, scale {scale:.3e}"
+
+
+def make_tf(K, C, mode, g):
+    scale = (torch.rand(C, generator=g) + 0.5)
+    shift = torch.randn(C, generator=g) * 0.3
+    slope = torch.rand(C, generator=g) * 0.5
+    tf = K.Tf(scale.to(DEV), shift.to(DEV), slope.to(DEV) if mode == 2 else None, mode)
+
+    def apply(x):   # x NCHW
+        z = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        if mode == 2:
+            z = torch.where(z > 0, z, z * slope.view(1, -1, 1, 1))
+        elif mode == 3:
+            z = z.relu()
+        return z
+    return tf, apply, (scale, shift, slope)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin,cout,kh,kw,stride,pad,dil,in_f32,mode", [
+    (64, 16, 1, 1, 1, (0, 0), 1, False, 0),      # block1x1_1 on a block output
+    (16, 16, 3, 3, 1, (1, 1), 1, True, 2),       # middle 3x3 on a raw input through BN+PReLU
+    (32, 32, 3, 3, 1, (4, 4), 4, True, 2),       # dilated
+    (32, 32, 5, 1, 1, (2, 0), 1, True, 3),       # asymmetric 5x1
+    (14, 16, 2, 2, 2, (0, 0), 1, False, 0),      # down-sampling 2x2 s2
+    (1, 13, 3, 3, 2, (1, 1), 1, True, 0),        # initial conv on the fp32 image
+    (3, 14, 1, 1, 1, (0, 0), 1, True, 3),        # tiny widths of the last up-sampling bottleneck
+])
+def test_enet_conv_direct_dgrad_wgrad(K, dt, cin, cout, kh, kw, stride, pad, dil, in_f32, mode):
+    g = torch.Generator().manual_seed(1)
+    B, H, W = 2, 12, 10
+    xs = torch.float32 if in_f32 else dt
+    x = q(torch.randn(B, cin, H, W, generator=g), xs)
+    w = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
+    bias = torch.randn(cout, generator=g)
+    tf, apply, _ = make_tf(K, cin, mode, g) if mode else (None, (lambda t: t), None)
+    xin = apply(x).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xin, wr, bias, stride=stride, padding=pad, dilation=dil)
+    wk = w.permute(0, 2, 3, 1).contiguous().to(DEV)          # [co][kh][kw][ci]
+    y = torch.empty(B, ref.shape[2], ref.shape[3], cout, dtype=torch.float32, device=DEV)   # raw outputs: fp32
+    xd = nhwc(x, xs)
+    K.enet_conv(xd, wk, bias.to(DEV), tf, y, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1],
+                ws=(kh * kw * cin, cin, 1))
+    close(nchw(y), ref.detach(), torch.float32, "conv fwd", r32=2e-4)
+    gy = q(torch.randn(ref.shape, generator=g), dt)
+    ref.backward(gy)
+    gyd = nhwc(gy, dt)
+    dx = torch.empty(B, H, W, cin, dtype=dt, device=DEV)
+    K.enet_conv(gyd, wk, None, None, dx, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1], transposed=True,
+                ws=(1, cin, kh * kw * cin))
+    close(nchw(dx), xin.grad, dt, "conv dgrad")
+    dw = torch.zeros(cout * kh * kw * cin, device=DEV)
+    K.enet_wgrad(gyd, None, xd, tf, dw, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1])
+    K.enet_wgrad(gyd, None, xd, tf, dw, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1])   # "+=" twice
+    close(dw.view(cout, kh, kw, cin).permute(0, 3, 1, 2).cpu(), 2 * wr.grad, torch.float32, "conv wgrad", r32=5e-4)
+    db = torch.zeros(cout, device=DEV)
+    K.enet_channel_sum(gyd, db)
+    close(db.cpu(), gy.sum((0, 2, 3)), torch.float32, "bias grad", r32=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,pad,opad,in_f32", [(16, 16, 3, 1, 1, True), (3, 3, 3, 1, 1, True), (14, 4, 2, 0, 0, False)])
+def test_enet_convT(K, dt, cin, cout, k, pad, opad, in_f32):
+    g = torch.Generator().manual_seed(2)
+    B, H, W = 2, 9, 7
+    xs = torch.float32 if in_f32 else dt
+    x = q(torch.randn(B, cin, H, W, generator=g), xs).requires_grad_(True)
+    w = (torch.randn(cin, cout, k, k, generator=g) / math.sqrt(cin * k * k)).requires_grad_(True)
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv_transpose2d(x, w, bias, stride=2, padding=pad, output_padding=opad)
+    wk = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV)     # [ci][kh][kw][co]
+    y = torch.empty(B, ref.shape[2], ref.shape[3], cout, dtype=torch.float32, device=DEV)
+    xd = nhwc(x.detach(), xs)
+    K.enet_conv(xd, wk, bias.to(DEV), None, y, R=k, S=k, stride=2, pad_h=pad, pad_w=pad, transposed=True, ws=(1, cout, k * k * cout))
+    close(nchw(y), ref.detach(), torch.float32, "convT fwd", r32=2e-4)
+    gy = q(torch.randn(ref.shape, generator=g), dt)
+    ref.backward(gy)
+    gyd = nhwc(gy, dt)
+    dx = torch.empty(B, H, W, cin, dtype=dt, device=DEV)
+    K.enet_conv(gyd, wk, None, None, dx, R=k, S=k, stride=2, pad_h=pad, pad_w=pad, ws=(k * k * cout, cout, 1))
+    close(nchw(dx), x.grad, dt, "convT dgrad")
+    dw = torch.zeros(cin * k * k * cout, device=DEV)
+    K.enet_wgrad(xd, None, gyd, None, dw, R=k, S=k, stride=2, pad_h=pad, pad_w=pad)
+    close(dw.view(cin, k, k, cout).permute(0, 3, 1, 2).cpu(), w.grad, torch.float32, "convT wgrad", r32=5e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C,act", [(16, 2), (64, 3), (13, 2), (3, 3), (64, 0)])
+@pytest.mark.parametrize("training", [True, False])
+def test_enet_bn_fwd_bwd(K, dt, C, act, training):
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 9, 11
+    raw = (torch.randn(B, C, H, W, generator=g) * 2 + 3).requires_grad_(True)       # raw conv outputs: fp32, mean >> 0
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, generator=g).requires_grad_(True)
+    slope = (torch.rand(C, generator=g) * 0.5).requires_grad_(True)
+    rm0, rv0 = torch.randn(C, generator=g) * 0.1 + 3, torch.rand(C, generator=g) + 3.5
+    rm, rv = rm0.clone(), rv0.clone()
+    z = F.batch_norm(raw, rm, rv, gamma, beta, training, 0.1, 1e-3)
+    a = torch.where(z > 0, z, z * slope.view(1, -1, 1, 1)) if act == 2 else (z.relu() if act == 3 else z)
+    rawd = nhwc(raw.detach(), torch.float32)
+    vec = torch.empty(4, C, device=DEV)
+    rmd, rvd = rm0.to(DEV), rv0.to(DEV)
+    K.enet_bn_fwd_stats(rawd, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-3, 0.1, rmd, rvd, training, vec[0], vec[1], vec[2], vec[3])
+    tf = K.Tf(vec[0], vec[1], slope.detach().to(DEV) if act == 2 else None, {2: 2, 3: 3, 0: 1}[act])
+    zz = rawd * vec[0] + vec[1]
+    close(nchw(zz), z.detach(), torch.float32, "bn scale/shift", r32=2e-5)
+    if training:
+        close(rmd.cpu(), rm, torch.float32, "running mean", r32=1e-5)
+        close(rvd.cpu(), rv, torch.float32, "running var", r32=1e-5)
+    # backward, gated by a ReLU mask as in the bottleneck tail
+    up = q(torch.randn(B, C, H, W, generator=g), dt)
+    mask = q(torch.randn(B, C, H, W, generator=g), dt)
+    a.backward(up * (mask > 0))
+    dg, db, ds = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    draw = torch.empty(B, H, W, C, dtype=dt, device=DEV)
+    K.enet_bn_bwd(rawd, nhwc(up, dt), nhwc(mask, dt), tf, vec[2], vec[3], dg, db, ds if act == 2 else None,
+                  torch.empty(2 * C, device=DEV), draw, training=training)
+    close(nchw(draw), raw.grad, dt, "bn bwd draw", r32=3e-4, r16=2e-2)
+    close(dg.cpu(), gamma.grad, torch.float32, "dgamma", r32=3e-4)
+    close(db.cpu(), beta.grad, torch.float32, "dbeta", r32=3e-4)
+    if act == 2:
+        close(ds.cpu(), slope.grad, torch.float32, "dslope", r32=3e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_enet_tails(K, dt):
+    g = torch.Generator().manual_seed(4)
+    B, h, w = 2, 6, 5
+    # ---- regular
+    C = 64
+    raw = torch.randn(B, C, h, w, generator=g)
+    x = q(torch.randn(B, C, h, w, generator=g), dt)
+    tf, apply, _ = make_tf(K, C, 2, g)
+    ref = (x + apply(raw)).relu()
+    out = torch.empty(B, h, w, C, dtype=dt, device=DEV)
+    K.enet_tail_fwd(nhwc(raw, torch.float32), tf, nhwc(x, dt), None, None, None, 0, 0, out)
+    close(nchw(out), q(ref, dt), dt, "tail regular", r16=1e-2)
+    # ---- down: maxpool with indices + zero channel pad; and its backward routing
+    Cm, Co = 14, 64
+    xin = q(torch.randn(B, Cm, 2 * h, 2 * w, generator=g), dt)
+    raw = torch.randn(B, Co, h, w, generator=g)
+    tf, apply, _ = make_tf(K, Co, 2, g)
+    pooled, idx_ref = F.max_pool2d(xin, 2, stride=2, return_indices=True)
+    main = torch.cat([pooled, torch.zeros(B, Co - Cm, h, w)], 1)
+    ref = (main + apply(raw)).relu()
+    out = torch.empty(B, h, w, Co, dtype=dt, device=DEV)
+    idx = torch.empty(B, h, w, Cm, dtype=torch.uint8, device=DEV)
+    K.enet_tail_fwd(nhwc(raw, torch.float32), tf, nhwc(xin, dt), None, None, idx, Cm, 1, out)
+    close(nchw(out), q(ref, dt), dt, "tail down", r16=1e-2)
+    dout = q(torch.randn(B, Co, h, w, generator=g), dt)
+    gz = dout * (q(ref, dt) > 0)
+    dx_ref = F.max_unpool2d(gz[:, :Cm], idx_ref, 2)
+    dx = torch.empty(B, 2 * h, 2 * w, Cm, dtype=dt, device=DEV)
+    K.enet_tail_bwd(nhwc(dout, dt), out, idx, Cm, 1, dx)
+    close(nchw(dx), dx_ref, dt, "tail down bwd")
+    # ---- up: unpool of bn(rawm) with those indices
+    rawm = torch.randn(B, Cm, h, w, generator=g)
+    tfm, applym, _ = make_tf(K, Cm, 0, g)
+    tfm.mode = 1
+    raw2 = torch.randn(B, Cm, 2 * h, 2 * w, generator=g)
+    tf2, apply2, _ = make_tf(K, Cm, 3, g)
+    zm = rawm * tfm.scale.cpu().view(1, -1, 1, 1) + tfm.shift.cpu().view(1, -1, 1, 1)
+    ref = (F.max_unpool2d(zm, idx_ref, 2) + apply2(raw2)).relu()
+    out2 = torch.empty(B, 2 * h, 2 * w, Cm, dtype=dt, device=DEV)
+    K.enet_tail_fwd(nhwc(raw2, torch.float32), tf2, None, nhwc(rawm, torch.float32), tfm, idx, Cm, 2, out2)
+    close(nchw(out2), q(ref, dt), dt, "tail up", r16=1e-2)
+    dout2 = q(torch.randn(B, Cm, 2 * h, 2 * w, generator=g), dt)
+    gz2 = dout2 * (q(ref, dt) > 0)
+    gm_ref = torch.gather(gz2.flatten(2), 2, idx_ref.flatten(2)).view(B, Cm, h, w)
+    gm = torch.empty(B, h, w, Cm, dtype=dt, device=DEV)
+    K.enet_tail_bwd(nhwc(dout2, dt), out2, idx, Cm, 2, gm)
+    close(nchw(gm), gm_ref, dt, "tail up bwd")
+    # ---- initial block
+    img = torch.rand(B, 1, 2 * h, 2 * w, generator=g)
+    raw13 = torch.randn(B, 13, h, w, generator=g)
+    tf13, apply13, _ = make_tf(K, 13, 2, g)
+    ref = torch.cat([apply13(raw13), F.max_pool2d(img, 2, stride=2)], 1)
+    out14 = torch.empty(B, h, w, 14, dtype=dt, device=DEV)
+    imgd = nhwc(img, torch.float32)
+    K.enet_tail_fwd(nhwc(raw13, torch.float32), tf13, imgd, None, None, None, 13, 3, out14)
+    close(nchw(out14), q(ref, dt), dt, "initial tail", r16=1e-2)
+    d14 = q(torch.randn(B, 14, h, w, generator=g), dt)
+    _, iidx = F.max_pool2d(img, 2, stride=2, return_indices=True)
+    dimg_ref = F.max_unpool2d(d14[:, 13:14], iidx, 2) + 1.0
+    dimg = torch.ones(B, 2 * h, 2 * w, 1, device=DEV)
+    K.enet_tail_bwd(nhwc(d14, dt), imgd, None, 13, 3, dimg, accumulate=True)
+    close(nchw(dimg), dimg_ref, torch.float32, "initial tail bwd")

@@ -13,9 +13,10 @@ from helpers import FakeLoader, batches, digest  # noqa: E402
 DEV = "cuda:0"
 
 
-def _seeded_state(C, seed):
+def _seeded_state(arch, C, seed):
     torch.manual_seed(seed)
-    return oracle.build_net("unet", C, dropout_p=0.0).state_dict()
+    kw = {"dropout_p": 0.0} if arch == "unet" else {}
+    return oracle.build_net(arch, C, **kw).state_dict()
 
 
 def _trainer(tmp_path, g, dtype, n_steps, fused=True):
@@ -23,12 +24,15 @@ def _trainer(tmp_path, g, dtype, n_steps, fused=True):
     from dct_amd.models import Segmentator
     from dct_amd.trainer import CoTrainer
     C, H, B = int(g["C"]), int(g["H"]), int(g["B"])
+    arch = str(g["arch"])
     segs = []
     for s in g["net_seeds"]:
-        seg = Segmentator({"name": "unet", "num_classes": C, "compute_dtype": dtype, "dropout_p": 0.0},
-                          {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+        arch_dict = {"name": arch, "num_classes": C, "compute_dtype": dtype}
+        if arch == "unet":
+            arch_dict["dropout_p"] = 0.0
+        seg = Segmentator(arch_dict, {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
                           {"name": "StepLR", "step_size": 90, "gamma": 0.1})
-        seg.torchnet.load_state_dict(_seeded_state(C, int(s)))
+        seg.torchnet.load_state_dict(_seeded_state(arch, C, int(s)))
         segs.append(seg)
     lab = [FakeLoader(batches(int(s), n_steps, B, H, C), B) for s in g["lab_seeds"]]
     unl = FakeLoader(batches(int(g["unl_seed"]), n_steps, B, H, C), B)
@@ -43,7 +47,7 @@ def _trainer(tmp_path, g, dtype, n_steps, fused=True):
     return tr, lab, unl
 
 
-@pytest.mark.parametrize("tag", ["g5_step_unet_jsd", "g5_step_unet_adv"])
+@pytest.mark.parametrize("tag", ["g5_step_unet_jsd", "g5_step_unet_adv", "g5_step_enet_jsd", "g5_step_enet_adv"])
 def test_train_loop_fp32_matches_reference_golden(golden, tmp_path, tag):
     from dct_amd import ModelMode
     g = golden(tag)
@@ -62,10 +66,14 @@ def test_train_loop_fp32_matches_reference_golden(golden, tmp_path, tag):
     np.random.seed(1234)
     dice_lab, dice_unl = tr._train_loop(lab, unl, epoch=0, mode=ModelMode.TRAIN, save=False, train_jsd=True, train_adv=adv)
     assert len(log) == n
+    # Enet (84 train-mode BatchNorms over 2x8x8 .. 2x32x32 samples) amplifies last-bit differences far more
+    # than UNet (tests/test_enet_gpu.py): 5x looser on everything after the first update
+    enet = str(g["arch"]) == "enet"
+    loose = 5.0 if enet else 1.0
     for k in range(n):
         # step 0 starts from identical weights: fp32 kernels vs ATen -> 1e-5; later steps inherit Adam's
         # lr*sign(g)-like first updates (chaotic in the last bits of g) -> 2e-3
-        tol = 1e-5 if k == 0 else 2e-3
+        tol = (2e-5 if enet else 1e-5) if k == 0 else 2e-3 * loose
         np.testing.assert_allclose([s.item() for s in log[k]["sup"]], g["sup"][k][:2], rtol=tol)
         np.testing.assert_allclose(log[k]["jsd"].item(), g["jsd"][k], rtol=max(tol, 1e-4), atol=1e-8)
         if adv:
@@ -73,17 +81,40 @@ def test_train_loop_fp32_matches_reference_golden(golden, tmp_path, tag):
             np.testing.assert_allclose(log[k]["adv"].item(), g["adv"][k], rtol=2e-2, atol=1e-7)
     # _train_loop's return value: per-class (mean, std) of the 2-D Dice, [S, C, 2]
     assert dice_lab.shape == (2, int(g["C"]), 2)
-    np.testing.assert_allclose(dice_lab[..., 0].numpy(), g["dice_lab"][..., 0], atol=2e-3)
-    np.testing.assert_allclose(dice_unl[..., 0].numpy(), g["dice_unl"][..., 0], atol=2e-3)
+    np.testing.assert_allclose(dice_lab[..., 0].numpy(), g["dice_lab"][..., 0], atol=2e-3 * loose)
+    np.testing.assert_allclose(dice_unl[..., 0].numpy(), g["dice_unl"][..., 0], atol=2e-3 * loose)
     for j, seg in enumerate(tr.segmentators):
         names = list(g[f"m{j}_names"])
         sd = seg.torchnet.state_dict()
         df = np.stack([digest(sd[k]) for k in names])
-        for col in (1, 2, 3):   # abs-sum, l2, max-abs of every tensor after the last step
-            np.testing.assert_allclose(df[:, col], g[f"m{j}_digest_final"][:, col], rtol=2e-3, atol=1e-5)
+        # conv biases in front of a BatchNorm have a mathematically-zero gradient; Adam turns its rounding noise
+        # into +-lr steps of arbitrary sign (chaotic parity points): bound those by n*lr per element
+        noise = np.array([enet and k.endswith(".bias") and not k.endswith(".1.bias") and "batch_norm" not in k
+                          and not k.startswith("decoder.layers.5") or (enet and k.endswith("middle_block.0.1.bias"))
+                          for k in names])
+        numel = np.array([sd[k].numel() for k in names], dtype=np.float64)
+        step_bound = 1.5 * n * 1e-3
+        for col, mult in ((1, numel), (2, np.sqrt(numel)), (3, np.ones_like(numel))):   # abs-sum, l2, max-abs after the last step
+            ref = g[f"m{j}_digest_final"][:, col]
+            # Enet: BatchNorm betas start at 0 and sit at O(n*lr) after n Adam steps, so a relative tolerance alone is
+            # meaningless for them: allow a fifth of the maximal Adam displacement on top
+            atol = 1e-5 + (0.2 * n * 1e-3 * mult[~noise] if enet else 0.0)
+            err = np.abs(df[~noise, col] - ref[~noise])
+            rtol = np.array([(3e-2 if (enet and "running_" in k) else 2e-3 * loose) for k in np.array(names)[~noise]])
+            bad = err > rtol * np.abs(ref[~noise]) + atol
+            assert not bad.any(), (col, [names[i] for i in np.flatnonzero(~noise)[bad]][:8], err[bad][:8], ref[~noise][bad][:8])
+            assert np.all(np.abs(df[noise, col] - ref[noise]) <= step_bound * mult[noise] + 1e-6)
         st = seg.optimizer.state
         ea = np.stack([digest(st[p]["exp_avg"]) for p in seg.torchnet.parameters()])
-        np.testing.assert_allclose(ea[:, 2], g[f"m{j}_exp_avg_digest"][:, 2], rtol=2e-2, atol=1e-9)
+        if not enet:
+            np.testing.assert_allclose(ea[:, 2], g[f"m{j}_exp_avg_digest"][:, 2], rtol=2e-2, atol=1e-9)
+        else:
+            # early-layer Enet gradients are chaotic in the last bits of the forward (tests/test_enet_gpu.py: a 1e-6
+            # perturbation moves them by tens of percent), and steps 2-3 start from Adam's sign-like first update:
+            # the first moments are compared in aggregate only
+            ref = g[f"m{j}_exp_avg_digest"][:, 2]
+            assert np.all(np.isfinite(ea))
+            assert abs(np.linalg.norm(ea[:, 2]) / np.linalg.norm(ref) - 1.0) < 0.1
 
 
 def test_fused_and_generic_paths_agree(golden, tmp_path):
