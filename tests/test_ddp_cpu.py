@@ -1,0 +1,117 @@
+"""Data-parallel gradient exchange on CPU: two processes over gloo (world_size 2) run CoTrainer._run_step
+on different per-rank batches through FlatGradSync and must end with (a) identical weights on both
+ranks and (b) the weights a single process gets from the averaged gradient -- the N>1 path of bench.py.
+Arithmetic comes from injected oracle modules (the product kernels are HIP-only)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(tmp, rank_seed_offset):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from helpers import FakeLoader, batches
+    from test_host_logic_cpu import OracleCE, OracleJSD, OracleKL, OracleFGSM, OracleDice
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    from dct_amd.trainer import cotraining_totalloss as mod
+    mod.DiceMeter = OracleDice
+    C, H, B = 2, 176, 1
+    segs = []
+    for s in (21, 22):
+        torch.manual_seed(s)                        # identical initial weights on every rank
+        net = oracle.build_net("unet", C, dropout_p=0.0)
+        segs.append(Segmentator({"name": "unet", "num_classes": C}, {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                                {"name": "StepLR", "step_size": 90, "gamma": 0.1}, torchnet=net,
+                                softmax_fn=oracle.softmax_channels))
+    lab = [FakeLoader(batches(31 + i + rank_seed_offset, 1, B, H, C), B) for i in range(2)]
+    unl = FakeLoader(batches(41 + rank_seed_offset, 1, B, H, C), B)
+    crit = {"sup": OracleCE(), "jsd": OracleJSD(), "adv": OracleJSD()}
+    tr = CoTrainer(segs, lab, unl, unl, crit, max_epoch=1, save_dir=tmp, device="cpu", axises=[1],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False, steps_per_epoch=1)
+    tr._fsgm_cls = OracleFGSM
+    tr._kl_override = OracleKL
+    for s in segs:
+        s.train()
+    return tr, lab, unl
+
+
+def _step(tr, lab, unl):
+    lb = [(lab[i][0][0][0], lab[i][0][0][1]) for i in range(2)]
+    ub = (unl[0][0][0], unl[0][0][1])
+    return tr._run_step(lb, ub, True, True, (0, 1))
+
+
+def _weights(tr):
+    return [torch.cat([p.detach().flatten() for p in s.torchnet.parameters()]).clone() for s in tr.segmentators]
+
+
+def _worker(rank, world, port, tmp, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from dct_amd import ddp
+    r, _, w = ddp.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    tr, lab, unl = _build(os.path.join(tmp, f"r{rank}"), 100 * rank)
+    # perturb rank 1's initial weights: broadcast_weights must restore rank 0's
+    if rank == 1:
+        with torch.no_grad():
+            for p in tr.segmentators[0].torchnet.parameters():
+                p.add_(0.5)
+    tr.grad_sync = ddp.FlatGradSync(tr.segmentators)
+    _step(tr, lab, unl)
+    torch.save([w_.numpy() for w_ in _weights(tr)], os.path.join(out, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_gloo_step_equals_averaged_gradient_step(tmp_path):
+    world, port = 2, _free_port()
+    out = str(tmp_path)
+    mp.spawn(_worker, args=(world, port, out, out), nprocs=world, join=True)
+    w0 = torch.load(os.path.join(out, "w0.pt"), weights_only=False)
+    w1 = torch.load(os.path.join(out, "w1.pt"), weights_only=False)
+    for a, b in zip(w0, w1):
+        np.testing.assert_array_equal(a, b)          # ranks stay bit-identical
+    # single-process reference: average the two ranks' gradients by hand, then one Adam step
+    torch.set_num_threads(4)
+    trs = [_build(os.path.join(out, f"s{r}"), 100 * r) for r in range(world)]
+    grads = []
+    for tr, lab, unl in trs:
+        steps = [s.optimizer.step for s in tr.segmentators]
+        for s in tr.segmentators:
+            s.optimizer.step = lambda: None          # gradients only
+        _step(tr, lab, unl)
+        grads.append([[p.grad.clone() for p in s.torchnet.parameters()] for s in tr.segmentators])
+        for s, st in zip(tr.segmentators, steps):
+            s.optimizer.step = st
+    tr0 = trs[0][0]
+    for m, seg in enumerate(tr0.segmentators):
+        for k, p in enumerate(seg.torchnet.parameters()):
+            p.grad = (grads[0][m][k] + grads[1][m][k]) / world
+        seg.optimizer.step()
+    for a, b in zip(w0, _weights(tr0)):
+        # gloo sums then scales, the hand average divides once: 1 ulp apart in g, which Adam's first step
+        # (lr * g / (|g| + eps)) turns into <= 1e-5 on elements whose |g| is comparable to eps = 1e-8
+        np.testing.assert_allclose(a, b.numpy(), rtol=0, atol=2e-5)
