@@ -422,11 +422,19 @@ static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc*
   pl.kiters = d->R * d->S * (x->c / pl.bk);
   pl.tiles = (long long)div_up(M, pl.bm) * (N / pl.bn);
   int splits = 1;
-  const int min_steps = pl.v2 ? 3 : 4;   // K-steps each split must keep
-  if (pl.tiles < 384) {
+  if (pl.v2) {
+    // measured on the UNet layer set (tools/bench_conv.py --ab): a layer with >= 200 tiles runs fastest unsplit
+    // (two resident blocks per CU interleave); below that ~450 blocks in total is the sweet spot, and each
+    // split must keep >= 4 K-steps to amortise its prologue and its fp32 slab
+    if (pl.tiles < 200) {
+      splits = (int)((450 + pl.tiles / 2) / pl.tiles);
+      if (splits > 8) splits = 8;
+      while (splits > 1 && pl.kiters / splits < 4) --splits;
+    }
+  } else if (pl.tiles < 384) {
     splits = (int)((768 + pl.tiles - 1) / pl.tiles);
     if (splits > 16) splits = 16;
-    while (splits > 1 && pl.kiters / splits < min_steps) --splits;
+    while (splits > 1 && pl.kiters / splits < 4) --splits;
   }
   if (g_tune_igemm_split >= 1) splits = g_tune_igemm_split;
   if (splits > pl.kiters) splits = pl.kiters;

@@ -484,7 +484,9 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
   const long long tiles = (long long)pl.ptiles * pl.qtiles * d->R * d->S;
   long long chunks;
   if (pl.v2) {
-    chunks = tiles >= 400 ? 1 : (768 + tiles - 1) / tiles;
+    // measured (tools/bench_conv.py chunk sweep): ~1150 blocks in total, at most 64 slabs to fold
+    chunks = (1150 + tiles / 2) / tiles;
+    if (chunks > 64) chunks = 64;
     const long long max_by_pix = (M + 4 * bkp - 1) / (4 * bkp);      // >= 4 K-steps per chunk
     if (chunks > max_by_pix) chunks = max_by_pix;
   } else {

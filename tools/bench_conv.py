@@ -119,11 +119,10 @@ def main():
     only = set(args.only.split(",")) if args.only else None
     run(args.batch, args.reps, what, "default", only)
     if args.ab:
-        lib.dct_tune_set(0, 0)
-        lib.dct_tune_set(2, 0)
-        run(args.batch, args.reps, what, "v1 kernels (register staged)", only)
-        lib.dct_tune_set(0, 1)
-        lib.dct_tune_set(2, 1)
+        for ch in (1, 2, 4, 8, 16, 32, 64):
+            lib.dct_tune_set(3, ch)
+            run(args.batch, args.reps, [w for w in what if w == "wgrad"], f"wgrad pixel chunks forced to {ch}", only)
+        lib.dct_tune_set(3, -1)
 
 
 if __name__ == "__main__":
