@@ -37,6 +37,10 @@ class FlatParams:
         self.flat: torch.Tensor = None
         self.gflat: torch.Tensor = None
         self.version = 0          # bumps whenever the flat buffer is rebuilt
+        # optional bf16 image of the flat buffer (same offsets), written by the fused Adam in the same pass
+        # that updates the masters: the forward weight "packs" of a bf16 network are views of it
+        self.want_shadow = False
+        self.shadow: torch.Tensor = None
 
     # -- parameters -------------------------------------------------------------------------
     def is_flat(self) -> bool:
@@ -60,8 +64,18 @@ class FlatParams:
             v.copy_(p.data)
             p.data = v
         self.flat, self.gflat = flat, None
+        self.shadow = None
         self.version += 1
         return True
+
+    def ensure_shadow(self) -> torch.Tensor:
+        if self.shadow is None or self.shadow.device != self.flat.device:
+            self.shadow = torch.empty(self.total, dtype=torch.bfloat16, device=self.flat.device)
+        return self.shadow
+
+    def shadow_dense(self, i: int) -> torch.Tensor:
+        off = self.offsets[i]
+        return self.shadow[off:off + self.params[i].numel()]
 
     def dense(self, i: int) -> torch.Tensor:
         """1-D view of parameter i's storage span (physical order)."""

@@ -120,6 +120,8 @@ class UNet(nn.Module):
 
         self._convs: List[_ConvP] = [m for m in self.modules() if isinstance(m, _ConvP)]
         self.flat_params = FlatParams(list(self.parameters()))
+        self.flat_params.want_shadow = compute_dtype == torch.bfloat16
+        self._shadow_fresh = False
         self._pidx = {id(p): i for i, p in enumerate(self.flat_params.params)}
         self._packs: Dict[int, dict] = {}
         self._pack_key = None
@@ -131,8 +133,10 @@ class UNet(nn.Module):
         self._debug: Optional[dict] = None   # tools/debug_unet_layers.py stashes backward intermediates here
 
     # ------------------------------------------------------------------------------ weights
-    def mark_weights_updated(self):
+    def mark_weights_updated(self, shadow_fresh: bool = False):
+        """fp32 masters changed; ``shadow_fresh``: the flat bf16 shadow was rewritten in the same pass (fused Adam)."""
         self._pack_key = None
+        self._shadow_fresh = bool(shadow_fresh)
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
@@ -156,11 +160,18 @@ class UNet(nn.Module):
     def _ensure_packs(self):
         """(Re)build compute-dtype weight packs when the fp32 masters changed."""
         fp = self.flat_params
-        fp.ensure()
+        if fp.ensure():
+            self._shadow_fresh = False
         key = (fp.version, self.compute_dtype, tuple(p._version for p in fp.params))
         if key == self._pack_key:
             return
         dt, dev = self.compute_dtype, fp.flat.device
+        use_shadow = dt == torch.bfloat16
+        if use_shadow:
+            shadow = fp.ensure_shadow()
+            if not self._shadow_fresh:          # weights changed outside the fused Adam (init, load, broadcast)
+                K.pack_weight(fp.flat, shadow, 1, 1, fp.total)
+            self._shadow_fresh = False
         for conv in self._convs:
             if conv is self.final or conv is self.dec1.down.at(0):
                 continue  # stem and head read the fp32 masters directly
@@ -172,23 +183,15 @@ class UNet(nn.Module):
                 n = w.numel()
                 if conv.transposed:
                     ent["fwd"] = torch.empty(n, dtype=dt, device=dev)                    # [(a,b,co)][ci]
-                    ent["dgrad"] = w if dt == torch.float32 else torch.empty(n, dtype=dt, device=dev)  # [ci][a][b][co]
                 else:
-                    ent["fwd"] = w if dt == torch.float32 else torch.empty(n, dtype=dt, device=dev)    # [co][r][s][ci]
                     ent["dgrad"] = torch.empty(n, dtype=dt, device=dev)                  # [ci][flip taps][co]
+            ws = fp.shadow_dense(self._pidx[id(conv.weight)]) if use_shadow else w       # K-major image in dt
             if conv.transposed:
                 K.pack_weight(w, ent["fwd"], conv.cin, 4, conv.cout, transpose=2)
-                if dt != torch.float32:
-                    K.pack_weight(w, ent["dgrad"], conv.cin, 4, conv.cout)
-                else:
-                    ent["dgrad"] = w
+                ent["dgrad"] = ws                                                        # [ci][a][b][co] as stored
             else:
-                taps = conv.k * conv.k
-                if dt != torch.float32:
-                    K.pack_weight(w, ent["fwd"], conv.cout, taps, conv.cin)
-                else:
-                    ent["fwd"] = w
-                K.pack_weight(w, ent["dgrad"], conv.cout, taps, conv.cin, transpose=1, flip_taps=True)
+                ent["fwd"] = ws                                                          # [co][r][s][ci] as stored
+                K.pack_weight(w, ent["dgrad"], conv.cout, conv.k * conv.k, conv.cin, transpose=1, flip_taps=True)
         self._pack_key = key
 
     # ------------------------------------------------------------------------------ forward

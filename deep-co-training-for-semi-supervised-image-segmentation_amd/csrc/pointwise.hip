@@ -69,14 +69,35 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* src, T* dst, int
   dst[i] = from_f32<T>(src[((long long)p * Tt + t) * Q + q]);
 }
 
+// dst[q][t'][p] = src[p][t][q] (t = flip ? T-1-t' : t'): one 32x32 (p, q) tile per block through LDS, so both
+// the fp32 reads (along q) and the packed writes (along p) are coalesced.  P, Q multiples of 32.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const float* src, T* dst, int P, int Tt, int Q, int flip) {
+  __shared__ float tile[32][33];
+  const int p0 = blockIdx.x * 32, q0 = blockIdx.y * 32, t2 = blockIdx.z;
+  const int t = flip ? Tt - 1 - t2 : t2;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;       // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int pr = ly + 8 * k;
+    tile[pr][lx] = src[((long long)(p0 + pr) * Tt + t) * Q + q0 + lx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int qr = ly + 8 * k;
+    dst[((long long)(q0 + qr) * Tt + t2) * P + p0 + lx] = from_f32<T>(tile[lx][qr]);
+  }
+}
+
 // ---- Cin = 1 stem --------------------------------------------------------------------------
 struct StemGeom { int R, S, stride, dil, pad_h, pad_w, relu, cout; };
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(View x, const float* w, const float* bias, View y, StemGeom g) {
-  extern __shared__ float sw[];  // [cout][R*S] then bias[cout]
+  extern __shared__ float sw[];  // [R*S][cout] (a thread's VEC channels of a tap are contiguous: conflict-free), then bias[cout]
   const int taps = g.R * g.S;
-  for (int i = threadIdx.x; i < g.cout * taps; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < g.cout * taps; i += 256) { const int c = i / taps, t = i - c * taps; sw[t * g.cout + c] = w[i]; }
   for (int i = threadIdx.x; i < g.cout; i += 256) sw[g.cout * taps + i] = bias ? bias[i] : 0.f;
   __syncthreads();
   const int cvecs = (g.cout + VEC - 1) / VEC;
@@ -95,7 +116,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(View x, const float* w, c
     const int c = id.cv * VEC + i;
     float a = 0.f;
     if (c < g.cout) {
-      for (int t = 0; t < taps; ++t) a = fmaf(xin[t], sw[c * taps + t], a);
+      for (int t = 0; t < taps; ++t) a = fmaf(xin[t], sw[t * g.cout + c], a);
       a += sw[g.cout * taps + c];
       if (g.relu) a = fmaxf(a, 0.f);
     }
@@ -411,6 +432,13 @@ extern "C" int dct_pack_weight(const float* src, void* dst, int P, int T_, int Q
   if (!src || !dst || P < 1 || T_ < 1 || Q < 1) return DCT_ERR_BAD_ARG;
   const long long total = (long long)P * T_ * Q;
   hipStream_t st = (hipStream_t)stream;
+  if (transpose == 1 && P % 32 == 0 && Q % 32 == 0) {
+    const dim3 grid(P / 32, Q / 32, T_);
+    if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, src, (bf16_t*)dst, P, T_, Q, flip_taps);
+    else if (dtype == DCT_F32) DCT_LAUNCH(DCT_PROF_POINTWISE, pack_transpose_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, P, T_, Q, flip_taps);
+    else return DCT_ERR_BAD_ARG;
+    return dct_check_launch();
+  }
   if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, pack_kernel<bf16_t>, dim3(div_up(total, 256)), dim3(256), 0, st, src, (bf16_t*)dst, P, T_, Q, transpose, flip_taps);
   else if (dtype == DCT_F32) DCT_LAUNCH(DCT_PROF_POINTWISE, pack_kernel<float>, dim3(div_up(total, 256)), dim3(256), 0, st, src, (float*)dst, P, T_, Q, transpose, flip_taps);
   else return DCT_ERR_BAD_ARG;

@@ -82,12 +82,16 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = g["betas"]
         bc1 = 1.0 - b1 ** self._steps
         bc2 = 1.0 - b2 ** self._steps
+        shadow = f.ensure_shadow() if f.want_shadow else None
         hip_ops.adam_flat(f.flat, f.gflat, self._m, self._v, g["lr"] / bc1, math.sqrt(bc2), b1, b2, g["eps"],
-                          g["weight_decay"])
+                          g["weight_decay"], bf16_shadow=shadow)
         for p in f.params:
             self.state[p]["step"] = torch.tensor(float(self._steps))
         if self._on_step is not None:
-            self._on_step()
+            try:
+                self._on_step(shadow_fresh=shadow is not None)
+            except TypeError:
+                self._on_step()
         return loss
 
     def load_state_dict(self, state_dict):
