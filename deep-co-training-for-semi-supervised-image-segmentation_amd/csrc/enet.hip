@@ -26,6 +26,26 @@ template <typename T> __device__ __forceinline__ void stv(const View& v, long lo
   if (f32) reinterpret_cast<float*>(v.ptr)[off] = val; else reinterpret_cast<T*>(v.ptr)[off] = from_f32<T>(val);
 }
 __device__ __forceinline__ long long voff(const View& v, int n, int y, int x) { return n * v.sn + y * v.sh + x * v.sw; }
+// flat pixel index -> (n, y, x); 32-bit divisions when the index fits (64-bit division is a long VALU routine)
+__device__ __forceinline__ void pix3(long long pix, int h, int w, int& n, int& y, int& x) {
+  if (pix <= 0x7fffffffll) {
+    const unsigned p = (unsigned)pix, row = p / (unsigned)w;
+    x = (int)(p - row * (unsigned)w);
+    const unsigned img = row / (unsigned)h;
+    y = (int)(row - img * (unsigned)h);
+    n = (int)img;
+  } else {
+    x = (int)(pix % w); pix /= w;
+    y = (int)(pix % h);
+    n = (int)(pix / h);
+  }
+}
+// flat element index -> (pixel, channel)
+__device__ __forceinline__ long long split_c(long long idx, int C, int& c) {
+  if (idx <= 0x7fffffffll) { const unsigned i = (unsigned)idx, p = i / (unsigned)C; c = (int)(i - p * (unsigned)C); return p; }
+  c = (int)(idx % C);
+  return idx / C;
+}
 
 struct Tf {            // input transform of the producer layer: act(scale*x + shift)
   const float* scale; const float* shift; const float* slope;   // slope: PReLU weights (mode 2)
@@ -69,9 +89,8 @@ __global__ __launch_bounds__(256) void enet_conv_kernel(ConvP p) {
   const long long pix = (long long)blockIdx.x * (256 / p.G) + threadIdx.x / p.G;
   const long long P = (long long)p.y.n * p.y.h * p.y.w;
   if (pix >= P) return;
-  const int hw = p.y.h * p.y.w;
-  const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
-  const int oy = rem / p.y.w, ox = rem - oy * p.y.w;
+  int n, oy, ox;
+  pix3(pix, p.y.h, p.y.w, n, oy, ox);
   float acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
@@ -156,12 +175,11 @@ __global__ __launch_bounds__(256) void enet_reduce_kernel(RedP p, double* partia
   const long long pbeg = (long long)blockIdx.x * p.ppb, pend = min(P, pbeg + p.ppb);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   if (c < C) {
-    const int hw = p.x.h * p.x.w;
     float sc = 0.f, sh = 0.f, sl = 0.f, mu = 0.f, is = 0.f;
     if (p.kind == 1) { sc = p.scale[c]; sh = p.shift[c]; mu = p.mean[c]; is = p.invstd[c]; if (p.act == 2) sl = p.slope[c]; }
     for (long long pix = pbeg + row; pix < pend; pix += rows) {
-      const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
-      const int y = rem / p.x.w, x = rem - y * p.x.w;
+      int n, y, x;
+      pix3(pix, p.x.h, p.x.w, n, y, x);
       const float v = ldv<T>(p.x, voff(p.x, n, y, x) + c, p.fm & 1);
       if (p.kind == 0) {
         a0 += (double)v; a1 += (double)v * (double)v;
@@ -250,11 +268,8 @@ __global__ __launch_bounds__(256) void enet_bn_bwd_apply_kernel(RedP p, const fl
   const int C = p.x.c;
   const long long total = (long long)p.x.n * p.x.h * p.x.w * C;
   if (idx >= total) return;
-  const int c = (int)(idx % C);
-  long long pix = idx / C;
-  const int x = (int)(pix % p.x.w); pix /= p.x.w;
-  const int y = (int)(pix % p.x.h);
-  const int n = (int)(pix / p.x.h);
+  int c, n, y, x;
+  pix3(split_c(idx, C, c), p.x.h, p.x.w, n, y, x);
   const float v = ldv<T>(p.x, voff(p.x, n, y, x) + c, p.fm & 1);
   const float g = grad_in<T>(p, n, y, x, c);
   const float z = fmaf(p.scale[c], v, p.shift[c]);
@@ -294,11 +309,8 @@ __global__ __launch_bounds__(256) void enet_tail_fwd_kernel(TailP p) {
   const int C = p.out.c;
   const long long total = (long long)p.out.n * p.out.h * p.out.w * C;
   if (i >= total) return;
-  const int c = (int)(i % C);
-  long long pix = i / C;
-  const int ox = (int)(pix % p.out.w); pix /= p.out.w;
-  const int oy = (int)(pix % p.out.h);
-  const int n = (int)(pix / p.out.h);
+  int c, n, oy, ox;
+  pix3(split_c(i, C, c), p.out.h, p.out.w, n, oy, ox);
   const long long oo = voff(p.out, n, oy, ox) + c;
   int code;
   if (p.mode == 3) {   // initial block: 13 conv channels through BN+PReLU, channel 13 = maxpool(image)
@@ -342,11 +354,8 @@ __global__ __launch_bounds__(256) void enet_tail_bwd_kernel(TailBP p) {
   const int C = p.dst.c;
   const long long total = (long long)p.dst.n * p.dst.h * p.dst.w * C;
   if (i >= total) return;
-  const int c = (int)(i % C);
-  long long pix = i / C;
-  const int x = (int)(pix % p.dst.w); pix /= p.dst.w;
-  const int y = (int)(pix % p.dst.h);
-  const int n = (int)(pix / p.dst.h);
+  int c, n, y, x;
+  pix3(split_c(i, C, c), p.dst.h, p.dst.w, n, y, x);
   const long long dof = voff(p.dst, n, y, x) + c;
   float g = 0.f;
   if (p.mode == 1) {          // dst = x-resolution; (y, x) in the 2x2 window of (y/2, x/2)
@@ -393,7 +402,6 @@ __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, 
   float acc[WG_MAXE];
 #pragma unroll
   for (int j = 0; j < WG_MAXE; ++j) acc[j] = 0.f;
-  const int hw = p.a.h * p.a.w;
   const int kb = taps * Cb;
   for (long long p0 = pbeg; p0 < pend; p0 += WG_PB) {
     __syncthreads();
@@ -402,8 +410,8 @@ __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, 
       const long long pix = p0 + q;
       float v = 0.f;
       if (pix < pend) {
-        const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
-        const int y = rem / p.a.w, x = rem - y * p.a.w;
+        int n, y, x;
+        pix3(pix, p.a.h, p.a.w, n, y, x);
         v = tf_apply(p.tfa, c, ldv<T>(p.a, voff(p.a, n, y, x) + c, p.fm & 1));
       }
       As[e] = v;
@@ -414,8 +422,8 @@ __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, 
       const long long pix = p0 + q;
       float v = 0.f;
       if (pix < pend) {
-        const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
-        const int y = rem / p.a.w, x = rem - y * p.a.w;
+        int n, y, x;
+        pix3(pix, p.a.h, p.a.w, n, y, x);
         const int by = y * p.stride - p.pad_h + (t / p.S) * p.dil, bx = x * p.stride - p.pad_w + (t % p.S) * p.dil;
         if ((unsigned)by < (unsigned)p.b.h && (unsigned)bx < (unsigned)p.b.w)
           v = tf_apply(p.tfb, c, ldv<T>(p.b, voff(p.b, n, by, bx) + c, p.fm & 2));

@@ -36,12 +36,24 @@ template <typename T> struct VecIO<T, 1> {
 template <typename T> struct VecOf { static constexpr int value = 16 / sizeof(T); };
 
 struct PixIdx { int n, y, x, cv; bool ok; };
-// idx -> (pixel of a [n,h,w] grid, channel-vector cv)
+// idx -> (pixel of a [n,h,w] grid, channel-vector cv).  32-bit divisions whenever the element count allows
+// (64-bit integer division is a ~100-instruction software routine on the VALU and used to dominate these kernels).
 __device__ __forceinline__ PixIdx decode(long long idx, int n, int h, int w, int cvecs) {
   PixIdx r;
   const long long total = (long long)n * h * w * cvecs;
   r.ok = idx < total;
   if (!r.ok) { r.n = r.y = r.x = r.cv = 0; return r; }
+  if (total <= 0x7fffffffll) {
+    const unsigned i = (unsigned)idx, cvu = (unsigned)cvecs, wu = (unsigned)w, hu = (unsigned)h;
+    unsigned pix = i / cvu;
+    r.cv = (int)(i - pix * cvu);
+    const unsigned row = pix / wu;
+    r.x = (int)(pix - row * wu);
+    const unsigned img = row / hu;
+    r.y = (int)(row - img * hu);
+    r.n = (int)img;
+    return r;
+  }
   r.cv = (int)(idx % cvecs);
   long long pix = idx / cvecs;
   r.x = (int)(pix % w); pix /= w;

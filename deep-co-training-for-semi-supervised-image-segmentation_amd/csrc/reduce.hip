@@ -31,10 +31,9 @@ template <> struct Vec<float> {
 // element offset of flat pixel index `pix` in an NHWC view
 __device__ __forceinline__ long long pix_off(const View& v, long long pix, int linear) {
   if (linear) return pix * v.sw;
-  const int hw = v.h * v.w;
-  const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
-  const int y = rem / v.w, x = rem - y * v.w;
-  return n * v.sn + y * v.sh + x * v.sw;
+  const unsigned p = (unsigned)pix, row = p / (unsigned)v.w;        // pixel counts are < 2^31 (checked on the host)
+  const unsigned x = p - row * (unsigned)v.w, n = row / (unsigned)v.h, y = row - n * (unsigned)v.h;
+  return (long long)n * v.sn + (long long)y * v.sh + (long long)x * v.sw;
 }
 static inline int view_linear(const dct_view* v) {
   return (v->sh == (long long)v->w * v->sw && v->sn == (long long)v->h * v->sh) ? 1 : 0;
@@ -137,10 +136,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_fast_kernel(View x, View dy, f
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
-  const int hw = dy.h * dy.w;
   for (long long pix = pbeg + row; pix < pend; pix += rows) {
-    const int n = (int)(pix / hw), rem = (int)(pix - (long long)n * hw);
-    const int oy = rem / dy.w, ox = rem - oy * dy.w;
+    const unsigned up = (unsigned)pix, urow = up / (unsigned)dy.w;
+    const int ox = (int)(up - urow * (unsigned)dy.w), n = (int)(urow / (unsigned)dy.h), oy = (int)(urow - (unsigned)n * (unsigned)dy.h);
     float d[VEC];
     Vec<T>::load(dbase + n * dy.sn + oy * dy.sh + ox * dy.sw, d);
     float xv[9];
