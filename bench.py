@@ -38,7 +38,15 @@ CONFIGS = {
                  desc="2xUNet co-training (CE + JSD), ACDC-shaped 256x256 C=4, bs 8+8 per GPU"),
     "cfg3": dict(arch="unet", H=256, C=4, B_l=8, B_u=8, train_adv=True, S=2,
                  desc="2xUNet co-training (CE + JSD + FGSM eps .03), 256x256 C=4, bs 8+8 per GPU"),
+    # BASELINE configs[3] / [4]: the Enet configurations (HBM/launch bound; roofline leg reports HBM GB/s)
+    "cfg4": dict(arch="enet", H=200, C=2, B_l=8, B_u=8, train_adv=True, S=2,
+                 desc="2xEnet co-training (CE + JSD + FGSM), spinal-cord-GM-shaped 200x200 C=2, bs 8+8 per GPU"),
+    "cfg5": dict(arch="enet", H=320, C=2, B_l=4, B_u=16, train_adv=True, S=3,
+                 desc="3xEnet co-training (CE + JSD + FGSM), prostate-shaped 320x320 C=2, lab:unlab 1:4 (4+16 per GPU)"),
 }
+
+# conv in+out activation elements per image, forward (measured on the reference modules)
+ENET_ACT_ELEMS = {200: 9.48e6, 256: 15.66e6, 320: 24.27e6, 64: 0.97e6}
 
 
 def unet_conv_flops(H: int, W: int, C: int):
@@ -66,6 +74,21 @@ def unet_conv_flops(H: int, W: int, C: int):
     gemm += 2.0 * (h - 2) * (w - 2) * 9 * 128 * 64 + 2.0 * (h - 4) * (w - 4) * 9 * 64 * 64
     small += 2.0 * (h - 4) * (w - 4) * 64 * C
     return gemm, small
+
+
+def pmc_traffic(config):
+    """HBM bytes per launch of the dominant conv kernel from the committed rocprofv3 --pmc passes
+    (profiles/*_pmc_traffic.json, produced by tools/pmc_traffic.py on this same command); None when absent."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{config}_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            d["source"] = os.path.relpath(path, ROOT)
+            return d
+        except Exception:
+            continue
+    return None
 
 
 def make_trainer(cfg, dtype, device, rank, world, grad_sync_factory, n_batches=4):
@@ -147,6 +170,7 @@ def cpu_baseline(cfg, seconds_budget=25.0):
         n += 1
     dt = (time.perf_counter() - t0) / n
     imgs = S * B + B
+    imgs_note = ""
     return {"value": imgs / dt, "unit": "imgs/sec", "cores": threads, "kind": "port",
             "sample": f"oracle (PyTorch-CPU fp32 restatement of the reference step) {S}x{cfg['arch']} {H}x{H} C={C}, "
                       f"bs {B}+{B} ({imgs} imgs/step), {n} timed steps after 1 warm-up, {dt:.2f} s/step, "
@@ -237,7 +261,8 @@ def main():
     value = imgs_per_step * world / (elapsed / args.steps)
 
     result = {
-        "metric": "co-train imgs/sec/node (lab+unlab), 2xUNet ACDC 256x256",
+        "metric": "co-train imgs/sec/node (lab+unlab), 2xUNet ACDC 256x256" if args.config in ("cfg2", "cfg3")
+        else f"co-train imgs/sec/node (lab+unlab), {cfg['S']}x{cfg['arch']} {cfg['H']}x{cfg['H']}",
         "value": value, "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
@@ -247,7 +272,7 @@ def main():
         "losses_last_step": losses,
     }
     if rank == 0:
-        if prof is not None:
+        if prof is not None and cfg["arch"] == "unet":
             gemm_f, small_f = unet_conv_flops(cfg["H"], cfg["H"], cfg["C"])
             passes = S * (cfg["B_l"] + cfg["B_u"])                      # image-passes with fwd+dgrad+wgrad
             fgsm_imgs = (cfg["B_l"] + cfg["B_u"]) if cfg["train_adv"] else 0
@@ -260,15 +285,35 @@ def main():
             ach = flops[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e12
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             result["roofline"] = {
-                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                "kernel": {"igemm": "igemm_kernel (conv fwd + data-grad implicit GEMM, incl. split-K epilogue)",
-                           "wgrad": "wgrad_kernel (weight-grad GEMM, incl. fixed-order reduce)"}[dom],
+                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(args.config),
+                "kernel": {"igemm": "igemm2_kernel (conv fwd + data-grad implicit GEMM, incl. split-K epilogue)",
+                           "wgrad": "wgrad2_kernel (weight-grad GEMM, incl. fixed-order reduce)"}[dom],
                 "algorithmic_flops_per_step": flops[dom], "kernel_ms_per_step": per[dom]["ms_per_step"],
                 "avg_launch_us": 1e3 * per[dom]["ms_per_step"] / max(per[dom]["launches_per_step"], 1),
+                "algorithmic_flops_per_launch": flops[dom] / max(per[dom]["launches_per_step"], 1),
                 "conv_stack": {"achieved": (flops["igemm"] + flops["wgrad"]) /
                                ((per["igemm"]["ms_per_step"] + per["wgrad"]["ms_per_step"]) * 1e-3) / 1e12,
                                "unit": "TFLOP/s"},
                 "per_class_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in per.items()},
+                "measured": "HIP events around every launch on the launch stream, over the same K steps re-run right after the timed region",
+            }
+        elif prof is not None:
+            # Enet: HBM bound.  Algorithmic bytes = conv in+out activation elements x 2 B (bf16) x 3 (fwd, dgrad, wgrad)
+            # per training image-pass; the FGSM generator pass counts fwd + dgrad (x 2).
+            elems = ENET_ACT_ELEMS[cfg["H"]]
+            esz = 2 if args.dtype == "bf16" else 4
+            passes = S * (cfg["B_l"] + cfg["B_u"])
+            fgsm_imgs = (cfg["B_l"] + cfg["B_u"]) if cfg["train_adv"] else 0
+            alg_bytes = elems * esz * (3 * passes + (2 + 3) * fgsm_imgs)
+            ms = prof["other"]["ms"] / args.steps
+            launches = prof["other"]["launches"] / args.steps
+            ach = alg_bytes / (ms * 1e-3) / 1e9
+            result["roofline"] = {
+                "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                "kernel": "enet_* kernel family (fused conv / BN / tail / wgrad; aggregate, the net is launch bound)",
+                "algorithmic_bytes_per_step": alg_bytes, "kernel_ms_per_step": ms,
+                "avg_launch_us": 1e3 * ms / max(launches, 1), "launches_per_step": launches,
+                "per_class_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in prof.items()},
                 "measured": "HIP events around every launch on the launch stream, over the same K steps re-run right after the timed region",
             }
         if world == 1 and not args.no_cpu_baseline:

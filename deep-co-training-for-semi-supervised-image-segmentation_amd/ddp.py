@@ -70,18 +70,24 @@ class FlatGradSync(object):
         flat = getattr(net, "flat_params", None)
         if flat is not None and flat.grads_attached():
             work, scale = self._reduce_tensor(flat.gflat, True)
-            self._pending.append((work, scale, None, None))
+            self._pending.append((model_index, work, scale, None, None))
             return
         params = [p for p in net.parameters() if p.grad is not None]
         if not params:
             return
         buf = torch.cat([p.grad.reshape(-1) for p in params])
         work, scale = self._reduce_tensor(buf, True)
-        self._pending.append((work, scale, buf, params))
+        self._pending.append((model_index, work, scale, buf, params))
 
     @torch.no_grad()
-    def finish(self):
-        for work, scale, buf, params in self._pending:
+    def finish(self, model_index: Optional[int] = None):
+        """Wait for the pending all-reduces (of one model, or all) and finish the averaging."""
+        keep = []
+        for ent in self._pending:
+            if model_index is not None and ent[0] != model_index:
+                keep.append(ent)
+                continue
+            _, work, scale, buf, params = ent
             work.wait()
             if scale is not None:
                 scale.mul_(1.0 / self.world)
@@ -91,7 +97,7 @@ class FlatGradSync(object):
                     n = p.grad.numel()
                     p.grad.copy_(buf[off:off + n].view_as(p.grad))
                     off += n
-        self._pending = []
+        self._pending = keep
 
     def all_reduce(self):
         for i in range(len(self.segmentators)):

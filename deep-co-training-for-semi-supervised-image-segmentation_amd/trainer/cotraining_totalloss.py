@@ -212,12 +212,12 @@ class CoTrainer(Trainer):
             call()
             if self.grad_sync is not None and idx is not None:
                 self.grad_sync.begin(idx)
-        if self.grad_sync is not None:
-            if any(idx is None for idx, _ in backward_calls):
-                self.grad_sync.all_reduce()
-            else:
-                self.grad_sync.finish()
-        map_(lambda x: x.optimizer.step(), self.segmentators)
+        if self.grad_sync is not None and any(idx is None for idx, _ in backward_calls):
+            self.grad_sync.all_reduce()
+        for i, seg in enumerate(self.segmentators):
+            if self.grad_sync is not None:
+                self.grad_sync.finish(i)     # model i's all-reduce only: later ones overlap this Adam launch
+            seg.optimizer.step()
 
     def _run_step_generic(self, lab, unl, train_jsd, train_adv, adv_choice) -> dict:
         S = len(self.segmentators)

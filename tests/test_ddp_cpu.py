@@ -95,7 +95,7 @@ def test_two_rank_gloo_step_equals_averaged_gradient_step(tmp_path):
     for a, b in zip(w0, w1):
         np.testing.assert_array_equal(a, b)          # ranks stay bit-identical
     # single-process reference: average the two ranks' gradients by hand, then one Adam step
-    torch.set_num_threads(4)
+    # (the parent keeps its ATen thread count: other tests in this process pin last-bit numerics to it)
     trs = [_build(os.path.join(out, f"s{r}"), 100 * r) for r in range(world)]
     grads = []
     for tr, lab, unl in trs:

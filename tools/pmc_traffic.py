@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of the conv GEMM kernels from two rocprofv3 --pmc passes of bench.py
+(FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md, rocprofv3 PMC slots), corrected as that
+guide prescribes for gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide streaming read -> x2;
+WRITE_SIZE is exact for 16-B stores; both are reported in KiB by rocprofv3.
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <config> > profiles/rNN_<config>_pmc_traffic.json
+"""
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    agg = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"]
+            key = "igemm2" if "igemm2_kernel" in name else "wgrad2" if "wgrad2_kernel" in name else None
+            if key is None:
+                continue
+            a = agg.setdefault(key, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    fetch, write, config = sys.argv[1], sys.argv[2], sys.argv[3]
+    fa, wa = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    out = {"unit": "bytes per launch (HBM-side, L2 fabric counters)", "config": config,
+           "correction": "FETCH_SIZE x 1024 (KiB) x 2 (gfx950 wide-read undercount); WRITE_SIZE x 1024"}
+    for k in sorted(fa):
+        n, v = fa[k]
+        nw, vw = wa.get(k, [0, 0.0])
+        out[k] = {"launches": n, "fetch_bytes_per_launch": v * 1024 * 2 / max(n, 1),
+                  "write_bytes_per_launch": vw * 1024 / max(nw, 1)}
+        out[k]["bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
