@@ -204,19 +204,43 @@ __global__ __launch_bounds__(256) void enet_reduce_kernel(RedP p, double* partia
   }
 }
 
-// BatchNorm forward finalize (one block): statistics -> scale/shift (+ running statistics)
-__global__ void enet_bn_finalize_kernel(const double* partial, int blocks, int C, double count,
+// Fixed-order fold of the per-block partials: thread (c, part) sums blocks part, part+NP, ... and the NP
+// partial sums of a channel are then added in ascending `part` -- deterministic, and 256/CP-way parallel
+// instead of one thread walking all blocks.  Result valid for threads with part == 0.
+__device__ __forceinline__ void fold_partials(const double* partial, int blocks, int C, double* red, double s[3]) {
+  int CP = 1;
+  while (CP < C) CP <<= 1;
+  const int NP = 256 / CP;
+  const int c = threadIdx.x % CP, part = threadIdx.x / CP;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (c < C)
+    for (int b = part; b < blocks; b += NP) {
+      const double* q = partial + ((long long)b * C + c) * 3;
+      a0 += q[0]; a1 += q[1]; a2 += q[2];
+    }
+  red[threadIdx.x * 3] = a0; red[threadIdx.x * 3 + 1] = a1; red[threadIdx.x * 3 + 2] = a2;
+  __syncthreads();
+  s[0] = s[1] = s[2] = 0.0;
+  if (part == 0 && c < C)
+    for (int k = 0; k < NP; ++k) { s[0] += red[(k * CP + c) * 3]; s[1] += red[(k * CP + c) * 3 + 1]; s[2] += red[(k * CP + c) * 3 + 2]; }
+}
+
+// BatchNorm forward finalize (one block of 256): statistics -> scale/shift (+ running statistics)
+__global__ __launch_bounds__(256) void enet_bn_finalize_kernel(const double* partial, int blocks, int C, double count,
                                         const float* gamma, const float* beta, float eps, float momentum,
                                         float* running_mean, float* running_var, int training,
                                         float* scale, float* shift, float* save_mean, float* save_invstd) {
+  __shared__ double red[256 * 3];
+  double s[3];
+  fold_partials(partial, training ? blocks : 0, C, red, s);
   const int c = threadIdx.x;
-  if (c >= C) return;
+  int CP = 1;
+  while (CP < C) CP <<= 1;
+  if (c >= C || threadIdx.x >= CP) return;
   float mean, var;
   if (training) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < blocks; ++b) { s0 += partial[((long long)b * C + c) * 3]; s1 += partial[((long long)b * C + c) * 3 + 1]; }
-    const double m = s0 / count;
-    double v = s1 / count - m * m;
+    const double m = s[0] / count;
+    double v = s[1] / count - m * m;
     if (v < 0.0) v = 0.0;
     mean = (float)m; var = (float)v;
     if (running_mean) {
@@ -235,30 +259,33 @@ __global__ void enet_bn_finalize_kernel(const double* partial, int blocks, int C
 }
 
 // BatchNorm backward finalize: dgamma/dbeta/dslope (+=) and the two per-channel means the apply pass needs
-__global__ void enet_bn_bwd_finalize_kernel(const double* partial, int blocks, int C, double count, int training,
+__global__ __launch_bounds__(256) void enet_bn_bwd_finalize_kernel(const double* partial, int blocks, int C, double count, int training,
                                             float* dgamma, float* dbeta, float* dslope, float* c1, float* c2) {
+  __shared__ double red[256 * 3];
+  double s[3];
+  fold_partials(partial, blocks, C, red, s);
   const int c = threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < blocks; ++b) {
-    const double* q = partial + ((long long)b * C + c) * 3;
-    s0 += q[0]; s1 += q[1]; s2 += q[2];
-  }
-  if (dbeta) dbeta[c] += (float)s0;
-  if (dgamma) dgamma[c] += (float)s1;
-  if (dslope) dslope[c] += (float)s2;
+  int CP = 1;
+  while (CP < C) CP <<= 1;
+  if (c >= C || threadIdx.x >= CP) return;
+  if (dbeta) dbeta[c] += (float)s[0];
+  if (dgamma) dgamma[c] += (float)s[1];
+  if (dslope) dslope[c] += (float)s[2];
   // eval mode: mean / invstd are constants (running statistics), so no correction terms
-  c1[c] = training ? (float)(s0 / count) : 0.f;
-  c2[c] = training ? (float)(s1 / count) : 0.f;
+  c1[c] = training ? (float)(s[0] / count) : 0.f;
+  c2[c] = training ? (float)(s[1] / count) : 0.f;
 }
 
 // plain per-channel sum finalize (bias gradient): out[c] += sum_b partial[b][c][0]
-__global__ void enet_sum_finalize_kernel(const double* partial, int blocks, int C, float* out) {
+__global__ __launch_bounds__(256) void enet_sum_finalize_kernel(const double* partial, int blocks, int C, float* out) {
+  __shared__ double red[256 * 3];
+  double s[3];
+  fold_partials(partial, blocks, C, red, s);
   const int c = threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += partial[((long long)b * C + c) * 3];
-  out[c] += (float)s;
+  int CP = 1;
+  while (CP < C) CP <<= 1;
+  if (c >= C || threadIdx.x >= CP) return;
+  out[c] += (float)s[0];
 }
 
 // draw = scale * (dz - c1 - xhat * c2)
@@ -388,74 +415,111 @@ struct WgP {
   int ppb;
   int fm;                         // f32 mask: bit0 a, bit1 b
 };
-constexpr int WG_PB = 8;           // pixels staged per round
-constexpr int WG_MAXE = 40;        // entries per thread (E <= 10240)
+constexpr int WG_PB = 32;          // pixels staged per round
+constexpr int WG_TPT = 2;          // 4x8 register tiles per thread (<= 512 tiles: E <= 16384)
 
+// Register-tiled: the [Ca] x [taps*Cb] gradient is cut into 4 x 8 tiles, a thread owns up to two of them
+// and per staged pixel reads 4 + 8 operands (three 16-B LDS reads) for 32 FMAs.  LDS rows are padded to
+// multiples of 4 / 8 floats and zero-filled, so ragged channel counts (3, 13, 14) need no branches.
 template <typename T>
 __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, int E) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Ca = p.a.c, Cb = p.b.c, taps = p.R * p.S;
-  float* As = sm;                             // [WG_PB][Ca]
-  float* Bs = sm + WG_PB * Ca;                // [WG_PB][taps][Cb]
+  const int kb = taps * Cb;
+  const int CaP = (Ca + 3) & ~3, kbP = (kb + 7) & ~7;
+  const int OT = CaP >> 2, KT = kbP >> 3, ntiles = OT * KT;
+  float* As = sm;                             // [WG_PB][CaP]
+  float* Bs = sm + WG_PB * CaP;               // [WG_PB][kbP]
+  __shared__ int pixn[WG_PB], pixy[WG_PB], pixx[WG_PB];
   const long long P = (long long)p.a.n * p.a.h * p.a.w;
   const long long pbeg = (long long)blockIdx.x * p.ppb, pend = min(P, pbeg + p.ppb);
-  float acc[WG_MAXE];
+  int to[WG_TPT], tk[WG_TPT];
+  float acc[WG_TPT][4][8];
 #pragma unroll
-  for (int j = 0; j < WG_MAXE; ++j) acc[j] = 0.f;
-  const int kb = taps * Cb;
+  for (int j = 0; j < WG_TPT; ++j) {
+    const int t = min(j * 256 + (int)threadIdx.x, ntiles - 1);
+    to[j] = (t / KT) * 4; tk[j] = (t % KT) * 8;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc[j][a][b] = 0.f;
+  }
+  for (int e = threadIdx.x; e < WG_PB * (CaP + kbP); e += 256) sm[e] = 0.f;     // the pads stay zero
   for (long long p0 = pbeg; p0 < pend; p0 += WG_PB) {
     __syncthreads();
-    for (int e = threadIdx.x; e < WG_PB * Ca; e += 256) {
-      const int q = e / Ca, c = e - q * Ca;
-      const long long pix = p0 + q;
-      float v = 0.f;
-      if (pix < pend) {
-        int n, y, x;
-        pix3(pix, p.a.h, p.a.w, n, y, x);
-        v = tf_apply(p.tfa, c, ldv<T>(p.a, voff(p.a, n, y, x) + c, p.fm & 1));
-      }
-      As[e] = v;
+    if (threadIdx.x < WG_PB) {
+      int n = -1, y = 0, x = 0;
+      if (p0 + threadIdx.x < pend) pix3(p0 + threadIdx.x, p.a.h, p.a.w, n, y, x);
+      pixn[threadIdx.x] = n; pixy[threadIdx.x] = y; pixx[threadIdx.x] = x;
     }
-    for (int e = threadIdx.x; e < WG_PB * kb; e += 256) {
-      const int q = e / kb, r2 = e - q * kb;
-      const int t = r2 / Cb, c = r2 - t * Cb;
-      const long long pix = p0 + q;
-      float v = 0.f;
-      if (pix < pend) {
-        int n, y, x;
-        pix3(pix, p.a.h, p.a.w, n, y, x);
+    __syncthreads();
+    // staging: 8 pixel slots x 32 channel lanes (no divisions, all of a round's loads in flight together)
+    const int tq = threadIdx.x >> 5, tc = threadIdx.x & 31;
+    for (int q = tq; q < WG_PB; q += 8) {
+      const int n = pixn[q], y = pixy[q], x = pixx[q];
+      for (int c = tc; c < Ca; c += 32)
+        As[q * CaP + c] = n >= 0 ? tf_apply(p.tfa, c, ldv<T>(p.a, voff(p.a, n, y, x) + c, p.fm & 1)) : 0.f;
+      for (int t = 0; t < taps; ++t) {
         const int by = y * p.stride - p.pad_h + (t / p.S) * p.dil, bx = x * p.stride - p.pad_w + (t % p.S) * p.dil;
-        if ((unsigned)by < (unsigned)p.b.h && (unsigned)bx < (unsigned)p.b.w)
-          v = tf_apply(p.tfb, c, ldv<T>(p.b, voff(p.b, n, by, bx) + c, p.fm & 2));
+        const bool ok = n >= 0 && (unsigned)by < (unsigned)p.b.h && (unsigned)bx < (unsigned)p.b.w;
+        for (int c = tc; c < Cb; c += 32)
+          Bs[q * kbP + t * Cb + c] = ok ? tf_apply(p.tfb, c, ldv<T>(p.b, voff(p.b, n, by, bx) + c, p.fm & 2)) : 0.f;
       }
-      Bs[e] = v;
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < WG_MAXE; ++j) {
-      const int e = j * 256 + threadIdx.x;
-      if (e < E) {
-        const int o = e / kb, k = e - o * kb;
-        float s = acc[j];
+    for (int j = 0; j < WG_TPT; ++j) {
+      if (j * 256 < ntiles) {      // block-uniform
+#pragma unroll 8
+        for (int q = 0; q < WG_PB; ++q) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(As + q * CaP + to[j]);
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + q * kbP + tk[j]);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs + q * kbP + tk[j] + 4);
 #pragma unroll
-        for (int q = 0; q < WG_PB; ++q) s = fmaf(As[q * Ca + o], Bs[q * kb + k], s);
-        acc[j] = s;
+          for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              acc[j][a][b] = fmaf(av[a], b0[b], acc[j][a][b]);
+              acc[j][a][b + 4] = fmaf(av[a], b1[b], acc[j][a][b + 4]);
+            }
+          }
+        }
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < WG_MAXE; ++j) {
-    const int e = j * 256 + threadIdx.x;
-    if (e < E) partial[(long long)blockIdx.x * E + e] = acc[j];
+  for (int j = 0; j < WG_TPT; ++j) {
+    const int t = j * 256 + threadIdx.x;
+    if (t < ntiles) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int o = to[j] + a;
+        if (o >= Ca) break;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const int k = tk[j] + b;
+          if (k < kb) partial[(long long)blockIdx.x * E + o * kb + k] = acc[j][a][b];
+        }
+      }
+    }
   }
 }
 
+// dw[e] += sum_b partial[b][e]: 16 entries per block, 16 strided partial sums each, folded in fixed order
 __global__ __launch_bounds__(256) void enet_wgrad_reduce_kernel(const float* partial, float* dw, int E, int blocks) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= E) return;
+  __shared__ float red[256];
+  const int e = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[(long long)b * E + e];
-  dw[e] += s;
+  if (e < E)
+    for (int b = part; b < blocks; b += 16) s += partial[(long long)b * E + e];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && e < E) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k * 16 + threadIdx.x];
+    dw[e] += t;
+  }
 }
 
 static inline bool ok_dtype(int d) { return d == DCT_F32 || d == DCT_BF16; }
@@ -540,7 +604,7 @@ extern "C" int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, co
     if (rc != DCT_OK) return rc;
   }
   const double count = (double)raw->n * raw->h * raw->w;
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_finalize_kernel, dim3(1), dim3(128), 0, st, (const double*)workspace, blocks, raw->c, count,
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, blocks, raw->c, count,
              gamma, beta, eps, momentum, running_mean, running_var, training ? 1 : 0, scale, shift, save_mean, save_invstd);
   return dct_check_launch();
 }
@@ -564,7 +628,7 @@ extern "C" int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct
   const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
   if (rc != DCT_OK) return rc;
   const double count = (double)raw->n * raw->h * raw->w;
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, st, (const double*)workspace, blocks, raw->c, count,
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, blocks, raw->c, count,
              training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, c1c2 + raw->c);
   const long long total = (long long)raw->n * raw->h * raw->w * raw->c;
   const View vo = to_view(draw);
@@ -583,7 +647,7 @@ extern "C" int dct_enet_channel_sum(const dct_view* x, float* out, int f32_mask,
   int blocks = 0;
   const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
   if (rc != DCT_OK) return rc;
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_sum_finalize_kernel, dim3(1), dim3(128), 0, st, (const double*)workspace, blocks, x->c, out);
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, blocks, x->c, out);
   return dct_check_launch();
 }
 
@@ -622,7 +686,7 @@ extern "C" int dct_enet_tail_bwd(const dct_view* dout, const dct_view* out_mask,
 
 extern "C" size_t dct_enet_wgrad_workspace_bytes(const dct_view* a, const dct_view* b, const dct_conv_desc* d) {
   if (!a || !b || !d) return 0;
-  return (size_t)128 * a->c * d->R * d->S * b->c * sizeof(float);
+  return (size_t)256 * a->c * d->R * d->S * b->c * sizeof(float);
 }
 
 extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const dct_view* b, const dct_enet_tf* tfb,
@@ -630,16 +694,17 @@ extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const d
                               void* workspace, size_t workspace_bytes, dct_stream stream) {
   if (!view_ok(a) || !view_ok(b) || !dw || !d || !ok_dtype(dtype) || a->n != b->n) return DCT_ERR_BAD_ARG;
   const int E = a->c * d->R * d->S * b->c;
-  if (E > 256 * WG_MAXE) return DCT_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)WG_PB * (a->c + d->R * d->S * b->c) * sizeof(float);
+  const int CaP = (a->c + 3) & ~3, kbP = (d->R * d->S * b->c + 7) & ~7;
+  if ((CaP / 4) * (kbP / 8) > 256 * WG_TPT) return DCT_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)WG_PB * (CaP + kbP) * sizeof(float);
   if (lds > 64 * 1024) return DCT_ERR_UNSUPPORTED;
   WgP p;
   p.a = to_view(a); p.b = to_view(b); p.tfa = to_tf(tfa); p.tfb = to_tf(tfb);
   p.R = d->R; p.S = d->S; p.stride = d->stride; p.dil = d->dil; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
   p.fm = f32_mask;
   const long long P = (long long)a->n * a->h * a->w;
-  long long blocks = (P + 8 * WG_PB - 1) / (8 * WG_PB);
-  if (blocks > 128) blocks = 128;
+  long long blocks = (P + 4 * WG_PB - 1) / (4 * WG_PB);
+  if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   long long ppb = (P + blocks - 1) / blocks;
   ppb = (ppb + WG_PB - 1) / WG_PB * WG_PB;
@@ -648,6 +713,6 @@ extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const d
   if (!workspace || workspace_bytes < (size_t)nb * E * sizeof(float)) return DCT_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_wgrad_kernel<T>, dim3(nb), dim3(256), lds, st, p, (float*)workspace, E));
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_wgrad_reduce_kernel, dim3(div_up(E, 256)), dim3(256), 0, st, (const float*)workspace, dw, E, nb);
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_wgrad_reduce_kernel, dim3(div_up(E, 16)), dim3(256), 0, st, (const float*)workspace, dw, E, nb);
   return dct_check_launch();
 }
