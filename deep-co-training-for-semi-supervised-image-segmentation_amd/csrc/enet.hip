@@ -73,6 +73,7 @@ struct ConvP {
   int ws_out, ws_tap, ws_in;      // weight strides (elements): W(o, tap, i)
   int G;                          // output-channel groups of 8
   int fm;                         // f32 mask: bit0 x, bit1 y, bit2 resid grad, bit3 resid mask
+  int vec;                        // input rows can be read 8 channels at a time
 };
 
 // One thread = one output pixel x 8 output channels.  Weights live in LDS as [tap][i][G*8].
@@ -117,14 +118,32 @@ __global__ __launch_bounds__(256) void enet_conv_kernel(ConvP p) {
       if ((unsigned)ix >= (unsigned)p.x.w) continue;
       const long long xo = voff(p.x, n, iy, ix);
       const float* wt = Ws + (r * p.S + s) * Cin * CO + g * 8;
-      for (int i = 0; i < Cin; ++i) {
-        const float v = tf_apply(p.tf, i, ldv<T>(p.x, xo + i, xf));
+      auto mac = [&](int i, float raw) {
+        const float v = tf_apply(p.tf, i, raw);
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + i * CO);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(wt + i * CO + 4);
         acc[0] = fmaf(v, w0[0], acc[0]); acc[1] = fmaf(v, w0[1], acc[1]);
         acc[2] = fmaf(v, w0[2], acc[2]); acc[3] = fmaf(v, w0[3], acc[3]);
         acc[4] = fmaf(v, w1[0], acc[4]); acc[5] = fmaf(v, w1[1], acc[5]);
         acc[6] = fmaf(v, w1[2], acc[6]); acc[7] = fmaf(v, w1[3], acc[7]);
+      };
+      if (p.vec) {      // Cin % 8 == 0 and 16-byte aligned rows: one (bf16) or two (fp32) 16-B loads per 8 channels
+        for (int i = 0; i < Cin; i += 8) {
+          float v8[8];
+          if (xf || sizeof(T) == 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.x.ptr) + xo + i);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.x.ptr) + xo + i + 4);
+            v8[0] = a[0]; v8[1] = a[1]; v8[2] = a[2]; v8[3] = a[3]; v8[4] = b[0]; v8[5] = b[1]; v8[6] = b[2]; v8[7] = b[3];
+          } else {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.x.ptr) + xo + i);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v8[k] = (float)a[k];
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) mac(i + k, v8[k]);
+        }
+      } else {
+        for (int i = 0; i < Cin; ++i) mac(i, ldv<T>(p.x, xo + i, xf));
       }
     }
   }
@@ -563,6 +582,10 @@ extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bia
   while (Gp < G) Gp <<= 1;                  // 1, 2, 4, 8, 16: divides 256
   p.G = Gp;
   p.fm = f32_mask;
+  {
+    const int xbytes = ((f32_mask & 1) || dtype == DCT_F32) ? 4 : 2;
+    p.vec = (x->c % 8 == 0 && x->sw % 8 == 0 && x->sh % 8 == 0 && x->sn % 8 == 0 && ((uintptr_t)x->ptr % (8 * xbytes)) == 0) ? 1 : 0;
+  }
   const size_t lds = (size_t)d->R * d->S * x->c * Gp * 8 * sizeof(float);
   if (lds > 64 * 1024) return DCT_ERR_UNSUPPORTED;
   const long long P = (long long)y->n * y->h * y->w;
