@@ -64,6 +64,7 @@ SIGNATURES = {
     "dct_conv2d": (_i, [_VP, _P, _P, _VP, _VP, _DP, _i, _P, _sz, _P]),
     "dct_conv2d_wgrad_workspace_bytes": (_sz, [_VP, _VP, _DP, _i]),
     "dct_conv2d_wgrad": (_i, [_VP, _VP, _P, _DP, _i, _P, _sz, _P]),
+    "dct_conv2d_wgrad_bias": (_i, [_VP, _VP, _P, _P, _DP, _i, _P, _sz, _P]),
     "dct_bias_grad": (_i, [_VP, _P, _i, _i, _P, _sz, _P]),
     "dct_bias_grad_workspace_bytes": (_sz, [_VP]),
     "dct_pack_weight": (_i, [_P, _P, _i, _i, _i, _i, _i, _i, _P]),

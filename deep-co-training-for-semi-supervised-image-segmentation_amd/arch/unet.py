@@ -307,8 +307,11 @@ class UNet(nn.Module):
         def conv_bwd(conv, x_in, dy, dx_out, mask=None, mask_channels=0, mask_scale=1.0, accumulate=False):
             """dy: grad wrt the conv's pre-activation output (already ReLU-masked)."""
             if need_dw:
-                K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=True)
-                K.bias_grad(dy, self._gb(conv), accumulate=True)
+                if dt == torch.bfloat16:     # bias gradient rides along in the weight-gradient launch
+                    K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=True, db=self._gb(conv))
+                else:
+                    K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=True)
+                    K.bias_grad(dy, self._gb(conv), accumulate=True)
             if dx_out is not None:
                 K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, pad_h=2, pad_w=2, mask=mask,
                          mask_channels=mask_channels, mask_scale=mask_scale, accumulate=accumulate)

@@ -260,6 +260,9 @@ struct Wgrad2Params {
   FastDiv dhw, dw_;
   int direct;      // chunks == 1: add straight into out (no partial slab)
   int accumulate;
+  float* bias;     // bias gradient (column sums of P): direct -> db itself, else unused (slab tail holds it)
+  int with_bias;
+  long long slab_stride;   // floats per slab: Cp*taps*Cq (+ Cp with the bias tail)
 };
 
 // Tile rows are RB bytes (128 or 256); a wave fills NI = RB / 64 ... see below.  A thread's LDS rows are
@@ -399,6 +402,16 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
   constexpr int Q_KK = (16 / GQ::NI) * RBQ, Q_HI = (4 / GQ::NI) * RBQ;
   constexpr int NRD = 2 * (TP + TQ);             // tr reads per 16-pixel sub-step
   const unsigned smem_off = lds_off(smem);
+  // bias gradient rides along in the blocks of tap 0 / first cin tile (their wq == 0 waves): see epilogue
+  const bool do_bias = pr.with_bias && tap == 0 && qt == 0 && wq == 0;
+  f32x16 accb[TP];
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
   for (int mit = mbeg; mit < mend; mit += BKP) {
     if (mit + BKP < mend) stage(smem + (cur ^ 1) * STAGE, mit + BKP);
     const unsigned Pl = smem_off + cur * STAGE;
@@ -435,6 +448,10 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
 #pragma unroll
         for (int j = 0; j < TQ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {        // wave-uniform: column sums of the dy tile = dy^T x ones
+#pragma unroll
+        for (int i = 0; i < TP; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, accb[i], 0, 0, 0);
+      }
     }
     __syncthreads();
     cur ^= 1;
@@ -442,7 +459,17 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
 
   const int half = lane >> 5, l31 = lane & 31;
   const int taps = p.R * p.S;
-  float* base = pr.direct ? p.out : p.out + (long long)chunk * p.Cp * taps * p.Cq;
+  float* base = pr.direct ? p.out : p.out + (long long)chunk * pr.slab_stride;
+  if (do_bias && l31 == 0) {
+    float* bb = pr.direct ? pr.bias : base + (long long)p.Cp * taps * p.Cq;
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int prow = p0 + wp * (BP / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (pr.direct && pr.accumulate) bb[prow] += accb[i][e]; else bb[prow] = accb[i][e];
+      }
+  }
 #pragma unroll
   for (int i = 0; i < TP; ++i)
 #pragma unroll
@@ -457,14 +484,24 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
     }
 }
 
-// dw[i] (=|+=) sum_chunk partial[chunk][i]   (float4 per thread, fixed order)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dw, long long n4,
-                                                           long long stride, int chunks, int accumulate) {
+// out[i] (=|+=) sum_slab partial[slab][i] for the n4w float4s of the weight gradient and, behind them in every
+// slab, the n4b float4s of the bias gradient.  Fixed order (four interleaved partial sums: loads in flight).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dw, float* db, long long n4w, long long n4b,
+                                                           long long stride, int slabs, int accumulate) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  f32x4 s = accumulate ? reinterpret_cast<const f32x4*>(dw)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int c = 0; c < chunks; ++c) s += reinterpret_cast<const f32x4*>(partial + c * stride)[i];
-  reinterpret_cast<f32x4*>(dw)[i] = s;
+  if (i >= n4w + n4b) return;
+  f32x4* outp = i < n4w ? reinterpret_cast<f32x4*>(dw) + i : reinterpret_cast<f32x4*>(db) + (i - n4w);
+  f32x4 s0 = accumulate ? *outp : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+  const f32x4* src = reinterpret_cast<const f32x4*>(partial) + i;
+  const long long st4 = stride / 4;
+  int c = 0;
+  for (; c + 3 < slabs; c += 4) {
+    s0 += src[(long long)c * st4]; s1 += src[(long long)(c + 1) * st4];
+    s2 += src[(long long)(c + 2) * st4]; s3 += src[(long long)(c + 3) * st4];
+  }
+  for (; c < slabs; ++c) s0 += src[(long long)c * st4];
+  *outp = (s0 + s1) + (s2 + s3);
 }
 
 struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct, slabs; };
@@ -547,11 +584,16 @@ extern "C" size_t dct_conv2d_wgrad_workspace_bytes(const dct_view* p, const dct_
   if (!p || !q || !d) return 0;
   WPlan pl;
   if (!make_wplan(p, q, d, dtype, pl)) return 0;
-  return pl.direct ? 16 : (size_t)pl.slabs * p->c * q->c * d->R * d->S * sizeof(float);
+  return pl.direct ? 16 : (size_t)pl.slabs * ((size_t)p->c * q->c * d->R * d->S + p->c) * sizeof(float);
 }
 
 extern "C" int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw, const dct_conv_desc* d, int dtype,
                                 void* workspace, size_t workspace_bytes, dct_stream stream) {
+  return dct_conv2d_wgrad_bias(p, q, dw, nullptr, d, dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float* dw, float* db, const dct_conv_desc* d, int dtype,
+                                     void* workspace, size_t workspace_bytes, dct_stream stream) {
   if (!view_ok(p) || !view_ok(q) || !dw || !d) return DCT_ERR_BAD_ARG;
   if (dtype != DCT_F32 && dtype != DCT_BF16) return DCT_ERR_BAD_ARG;
   if (p->n != q->n) return DCT_ERR_BAD_ARG;
@@ -566,7 +608,10 @@ extern "C" int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw,
     return DCT_ERR_UNSUPPORTED;
   WPlan pl;
   if (!make_wplan(p, q, d, dtype, pl)) return DCT_ERR_UNSUPPORTED;
-  const size_t need = pl.direct ? 0 : (size_t)pl.slabs * p->c * q->c * d->R * d->S * sizeof(float);
+  if (db && (!pl.v2 || ((uintptr_t)db & 15))) return DCT_ERR_UNSUPPORTED;   // the fused bias gradient lives in the bf16 LDS-DMA kernel
+  const long long E = (long long)p->c * q->c * d->R * d->S;
+  const long long slab_stride = E + (db ? p->c : 0);
+  const size_t need = pl.direct ? 0 : (size_t)pl.slabs * slab_stride * sizeof(float);
   if (need && (!workspace || workspace_bytes < need)) return DCT_ERR_WORKSPACE;
   WgradParams wp;
   wp.P = (const char*)p->ptr; wp.Q = (const char*)q->ptr; wp.out = pl.direct ? dw : (float*)workspace;
@@ -582,13 +627,14 @@ extern "C" int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw,
     pr.dhw.d = p->h * p->w; pr.dhw.rcp = 1.0f / (float)pr.dhw.d;
     pr.dw_.d = p->w; pr.dw_.rcp = 1.0f / (float)pr.dw_.d;
     pr.direct = pl.direct; pr.accumulate = d->accumulate;
+    pr.bias = db; pr.with_bias = db ? 1 : 0; pr.slab_stride = slab_stride;
     launch_w2(pr, pl, st);
   } else if (dtype == DCT_BF16) launch_w<bf16_t>(wp, pl, st);
   else launch_w<float>(wp, pl, st);
   if (!pl.direct) {
-    const long long n = (long long)p->c * q->c * d->R * d->S;
-    DCT_LAUNCH(DCT_PROF_WGRAD, wgrad_reduce_kernel, dim3(div_up(n / 4, 256)), dim3(256), 0, st,
-               (const float*)workspace, dw, n / 4, n, pl.slabs, d->accumulate);
+    const long long n4b = db ? p->c / 4 : 0;
+    DCT_LAUNCH(DCT_PROF_WGRAD, wgrad_reduce_kernel, dim3(div_up(E / 4 + n4b, 256)), dim3(256), 0, st,
+               (const float*)workspace, dw, db, E / 4, n4b, slab_stride, pl.slabs, d->accumulate);
   }
   return dct_check_launch();
 }

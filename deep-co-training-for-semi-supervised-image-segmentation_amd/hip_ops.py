@@ -39,8 +39,9 @@ def conv2d(x, w_packed, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0,
     return y
 
 
-def conv2d_wgrad(p, q, dw, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, accumulate=False):
-    """dw[p.c][R][S][q.c] (fp32, dense) (+)= sum_m p[m] (x) q[shifted m]."""
+def conv2d_wgrad(p, q, dw, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, accumulate=False, db=None):
+    """dw[p.c][R][S][q.c] (fp32, dense) (+)= sum_m p[m] (x) q[shifted m]; with ``db`` (bf16 only) also
+    db[p.c] (+)= sum_m p[m] in the same launch."""
     d = conv_desc(R, S, stride, dil, pad_h, pad_w, accumulate=accumulate)
     vp, vq = view(p), view(q)
     lib = _lib.load()
@@ -49,7 +50,10 @@ def conv2d_wgrad(p, q, dw, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, accum
     if need == 0:
         raise RuntimeError("dct_amd: conv2d_wgrad unsupported shape")
     ws = _ws(need, p.device)
-    call("dct_conv2d_wgrad", C.byref(vp), C.byref(vq), ptr(dw), C.byref(d), dt, ptr(ws), ws.numel(), stream())
+    if db is not None:
+        call("dct_conv2d_wgrad_bias", C.byref(vp), C.byref(vq), ptr(dw), ptr(db), C.byref(d), dt, ptr(ws), ws.numel(), stream())
+    else:
+        call("dct_conv2d_wgrad", C.byref(vp), C.byref(vq), ptr(dw), C.byref(d), dt, ptr(ws), ws.numel(), stream())
     return dw
 
 

@@ -83,6 +83,10 @@ int dct_conv2d(const dct_view* x, const void* w_packed, const float* bias, const
 size_t dct_conv2d_wgrad_workspace_bytes(const dct_view* p, const dct_view* q, const dct_conv_desc* d, int dtype);
 int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw, const dct_conv_desc* d, int dtype,
                      void* workspace, size_t workspace_bytes, dct_stream stream);
+/* Same, and db[c] (+)= sum over pixels of p[.., c] in the same launch (the bias gradient of a Conv2d is the column
+ * sum of the dy tiles the kernel already holds: one extra MFMA against a ones vector).  bf16 only; db nullable. */
+int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float* dw, float* db, const dct_conv_desc* d, int dtype,
+                          void* workspace, size_t workspace_bytes, dct_stream stream);
 
 /* db[c] (+)= sum over pixels of dy[.., c]  (bias half of conv backward). */
 int dct_bias_grad(const dct_view* dy, float* db, int accumulate, int dtype,

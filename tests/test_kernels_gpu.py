@@ -135,6 +135,15 @@ def test_conv2d_wgrad(ops, dtype, B, Cin, H, W, Cout, pad):
     dw2 = torch.full_like(dw, float("nan"))
     ops.conv2d_wgrad(to_dev(dy, dtype), to_dev(x, dtype), dw2, pad_h=pad, pad_w=pad, accumulate=False)
     close(dw2.cpu(), ref.permute(0, 2, 3, 1), dtype, "wgrad overwrite", rtol32=3e-4)
+    if dtype == torch.bfloat16:      # fused bias gradient (column sums of dy) in the same launch, both epilogue modes
+        bref = dy.sum((0, 2, 3))
+        for acc in (True, False):
+            dw3 = old.clone().to(DEV) if acc else torch.full_like(dw, float("nan"))
+            oldb = torch.randn(Cout, generator=g)
+            db = oldb.clone().to(DEV) if acc else torch.full((Cout,), float("nan"), device=DEV)
+            ops.conv2d_wgrad(to_dev(dy, dtype), to_dev(x, dtype), dw3, pad_h=pad, pad_w=pad, accumulate=acc, db=db)
+            close(dw3.cpu() - (old if acc else 0), ref.permute(0, 2, 3, 1), dtype, "wgrad+bias: dw")
+            close(db.cpu() - (oldb if acc else 0), bref, dtype, "wgrad+bias: db", rtol16=1e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
