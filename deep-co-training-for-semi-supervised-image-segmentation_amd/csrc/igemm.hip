@@ -33,6 +33,7 @@ struct IgemmParams {
   float mask_scale;
   int kiters, kiters_per_split, cin_iters;
   int cout;  // real Cout (N/4 in scatter mode)
+  int staged;  // v2: LDS-staged epilogue with 16-byte row stores (host-checked alignment / 32-bit offsets)
 };
 
 template <typename T> struct Mfma;
@@ -327,25 +328,109 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
     if (it + 1 < kend) stage(smem + (cur ^ 1) * STAGE);
     const char* A = smem + cur * STAGE + (wn * WTN + l31) * ROWB;
     const char* B = smem + cur * STAGE + (BN + wm * WTM + l31) * ROWB;
+    // fragments of sub-step kk+1 are read while the MFMAs of sub-step kk run (two register sets)
+    bf16x8 a[2][TN], b[2][TM];
+    auto load_frags = [&](int set, int kk) {
+      const int coff = ((2 * kk + half) ^ swz) * 16;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) a[set][i] = *reinterpret_cast<const bf16x8*>(A + i * 32 * ROWB + coff);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) b[set][j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * ROWB + coff);
+    };
+    load_frags(0, 0);
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      const int coff = ((2 * kk + half) ^ swz) * 16;
-      bf16x8 a[TN], b[TM];
-#pragma unroll
-      for (int i = 0; i < TN; ++i) a[i] = *reinterpret_cast<const bf16x8*>(A + i * 32 * ROWB + coff);
-#pragma unroll
-      for (int j = 0; j < TM; ++j) b[j] = *reinterpret_cast<const bf16x8*>(B + j * 32 * ROWB + coff);
+      if (kk + 1 < BK / 16) load_frags((kk + 1) & 1, kk + 1);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
     cur ^= 1;
   }
 
   // ---- epilogue
+  if (p.staged) {
+    // Staged through LDS: every wave drops its accumulators (bias + ReLU applied, rounded to bf16) into a
+    // [pixel][channel] image of the tile, then the block streams whole pixel rows out with 16-byte stores
+    // (a wave-instruction covers 4 x 256-B / 8 x 128-B contiguous runs instead of 32 scattered 16-B pieces --
+    // the scattered form kept the last waves in the store queue for 15-18k cycles, a quarter of the block's life).
+    // 16-B chunk c of row r sits at chunk c ^ (r % CPR): conflict-light 8-B writes, conflict-free 16-B reads.
+    constexpr int CPR = BN / 8;                  // 16-B chunks per tile row
+    char* tile = smem;                           // BM * BN * 2 bytes <= one stage
+    // row table (second stage buffer, free now): element offset of each tile row in y and in the mask, -1 past M
+  int* rowY = reinterpret_cast<int*>(smem + STAGE);
+  int* rowM = rowY + BM;
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int oy_ = -1, om_ = -1;
+    if (m < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int n = m / hw, rem = m - n * hw;
+      int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      if (p.scatter) { oy *= 2; ox *= 2; }
+      oy_ = (int)(n * p.ysN + oy * p.ysH + ox * p.ysW);
+      om_ = (int)(n * p.msN + oy * p.msH + ox * p.msW);
+    }
+    rowY[tid] = oy_; rowM[tid] = om_;
+  }
+
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int row = wm * WTM + j * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cl = wn * WTN + i * 32 + 8 * q + 4 * half;       // channel within the tile
+          float v[4] = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          if (p.bias) {
+            int co = n0 + cl;
+            if (p.scatter) co %= p.cout;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += p.bias[co + e];
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+          const int chunk = (cl >> 3) ^ (row & (CPR - 1));
+          *reinterpret_cast<bf16x4*>(tile + row * (BN * 2) + chunk * 16 + (cl & 4) * 2) = o;
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int NCH = BM * CPR / (NW * 64);    // chunks per thread
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+      const int id = t * (NW * 64) + tid;
+      const int row = id / CPR, cc = id % CPR;
+      const int yo = rowY[row];
+      if (yo < 0) continue;
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
+      int c = n0 + cc * 8, co = c;
+      long long off = yo;
+      long long moff = rowM[row];
+      if (p.scatter) {
+        const int ab = c / p.cout;
+        co = c - ab * p.cout;
+        off += (ab >> 1) * p.ysH + (ab & 1) * p.ysW;
+        moff += (ab >> 1) * p.msH + (ab & 1) * p.msW;
+      }
+      if (p.mask && co < p.mask_channels) {
+        const bf16x8 mk = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + moff + co);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + off + co) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = m0 + wm * WTM + j * 32 + l31;
@@ -399,6 +484,7 @@ struct Plan {
 
 int g_tune_igemm_v2 = 1;        // dct_tune_set(DCT_TUNE_IGEMM_V2, 0) forces the register-staged kernel
 int g_tune_igemm_split = -1;    // >= 1 forces the split-K factor
+int g_tune_igemm_staged = 1;    // 0: scattered 8-byte epilogue stores instead of the LDS-staged epilogue
 
 static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int M, int N, Plan& pl) {
   const int bk0 = dtype == DCT_BF16 ? 32 : 16;
@@ -538,6 +624,14 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   p.kiters = pl.kiters; p.kiters_per_split = pl.kiters_per_split;
   p.cin_iters = x->c / pl.bk;
   p.partial = nullptr;
+  p.staged = 0;
+  if (pl.v2 && pl.splits == 1 && !d->accumulate && g_tune_igemm_staged) {
+    const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
+                     (long long)y->n * y->sn < (1ll << 31);
+    const bool m16 = !mask || (!((uintptr_t)mask->ptr & 15) && mask->sw % 8 == 0 && mask->sh % 8 == 0 && mask->sn % 8 == 0 &&
+                               p.mask_channels % 8 == 0 && (long long)mask->n * mask->sn < (1ll << 31));
+    p.staged = (y16 && m16) ? 1 : 0;
+  }
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * p.M * p.N * sizeof(float);
     if (!workspace || workspace_bytes < need) return DCT_ERR_WORKSPACE;
@@ -553,6 +647,7 @@ extern "C" int dct_tune_set(int knob, int value) {
   switch (knob) {
     case DCT_TUNE_IGEMM_V2: g_tune_igemm_v2 = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT: g_tune_igemm_split = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_STAGED: g_tune_igemm_staged = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }
 }

@@ -297,7 +297,8 @@ int dct_prof_enable(int on);
 enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0: register-staged kernel */
        DCT_TUNE_IGEMM_SPLIT = 1,   /* >= 1: force the split-K factor; -1 (default): planner's choice */
        DCT_TUNE_WGRAD_V2 = 2,      /* 1 (default): LDS-DMA staged bf16 wgrad kernel; 0: register-staged */
-       DCT_TUNE_WGRAD_CHUNKS = 3 };/* >= 1: force the number of pixel chunks (split-K) of wgrad */
+       DCT_TUNE_WGRAD_CHUNKS = 3,  /* >= 1: force the number of pixel chunks (split-K) of wgrad */
+       DCT_TUNE_IGEMM_STAGED = 4 };/* 1 (default): LDS-staged epilogue with 16-byte row stores; 0: scattered 8-byte stores */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 

@@ -152,3 +152,36 @@ def test_bf16_step_tracks_oracle(tmp_path, golden):
     for s in tr.segmentators:
         for p in s.torchnet.parameters():
             assert torch.isfinite(p).all()
+
+
+def test_rccl_gradient_exchange_single_rank(tmp_path, golden):
+    """The N>1 code path of bench.py on the one GPU a test box has: a world_size-1 RCCL process group, flat
+    gradient all-reduce (ReduceOp.AVG, async) out of the flat buffers, per-model wait + fused Adam.  With one
+    rank the exchange must leave the step bit-identical to the single-process step."""
+    import os
+    import torch.distributed as dist
+    from dct_amd.ddp import FlatGradSync
+    g = golden("g5_step_unet_jsd")
+    res = []
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        created = True
+    try:
+        for sync in (False, True):
+            tr, lab, unl = _trainer(tmp_path, g, torch.bfloat16, 1)
+            for s in tr.segmentators:
+                s.train()
+            if sync:
+                tr.grad_sync = FlatGradSync(tr.segmentators)
+            lb = [lab[i][0][0] for i in range(2)]
+            tr._run_step([(lb[0][0], lb[0][1]), (lb[1][0], lb[1][1])], (unl[0][0][0], unl[0][0][1]), True, False)
+            torch.cuda.synchronize()
+            res.append([torch.cat([p.detach().flatten() for p in s.torchnet.parameters()]).cpu() for s in tr.segmentators])
+    finally:
+        if created:
+            dist.destroy_process_group()
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -119,10 +119,11 @@ def main():
     only = set(args.only.split(",")) if args.only else None
     run(args.batch, args.reps, what, "default", only)
     if args.ab:
-        for ch in (1, 2, 4, 8, 16, 32, 64):
-            lib.dct_tune_set(3, ch)
-            run(args.batch, args.reps, [w for w in what if w == "wgrad"], f"wgrad pixel chunks forced to {ch}", only)
-        lib.dct_tune_set(3, -1)
+        for rnd in range(2):       # interleaved rounds in ONE process (devices / DVFS differ between runs)
+            lib.dct_tune_set(4, 0)
+            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: scattered epilogue", only)
+            lib.dct_tune_set(4, 1)
+            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: staged epilogue", only)
 
 
 if __name__ == "__main__":
