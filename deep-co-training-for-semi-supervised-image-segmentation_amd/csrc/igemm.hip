@@ -431,6 +431,37 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
     }
     return;
   }
+  if (p.partial) {
+    // split-K slab: the fp32 tile goes through LDS the same way (BM * BN * 4 bytes = both stage buffers), so the
+    // slab rows (BN * 4 contiguous bytes each) are written with full-row 16-byte stores
+    constexpr int CPR4 = BN / 4;                 // 16-B chunks (4 floats) per tile row
+    char* tile = smem;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int row = wm * WTM + j * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cl = wn * WTN + i * 32 + 8 * q + 4 * half;
+          const int chunk = (cl >> 2) ^ (row & (CPR4 - 1));
+          *reinterpret_cast<f32x4*>(tile + row * (BN * 4) + chunk * 16) =
+              f32x4{acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        }
+    }
+    __syncthreads();
+    constexpr int NCH4 = BM * CPR4 / (NW * 64);
+    float* slab = p.partial + ((long long)blockIdx.z * p.M + m0) * p.N + n0;
+#pragma unroll
+    for (int t = 0; t < NCH4; ++t) {
+      const int id = t * (NW * 64) + tid;
+      const int row = id / CPR4, cc = id % CPR4;
+      if (m0 + row >= p.M) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * (BN * 4) + ((cc ^ (row & (CPR4 - 1))) * 16));
+      *reinterpret_cast<f32x4*>(slab + (long long)row * p.N + cc * 4) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = m0 + wm * WTM + j * 32 + l31;
@@ -444,12 +475,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
       for (int q = 0; q < 4; ++q) {
         const int c = n0 + wn * WTN + i * 32 + 8 * q + 4 * half;
         float v[4] = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        if (p.partial) {
-          float* pp = p.partial + ((long long)blockIdx.z * p.M + m) * p.N + c;
-          *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-          epilogue_store4<bf16_t>(p, n, oy, ox, c, v);
-        }
+        epilogue_store4<bf16_t>(p, n, oy, ox, c, v);
       }
     }
   }
