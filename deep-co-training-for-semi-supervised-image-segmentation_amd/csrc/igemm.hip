@@ -510,6 +510,8 @@ struct Plan {
 
 int g_tune_igemm_v2 = 1;        // dct_tune_set(DCT_TUNE_IGEMM_V2, 0) forces the register-staged kernel
 int g_tune_igemm_split = -1;    // >= 1 forces the split-K factor
+int g_tune_igemm_waves8 = 1;    // 8 waves per tile (32 pixels x 64 channels each) instead of 4: an LDS-DMA piece costs ~100 issue
+                                // cycles, so halving the pieces per wave shortens every K-step (+4..15 % in-process A/B)
 int g_tune_igemm_staged = 1;    // 0: scattered 8-byte epilogue stores instead of the LDS-staged epilogue
 
 static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int M, int N, Plan& pl) {
@@ -572,9 +574,13 @@ static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
   dim3 grid(div_up(p.M, pl.bm), p.N / pl.bn, pl.splits);
   if (pl.v2) {
     if (pl.bn == 128) {
-      if (pl.bounds) launch_v2<128, 128, 2, 2, true>(p, grid, st); else launch_v2<128, 128, 2, 2, false>(p, grid, st);
+      if (g_tune_igemm_waves8) {
+        if (pl.bounds) launch_v2<128, 128, 4, 2, true>(p, grid, st); else launch_v2<128, 128, 4, 2, false>(p, grid, st);
+      } else if (pl.bounds) launch_v2<128, 128, 2, 2, true>(p, grid, st); else launch_v2<128, 128, 2, 2, false>(p, grid, st);
     } else {
-      if (pl.bounds) launch_v2<256, 64, 4, 1, true>(p, grid, st); else launch_v2<256, 64, 4, 1, false>(p, grid, st);
+      if (g_tune_igemm_waves8) {
+        if (pl.bounds) launch_v2<256, 64, 8, 1, true>(p, grid, st); else launch_v2<256, 64, 8, 1, false>(p, grid, st);
+      } else if (pl.bounds) launch_v2<256, 64, 4, 1, true>(p, grid, st); else launch_v2<256, 64, 4, 1, false>(p, grid, st);
     }
   } else if (pl.bn == 128) {
     DCT_LAUNCH(DCT_PROF_IGEMM, (igemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, p);
@@ -674,6 +680,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_V2: g_tune_igemm_v2 = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT: g_tune_igemm_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_STAGED: g_tune_igemm_staged = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_WAVES8: g_tune_igemm_waves8 = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }
 }

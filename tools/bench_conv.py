@@ -120,11 +120,11 @@ def main():
     run(args.batch, args.reps, what, "default", only)
     if args.ab:
         for rnd in range(2):       # interleaved rounds in ONE process (devices / DVFS differ between runs)
-            lib.dct_tune_set(4, 0)
-            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: scattered epilogue", only)
-            lib.dct_tune_set(4, 1)
-            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: staged epilogue", only)
-
+            lib.dct_tune_set(5, 0)
+            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: 4 waves per 128x128 tile", only)
+            lib.dct_tune_set(5, 1)
+            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: 8 waves per 128x128 tile", only)
+        lib.dct_tune_set(5, 0)
 
 if __name__ == "__main__":
     main()
