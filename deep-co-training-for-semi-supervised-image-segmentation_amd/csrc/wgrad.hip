@@ -265,44 +265,37 @@ struct Wgrad2Params {
   long long slab_stride;   // floats per slab: Cp*taps*Cq (+ Cp with the bias tail)
 };
 
-// Tile rows are RB bytes (128 or 256); a wave fills NI = RB / 64 ... see below.  A thread's LDS rows are
-// rho_i = RS * i + c (RS = 64 / NI), and LDS row rho holds pixel k = NI * (rho % RS) + rho / RS of the step,
-// so the thread's NI pixels are consecutive.  The 16-B chunk index is XORed with swz(rho) << 2.
-template <int RB> struct TileGeo {
+// Tile rows are RB bytes (128 or 256); the NW waves of a block each issue NI wave-instructions (RPI rows apiece) per
+// stage.  A thread's LDS rows are rho_i = RS * i + c (RS = 64 / NI, c = wave * RPI + lane / CPR), and LDS row rho
+// holds pixel k = NI * (rho % RS) + rho / RS of the step, so the thread's NI pixels are consecutive.  The 16-B chunk
+// index of pixel k's row is XORed with swz_k(k): the four pixels k0 .. k0+3 a 32-lane half reads with one transposing
+// read then sit in four different 64-B quarters of the 256-B bank row.
+template <int RB, int NW> struct TileGeo {
   static constexpr int CPR = RB / 16;          // chunks per row: 8 | 16
   static constexpr int RPI = 64 / CPR;         // rows per wave-instruction: 8 | 4
-  static constexpr int NI = 64 / (4 * RPI);    // instructions per wave per stage: 2 | 4
-  static constexpr int RS = 64 / NI;           // row stride between a thread's instructions: 32 | 16
-  __device__ static __forceinline__ int swz(int rho) { return ((rho / RS) & (NI - 1)) << 2; }
+  static constexpr int NI = 64 / (NW * RPI);   // instructions per wave per stage
+  static constexpr int RS = 64 / NI;           // row stride between a thread's instructions
+  static_assert(NI >= 1 && 4 % NI == 0, "wave count / tile width mismatch");
   __device__ static __forceinline__ int row_of(int k) { return RS * (k % NI) + k / NI; }
+  // RB = 256: a row spans the bank row, quarter ^= k % 4.  RB = 128: two rows per bank row; the row parity already
+  // separates two of the four pixels, the 64-B half is XORed with the bit of k % 4 that the parity does not cover.
+  __device__ static __forceinline__ int swz_k(int k) {
+    if (RB == 256) return (k & 3) << 2;
+    return (NI == 1 ? ((k >> 1) & 1) : (k & 1)) << 2;
+  }
 };
 
-// transposed fragment: 16 pixels (k) x 32 channels starting at channel cbase
-template <int RB>
-__device__ __forceinline__ bf16x8 tr_frag2(const char* tile, int cbase, int kk, int lane) {
-  using G = TileGeo<RB>;
-  const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = g >> 1;
-  const int colb = (cbase + 16 * (g & 1) + 4 * pp) * 2;          // byte column of this lane's 8 bytes
-  const int k0 = kk * 16 + 8 * h + q, k1 = k0 + 4;               // pixel index within the step
-  const int r0 = G::row_of(k0), r1 = G::row_of(k1);
-  const char* a0 = tile + r0 * RB + (colb ^ (G::swz(r0) << 4));
-  const char* a1 = tile + r1 * RB + (colb ^ (G::swz(r1) << 4));
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a1));
-  bf16x8 r;
-  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-  return r;
-}
-
-template <int BP, int BQ>
-__global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
+template <int BP, int BQ, int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad2_kernel(Wgrad2Params pr) {
   const WgradParams& p = pr.w;
   constexpr int BKP = 64;
   constexpr int RBP = BP * 2, RBQ = BQ * 2;                 // row bytes
-  using GP = TileGeo<RBP>;
-  using GQ = TileGeo<RBQ>;
-  constexpr int TP = BP / 64, TQ = BQ / 64;
+  using GP = TileGeo<RBP, NW>;
+  using GQ = TileGeo<RBQ, NW>;
+  constexpr int WPR = BP / (NW / 2);                        // P rows per wave (waves: NW/2 along P x 2 along Q)
+  constexpr int TP = WPR / 32, TQ = BQ / 64;
+  constexpr int PPW = 64 / NW;                              // pixels of a step staged by one wave
+  static_assert(TP >= 1, "too many waves for this tile");
   constexpr int STAGE = BKP * (RBP + RBQ);
   extern __shared__ __attribute__((aligned(128))) char smem[];
 
@@ -323,8 +316,8 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
   const char* Qb = p.Q + (long long)q0 * 2;
   const char* zero = reinterpret_cast<const char*>(g_wzero_page) + (lane & 7) * 16;
   const int tyo = tr * p.dil - p.pad_h, txo = ts * p.dil - p.pad_w;
-  // Staging addresses.  Wave w stages the 16 pixels [16w, 16w + 16) of a step (rows rho = RS*i + c hold
-  // pixel NI*c + i).  Per step, lane l decodes ONE pixel (16w + l % 16) into 32-bit element offsets of
+  // Staging addresses.  Wave w stages the PPW = 64 / NW pixels [PPW*w, PPW*(w+1)) of a step (rows rho = RS*i + c
+  // hold pixel NI*c + i).  Per step, lane l decodes ONE pixel (PPW*w + l % PPW) into 32-bit element offsets of
   // its dy / x rows (-1: contributes zero), and every lane then fetches the offsets of the pixels it
   // stages with a lane permute -- instead of every lane decoding all of its rows.
   const int cP = lane / GP::CPR, cQ = lane / GQ::CPR;          // row within a wave-instruction
@@ -333,18 +326,18 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
 #pragma unroll
   for (int i = 0; i < GP::NI; ++i) {
     srcP[i] = (GP::NI * cP + i) * 4;
-    chP[i] = ((lane % GP::CPR) ^ GP::swz(GP::RS * i + wave * GP::RPI + cP)) * 16;
+    chP[i] = ((lane % GP::CPR) ^ GP::swz_k(GP::NI * (wave * GP::RPI + cP) + i)) * 16;
   }
 #pragma unroll
   for (int i = 0; i < GQ::NI; ++i) {
     srcQ[i] = (GQ::NI * cQ + i) * 4;
-    chQ[i] = ((lane % GQ::CPR) ^ GQ::swz(GQ::RS * i + wave * GQ::RPI + cQ)) * 16;
+    chQ[i] = ((lane % GQ::CPR) ^ GQ::swz_k(GQ::NI * (wave * GQ::RPI + cQ) + i)) * 16;
   }
   const int psN = (int)p.psN, psH = (int)p.psH, psW = (int)p.psW;
   const int qsN = (int)p.qsN, qsH = (int)p.qsH, qsW = (int)p.qsW;
 
   auto stage = [&](char* buf, int mit) {
-    const int m = mit + 16 * wave + (lane & 15);
+    const int m = mit + PPW * wave + (lane % PPW);
     int offP = -1, offQ = -1;
     {
       int rem, x;
@@ -389,13 +382,13 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
     const int rp = GP::row_of(kq0), rq = GQ::row_of(kq0);
 #pragma unroll
     for (int i = 0; i < TP; ++i) {
-      const int colb = (wp * (BP / 2) + i * 32 + 16 * (g & 1) + 4 * lpp) * 2;
-      pbase[i] = rp * RBP + (colb ^ (GP::swz(rp) << 4));
+      const int colb = (wp * WPR + i * 32 + 16 * (g & 1) + 4 * lpp) * 2;
+      pbase[i] = rp * RBP + (colb ^ (GP::swz_k(kq0) << 4));
     }
 #pragma unroll
     for (int j = 0; j < TQ; ++j) {
       const int colb = (wq * (BQ / 2) + j * 32 + 16 * (g & 1) + 4 * lpp) * 2;
-      qbase[j] = BKP * RBP + rq * RBQ + (colb ^ (GQ::swz(rq) << 4));
+      qbase[j] = BKP * RBP + rq * RBQ + (colb ^ (GQ::swz_k(kq0) << 4));
     }
   }
   constexpr int P_KK = (16 / GP::NI) * RBP, P_HI = (4 / GP::NI) * RBP;
@@ -466,7 +459,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
     for (int i = 0; i < TP; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int prow = p0 + wp * (BP / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int prow = p0 + wp * WPR + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
         if (pr.direct && pr.accumulate) bb[prow] += accb[i][e]; else bb[prow] = accb[i][e];
       }
   }
@@ -477,7 +470,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Params pr) {
       const int qc = q0 + wq * (BQ / 2) + j * 32 + l31;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int prow = p0 + wp * (BP / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int prow = p0 + wp * WPR + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
         float* dst = base + ((long long)prow * taps + tap) * p.Cq + qc;
         if (pr.direct && pr.accumulate) *dst += acc[i][j][e]; else *dst = acc[i][j][e];
       }
@@ -559,23 +552,25 @@ static void launch_w(const WgradParams& wp, const WPlan& pl, hipStream_t st) {
   else DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad_kernel<T, 64, 64>), dim3(grid), dim3(256), 0, st, wp);
 }
 
-template <int BP, int BQ>
+int g_tune_wgrad_waves8 = 1;    // 8 waves on the 128 x 128 tile (half the LDS-DMA pieces and decode work per wave)
+template <int BP, int BQ, int NW>
 static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
   constexpr size_t lds = 2 * 64 * (size_t)(BP + BQ) * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<BP, BQ>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<BP, BQ, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ>), dim3(grid), dim3(256), lds, st, pr);
+  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ, NW>), dim3(grid), dim3(NW * 64), lds, st, pr);
 }
 static void launch_w2(const Wgrad2Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, pr.w.R * pr.w.S);
-  if (pl.bp == 128 && pl.bq == 128) launch_w2_t<128, 128>(pr, grid, st);
-  else if (pl.bp == 128) launch_w2_t<128, 64>(pr, grid, st);
-  else if (pl.bq == 128) launch_w2_t<64, 128>(pr, grid, st);
-  else launch_w2_t<64, 64>(pr, grid, st);
+  if (pl.bp == 128 && pl.bq == 128) {
+    if (g_tune_wgrad_waves8) launch_w2_t<128, 128, 8>(pr, grid, st); else launch_w2_t<128, 128, 4>(pr, grid, st);
+  } else if (pl.bp == 128) launch_w2_t<128, 64, 4>(pr, grid, st);
+  else if (pl.bq == 128) launch_w2_t<64, 128, 4>(pr, grid, st);
+  else launch_w2_t<64, 64, 4>(pr, grid, st);
 }
 
 }  // namespace
@@ -642,5 +637,6 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float
 int dct_tune_set_wgrad(int knob, int value) {
   if (knob == DCT_TUNE_WGRAD_V2) { g_tune_wgrad_v2 = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_CHUNKS) { g_tune_wgrad_chunks = value; return DCT_OK; }
+  if (knob == DCT_TUNE_WGRAD_WAVES8) { g_tune_wgrad_waves8 = value; return DCT_OK; }
   return DCT_ERR_BAD_ARG;
 }
