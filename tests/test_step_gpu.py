@@ -185,3 +185,48 @@ def test_rccl_gradient_exchange_single_rank(tmp_path, golden):
             dist.destroy_process_group()
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("arch,H,pair", [("enet", 64, (0, 2)), ("unet", 176, (1, 2))])
+def test_three_view_step_vs_oracle(tmp_path, arch, H, pair):
+    """S = 3 co-training (the multi-view runs of script/ACDC/5_multiple_views.sh; BASELINE configs[4]): JSD over three
+    models, FGSM on an arbitrary pair (a, b), one backward, three Adam steps -- fp32 fused path vs the oracle step."""
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    C, B = 3, 1
+    segs, omodels = [], []
+    for seed in (5, 6, 7):
+        sd = _seeded_state(arch, C, seed)
+        torch.manual_seed(seed)
+        onet = oracle.build_net(arch, C, **({"dropout_p": 0.0} if arch == "unet" else {})).train()
+        onet.load_state_dict(sd)
+        arch_dict = {"name": arch, "num_classes": C, "compute_dtype": torch.float32}
+        if arch == "unet":
+            arch_dict["dropout_p"] = 0.0
+        seg = Segmentator(arch_dict, {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                          {"name": "StepLR", "step_size": 90, "gamma": 0.1})
+        seg.torchnet.load_state_dict(sd)
+        segs.append(seg)
+        omodels.append(oracle.OracleModel.make(onet))
+    lab = [FakeLoader(batches(61 + i, 1, B, H, C), B) for i in range(3)]
+    unl = FakeLoader(batches(71, 1, B, H, C), B)
+    crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tr = CoTrainer(segs, lab, unl, unl, crit, max_epoch=1, save_dir=str(tmp_path), device=DEV, axises=[1, 2],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False, steps_per_epoch=1)
+    assert tr._fused_ok()
+    for s in segs:
+        s.train()
+    lb = [(lab[i][0][0][0], lab[i][0][0][1]) for i in range(3)]
+    ub = (unl[0][0][0], unl[0][0][1])
+    out = tr._run_step(lb, ub, True, True, pair)
+    ref = oracle.cotrain_step(omodels, lb, ub[0], True, True, lam_cot=0.5, lam_adv=0.05, eps=0.03, adv_choice=pair)
+    np.testing.assert_allclose([s.item() for s in out["sup"]], [s.item() for s in ref["sup"]], rtol=2e-5)
+    np.testing.assert_allclose(out["jsd"].item(), ref["jsd"].item(), rtol=1e-4)
+    np.testing.assert_allclose(out["adv"].item(), ref["adv"].item(), rtol=3e-2)      # FGSM sign flips at |grad| ~ 0
+    for seg, om in zip(segs, omodels):
+        a = torch.cat([p.detach().flatten().cpu() for p in seg.torchnet.parameters()]).double()
+        b = torch.cat([p.detach().flatten() for p in om.net.parameters()]).double()
+        assert ((a - b).norm() / b.norm()).item() < 1e-3
