@@ -105,39 +105,125 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* src, T
 // ---- Cin = 1 stem --------------------------------------------------------------------------
 struct StemGeom { int R, S, stride, dil, pad_h, pad_w, relu, cout; };
 
-template <typename T, int VEC>
+// RS > 0: R = S = RS known at compile time (the tap array stays in registers; with run-time R, S the
+// dynamically indexed xin[] lives in scratch memory and the kernel runs at a fifth of HBM speed).
+template <typename T, int VEC, int RS>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(View x, const float* w, const float* bias, View y, StemGeom g) {
   extern __shared__ float sw[];  // [R*S][cout] (a thread's VEC channels of a tap are contiguous: conflict-free), then bias[cout]
-  const int taps = g.R * g.S;
+  const int R = RS > 0 ? RS : g.R, S = RS > 0 ? RS : g.S;
+  const int taps = R * S;
   for (int i = threadIdx.x; i < g.cout * taps; i += 256) { const int c = i / taps, t = i - c * taps; sw[t * g.cout + c] = w[i]; }
   for (int i = threadIdx.x; i < g.cout; i += 256) sw[g.cout * taps + i] = bias ? bias[i] : 0.f;
   __syncthreads();
   const int cvecs = (g.cout + VEC - 1) / VEC;
   const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, y.n, y.h, y.w, cvecs);
   if (!id.ok) return;
-  float xin[25];
+  constexpr int MAXT = RS > 0 ? RS * RS : 25;
+  float xin[MAXT];
   const float* xp = reinterpret_cast<const float*>(x.ptr);
-  for (int r = 0; r < g.R; ++r)
-    for (int s = 0; s < g.S; ++s) {
-      const int iy = id.y * g.stride + r * g.dil - g.pad_h, ix = id.x * g.stride + s * g.dil - g.pad_w;
-      xin[r * g.S + s] = ((unsigned)iy < (unsigned)x.h && (unsigned)ix < (unsigned)x.w) ? xp[voff(x, id.n, iy, ix)] : 0.f;
-    }
-  float out[VEC];
+  if constexpr (RS > 0) {
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    const int c = id.cv * VEC + i;
-    float a = 0.f;
-    if (c < g.cout) {
-      for (int t = 0; t < taps; ++t) a = fmaf(xin[t], sw[t * g.cout + c], a);
-      a += sw[g.cout * taps + c];
-      if (g.relu) a = fmaxf(a, 0.f);
+    for (int r = 0; r < RS; ++r)
+#pragma unroll
+      for (int s = 0; s < RS; ++s) {
+        const int iy = id.y * g.stride + r * g.dil - g.pad_h, ix = id.x * g.stride + s * g.dil - g.pad_w;
+        xin[r * RS + s] = ((unsigned)iy < (unsigned)x.h && (unsigned)ix < (unsigned)x.w) ? xp[voff(x, id.n, iy, ix)] : 0.f;
+      }
+  } else {
+    for (int r = 0; r < R; ++r)
+      for (int s = 0; s < S; ++s) {
+        const int iy = id.y * g.stride + r * g.dil - g.pad_h, ix = id.x * g.stride + s * g.dil - g.pad_w;
+        xin[r * S + s] = ((unsigned)iy < (unsigned)x.h && (unsigned)ix < (unsigned)x.w) ? xp[voff(x, id.n, iy, ix)] : 0.f;
+      }
+  }
+  float out[VEC];
+  const bool full = id.cv * VEC + VEC <= g.cout;
+  if (RS > 0 && full) {
+    const float* swc = sw + id.cv * VEC;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) out[i] = fmaf(xin[t], swc[t * g.cout + i], out[i]);   // tap order 0..T-1 per channel, as below
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      out[i] += swc[g.cout * taps + i];
+      if (g.relu) out[i] = fmaxf(out[i], 0.f);
     }
-    out[i] = a;
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int c = id.cv * VEC + i;
+      float a = 0.f;
+      if (c < g.cout) {
+        for (int t = 0; t < taps; ++t) a = fmaf(xin[t], sw[t * g.cout + c], a);
+        a += sw[g.cout * taps + c];
+        if (g.relu) a = fmaxf(a, 0.f);
+      }
+      out[i] = a;
+    }
   }
   T* yp = reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, id.x) + id.cv * VEC;
-  if (id.cv * VEC + VEC <= g.cout) VecIO<T, VEC>::store(yp, out);
+  if (full) VecIO<T, VEC>::store(yp, out);
   else
     for (int i = 0; i < VEC && id.cv * VEC + i < g.cout; ++i) yp[i] = from_f32<T>(out[i]);
+}
+
+// 3x3, stride 1, dilation 1, cout a multiple of VEC: one thread per (row, 4 adjacent output pixels, VEC-channel
+// slice).  The 3x6 input window and the slice's 9xVEC weights sit in registers, so a pixel costs its 9xVEC FMAs
+// plus a quarter of the address arithmetic; per channel the taps accumulate in the same order as stem_fwd_kernel.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void stem_fwd3x3_kernel(View x, const float* w, const float* bias, View y, StemGeom g) {
+  extern __shared__ float sw[];  // [9][cout], then bias[cout]
+  for (int i = threadIdx.x; i < g.cout * 9; i += 256) { const int c = i / 9, t = i - c * 9; sw[t * g.cout + c] = w[i]; }
+  for (int i = threadIdx.x; i < g.cout; i += 256) sw[g.cout * 9 + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  constexpr int PX = 4;
+  const int cvecs = g.cout / VEC, wq = (y.w + PX - 1) / PX;
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, y.n, y.h, wq, cvecs);
+  if (!id.ok) return;
+  const int x0 = id.x * PX;
+  const float* xp = reinterpret_cast<const float*>(x.ptr) + (long long)id.n * x.sn;
+  float xin[3][PX + 2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int iy = id.y + r - g.pad_h;
+    const bool rok = (unsigned)iy < (unsigned)x.h;
+#pragma unroll
+    for (int j = 0; j < PX + 2; ++j) {
+      const int ix = x0 + j - g.pad_w;
+      xin[r][j] = (rok && (unsigned)ix < (unsigned)x.w) ? xp[iy * x.sh + ix * x.sw] : 0.f;
+    }
+  }
+  float wv[9][VEC], bv[VEC];
+  const float* swc = sw + id.cv * VEC;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) wv[t][i] = swc[t * g.cout + i];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) bv[i] = swc[9 * g.cout + i];
+  T* yp = reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, x0) + id.cv * VEC;
+#pragma unroll
+  for (int p = 0; p < PX; ++p) {
+    if (x0 + p >= y.w) break;
+    float out[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) out[i] = fmaf(xin[r][p + s], wv[r * 3 + s][i], out[i]);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      out[i] += bv[i];
+      if (g.relu) out[i] = fmaxf(out[i], 0.f);
+    }
+    VecIO<T, VEC>::store(yp + p * y.sw, out);
+  }
 }
 
 // dx[n,iy,ix] = sum_{co,r,s} dy[n,oy,ox,co] * w[co][r][s]  with oy*stride + r*dil - pad = iy.
@@ -247,38 +333,44 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(View x, View y) {
     }
   VecIO<T, VEC>::store(reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, id.x) + id.cv * VEC, m);
 }
+// thread per (pooled pixel, VEC slice): reads the 2x2 window once, routes dy to the first maximum (strict '>': first
+// max wins, as torch) and writes all four dx pixels (ceil-mode edge windows have fewer).
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View x, View dy, View dx, int relu_mask, float scale) {
-  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, x.n, x.h, x.w, x.c / VEC);
+  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, dy.n, dy.h, dy.w, x.c / VEC);
   if (!id.ok) return;
-  const int py = id.y >> 1, px = id.x >> 1;
-  const int me = (id.y & 1) * 2 + (id.x & 1);
-  float best[VEC];
+  float v[4][VEC];
+  bool in[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int iy = 2 * id.y + (k >> 1), ix = 2 * id.x + (k & 1);
+    in[k] = iy < x.h && ix < x.w;
+    if (in[k]) VecIO<T, VEC>::load(reinterpret_cast<const T*>(x.ptr) + voff(x, id.n, iy, ix) + id.cv * VEC, v[k]);
+  }
+  float g[VEC];
+  VecIO<T, VEC>::load(reinterpret_cast<const T*>(dy.ptr) + voff(dy, id.n, id.y, id.x) + id.cv * VEC, g);
   int arg[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { best[i] = -INFINITY; arg[i] = -1; }
-  float mine[VEC];
-  for (int k = 0; k < 4; ++k) {
-    const int iy = 2 * py + (k >> 1), ix = 2 * px + (k & 1);
-    if (iy < x.h && ix < x.w) {
-      float v[VEC];
-      VecIO<T, VEC>::load(reinterpret_cast<const T*>(x.ptr) + voff(x, id.n, iy, ix) + id.cv * VEC, v);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        if (v[i] > best[i]) { best[i] = v[i]; arg[i] = k; }   // strict '>' : first max wins
-        if (k == me) mine[i] = v[i];
-      }
-    }
-  }
-  float g[VEC], out[VEC];
-  VecIO<T, VEC>::load(reinterpret_cast<const T*>(dy.ptr) + voff(dy, id.n, py, px) + id.cv * VEC, g);
-#pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    float o = arg[i] == me ? g[i] : 0.f;
-    if (relu_mask) o = mine[i] > 0.f ? o * scale : 0.f;
-    out[i] = o;
+    float best = -INFINITY;
+    arg[i] = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (in[k] && v[k][i] > best) { best = v[k][i]; arg[i] = k; }
   }
-  VecIO<T, VEC>::store(reinterpret_cast<T*>(dx.ptr) + voff(dx, id.n, id.y, id.x) + id.cv * VEC, out);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!in[k]) continue;
+    float out[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float o = arg[i] == k ? g[i] : 0.f;
+      if (relu_mask) o = v[k][i] > 0.f ? o * scale : 0.f;
+      out[i] = o;
+    }
+    const int iy = 2 * id.y + (k >> 1), ix = 2 * id.x + (k & 1);
+    VecIO<T, VEC>::store(reinterpret_cast<T*>(dx.ptr) + voff(dx, id.n, iy, ix) + id.cv * VEC, out);
+  }
 }
 
 // ---- bilinear, align_corners = True ---------------------------------------------------------
@@ -467,7 +559,13 @@ extern "C" int dct_conv_cin1_fwd(const dct_view* x, const float* w, const float*
   DISPATCH_T(dtype, {
     if (!vec_ok(y, 1, sizeof(T)) || (y->sw % VEC) || (y->sh % VEC) || (y->sn % VEC) || ((uintptr_t)y->ptr % 16)) return DCT_ERR_UNSUPPORTED;
     const long long total = (long long)y->n * y->h * y->w * ((y->c + VEC - 1) / VEC);
-    DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_fwd_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), g);
+    if (d->R == 3 && d->S == 3 && d->stride == 1 && d->dil == 1 && y->c % VEC == 0) {
+      const long long quads = (long long)y->n * y->h * ((y->w + 3) / 4) * (y->c / VEC);
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_fwd3x3_kernel<T, VEC>), dim3(div_up(quads, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), g);
+    } else if (d->R == 3 && d->S == 3)
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_fwd_kernel<T, VEC, 3>), dim3(div_up(total, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), g);
+    else
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_fwd_kernel<T, VEC, 0>), dim3(div_up(total, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), g);
   });
   return dct_check_launch();
 }
@@ -544,7 +642,7 @@ extern "C" int dct_maxpool2x2_bwd(const dct_view* x, const dct_view* dy, const d
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_T(dtype, {
     if (!vec_ok(x, VEC, sizeof(T)) || !vec_ok(dy, VEC, sizeof(T)) || !vec_ok(dx, VEC, sizeof(T))) return DCT_ERR_UNSUPPORTED;
-    const long long total = (long long)x->n * x->h * x->w * (x->c / VEC);
+    const long long total = (long long)dy->n * dy->h * dy->w * (x->c / VEC);
     DCT_LAUNCH(DCT_PROF_POINTWISE, (maxpool_bwd_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), 0, st, to_view(x), to_view(dy), to_view(dx), relu_mask, scale);
   });
   return dct_check_launch();

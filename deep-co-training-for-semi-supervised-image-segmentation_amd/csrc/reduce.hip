@@ -7,6 +7,7 @@
 //
 // Thread layout: tid = row * CV + cv with CV = C / VEC channel vectors; `rows` = 256 / CV pixels
 // are in flight per block iteration.
+#include <algorithm>
 #include "dct_common.h"
 
 namespace {
@@ -118,7 +119,9 @@ static int bias_plan(const dct_view* dy, int vec, int& ppb) {
 struct StemG { int R, S, stride, dil, pad_h, pad_w; };
 
 // partial[blk][co][taps+1] (taps of dw, then db).  x fp32 [N,H,W,1], dy T [N,Ho,Wo,Cout]
-template <typename T>
+// QUAD (3x3, stride 1, dilation 1): the unit of work is 4 adjacent output pixels of a row -- one decode and one
+// 3x6 input window per 4 channel-vector loads, which are all in flight together; ppb then counts quads.
+template <typename T, bool QUAD>
 __global__ __launch_bounds__(256) void stem_wgrad_fast_kernel(View x, View dy, float* partial, StemG g, int ppb) {
   constexpr int VEC = Vec<T>::N;
   constexpr int NT = 10;                 // 9 taps + bias
@@ -136,6 +139,44 @@ __global__ __launch_bounds__(256) void stem_wgrad_fast_kernel(View x, View dy, f
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
+  if constexpr (QUAD) {
+    const int wq = (dy.w + 3) >> 2;
+    const long long Q = (long long)dy.n * dy.h * wq;
+    const long long qbeg = (long long)blockIdx.x * ppb, qend = min(Q, qbeg + ppb);
+    for (long long q = qbeg + row; q < qend; q += rows) {
+      const unsigned uq = (unsigned)q, urow = uq / (unsigned)wq;
+      const int x0 = (int)(uq - urow * (unsigned)wq) * 4, n = (int)(urow / (unsigned)dy.h), oy = (int)(urow - (unsigned)n * (unsigned)dy.h);
+      float d[4][VEC];
+      const T* dp = dbase + n * dy.sn + oy * dy.sh + x0 * dy.sw;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (x0 + p < dy.w) Vec<T>::load(dp + p * dy.sw, d[p]);
+        else
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) d[p][i] = 0.f;
+      }
+      float xw[3][6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int iy = oy + r - g.pad_h;
+        const bool rok = (unsigned)iy < (unsigned)x.h;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int ix = x0 + j - g.pad_w;
+          xw[r][j] = (rok && (unsigned)ix < (unsigned)x.w) ? xp[n * x.sn + iy * x.sh + ix * x.sw] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[t][i] = fmaf(d[p][i], xw[t / 3][p + t % 3], acc[t][i]);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[9][i] += d[p][i];
+      }
+    }
+  } else
   for (long long pix = pbeg + row; pix < pend; pix += rows) {
     const unsigned up = (unsigned)pix, urow = up / (unsigned)dy.w;
     const int ox = (int)(up - urow * (unsigned)dy.w), n = (int)(urow / (unsigned)dy.h), oy = (int)(urow - (unsigned)n * (unsigned)dy.h);
@@ -273,6 +314,16 @@ static int pix_plan(long long P, int rows, int iters, int max_blocks, int& ppb) 
 
 static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// resident blocks of `kernel` on the whole device (one full round of the grid: no half-empty second round)
+template <typename K>
+static int resident_blocks(K kernel, int fallback) {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fallback;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return fallback;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) return fallback;
+  return cus * per_cu;
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -322,12 +373,25 @@ extern "C" int dct_conv_cin1_wgrad(const dct_view* x, const dct_view* dy, float*
   if (((uintptr_t)dy->ptr % 16) || (dy->sw % vec) || (dy->sh % vec) || (dy->sn % vec)) return DCT_ERR_UNSUPPORTED;
   const int taps = d->R * d->S;
   int ppb;
-  const int blocks = pix_plan((long long)dy->n * dy->h * dy->w, 256 / cv, 8, 1024, ppb);
+  const bool quad = d->R == 3 && d->S == 3 && d->stride == 1 && d->dil == 1;
+  const long long units = quad ? (long long)dy->n * dy->h * ((dy->w + 3) / 4) : (long long)dy->n * dy->h * dy->w;
+  int max_blocks = 1024;
+  if (quad) {
+    static const int res_bf16 = resident_blocks(stem_wgrad_fast_kernel<bf16_t, true>, 512);
+    static const int res_f32 = resident_blocks(stem_wgrad_fast_kernel<float, true>, 512);
+    max_blocks = std::min(1024, dtype == DCT_BF16 ? res_bf16 : res_f32);
+  }
+  const int blocks = pix_plan(units, 256 / cv, quad ? 4 : 8, max_blocks, ppb);
   if (!workspace || workspace_bytes < (size_t)blocks * dy->c * (taps + 1) * sizeof(float)) return DCT_ERR_WORKSPACE;
   StemG g; g.R = d->R; g.S = d->S; g.stride = d->stride; g.dil = d->dil; g.pad_h = d->pad_h; g.pad_w = d->pad_w;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, stem_wgrad_fast_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
-  else DCT_LAUNCH(DCT_PROF_POINTWISE, stem_wgrad_fast_kernel<float>, dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
+  if (dtype == DCT_BF16) {
+    if (quad) DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_wgrad_fast_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
+    else DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_wgrad_fast_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
+  } else {
+    if (quad) DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_wgrad_fast_kernel<float, true>), dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
+    else DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_wgrad_fast_kernel<float, false>), dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
+  }
   DCT_LAUNCH(DCT_PROF_POINTWISE, split_dw_db_kernel, dim3(div_up(dy->c * (taps + 1), 16)), dim3(256), 0, st,
              (const float*)workspace, dw, db, dy->c, taps, blocks, accumulate);
   return dct_check_launch();
