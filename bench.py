@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--no-wgrad-stream", action="store_true", help="keep weight gradients on the model's stream")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="queue all models on one stream (the mode the per-kernel roofline leg and rocprofv3 kernel durations use)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -214,6 +217,13 @@ def main():
     tr, lab, unl = make_trainer(cfg, dtype, device, rank, world, sync_factory)
     S = cfg["S"]
     nb = len(unl)
+    tr.model_streams = not args.single_stream
+
+    def set_side_streams(flag):
+        for seg in tr.segmentators:
+            if hasattr(seg.torchnet, "wgrad_side_stream"):
+                seg.torchnet.wgrad_side_stream = flag
+    set_side_streams(not args.single_stream and not args.no_wgrad_stream)
 
     def one_step(i):
         lb = [(lab[m][i % nb][0][0], lab[m][i % nb][0][1]) for m in range(S)]
@@ -240,6 +250,8 @@ def main():
     prof = None
     use_events = not args.no_kernel_events and rank == 0
     if use_events:
+        set_side_streams(False)
+        tr.model_streams = False      # per-kernel durations are taken with one kernel on the device at a time
         _lib.prof_read(reset=True)
         _lib.prof_enable(True)
         for i in range(args.steps):

@@ -80,6 +80,7 @@ SIGNATURES = {
     "dct_bilinear_fwd": (_i, [_VP, _VP, _i, _i, _P]),
     "dct_bilinear_bwd": (_i, [_VP, _VP, _i, _i, _i, _P]),
     "dct_dropout_fwd": (_i, [_VP, _VP, _P, _f, _u64, _u64, _i, _P]),
+    "dct_dropout_fwd_dev": (_i, [_VP, _VP, _P, _f, _u64, _P, _i, _P]),
     "dct_dropout_apply": (_i, [_VP, _VP, _P, _f, _i, _P]),
     "dct_relu_bwd": (_i, [_VP, _VP, _VP, _f, _i, _P]),
     "dct_cast": (_i, [_VP, _VP, _i, _i, _P]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     "dct_argmax": (_i, [_P, _P, _i64, _i, _P]),
     "dct_fgsm_step": (_i, [_P, _P, _f, _P, _P, _i64, _P]),
     "dct_adam_flat": (_i, [_P, _P, _P, _P, _i64, _f, _f, C.c_double, C.c_double, _f, _f, _P, _P]),
+    "dct_adam_flat_dev": (_i, [_P, _P, _P, _P, _i64, _P, _P, C.c_double, C.c_double, _f, _f, _P, _P]),
     "dct_enet_conv": (_i, [_VP, _P, _P, _TP, _VP, _DP, _i, _i, _i, _i, _VP, _VP, _i, _i, _P]),
     "dct_enet_reduce_workspace_bytes": (_sz, [_i]),
     "dct_enet_bn_fwd_stats": (_i, [_VP, _P, _P, _f, _f, _P, _P, _i, _P, _P, _P, _P, _i, _i, _P, _sz, _P]),

@@ -202,13 +202,28 @@ class Enet(nn.Module):
     def _g(self, p):
         return self.flat_params.grad_dense(self._pidx[id(p)])
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _check_input(self, x: torch.Tensor):
         if not x.is_cuda:
             raise RuntimeError("dct_amd Enet runs on the HIP device only (no CPU fallback)")
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError(f"expected [B,1,H,W], got {tuple(x.shape)}")
         if x.shape[2] % 8 or x.shape[3] % 8:
             raise RuntimeError("Enet needs H and W divisible by 8 (three stride-2 stages, enet.py:26,132)")
+
+    # Autograd-free entry points of the execution plan (see arch/unet.py::plan_forward)
+    def plan_forward(self, x: torch.Tensor, save: bool = True):
+        self._check_input(x)
+        self.flat_params.ensure()
+        return self._run_forward(x, save)
+
+    def plan_backward(self, tape, dlogits: torch.Tensor, need_dx: bool = False, need_dw: bool = True):
+        if need_dw:
+            self.flat_params.ensure_grads()
+        dx = self._run_backward(tape, dlogits, need_dx, need_dw)
+        return dx.reshape(dx.shape[0], 1, dx.shape[1], dx.shape[2]) if dx is not None else None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._check_input(x)
         self.flat_params.ensure()
         params = self.flat_params.params
         save = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))

@@ -19,6 +19,7 @@ No CPU path: inputs must be on the HIP device.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, List, Optional
 
 import torch
@@ -128,9 +129,12 @@ class UNet(nn.Module):
         self.external_dropout_masks: Optional[List[torch.Tensor]] = None  # parity replay hook
         self.last_dropout_masks: Optional[List[torch.Tensor]] = None
         self.record_dropout_masks = False
-        self._drop_calls = 0
+        self._drop_calls = 0                  # host mirror of the device call counter below
+        self._drop_state: Optional[torch.Tensor] = None   # int64[1] on the device: Philox offset = calls << 40
         self.dropout_seed = 0x5DEECE66D
         self._debug: Optional[dict] = None   # tools/debug_unet_layers.py stashes backward intermediates here
+        self.wgrad_side_stream = True        # weight gradients on a second HIP stream (see _run_backward)
+        self._wgrad_stream = None
 
     # ------------------------------------------------------------------------------ weights
     def mark_weights_updated(self, shadow_fresh: bool = False):
@@ -195,7 +199,7 @@ class UNet(nn.Module):
         self._pack_key = key
 
     # ------------------------------------------------------------------------------ forward
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _check_input(self, x: torch.Tensor):
         if not x.is_cuda:
             raise RuntimeError("dct_amd UNet runs on the HIP device only (no CPU fallback)")
         if x.dim() != 4 or x.shape[1] != 1:
@@ -203,10 +207,36 @@ class UNet(nn.Module):
         if min(x.shape[2], x.shape[3]) < 176:
             # same failure the reference has (valid convs): SURVEY.md fact 3
             raise RuntimeError("Kernel size can't be greater than actual input size (UNet needs H,W >= 176)")
+
+    # Autograd-free entry points of the execution plan (the fused trainer step drives them directly: no autograd
+    # engine thread hop, and the whole step is a plain launch sequence that a HIP graph can capture).
+    def plan_forward(self, x: torch.Tensor, save: bool = True):
+        """-> (logits, tape): logits physical NHWC fp32 [B,H,W,C]; tape feeds plan_backward (None if not save)."""
+        self._check_input(x)
+        self._ensure_packs()
+        return self._run_forward(x, save)
+
+    def plan_backward(self, tape, dlogits: torch.Tensor, need_dx: bool = False, need_dw: bool = True):
+        """dlogits: NHWC fp32 like the logits.  Parameter gradients accumulate into the flat gradient buffer
+        (attached as p.grad); returns d/dx as [B,1,H,W] when need_dx."""
+        if need_dw:
+            self.flat_params.ensure_grads()
+        dx = self._run_backward(tape, dlogits, need_dx, need_dw)
+        return dx.reshape(dx.shape[0], 1, dx.shape[1], dx.shape[2]) if dx is not None else None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._check_input(x)
         self._ensure_packs()
         params = self.flat_params.params
         save = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         return _UNetFn.apply(self, save, x, *params)
+
+    def _side_stream(self, dev):
+        if not self.wgrad_side_stream:
+            return None
+        if self._wgrad_stream is None or self._wgrad_stream.device != dev:
+            self._wgrad_stream = torch.cuda.Stream(device=dev)
+        return self._wgrad_stream
 
     # The plan itself ------------------------------------------------------------------------
     def _run_forward(self, x: torch.Tensor, save: bool):
@@ -238,8 +268,10 @@ class UNet(nn.Module):
                 return src
             dst = torch.empty_like(src)
             m = torch.empty(src.shape, dtype=torch.uint8, device=dev) if masks_out is not None else None
-            self._drop_calls += 1
-            K.dropout_fwd(src, dst, self.dropout_p, self.dropout_seed, self._drop_calls << 40, mask_out=m)
+            if self._drop_state is None or self._drop_state.device != dev:
+                self._drop_state = torch.tensor([self._drop_calls], dtype=torch.int64, device=dev)
+            self._drop_calls += 1       # the kernel increments the device copy in stream order (graph-replayable)
+            K.dropout_fwd(src, dst, self.dropout_p, self.dropout_seed, 0, mask_out=m, calls_dev=self._drop_state)
             if masks_out is not None:
                 masks_out.append(m)
             return dst
@@ -304,14 +336,30 @@ class UNet(nn.Module):
         def new_like(t, c=None):
             return torch.empty(t.shape[:3] + ((c,) if c else t.shape[3:]), dtype=dt, device=dev)
 
+        # Weight gradients are off the critical path (only the data-gradient chain feeds the next layer): they
+        # are queued on a second stream, ordered after the producer of dy by an event, and joined at the end.
+        # Their operands stay referenced until the join (`keep`), so the caching allocator cannot hand a dy
+        # buffer to a later data-gradient while a weight-gradient kernel still reads it.
+        cur = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if need_dw else None
+        keep: List[torch.Tensor] = []
+
+        def on_side(*operands):
+            if side is None:
+                return contextlib.nullcontext()
+            side.wait_stream(cur)
+            keep.extend(operands)
+            return torch.cuda.stream(side)
+
         def conv_bwd(conv, x_in, dy, dx_out, mask=None, mask_channels=0, mask_scale=1.0, accumulate=False):
             """dy: grad wrt the conv's pre-activation output (already ReLU-masked)."""
             if need_dw:
-                if dt == torch.bfloat16:     # bias gradient rides along in the weight-gradient launch
-                    K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=True, db=self._gb(conv))
-                else:
-                    K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=True)
-                    K.bias_grad(dy, self._gb(conv), accumulate=True)
+                with on_side(dy, x_in):
+                    if dt == torch.bfloat16:     # bias gradient rides along in the weight-gradient launch
+                        K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=True, db=self._gb(conv))
+                    else:
+                        K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=True)
+                        K.bias_grad(dy, self._gb(conv), accumulate=True)
             if dx_out is not None:
                 K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, pad_h=2, pad_w=2, mask=mask,
                          mask_channels=mask_channels, mask_scale=mask_scale, accumulate=accumulate)
@@ -319,8 +367,9 @@ class UNet(nn.Module):
 
         def convT_bwd(conv, x_in, dy, dx_out, mask, mask_scale=1.0):
             if need_dw:
-                K.conv2d_wgrad(x_in, dy, self._gw(conv), R=2, S=2, stride=2, accumulate=True)
-                K.bias_grad(dy, self._gb(conv), accumulate=True)
+                with on_side(dy, x_in):
+                    K.conv2d_wgrad(x_in, dy, self._gw(conv), R=2, S=2, stride=2, accumulate=True)
+                    K.bias_grad(dy, self._gb(conv), accumulate=True)
             K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, R=2, S=2, stride=2, mask=mask, mask_scale=mask_scale)
             return dx_out
 
@@ -366,9 +415,12 @@ class UNet(nn.Module):
             else:
                 c0 = blk.at(0)
                 if need_dw:
-                    K.conv_cin1_wgrad(A["x"], da, self._gw(c0), self._gb(c0), accumulate=True)
+                    with on_side(da):
+                        K.conv_cin1_wgrad(A["x"], da, self._gw(c0), self._gb(c0), accumulate=True)
                 if need_dx:
                     dx = K.conv_cin1_dgrad(da, self._w(c0), torch.empty_like(A["x"]), pad_h=0, pad_w=0)
+        if side is not None:
+            cur.wait_stream(side)
         return dx
 
 

@@ -460,9 +460,14 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned 
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 // thread per 4 consecutive channels of a pixel
+// calls (nullable): device-resident call counter; the Philox offset is then calls[0] << 40 (what the host passes as
+// `offset` otherwise), so a captured HIP graph draws a fresh mask on every replay.
+__global__ void dropout_advance_kernel(unsigned long long* calls) { calls[0] += 1ull; }
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(View x, View y, unsigned char* mask_out, const unsigned char* mask_in,
-                                                       float p, unsigned long long seed, unsigned long long offset) {
+                                                       float p, unsigned long long seed, unsigned long long offset,
+                                                       const unsigned long long* calls) {
+  if (calls) offset = calls[0] << 40;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const PixIdx id = decode(idx, x.n, x.h, x.w, x.c / 4);
   if (!id.ok) return;
@@ -681,20 +686,27 @@ extern "C" int dct_bilinear_bwd(const dct_view* dy, const dct_view* dx, int dtyp
 }
 
 static int dropout_impl(const dct_view* x, const dct_view* y, uint8_t* mask_out, const uint8_t* mask_in, float p,
-                        uint64_t seed, uint64_t offset, int dtype, dct_stream stream) {
+                        uint64_t seed, uint64_t offset, int dtype, dct_stream stream, uint64_t* calls = nullptr) {
   if (!view_ok(x) || !view_ok(y) || !same_nhw(x, y) || x->c != y->c || p < 0.f || p >= 1.f) return DCT_ERR_BAD_ARG;
   if (x->c % 4) return DCT_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const long long total = (long long)x->n * x->h * x->w * (x->c / 4);
+  if (calls) DCT_LAUNCH(DCT_PROF_POINTWISE, dropout_advance_kernel, dim3(1), dim3(1), 0, st, (unsigned long long*)calls);
   DISPATCH_T(dtype, {
     DCT_LAUNCH(DCT_PROF_POINTWISE, dropout_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, to_view(x), to_view(y),
-               (unsigned char*)mask_out, (const unsigned char*)mask_in, p, (unsigned long long)seed, (unsigned long long)offset);
+               (unsigned char*)mask_out, (const unsigned char*)mask_in, p, (unsigned long long)seed, (unsigned long long)offset,
+               (const unsigned long long*)calls);
   });
   return dct_check_launch();
 }
 extern "C" int dct_dropout_fwd(const dct_view* x, const dct_view* y, uint8_t* mask_out, float p,
                                uint64_t seed, uint64_t offset, int dtype, dct_stream stream) {
   return dropout_impl(x, y, mask_out, nullptr, p, seed, offset, dtype, stream);
+}
+extern "C" int dct_dropout_fwd_dev(const dct_view* x, const dct_view* y, uint8_t* mask_out, float p,
+                                   uint64_t seed, uint64_t* calls, int dtype, dct_stream stream) {
+  if (!calls || ((uintptr_t)calls & 7)) return DCT_ERR_BAD_ARG;
+  return dropout_impl(x, y, mask_out, nullptr, p, seed, 0, dtype, stream, calls);
 }
 extern "C" int dct_dropout_apply(const dct_view* x, const dct_view* y, const uint8_t* mask, float p, int dtype,
                                  dct_stream stream) {

@@ -133,8 +133,13 @@ def bilinear_bwd(dy, dx, accumulate=False):
     return dx
 
 
-def dropout_fwd(x, y, p, seed, offset, mask_out=None):
+def dropout_fwd(x, y, p, seed, offset, mask_out=None, calls_dev=None):
+    """``calls_dev`` (int64[1] device tensor): the call counter lives on the device (incremented in stream order,
+    offset = counter << 40) and ``offset`` is ignored -- the graph-replayable form."""
     vx, vy = view(x), view(y)
+    if calls_dev is not None:
+        call("dct_dropout_fwd_dev", C.byref(vx), C.byref(vy), ptr(mask_out), float(p), int(seed), ptr(calls_dev), _dt(x), stream())
+        return y
     call("dct_dropout_fwd", C.byref(vx), C.byref(vy), ptr(mask_out), float(p), int(seed), int(offset), _dt(x), stream())
     return y
 
@@ -276,6 +281,14 @@ def adam_flat(p, g, m, v, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, 
          float(beta2), float(eps), float(weight_decay), ptr(bf16_shadow), stream())
 
 
+def adam_flat_dev(p, g, m, v, state, table, beta1, beta2, eps, weight_decay, bf16_shadow=None):
+    """Adam with {step count, lr, table base, table length} in the float64[4] device tensor ``state`` and the
+    host-computed {step_size, bc2_sqrt} pairs in the float32 device tensor ``table`` (dct_adam_flat_dev)."""
+    call("dct_adam_flat_dev", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(state), ptr(table), float(beta1), float(beta2),
+         float(eps), float(weight_decay), ptr(bf16_shadow), stream())
+    return p
+
+
 def dice_counts(logits_bpc, gt_bp, B, C_):
     """logits [B, pix, C] fp32 dense, gt [B, pix] int64 -> (inter, psum, gsum) int32 [B, C]."""
     dev = logits_bpc.device
@@ -308,7 +321,11 @@ _red_ws = {}
 
 
 def _enet_ws(device, nbytes):
-    key = (str(device), "red")
+    """Reduction scratch, cached per (device, stream): kernels of two models queued on different streams must not
+    share it.  While a HIP graph is being captured the buffer comes from the graph's own pool instead."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     t = _red_ws.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

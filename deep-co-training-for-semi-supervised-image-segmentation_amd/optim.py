@@ -32,6 +32,12 @@ class FusedAdam(torch.optim.Optimizer):
         self._steps = 0
         self._flat_version = -1
         self._on_step = on_step
+        # {step count, lr} as float64[2] ON THE DEVICE: the kernel forms the bias corrections itself
+        # (dct_adam_flat_dev), so step() has no per-step host scalar and can be replayed from a HIP graph.
+        self._dev_state = None
+        self._dev_table = None
+        self._dev_lr = None
+        self._table_base = 0
 
     def _state_views(self):
         f = self.flat
@@ -40,6 +46,41 @@ class FusedAdam(torch.optim.Optimizer):
             st["exp_avg"] = self._m.as_strided(p.shape, p.stride(), off)
             st["exp_avg_sq"] = self._v.as_strided(p.shape, p.stride(), off)
             st["step"] = torch.tensor(float(self._steps))
+
+    TABLE_STEPS = 2048
+
+    def _ensure_dev_state(self, dev, lr):
+        """Device state of dct_adam_flat_dev: {t, lr, table base, table length} + the table of host-computed
+        {lr / (1 - beta1^t), sqrt(1 - beta2^t)} for the next TABLE_STEPS steps (python doubles rounded to fp32,
+        exactly what torch.optim.Adam hands its kernels).  Rebuilt when the table runs out, the learning rate
+        changes or the moments were re-imported -- a few small copies every TABLE_STEPS steps, never inside a
+        captured graph."""
+        lr = float(lr)
+        fresh = self._dev_state is None or self._dev_state.device != dev
+        if not fresh and lr == self._dev_lr and self._steps + 1 <= self._table_base + self.TABLE_STEPS:
+            return self._dev_state
+        b1, b2 = self.param_groups[0]["betas"]
+        base = self._steps
+        rows = [(lr / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t)) for t in range(base + 1, base + 1 + self.TABLE_STEPS)]
+        table = torch.tensor(rows, dtype=torch.float32)
+        state = torch.tensor([float(self._steps), lr, float(base), float(self.TABLE_STEPS)], dtype=torch.float64)
+        if fresh:
+            self._dev_state, self._dev_table = state.to(dev), table.to(dev)
+        else:                                     # in place: captured graphs hold these addresses
+            self._dev_table.copy_(table)
+            self._dev_state[1:].copy_(state[1:])  # the device owns the step count
+        self._dev_lr, self._table_base = lr, base
+        return self._dev_state
+
+    def refresh_lr(self):
+        """Push a changed learning rate / an exhausted table to the device (call between graph replays)."""
+        if self._dev_state is not None:
+            self._ensure_dev_state(self._dev_state.device, self.param_groups[0]["lr"])
+
+    def note_replayed_steps(self, n: int = 1):
+        """A captured graph containing step() was replayed n times: keep the host step count in line with the
+        device counter (state_dict() reports it)."""
+        self._steps += int(n)
 
     def _ensure_state(self):
         f = self.flat
@@ -67,6 +108,7 @@ class FusedAdam(torch.optim.Optimizer):
                 v.as_strided(p.shape, p.stride(), off).copy_(st["exp_avg_sq"])
                 steps = max(steps, int(float(st.get("step", 0))))
         self._m, self._v, self._steps = m, v, steps
+        self._dev_state = None
         self._state_views()
 
     @torch.no_grad()
@@ -78,15 +120,12 @@ class FusedAdam(torch.optim.Optimizer):
             raise RuntimeError("FusedAdam.step(): gradients are not in the network's flat gradient buffer "
                                "(backward of a dct_amd network attaches them)")
         g = self.param_groups[0]
-        self._steps += 1
         b1, b2 = g["betas"]
-        bc1 = 1.0 - b1 ** self._steps
-        bc2 = 1.0 - b2 ** self._steps
+        state = self._ensure_dev_state(f.flat.device, g["lr"])
+        self._steps += 1                    # the kernel increments the device copy in stream order
         shadow = f.ensure_shadow() if f.want_shadow else None
-        hip_ops.adam_flat(f.flat, f.gflat, self._m, self._v, g["lr"] / bc1, math.sqrt(bc2), b1, b2, g["eps"],
-                          g["weight_decay"], bf16_shadow=shadow)
-        for p in f.params:
-            self.state[p]["step"] = torch.tensor(float(self._steps))
+        hip_ops.adam_flat_dev(f.flat, f.gflat, self._m, self._v, state, self._dev_table, b1, b2, g["eps"],
+                              g["weight_decay"], bf16_shadow=shadow)
         if self._on_step is not None:
             try:
                 self._on_step(shadow_fresh=shadow is not None)
@@ -100,5 +139,5 @@ class FusedAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         if self._m is not None:
-            self._state_views()
+            self._state_views()         # refreshes the per-parameter "step" entries from the host count
         return super().state_dict()

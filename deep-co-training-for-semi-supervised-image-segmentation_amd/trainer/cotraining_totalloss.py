@@ -18,6 +18,7 @@ all optimizers step.  The numpy RNG is consumed once per step when ``train_adv``
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from operator import itemgetter
 from pathlib import Path
@@ -119,6 +120,8 @@ class CoTrainer(Trainer):
         self.use_tqdm = use_tqdm and tqdm_ is not None
         self.grad_sync = grad_sync          # dct_amd.ddp.FlatGradSync or None (single process)
         self.batch_lab_unlab = True         # one B_l+B_u pass per batch-independent net (see _run_step_fused)
+        self.model_streams = True           # one HIP stream per model in the fused step (see _streams)
+        self._stream_pool = None
         self.last_step = None
 
     def to(self, device: torch.device):
@@ -176,7 +179,8 @@ class CoTrainer(Trainer):
             return False
         if type(self.criterions['sup']) is not CrossEntropyLoss2d or type(self.criterions['jsd']) is not JSD_2D:
             return False
-        return all(hasattr(s.torchnet, "flat_params") for s in self.segmentators) and len(self.segmentators) <= 4
+        return all(hasattr(s.torchnet, "flat_params") and hasattr(s.torchnet, "plan_forward")
+                   for s in self.segmentators) and len(self.segmentators) <= 4
 
     def _draw_adv_choice(self) -> Tuple[int, int]:
         S = len(self.segmentators)
@@ -203,21 +207,40 @@ class CoTrainer(Trainer):
         self.last_step = out
         return out
 
-    def _finish_step(self, backward_calls):
+    def _streams(self):
+        """One HIP stream per model for the fused step, or None.  The S networks are independent between the
+        points where the losses couple them (JSD, the FGSM hand-over), and many of their launches cannot fill
+        256 CUs alone (deep UNet levels: a few hundred tiles; every kernel's last round of blocks): queued on
+        separate streams, the tail of one model's kernel is filled with blocks of the other's.  Ordering is by
+        stream events only (wait_stream); no host synchronisation is added."""
+        if not self.model_streams or self.device.type != 'cuda' or len(self.segmentators) < 2:
+            return None
+        if self._stream_pool is None or len(self._stream_pool) != len(self.segmentators):
+            self._stream_pool = [torch.cuda.Stream(device=self.device) for _ in self.segmentators]
+        return self._stream_pool
+
+    def _finish_step(self, backward_calls, streams=None):
         """zero_grad (after the forwards, :245) -> backward (:246-247) -> [gradient all-reduce] -> step (:248).
         ``backward_calls``: list of (model index or None, callable).  With data parallelism each
-        model's all-reduce starts as soon as its backward is enqueued and overlaps the next one."""
-        map_(lambda x: x.optimizer.zero_grad(), self.segmentators)
+        model's all-reduce starts as soon as its backward is enqueued and overlaps the next one.
+        With ``streams`` model i's zero_grad / backward / all-reduce / Adam are all queued on streams[i]."""
+        def on(i):
+            return torch.cuda.stream(streams[i]) if streams is not None and i is not None else contextlib.nullcontext()
+        for i, seg in enumerate(self.segmentators):
+            with on(i):
+                seg.optimizer.zero_grad()
         for idx, call in backward_calls:
-            call()
-            if self.grad_sync is not None and idx is not None:
-                self.grad_sync.begin(idx)
+            with on(idx):
+                call()
+                if self.grad_sync is not None and idx is not None:
+                    self.grad_sync.begin(idx)
         if self.grad_sync is not None and any(idx is None for idx, _ in backward_calls):
             self.grad_sync.all_reduce()
         for i, seg in enumerate(self.segmentators):
-            if self.grad_sync is not None:
-                self.grad_sync.finish(i)     # model i's all-reduce only: later ones overlap this Adam launch
-            seg.optimizer.step()
+            with on(i):
+                if self.grad_sync is not None:
+                    self.grad_sync.finish(i)     # model i's all-reduce only: later ones overlap this Adam launch
+                seg.optimizer.step()
 
     def _run_step_generic(self, lab, unl, train_jsd, train_adv, adv_choice) -> dict:
         S = len(self.segmentators)
@@ -242,87 +265,115 @@ class CoTrainer(Trainer):
         return dict(sup=sup, jsd=jsdLoss.detach() if train_jsd else 0, adv=advLoss.detach() if train_adv else 0,
                     preds=preds, unlab_probs=[p.detach() for p in unlab_preds])
 
-    def _run_step_fused(self, lab, unl, train_jsd, train_adv, adv_choice) -> dict:
+    def _run_step_fused(self, lab, unl, train_jsd, train_adv, adv_choice, lam_dev=None) -> dict:
+        """The step as one launch sequence over the networks' execution plans (plan_forward / plan_backward: no
+        autograd graph), the fused loss kernels and the flat Adam.  ``lam_dev`` (float32[2] device tensor holding
+        lambda_cot, lambda_adv): the loss weights are then read on the device, as a captured graph needs."""
         from .. import hip_ops as K
-        from ..loss.loss import _pc, _nchw
+        from ..loss.loss import _nchw
         S, C = len(self.segmentators), self.C
+        nets = [s.torchnet for s in self.segmentators]
         ignore = self.criterions['sup'].ignore_index
         lam_cot, lam_adv = float(self.cot_scheduler.value), float(self.adv_scheduler.value)
-        heads: List[List[Tensor]] = [[] for _ in range(S)]
-        grads: List[List[Tensor]] = [[] for _ in range(S)]
+        g_cot = dict(gscale=lam_dev[0:1], gmul=1.0) if lam_dev is not None else dict(gmul=lam_cot)
+        g_adv = dict(gscale=lam_dev[1:2], gmul=1.0) if lam_dev is not None else dict(gmul=lam_adv)
+        passes: List[List[Tuple[object, Tensor]]] = [[] for _ in range(S)]     # per model: (tape, dlogits) to back-propagate
         sup, preds = [], []
         # Networks whose samples do not interact (UNet: no BatchNorm) run the labeled and the
         # unlabeled batch as ONE pass of B_l + B_u images: same per-pixel results, twice the GEMM
         # rows per launch and half the launches.  Nets with batch statistics keep separate passes
         # (three separate BN-statistics batches per model per step, SURVEY.md 3.3).
         fuse = bool(train_jsd and unl is not None and self.batch_lab_unlab and
-                    all(getattr(s.torchnet, "batch_independent", False) and
-                        getattr(s.torchnet, "external_dropout_masks", None) is None for s in self.segmentators))
-        full_logits, full_dl = [], []
+                    all(getattr(n, "batch_independent", False) and
+                        getattr(n, "external_dropout_masks", None) is None for n in nets))
+        streams = self._streams()
+        main = torch.cuda.current_stream(self.device)
+
+        def on(i):
+            return torch.cuda.stream(streams[i]) if streams is not None else contextlib.nullcontext()
+
+        def fork():
+            if streams is not None:
+                for st in streams:
+                    st.wait_stream(main)
+
+        def join():
+            if streams is not None:
+                for st in streams:
+                    main.wait_stream(st)
+        fork()
+        full = []                                                              # fuse: (tape, logits, dlogits) of the joint pass
         for i in range(S):                                                     # :208-218
-            img, gt = lab[i]
-            if fuse:
-                logits_all = self.segmentators[i].torchnet(torch.cat((img, unl[0]), dim=0))
-                lp_all = _pc(logits_all.detach())
-                dl_all = torch.empty_like(lp_all)
-                full_logits.append((logits_all, lp_all))
-                full_dl.append(dl_all)
+            with on(i):
+                img, gt = lab[i]
                 B_l = img.shape[0]
-                logits, lp, dl_out = logits_all[:B_l], lp_all[:B_l], dl_all[:B_l]
-            else:
-                logits = self.segmentators[i].torchnet(img)
-                lp = _pc(logits.detach())
-                dl_out = torch.empty_like(lp)
-            t = gt.reshape(-1)
-            out = K.ce_fwd(lp, t, C, ignore)
-            K.ce_bwd(lp, t, C, out[1:2], dl_out, ignore_index=ignore)
-            if not fuse:
-                heads[i].append(logits)
-                grads[i].append(_nchw(dl_out))
-            sup.append(out[0])
-            preds.append(logits.detach())
+                if fuse:
+                    lp_all, tape = nets[i].plan_forward(torch.cat((img, unl[0]), dim=0), True)
+                    dl_all = torch.empty_like(lp_all)
+                    full.append((tape, lp_all, dl_all))
+                    lp, dl_out = lp_all[:B_l], dl_all[:B_l]
+                else:
+                    lp, tape = nets[i].plan_forward(img, True)
+                    dl_out = torch.empty_like(lp)
+                    passes[i].append((tape, dl_out))
+                t = gt.reshape(-1)
+                out = K.ce_fwd(lp, t, C, ignore)
+                K.ce_bwd(lp, t, C, out[1:2], dl_out, ignore_index=ignore)
+                sup.append(out[0])
+                preds.append(_nchw(lp))
         jsd, unlab_probs = 0, []
         if train_jsd:                                                          # :219-227
             if fuse:
                 B_l = lab[0][0].shape[0]
-                ulogits = [fl[0][B_l:] for fl in full_logits]
-                lps = [fl[1][B_l:] for fl in full_logits]
-                dl_outs = [d[B_l:] for d in full_dl]
+                lps = [f[1][B_l:] for f in full]
+                dl_outs = [f[2][B_l:] for f in full]
             else:
-                ulogits = [s.torchnet(unl[0]) for s in self.segmentators]
-                lps = [_pc(l.detach()) for l in ulogits]
-                dl_outs = [torch.empty_like(lp) for lp in lps]
+                lps, dl_outs, utapes = [], [], []
+                for i in range(S):
+                    with on(i):
+                        lp_u, tape = nets[i].plan_forward(unl[0], True)
+                        lps.append(lp_u)
+                        utapes.append(tape)
+                        dl_outs.append(torch.empty_like(lp_u))
+            join()                                  # the JSD couples all S models: main stream, then fork again
             jsd = K.jsd_logits_fwd(lps, C)[0]
             unlab_probs = [_nchw(K.softmax_fwd(lp, C)) for lp in lps]
             if lam_cot != 0.0:
-                K.jsd_logits_bwd(lps, C, dl_outs, gmul=lam_cot)
+                K.jsd_logits_bwd(lps, C, dl_outs, **g_cot)
                 if not fuse:
                     for i in range(S):
-                        heads[i].append(ulogits[i])
-                        grads[i].append(_nchw(dl_outs[i]))
+                        passes[i].append((utapes[i], dl_outs[i]))
             elif fuse:
                 for d in dl_outs:
                     d.zero_()
-        if fuse:
-            for i in range(S):
-                heads[i].append(full_logits[i][0])
-                grads[i].append(_nchw(full_dl[i]))
+            fork()
+        for i, f in enumerate(full):
+            passes[i].append((f[0], f[2]))
         adv = 0
         if train_adv:                                                          # :233-244 -> :371-392
             a, b = adv_choice
             eps = float(self.adv_training_dict.get('eplision', 0.05))
             img_b, gt_b = lab[b]
-            x = torch.cat((img_b, unl[0]), dim=0)
-            net_b = self.segmentators[b].torchnet
-            x_adv, noise, lp_real = self._fgsm_fused(net_b, x, gt_b, eps, ignore)
-            logits_adv = self.segmentators[a].torchnet(x_adv)
-            lp_adv = _pc(logits_adv.detach())
-            adv = K.kl_logits_fwd(lp_adv, lp_real, C)[0]
-            if lam_adv != 0.0:
-                da = K.kl_logits_bwd(lp_adv, lp_real, C, torch.empty_like(lp_adv), gmul=lam_adv)
-                heads[a].append(logits_adv)
-                grads[a].append(_nchw(da))
-        self._finish_step([(i, (lambda h=heads[i], g=grads[i]: torch.autograd.backward(h, g))) for i in range(S)])
+            with on(b):
+                x = torch.cat((img_b, unl[0]), dim=0)
+                x_adv, noise, lp_real = self._fgsm_fused(nets[b], x, gt_b, eps, ignore)
+            if streams is not None and a != b:
+                streams[a].wait_stream(streams[b])  # the adversarial images and the detached target come from model b
+            with on(a):
+                lp_adv, tape = nets[a].plan_forward(x_adv, True)
+                adv = K.kl_logits_fwd(lp_adv, lp_real, C)[0]
+                if lam_adv != 0.0:
+                    da = K.kl_logits_bwd(lp_adv, lp_real, C, torch.empty_like(lp_adv), **g_adv)
+                    passes[a].append((tape, da))
+
+        def backward_of(i):
+            def run():
+                for tape, dl in passes[i]:
+                    nets[i].plan_backward(tape, dl, need_dx=False, need_dw=True)
+                passes[i].clear()
+            return run
+        self._finish_step([(i, backward_of(i)) for i in range(S)], streams)
+        join()
         return dict(sup=sup, jsd=jsd, adv=adv, preds=preds, unlab_probs=unlab_probs)
 
     def _fgsm_fused(self, net, x, gt, eps, ignore):
@@ -330,25 +381,15 @@ class CoTrainer(Trainer):
         unlabeled tail, CE, backward to the input only, x + eps*sign(g).  Returns the physical
         NHWC logits of the clean pass (their softmax is the detached KL target)."""
         from .. import hip_ops as K
-        from ..loss.loss import _pc, _nchw
         C = self.C
-        x = x.detach().requires_grad_(True)
-        params = [p for p in net.parameters() if p.requires_grad]
-        for p in params:
-            p.requires_grad_(False)
-        try:
-            logits = net(x)
-        finally:
-            for p in params:
-                p.requires_grad_(True)
-        lp = _pc(logits.detach())
+        lp, tape = net.plan_forward(x, True)
         t = gt.reshape(-1)
         if x.shape[0] > gt.shape[0]:
             pseudo = K.argmax(lp, C)
             t = torch.cat((t, pseudo[t.numel():]))
         out = K.ce_fwd(lp, t, C, ignore)
         dl = K.ce_bwd(lp, t, C, out[1:2], torch.empty_like(lp), ignore_index=ignore)
-        (gx,) = torch.autograd.grad(logits, x, _nchw(dl))
+        gx = net.plan_backward(tape, dl, need_dx=True, need_dw=False)
         x_adv, noise = K.fgsm_step(x.detach().contiguous(), gx.contiguous(), eps)
         return x_adv, noise, lp
 

@@ -143,6 +143,11 @@ int dct_bilinear_bwd(const dct_view* dy, const dct_view* dx, int dtype_dy, int d
  * index); y = keep ? x/(1-p) : 0.  mask_out (uint8, nullable, dense NHWC) receives the keep mask. */
 int dct_dropout_fwd(const dct_view* x, const dct_view* y, uint8_t* mask_out, float p,
                     uint64_t seed, uint64_t offset, int dtype, dct_stream stream);
+/* Same, with the call counter in device memory: *calls += 1 (stream-ordered), then offset = *calls << 40.
+ * Nothing in the launch depends on a per-step host value, so a captured HIP graph of the training step
+ * draws a fresh mask on every replay. */
+int dct_dropout_fwd_dev(const dct_view* x, const dct_view* y, uint8_t* mask_out, float p,
+                        uint64_t seed, uint64_t* calls, int dtype, dct_stream stream);
 /* y = x * (mask_u8 ? 1/(1-p) : 0) with a caller-supplied dense mask (parity replay). */
 int dct_dropout_apply(const dct_view* x, const dct_view* y, const uint8_t* mask, float p, int dtype,
                       dct_stream stream);
@@ -210,6 +215,16 @@ int dct_fgsm_step(const float* x, const float* g, float eps, float* x_adv, float
 int dct_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float step_size,
                   float bc2_sqrt, double beta1, double beta2, float eps, float weight_decay,
                   void* bf16_shadow, dct_stream stream);
+/* Same update with the step-dependent scalars in device memory: state = {step count t, learning rate,
+ * table base, table length} (four doubles), table (nullable) = {step_size, bc2_sqrt} float pairs the host
+ * computed for steps base+1 .. base+length.  Stream-ordered: t += 1, then the pair for step t is read from
+ * the table (bit-identical to dct_adam_flat with the same host scalars); outside the table it is formed on
+ * the device in double: step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t).  No per-step host
+ * scalar, so the launch can be replayed from a captured HIP graph (torch.optim.Adam's `capturable` mode is
+ * the reference-side analogue). */
+int dct_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, double* state,
+                      const float* table, double beta1, double beta2, float eps, float weight_decay,
+                      void* bf16_shadow, dct_stream stream);
 
 /* ---- K2/K3/K4/K6/K7/K8: Enet layers (arch/enet.py:8-243) -------------------------------------
  * Enet's widths are 1..128 channels (internal 3/16/32): HBM- and launch-bound, so these are direct
