@@ -186,7 +186,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
-    ap.add_argument("--no-wgrad-stream", action="store_true", help="keep weight gradients on the model's stream")
+    ap.add_argument("--wgrad-stream", action="store_true", help="weight gradients on a second stream per model (eager only)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
     ap.add_argument("--single-stream", action="store_true",
                     help="queue all models on one stream (the mode the per-kernel roofline leg and rocprofv3 kernel durations use)")
     args = ap.parse_args()
@@ -223,7 +224,8 @@ def main():
         for seg in tr.segmentators:
             if hasattr(seg.torchnet, "wgrad_side_stream"):
                 seg.torchnet.wgrad_side_stream = flag
-    set_side_streams(not args.single_stream and not args.no_wgrad_stream)
+    set_side_streams(args.wgrad_stream and not args.single_stream)
+    tr.use_hip_graph = not args.no_graph
 
     def one_step(i):
         lb = [(lab[m][i % nb][0][0], lab[m][i % nb][0][1]) for m in range(S)]
@@ -251,6 +253,7 @@ def main():
     use_events = not args.no_kernel_events and rank == 0
     if use_events:
         set_side_streams(False)
+        tr.use_hip_graph = False      # event records are host calls around each launch
         tr.model_streams = False      # per-kernel durations are taken with one kernel on the device at a time
         _lib.prof_read(reset=True)
         _lib.prof_enable(True)

@@ -133,7 +133,7 @@ class UNet(nn.Module):
         self._drop_state: Optional[torch.Tensor] = None   # int64[1] on the device: Philox offset = calls << 40
         self.dropout_seed = 0x5DEECE66D
         self._debug: Optional[dict] = None   # tools/debug_unet_layers.py stashes backward intermediates here
-        self.wgrad_side_stream = True        # weight gradients on a second HIP stream (see _run_backward)
+        self.wgrad_side_stream = False       # opt-in: weight gradients on a second HIP stream (see _run_backward)
         self._wgrad_stream = None
 
     # ------------------------------------------------------------------------------ weights

@@ -122,6 +122,8 @@ class CoTrainer(Trainer):
         self.batch_lab_unlab = True         # one B_l+B_u pass per batch-independent net (see _run_step_fused)
         self.model_streams = True           # one HIP stream per model in the fused step (see _streams)
         self._stream_pool = None
+        self.use_hip_graph = True           # replay the fused step from a captured HIP graph (trainer/step_graph.py)
+        self._step_graphs = None
         self.last_step = None
 
     def to(self, device: torch.device):
@@ -201,7 +203,13 @@ class CoTrainer(Trainer):
         if unlab_batch is not None and (train_jsd or train_adv):
             unl = (unlab_batch[0].to(self.device), unlab_batch[1].to(self.device) if unlab_batch[1] is not None else None)
         if self._fused_ok():
-            out = self._run_step_fused(lab, unl, train_jsd, train_adv, adv_choice)
+            if self.use_hip_graph and self.grad_sync is None and all(s.torchnet.training for s in self.segmentators):
+                if self._step_graphs is None:
+                    from .step_graph import StepGraphCache
+                    self._step_graphs = StepGraphCache(self)
+                out = self._step_graphs.run(lab, unl, train_jsd, train_adv, adv_choice)
+            else:
+                out = self._run_step_fused(lab, unl, train_jsd, train_adv, adv_choice)
         else:
             out = self._run_step_generic(lab, unl, train_jsd, train_adv, adv_choice)
         self.last_step = out

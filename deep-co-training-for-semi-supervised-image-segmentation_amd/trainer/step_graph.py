@@ -1,0 +1,152 @@
+"""HIP-graph replay of the fused co-training step.
+
+The fused step (CoTrainer._run_step_fused) is a fixed launch sequence for fixed batch shapes: ~340 launches for
+2 x UNet, ~5000 for 2 x Enet, each costing 15-20 us of Python + ctypes on the host -- more than the kernels take
+on an MI355X, so the eager step is launch-bound.  Here the sequence is captured ONCE per step signature into a HIP
+graph (torch.cuda.CUDAGraph == hipGraph on ROCm; the per-model streams fork and join inside the capture) and
+replayed with one launch per step.
+
+What makes the step replayable -- nothing in a launch may depend on a per-step host value:
+  * Adam's bias-correction scalars and step count live on the device (optim.FusedAdam, dct_adam_flat_dev);
+  * the dropout call counter lives on the device (dct_dropout_fwd_dev);
+  * the loss weights lambda_cot / lambda_adv are read from a device tensor (the ``gscale`` argument of the loss
+    backward kernels), refreshed only when a scheduler changes them;
+  * the mini-batches are copied into static input buffers before each replay.
+Host-side counters that the captured Python code advanced once (optimizer step count, dropout calls) are advanced
+by the same amount after every replay.
+
+A signature is captured after WARMUP eager steps (which are ordinary training steps), so lazy initialisation
+(flat buffers, weight packs, kernel attributes) has happened and the capture sees the steady-state sequence.
+Anything that re-allocates the weights, gradients or moments (load_state_dict, .to()) changes the signature and
+leads to a new capture.  Not used under data parallelism (the gradient all-reduce stays an eager RCCL call there).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+
+class _Captured(object):
+    __slots__ = ("graph", "lab", "unl", "out", "counters")
+
+
+class StepGraphCache(object):
+    WARMUP = 2
+    MAX_GRAPHS = 8
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        self._seen: Dict[tuple, int] = {}
+        self._graphs: Dict[tuple, _Captured] = {}
+        self._lam_dev: Optional[torch.Tensor] = None
+        self._lam_host: Tuple[float, float] = (float("nan"), float("nan"))
+        self.replays = 0
+        self.captures = 0
+
+    # ------------------------------------------------------------------------------ signature
+    def _signature(self, lab, unl, train_jsd, train_adv, adv_choice, lam) -> tuple:
+        tr = self.tr
+        sig: List = [bool(train_jsd), bool(train_adv), tuple(adv_choice) if adv_choice is not None else None,
+                     lam[0] != 0.0, lam[1] != 0.0, bool(tr.model_streams), bool(tr.batch_lab_unlab)]
+        for img, gt in lab:
+            sig.append((tuple(img.shape), img.dtype, tuple(gt.shape), gt.dtype))
+        if unl is not None:
+            sig.append((tuple(unl[0].shape), unl[0].dtype))
+        for seg in tr.segmentators:
+            net, opt = seg.torchnet, seg.optimizer
+            fp = net.flat_params
+            sig.append((id(net), net.training, fp.version,
+                        fp.flat.data_ptr() if fp.flat is not None else 0,
+                        fp.gflat.data_ptr() if fp.gflat is not None else 0,
+                        opt._m.data_ptr() if getattr(opt, "_m", None) is not None else 0,
+                        getattr(net, "external_dropout_masks", None) is None,
+                        bool(getattr(net, "record_dropout_masks", False))))
+        return tuple(sig)
+
+    def _lam(self) -> torch.Tensor:
+        tr = self.tr
+        lam = (float(tr.cot_scheduler.value), float(tr.adv_scheduler.value))
+        if self._lam_dev is None or self._lam_dev.device != tr.device:
+            self._lam_dev = torch.tensor(lam, dtype=torch.float32, device=tr.device)
+            self._lam_host = lam
+        elif lam != self._lam_host:              # once per epoch at most: two async fills
+            self._lam_dev[0:1].fill_(lam[0])
+            self._lam_dev[1:2].fill_(lam[1])
+            self._lam_host = lam
+        return self._lam_dev
+
+    def _counters(self):
+        out = []
+        for seg in self.tr.segmentators:
+            out.append((seg.optimizer, "_steps"))
+            if hasattr(seg.torchnet, "_drop_calls"):
+                out.append((seg.torchnet, "_drop_calls"))
+        return out
+
+    # ------------------------------------------------------------------------------ run
+    def run(self, lab, unl, train_jsd, train_adv, adv_choice) -> dict:
+        tr = self.tr
+        lam_dev = self._lam()
+        for seg in tr.segmentators:
+            if hasattr(seg.optimizer, "refresh_lr"):
+                seg.optimizer.refresh_lr()
+        sig = self._signature(lab, unl, train_jsd, train_adv, adv_choice, self._lam_host)
+        cap = self._graphs.get(sig)
+        if cap is None:
+            n = self._seen.get(sig, 0)
+            self._seen[sig] = n + 1
+            if n < self.WARMUP or len(self._graphs) >= self.MAX_GRAPHS:
+                return tr._run_step_fused(lab, unl, train_jsd, train_adv, adv_choice, lam_dev=lam_dev)
+            cap = self._capture(sig, lab, unl, train_jsd, train_adv, adv_choice, lam_dev)
+            if cap is None:
+                return tr._run_step_fused(lab, unl, train_jsd, train_adv, adv_choice, lam_dev=lam_dev)
+            first = True
+        else:
+            first = False
+        for (s_img, s_gt), (img, gt) in zip(cap.lab, lab):
+            s_img.copy_(img, non_blocking=True)
+            s_gt.copy_(gt, non_blocking=True)
+        if cap.unl is not None:
+            cap.unl[0].copy_(unl[0], non_blocking=True)
+        cap.graph.replay()
+        self.replays += 1
+        if not first:                     # the capture pass already advanced the host counters once
+            for (obj, name), d in zip(self._counters(), cap.counters):
+                setattr(obj, name, getattr(obj, name) + d)
+        o = cap.out
+        # the small results are copied out (callers may keep them across steps); the prediction maps are the
+        # graph's static buffers, valid until the next step
+        return dict(sup=[s.clone() for s in o["sup"]],
+                    jsd=o["jsd"].clone() if torch.is_tensor(o["jsd"]) else o["jsd"],
+                    adv=o["adv"].clone() if torch.is_tensor(o["adv"]) else o["adv"],
+                    preds=o["preds"], unlab_probs=o["unlab_probs"])
+
+    def _capture(self, sig, lab, unl, train_jsd, train_adv, adv_choice, lam_dev) -> Optional[_Captured]:
+        tr = self.tr
+        cap = _Captured()
+        cap.lab = [(torch.empty_like(img), torch.empty_like(gt)) for img, gt in lab]
+        cap.unl = (torch.empty_like(unl[0]), None) if unl is not None else None
+        before = [getattr(o, n) for o, n in self._counters()]
+        side = [getattr(seg.torchnet, "wgrad_side_stream", None) for seg in tr.segmentators]
+        for seg in tr.segmentators:          # a fork nested inside a forked stream crashes hipStreamEndCapture (ROCm 7.2)
+            if tr.model_streams and hasattr(seg.torchnet, "wgrad_side_stream"):
+                seg.torchnet.wgrad_side_stream = False
+        torch.cuda.synchronize(tr.device)
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                cap.out = tr._run_step_fused(cap.lab, cap.unl, train_jsd, train_adv, adv_choice, lam_dev=lam_dev)
+        finally:
+            for seg, s in zip(tr.segmentators, side):
+                if s is not None:
+                    seg.torchnet.wgrad_side_stream = s
+        cap.graph = graph
+        cap.counters = [getattr(o, n) - b for (o, n), b in zip(self._counters(), before)]
+        # a re-allocation during the capture (first gradient buffer, moments) would have changed the signature
+        if self._signature(lab, unl, train_jsd, train_adv, adv_choice, self._lam_host) != sig:
+            raise RuntimeError("dct_amd: weights / gradients / Adam moments were (re)allocated while the step was being "
+                               "captured; they would live in the graph's private pool")
+        self._graphs[sig] = cap
+        self.captures += 1
+        return cap

@@ -24,14 +24,16 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--single-stream", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
     cfg = bench.CONFIGS[args.config]
     dev = torch.device("cuda", 0)
     tr, lab, unl = bench.make_trainer(cfg, torch.bfloat16, dev, 0, 1, None)
     tr.model_streams = not args.single_stream
+    tr.use_hip_graph = not args.no_graph
     for seg in tr.segmentators:
         if hasattr(seg.torchnet, "wgrad_side_stream"):
-            seg.torchnet.wgrad_side_stream = not args.single_stream
+            seg.torchnet.wgrad_side_stream = False
     S, nb = cfg["S"], len(unl)
 
     def one_step(i):
