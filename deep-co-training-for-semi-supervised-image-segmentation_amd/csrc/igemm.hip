@@ -246,6 +246,10 @@ __device__ __attribute__((aligned(128))) const uint4 g_zero_page[8] = {};
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) const char* lptr_c;
+__device__ __forceinline__ void rd128(unsigned addr, bf16x8& dst) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); }
+template <int N> __device__ __forceinline__ void lgkm_wait3() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void touch8(bf16x8& r) { asm volatile("" : "+v"(r)); }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool BOUNDS>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmParams p) {
@@ -481,6 +485,206 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 3x3 stride-1 kernel with a shared input halo ("v3").  At 128 x 128 x 64 per K-step the v2 kernel moves
+// 32 KiB from L2 through the CU's vector-memory path into LDS per 2.1 MFLOP = 64 FLOP/B, which is exactly the
+// CU's ratio of MFMA rate (4069 FLOP/clk) to L1 fill rate (64 B/clk): it cannot run much beyond half the MFMA
+// peak however the loop is scheduled.  Nine taps of a 3x3 filter read the SAME input pixels shifted by one, so
+// here a block owns an 8 x 16 patch of output pixels of one image and stages the 10 x 18 input halo of a 64-channel
+// slice ONCE for all nine taps (22.5 KiB per nine K-steps instead of 16 KiB per step); only the weight tile of
+// the tap (BN rows x 128 B) streams every step: (BN * 128 + 2.5 KiB) per step = 113 FLOP/B at BN = 128.
+// A tap's pixel fragment is the same LDS image read at rows (py + r) * 18 + px + s.  Lane l of a 32-pixel
+// fragment holds patch pixel (2 * wm + G(l), I(l)) with (G, I) chosen so that each 16-lane group of a ds_read_b128
+// reads 16 consecutive LDS rows (conflict-free under the row-pair XOR swizzle shared with v2).
+// K order: channel slice outermost, taps inside; weights [cout][tap][cin] as for v2; LDS-staged epilogue as v2,
+// plus read-modify-write for accumulate.
+// ABUFS: halo stages -- 1 when Cin == 64 (a single channel slice: nothing to prefetch), which lets four
+// BN = 64 blocks (or two BN = 128 blocks) share a CU's LDS.
+template <int BN, int NWM, int NWN, int ABUFS>
+__global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, int tiles_x, int tiles_y) {
+  constexpr int NW = NWM * NWN;
+  constexpr int TH = 8, TW = 16, BM = TH * TW, HW = TW + 2, HROWS = (TH + 2) * HW;   // 180 halo rows of 128 B
+  constexpr int APIECES = (HROWS + 7) / 8, A_BYTES = APIECES * 8 * 128;              // 23 pieces, 23552 B
+  constexpr int B_BYTES = BN * 128, BPIECES = BN / 8;
+  constexpr int NPA = (APIECES + NW - 1) / NW, NPB = BPIECES / NW;
+  constexpr int WTN = BN / NWN, TN = WTN / 32;
+  static_assert(NWM == 4 && BPIECES % NW == 0 && TN >= 1, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  char* Abuf = smem;                       // halo stage(s)
+  char* Bbuf = smem + ABUFS * A_BYTES;     // two weight stages
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / NWM, wm = wave % NWM;
+  int bx = blockIdx.x;
+  const int tx = bx % tiles_x; bx /= tiles_x;
+  const int ty = bx % tiles_y; const int img = bx / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * BN;
+  const long long Ktot = 9ll * p.Cin;
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
+
+  // halo staging: wave w issues pieces w, w + NW, ...; lane -> (row = piece * 8 + lane / 8, its swizzled source chunk)
+  long long aoff[NPA];
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    const int piece = wave + i * NW;
+    const int row = piece * 8 + (lane >> 3);
+    aoff[i] = -1;
+    if (piece < APIECES && row < HROWS) {
+      const int hy = row / HW, hx = row - hy * HW;
+      const int iy = y0 - p.pad_h + hy, ix = x0 - p.pad_w + hx;
+      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+        aoff[i] = img * p.xsN + iy * p.xsH + ix * p.xsW + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+    }
+  }
+  auto stageA = [&](char* buf, int c0) {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int piece = wave + i * NW;
+      if (piece < APIECES) {
+        const char* src = aoff[i] >= 0 ? reinterpret_cast<const char*>(xb + aoff[i] + c0) : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + piece * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // weight staging: piece = 8 cout rows
+  const bf16_t* wsrc[NPB];
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int row = (wave + i * NW) * 8 + (lane >> 3);
+    wsrc[i] = reinterpret_cast<const bf16_t*>(p.w) + (long long)(n0 + row) * Ktot + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+  }
+  auto stageB = [&](char* buf, int tap, int c0) {
+    const long long woff = (long long)tap * p.Cin + c0;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + woff), (lptr_t)(buf + (wave + i * NW) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int half = lane >> 5, l31 = lane & 31;
+  // fragment lane -> patch pixel: ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} each get one patch row
+  const int q4 = l31 >> 2;                                     // 0..7
+  const int grp = (q4 == 1 || q4 == 2 || q4 == 4 || q4 == 7) ? 1 : 0;
+  const int idx = grp ? (q4 == 1 ? l31 - 4 : q4 == 2 ? l31 - 4 : q4 == 4 ? l31 - 8 : l31 - 16)
+                      : (q4 == 0 ? l31 : q4 == 3 ? l31 - 8 : l31 - 12);
+  const int prow = 2 * wm + grp, pcol = idx;                   // pixel within the 8 x 16 patch
+  const int rho0 = prow * HW + pcol;
+  const int aswz = (l31 >> 1) & 7;
+
+  const int nch = p.Cin / 64;
+  const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
+  stageA(Abuf, 0);
+  stageB(Bbuf, 0, 0);
+  __syncthreads();
+  int ab = 0, bb = 0;
+  for (int c = 0; c < nch; ++c) {
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
+      else if (c + 1 < nch) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
+      if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
+      const int r = t / 3, s = t - 3 * r;
+      const int rho = rho0 + r * HW + s;
+      const int pswz = (rho >> 1) & 7;
+      // Fragment reads are inline asm with counted waits: the reads of sub-step kk + 1 are issued first, then the
+      // wave waits only for the (older) reads of sub-step kk.  Left to the compiler the loads sink between the MFMAs
+      // behind an lgkmcnt(0) and every sub-step exposes a full LDS round trip.
+      const unsigned Wl = smem_l + ABUFS * A_BYTES + bb * B_BYTES + (wn * WTN + l31) * 128 + ((half ^ aswz) * 16);
+      const unsigned Xl = smem_l + ab * A_BYTES + rho * 128 + ((half ^ pswz) * 16);
+      bf16x8 a[2][TN], b[2];
+      auto issue = [&](int set, int kk) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) rd128((Wl + i * 32 * 128) ^ (kk * 32), a[set][i]);
+        rd128(Xl ^ (kk * 32), b[set]);
+      };
+      issue(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int set = kk & 1;
+        if (kk + 1 < 4) { issue(set ^ 1, kk + 1); lgkm_wait3<TN + 1>(); } else { lgkm_wait3<0>(); }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) touch8(a[set][i]);
+        touch8(b[set]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][i], b[set], acc[i], 0, 0, 0);
+      }
+      __syncthreads();
+      bb ^= 1;
+    }
+    ab ^= 1;
+  }
+
+  // ---- epilogue (staged through LDS as in v2): tile row = patch pixel py * 16 + px
+  constexpr int CPR = BN / 8;
+  static_assert(BM * BN * 2 <= ABUFS * A_BYTES + (BN * 128 * 2 - BM * 8), "epilogue tile does not fit");
+  char* tile = smem;                                   // BM * BN * 2 bytes: the halo stage(s) and, if needed, the head of the weight stages
+  int* rowY = reinterpret_cast<int*>(smem + ABUFS * A_BYTES + 2 * B_BYTES - BM * 8);   // tail of the weight stages
+  int* rowM = rowY + BM;
+  if (tid < BM) {
+    const int oy = y0 + (tid >> 4), ox = x0 + (tid & 15);
+    int oy_ = -1, om_ = -1;
+    if (oy < p.Ho && ox < p.Wo) {
+      oy_ = (int)(img * p.ysN + oy * p.ysH + ox * p.ysW);
+      om_ = (int)(img * p.msN + oy * p.msH + ox * p.msW);
+    }
+    rowY[tid] = oy_; rowM[tid] = om_;
+  }
+  {
+    const int row = prow * TW + pcol;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cl = wn * WTN + i * 32 + 8 * q + 4 * half;
+        float v[4] = {acc[i][4 * q + 0], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += p.bias[n0 + cl + e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+        const int chunk = (cl >> 3) ^ (row & (CPR - 1));
+        *reinterpret_cast<bf16x4*>(tile + row * (BN * 2) + chunk * 16 + (cl & 4) * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NCH = BM * CPR / (NW * 64);
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    const int id = t * (NW * 64) + tid;
+    const int row = id / CPR, cc = id % CPR;
+    const int yo = rowY[row];
+    if (yo < 0) continue;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
+    const int co = n0 + cc * 8;
+    if (p.mask && co < p.mask_channels) {
+      const bf16x8 mk = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
+    }
+    bf16x8* dst = reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo + co);
+    if (p.accumulate) {
+      const bf16x8 old = *dst;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
+    }
+    *dst = v;
+  }
+}
+
 // Sum split-K partial slabs and apply the epilogue.  One thread per (pixel, 4 channels).
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmParams p, int splits) {
@@ -513,6 +717,8 @@ int g_tune_igemm_split = -1;    // >= 1 forces the split-K factor
 int g_tune_igemm_waves8 = 1;    // 8 waves per tile (32 pixels x 64 channels each) instead of 4: an LDS-DMA piece costs ~100 issue
                                 // cycles, so halving the pieces per wave shortens every K-step (+4..15 % in-process A/B)
 int g_tune_igemm_staged = 1;    // 0: scattered 8-byte epilogue stores instead of the LDS-staged epilogue
+int g_tune_igemm_halo_min_blocks = 400;
+int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3_kernel); 0: always v2
 
 static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int M, int N, Plan& pl) {
   const int bk0 = dtype == DCT_BF16 ? 32 : 16;
@@ -567,6 +773,19 @@ static void launch_v2(const IgemmParams& p, dim3 grid, hipStream_t st) {
     attr_set = true;
   }
   DCT_LAUNCH(DCT_PROF_IGEMM, (igemm2_kernel<BM, BN, WM, WN, BOUNDS>), grid, dim3(WM * WN * 64), lds, st, p);
+}
+
+template <int BN, int NWN, int ABUFS>
+static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images, hipStream_t st) {
+  constexpr size_t lds = ABUFS * (size_t)(23 * 1024) + 2 * (size_t)BN * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3_kernel<BN, 4, NWN, ABUFS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(images * tiles_y * tiles_x), p.N / BN, 1);
+  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3_kernel<BN, 4, NWN, ABUFS>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
 }
 
 template <typename T>
@@ -670,6 +889,25 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     p.partial = (float*)workspace;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (pl.v2 && pl.splits == 1 && g_tune_igemm_halo && g_tune_igemm_staged && d->R == 3 && d->S == 3 && d->stride == 1 &&
+      d->dil == 1 && !p.scatter) {
+    // shared-halo kernel: 8 x 16 output patches; worth it when the patches cover the image well and fill the device
+    const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
+                     (long long)y->n * y->sn < (1ll << 31);
+    const bool m16 = !mask || (!((uintptr_t)mask->ptr & 15) && mask->sw % 8 == 0 && mask->sh % 8 == 0 && mask->sn % 8 == 0 &&
+                               p.mask_channels % 8 == 0 && (long long)mask->n * mask->sn < (1ll << 31));
+    const int tiles_y = (p.Ho + 7) / 8, tiles_x = (p.Wo + 15) / 16;
+    const int bn = p.N % 128 == 0 ? 128 : 64;
+    const long long blocks = (long long)y->n * tiles_y * tiles_x * (p.N / bn);
+    const double cover = (double)p.Ho * p.Wo / ((double)tiles_y * 8 * tiles_x * 16);
+    // measured (tools/bench_conv.py --ab): the 64-channel tile only pays with a single channel slice (four blocks per CU)
+    if (y16 && m16 && cover >= 0.75 && blocks >= g_tune_igemm_halo_min_blocks && (bn == 128 || x->c == 64)) {
+      if (bn == 128) {
+        if (x->c == 64) launch_v3<128, 2, 1>(p, tiles_x, tiles_y, y->n, st); else launch_v3<128, 2, 2>(p, tiles_x, tiles_y, y->n, st);
+      } else launch_v3<64, 1, 1>(p, tiles_x, tiles_y, y->n, st);
+      return dct_check_launch();
+    }
+  }
   return dtype == DCT_BF16 ? launch<bf16_t>(p, pl, st) : launch<float>(p, pl, st);
 }
 
@@ -681,6 +919,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_SPLIT: g_tune_igemm_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_STAGED: g_tune_igemm_staged = value; return DCT_OK;
     case DCT_TUNE_IGEMM_WAVES8: g_tune_igemm_waves8 = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_HALO: g_tune_igemm_halo = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }
 }

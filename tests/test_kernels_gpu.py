@@ -100,6 +100,52 @@ def test_conv2d_epilogue_mask_accumulate_views(ops, dtype):
     close(to_cpu(yd), ref, dtype, "conv2d mask/accumulate/views")
 
 
+# shared-halo 3x3 kernel (igemm3_kernel): taken for bf16 3x3 stride-1 layers whose 8 x 16 output patches cover the
+# image well and fill the device; checked against F.conv2d and, bit for bit where both round once, against the
+# per-tap kernel (dct_tune_set(DCT_TUNE_IGEMM_HALO, 0)).
+@pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [
+    (4, 64, 130, 130, 128, 0),      # exact patch cover, Cout tile 128, one channel slice (single halo stage)
+    (4, 64, 101, 117, 64, 0),       # ragged patches at the right / bottom edge, Cout tile 64 (four blocks per CU)
+    (4, 64, 100, 116, 64, 2),       # the same tile in data-gradient form
+    (5, 128, 122, 90, 128, 2),      # data-gradient form: pad 2, halo outside the image reads the zero page; two slices
+    (3, 192, 96, 96, 256, 0),       # three channel slices, two Cout tiles
+])
+def test_conv2d_3x3_shared_halo(ops, B, Cin, H, W, Cout, pad):
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9), dtype)
+    b = torch.randn(Cout, generator=g)
+    conv = F.conv2d(x, w, b, padding=pad)
+    Ho, Wo = conv.shape[2], conv.shape[3]
+    xd, wd, bd = to_dev(x, dtype), kmajor(w, dtype), b.to(DEV)
+    y = torch.empty(B, Ho, Wo, Cout, dtype=dtype, device=DEV)
+    ops.conv2d(xd, wd, bd, y, pad_h=pad, pad_w=pad, relu=True)
+    close(to_cpu(y), F.relu(conv), dtype, "halo conv fwd")
+    lib = _lib.load()
+    lib.dct_tune_set(7, 0)
+    try:
+        y2 = torch.empty_like(y)
+        ops.conv2d(xd, wd, bd, y2, pad_h=pad, pad_w=pad, relu=True)
+    finally:
+        lib.dct_tune_set(7, 1)
+    # same products, different K order (slice-major vs tap-major): fp32 accumulation differs in the last bits only
+    assert (y.float() - y2.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, y2.float().abs().max().item())
+    # mask (ReLU gate of the destination) + channel-slice views + accumulate
+    maskt = q(torch.randn(B, Cout, Ho, Wo, generator=g), dtype)
+    old = q(torch.randn(B, Cout + 64, Ho, Wo, generator=g), dtype)
+    plain = F.conv2d(x, w, padding=pad)
+    masked = plain.clone()
+    masked[:, :64] = torch.where(maskt[:, :64] > 0, plain[:, :64] * 2.0, torch.zeros(()))
+    ref = old.clone()
+    ref[:, :Cout] += masked
+    yd = to_dev(old, dtype)
+    ops.conv2d(xd, wd, None, yd[..., :Cout], pad_h=pad, pad_w=pad, mask=to_dev(maskt, dtype), mask_channels=64,
+               mask_scale=2.0, accumulate=True)
+    close(to_cpu(yd), ref, dtype, "halo conv mask/accumulate/views")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 128, 10, 9, 64), (1, 1024, 9, 9, 512)])
 def test_convT2x2_fwd_scatter(ops, dtype, B, Cin, H, W, Cout):

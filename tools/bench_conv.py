@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--only", default="", help="comma-separated layer names")
-    ap.add_argument("--ab", action="store_true", help="also run with the register-staged igemm kernel")
+    ap.add_argument("--ab", action="store_true", help="A/B the shared-halo 3x3 kernel against the per-tap kernel, interleaved in one process")
     args = ap.parse_args()
     what = args.what.split(",")
     lib = _lib.load()
@@ -120,11 +120,10 @@ def main():
     run(args.batch, args.reps, what, "default", only)
     if args.ab:
         for rnd in range(2):       # interleaved rounds in ONE process (devices / DVFS differ between runs)
-            lib.dct_tune_set(5, 0)
-            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: 4 waves per 128x128 tile", only)
-            lib.dct_tune_set(5, 1)
-            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: 8 waves per 128x128 tile", only)
-        lib.dct_tune_set(5, 0)
+            lib.dct_tune_set(7, 0)
+            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: per-tap kernel (v2) everywhere", only)
+            lib.dct_tune_set(7, 1)
+            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: shared-halo kernel (v3) where eligible", only)
 
 if __name__ == "__main__":
     main()
