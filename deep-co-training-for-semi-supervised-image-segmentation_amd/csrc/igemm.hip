@@ -244,6 +244,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 // (their results are never stored).
 __device__ __attribute__((aligned(128))) const uint4 g_zero_page[8] = {};
 
+#ifdef DCT_STAMPS
+#define DCT_STAMP_WAVES 65536
+__device__ unsigned long long* g_stamp_buf = nullptr;   // diagnostic build only (make EXTRA=-DDCT_STAMPS): per-phase cycle sums
+#endif
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((address_space(3))) const char* lptr_c;
@@ -381,6 +385,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
     rowY[tid] = oy_; rowM[tid] = om_;
   }
 
+    // all bias vectors in ONE batch of loads (a load + wait per use costs a memory round trip each)
+    f32x4 bv[TN][4];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int co = n0 + wn * WTN + i * 32 + 8 * q + 4 * half;
+          if (p.scatter) co %= p.cout;
+          bv[i][q] = *reinterpret_cast<const f32x4*>(p.bias + co);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int row = wm * WTM + j * 32 + l31;
@@ -389,13 +409,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int cl = wn * WTN + i * 32 + 8 * q + 4 * half;       // channel within the tile
-          float v[4] = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-          if (p.bias) {
-            int co = n0 + cl;
-            if (p.scatter) co %= p.cout;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += p.bias[co + e];
-          }
+          float v[4] = {acc[i][j][4 * q + 0] + bv[i][q][0], acc[i][j][4 * q + 1] + bv[i][q][1],
+                        acc[i][j][4 * q + 2] + bv[i][q][2], acc[i][j][4 * q + 3] + bv[i][q][3]};
           if (p.relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -410,13 +425,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
     }
     __syncthreads();
     constexpr int NCH = BM * CPR / (NW * 64);    // chunks per thread
+    // the mask loads of all NCH chunks go out together (one memory round trip instead of NCH), then the stores
+    long long yoff[NCH];
+    bf16x8 mk[NCH];
+    bool use_mask[NCH];
 #pragma unroll
     for (int t = 0; t < NCH; ++t) {
       const int id = t * (NW * 64) + tid;
       const int row = id / CPR, cc = id % CPR;
       const int yo = rowY[row];
+      yoff[t] = -1;
+      use_mask[t] = false;
       if (yo < 0) continue;
-      bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
       int c = n0 + cc * 8, co = c;
       long long off = yo;
       long long moff = rowM[row];
@@ -426,12 +446,23 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
         off += (ab >> 1) * p.ysH + (ab & 1) * p.ysW;
         moff += (ab >> 1) * p.msH + (ab & 1) * p.msW;
       }
+      yoff[t] = off + co;
       if (p.mask && co < p.mask_channels) {
-        const bf16x8 mk = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + moff + co);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
+        use_mask[t] = true;
+        mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + moff + co);
       }
-      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + off + co) = v;
+    }
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+      if (yoff[t] < 0) continue;
+      const int id = t * (NW * 64) + tid;
+      const int row = id / CPR, cc = id % CPR;
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
+      if (use_mask[t]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yoff[t]) = v;
     }
     return;
   }
@@ -579,16 +610,28 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
 
   const int nch = p.Cin / 64;
   const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
+#ifdef DCT_STAMPS
+  unsigned long long st_issue = 0, st_comp = 0, st_vm = 0, st_bar = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_pro;
+#endif
   stageA(Abuf, 0);
   stageB(Bbuf, 0, 0);
   __syncthreads();
+#ifdef DCT_STAMPS
+  st_pro = __builtin_amdgcn_s_memtime() - st_t0;
+#endif
   int ab = 0, bb = 0;
   for (int c = 0; c < nch; ++c) {
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {
+#ifdef DCT_STAMPS
+      const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#endif
       if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
       else if (c + 1 < nch) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
       if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
+#ifdef DCT_STAMPS
+      const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+#endif
       const int r = t / 3, s = t - 3 * r;
       const int rho = rho0 + r * HW + s;
       const int pswz = (rho >> 1) & 7;
@@ -615,12 +658,24 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
 #pragma unroll
         for (int i = 0; i < TN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][i], b[set], acc[i], 0, 0, 0);
       }
+#ifdef DCT_STAMPS
+      const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long s3 = __builtin_amdgcn_s_memtime();
       __syncthreads();
+      const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+      st_issue += s1 - s0; st_comp += s2 - s1; st_vm += s3 - s2; st_bar += s4 - s3;
+#else
+      __syncthreads();
+#endif
       bb ^= 1;
     }
     ab ^= 1;
   }
 
+#ifdef DCT_STAMPS
+  const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue (staged through LDS as in v2): tile row = patch pixel py * 16 + px
   constexpr int CPR = BN / 8;
   static_assert(BM * BN * 2 <= ABUFS * A_BYTES + (BN * 128 * 2 - BM * 8), "epilogue tile does not fit");
@@ -636,18 +691,31 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
     }
     rowY[tid] = oy_; rowM[tid] = om_;
   }
+#ifdef DCT_STAMPS
+  const unsigned long long e0 = __builtin_amdgcn_s_memtime();
+#endif
   {
     const int row = prow * TW + pcol;
+    // all bias vectors in ONE batch of loads (a load + wait per use costs a memory round trip each: 8 x ~450 cycles)
+    f32x4 bv[TN][4];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          bv[i][q] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WTN + i * 32 + 8 * q + 4 * half);
+    }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int cl = wn * WTN + i * 32 + 8 * q + 4 * half;
-        float v[4] = {acc[i][4 * q + 0], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += p.bias[n0 + cl + e];
-        }
+        float v[4] = {acc[i][4 * q + 0] + bv[i][q][0], acc[i][4 * q + 1] + bv[i][q][1], acc[i][4 * q + 2] + bv[i][q][2],
+                      acc[i][4 * q + 3] + bv[i][q][3]};
         if (p.relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -660,29 +728,56 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
       }
     }
   }
+#ifdef DCT_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long e1 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
+#ifdef DCT_STAMPS
+  const unsigned long long e2 = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int NCH = BM * CPR / (NW * 64);
+  // the mask / old-value loads of all NCH chunks go out together, then the stores
+  int yo[NCH];
+  bf16x8 mk[NCH], old[NCH];
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    const int id = t * (NW * 64) + tid;
+    const int row = id / CPR, co = n0 + (id % CPR) * 8;
+    yo[t] = rowY[row];
+    if (yo[t] >= 0) {
+      if (p.mask && co < p.mask_channels) mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
+      if (p.accumulate) old[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.y) + yo[t] + co);
+    }
+  }
 #pragma unroll
   for (int t = 0; t < NCH; ++t) {
     const int id = t * (NW * 64) + tid;
     const int row = id / CPR, cc = id % CPR;
-    const int yo = rowY[row];
-    if (yo < 0) continue;
+    if (yo[t] < 0) continue;
     bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
     const int co = n0 + cc * 8;
     if (p.mask && co < p.mask_channels) {
-      const bf16x8 mk = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
+      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
     }
-    bf16x8* dst = reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo + co);
     if (p.accumulate) {
-      const bf16x8 old = *dst;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
     }
-    *dst = v;
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
   }
+#ifdef DCT_STAMPS
+  if (lane == 0 && g_stamp_buf) {
+    const unsigned long long st_end = __builtin_amdgcn_s_memtime();
+    // one 16-counter record per wave (no atomics: a same-address atomic storm stalls the very loads being timed)
+    const unsigned long long wid = ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave;
+    unsigned long long* o = g_stamp_buf + (wid % DCT_STAMP_WAVES) * 16;
+    o[0] += 1ull; o[1] += st_pro; o[2] += st_issue; o[3] += st_comp; o[4] += st_vm; o[5] += st_bar;
+    o[6] += st_end - st_loop_end; o[7] += st_end - st_t0; o[8] += (unsigned long long)(nch * 9);
+    o[9] += e0 - st_loop_end; o[10] += e1 - e0; o[11] += e2 - e1; o[12] += st_end - e2;
+  }
+#endif
 }
 
 // Sum split-K partial slabs and apply the epilogue.  One thread per (pixel, 4 channels).
@@ -881,7 +976,8 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
                      (long long)y->n * y->sn < (1ll << 31);
     const bool m16 = !mask || (!((uintptr_t)mask->ptr & 15) && mask->sw % 8 == 0 && mask->sh % 8 == 0 && mask->sn % 8 == 0 &&
                                p.mask_channels % 8 == 0 && (long long)mask->n * mask->sn < (1ll << 31));
-    p.staged = (y16 && m16) ? 1 : 0;
+    const bool b16 = !bias || !((uintptr_t)bias & 15);      // the staged epilogues read the bias as float4
+    p.staged = (y16 && m16 && b16) ? 1 : 0;
   }
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * p.M * p.N * sizeof(float);
@@ -889,7 +985,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     p.partial = (float*)workspace;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (pl.v2 && pl.splits == 1 && g_tune_igemm_halo && g_tune_igemm_staged && d->R == 3 && d->S == 3 && d->stride == 1 &&
+  if (pl.v2 && pl.splits == 1 && g_tune_igemm_halo && g_tune_igemm_staged && (!bias || !((uintptr_t)bias & 15)) && d->R == 3 && d->S == 3 && d->stride == 1 &&
       d->dil == 1 && !p.scatter) {
     // shared-halo kernel: 8 x 16 output patches; worth it when the patches cover the image well and fill the device
     const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
@@ -910,6 +1006,30 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   }
   return dtype == DCT_BF16 ? launch<bf16_t>(p, pl, st) : launch<float>(p, pl, st);
 }
+
+#ifdef DCT_STAMPS
+// diagnostic build only: read (summed over the per-wave records) / zero the 16 per-phase counters of igemm3_kernel
+extern "C" int dct_debug_stamps(unsigned long long* out16, int reset) {
+  static unsigned long long* dev = nullptr;
+  const size_t bytes = (size_t)DCT_STAMP_WAVES * 16 * sizeof(unsigned long long);
+  if (!dev) {
+    if (hipMalloc(&dev, bytes) != hipSuccess) return DCT_ERR_LAUNCH;
+    (void)hipMemset(dev, 0, bytes);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dev, sizeof(dev));
+  }
+  (void)hipDeviceSynchronize();
+  if (out16) {
+    unsigned long long* host = (unsigned long long*)malloc(bytes);
+    (void)hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
+    for (int k = 0; k < 16; ++k) out16[k] = 0;
+    for (size_t w = 0; w < DCT_STAMP_WAVES; ++w)
+      for (int k = 0; k < 16; ++k) out16[k] += host[w * 16 + k];
+    free(host);
+  }
+  if (reset) (void)hipMemset(dev, 0, bytes);
+  return DCT_OK;
+}
+#endif
 
 int dct_tune_set_wgrad(int knob, int value);  // wgrad.hip
 
