@@ -477,6 +477,242 @@ __global__ __launch_bounds__(NW * 64) void wgrad2_kernel(Wgrad2Params pr) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 3x3 stride-1 kernel that shares pixels between taps ("v3").  Per 64-pixel step the v2 tile moves
+// 64 x (BP + BQ) x 2 bytes from L2 into LDS for ONE tap: 64 FLOP/B at 128 x 128 and 32 FLOP/B at 64 x 64, at or
+// below the CU's ratio of MFMA rate to L1 fill rate (64 FLOP/B) -- the 64-channel layers ran at 300 TFLOP/s.
+// Here a block owns one filter ROW r and computes its three taps s = 0..2 together: a K-step is a run of up to
+// 64 dy pixels of one image row; the x strip of that run is staged once with two extra pixels (66 rows) and tap s
+// reads it shifted by s rows.  (8 + 8.25) KiB per 3 x 0.52 MFLOP = 95 FLOP/B at 64 x 64, 185 FLOP/B at 128 x 128.
+// LDS rows are pixels in natural order; the 64-B column group of pixel row k is XORed with a function of k that
+// is invariant under k += 4 and takes four different values on any four consecutive rows, so the transposing reads
+// stay conflict-free for every shift.  Staging needs no per-pixel decode: (image, row, run) advance incrementally
+// and a lane's source address is the run's base plus a constant.
+struct Wgrad3Params {
+  WgradParams w;
+  int segs_per_row, nseg, seg_per_chunk;
+  int direct, accumulate, with_bias;
+  float* bias;
+  long long slab_stride;
+};
+
+template <int RB> __device__ __forceinline__ int swz3(int k) {       // in 16-B chunks
+  return RB == 256 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2);
+}
+
+template <int BP, int BQ, int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
+  const WgradParams& p = pr.w;
+  constexpr int RBP = BP * 2, RBQ = BQ * 2;
+  constexpr int CPRP = RBP / 16, CPRQ = RBQ / 16, RPIP = 64 / CPRP, RPIQ = 64 / CPRQ;
+  constexpr int QROWS = 72;                                         // 64 + 2 halo pixels, rounded up to whole pieces
+  constexpr int NPCP = 64 / RPIP, NPCQ = QROWS / RPIQ, NPC = NPCP + NPCQ;
+  constexpr int NPW = (NPC + NW - 1) / NW;                          // pieces per wave per stage
+  constexpr int WPR = BP / (NW / 2), TP = WPR / 32, TQ = BQ / 64;
+  constexpr int STAGE = 64 * RBP + QROWS * RBQ;
+  static_assert(TP >= 1 && TQ >= 1, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp = wave >> 1, wq = wave & 1;
+
+  const int tiles_per_chunk = p.ptiles * 3 * p.qtiles;
+  int chunk, tile;
+  {
+    const int bid = blockIdx.x;
+    if (p.chunks >= 8) { const int xcd = bid & 7, slot = bid >> 3; chunk = (slot / tiles_per_chunk) * 8 + xcd; tile = slot % tiles_per_chunk; }
+    else { chunk = bid / tiles_per_chunk; tile = bid - chunk * tiles_per_chunk; }
+    if (chunk >= p.chunks) return;
+  }
+  const int qt = tile % p.qtiles; tile /= p.qtiles;
+  const int tr = tile % 3;
+  const int pt = tile / 3;
+  const int p0 = pt * BP, q0 = qt * BQ;
+  const int gbeg = chunk * pr.seg_per_chunk, gend = min(pr.nseg, gbeg + pr.seg_per_chunk);
+
+  const char* Pb = p.P + (long long)p0 * 2;
+  const char* Qb = p.Q + (long long)q0 * 2;
+  const char* zero = reinterpret_cast<const char*>(g_wzero_page) + (lane & 7) * 16;
+  const int psW = (int)p.psW, qsW = (int)p.qsW;
+
+  // per-lane staging constants: piece (wave + i * NW) is a dy piece (8 or 4 pixel rows) or an x piece
+  int krow[NPW], loff[NPW], ldst[NPW];
+  bool isP[NPW], live[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int piece = wave + i * NW;
+    live[i] = piece < NPC;
+    isP[i] = piece < NPCP;
+    if (isP[i]) {
+      const int k = piece * RPIP + lane / CPRP;
+      krow[i] = k;
+      loff[i] = k * psW * 2 + (((lane % CPRP) ^ swz3<RBP>(k)) * 16);
+      ldst[i] = piece * 1024;
+    } else {
+      const int k = (piece - NPCP) * RPIQ + lane / CPRQ;
+      krow[i] = k;
+      loff[i] = k * qsW * 2 + (((lane % CPRQ) ^ swz3<RBQ>(k)) * 16);
+      ldst[i] = 64 * RBP + (piece - NPCP) * 1024;
+    }
+  }
+  // run (image n, row y, run xs) of the first segment; then incremental
+  int n, y, xs;
+  {
+    const int rows = gbeg / pr.segs_per_row;
+    xs = gbeg - rows * pr.segs_per_row;
+    n = rows / p.Hp;
+    y = rows - n * p.Hp;
+  }
+  // A stage is issued piece by piece (stage_begin fixes the run, stage_piece(i) issues this wave's i-th piece) so that
+  // the main loop can spread the LDS-DMA issue stalls between the MFMA groups of a step.
+  int s_len = 0; bool s_rowok = false; int s_x0 = 0;
+  long long s_baseP = 0, s_baseQ = 0;
+  auto stage_begin = [&]() {
+    s_x0 = xs * 64;
+    s_len = min(64, p.Wp - s_x0);
+    const int iy = y + tr - p.pad_h;
+    s_rowok = (unsigned)iy < (unsigned)p.Hq;
+    s_baseP = ((long long)n * p.psN + (long long)y * p.psH + (long long)s_x0 * p.psW) * 2;
+    s_baseQ = ((long long)n * p.qsN + (long long)iy * p.qsH + (long long)(s_x0 - p.pad_w) * p.qsW) * 2;
+    if (++xs == pr.segs_per_row) { xs = 0; if (++y == p.Hp) { y = 0; ++n; } }
+  };
+  auto stage_piece = [&](char* buf, int i) {
+    if (!live[i]) return;
+    const char* src;
+    if (isP[i]) src = krow[i] < s_len ? Pb + s_baseP + loff[i] : zero;
+    else {
+      const int ix = s_x0 - p.pad_w + krow[i];
+      src = (s_rowok && krow[i] < s_len + 2 && (unsigned)ix < (unsigned)p.Wq) ? Qb + s_baseQ + loff[i] : zero;
+    }
+    __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(buf + ldst[i]), 16, 0, 0);
+  };
+  auto stage = [&](char* buf) {
+    stage_begin();
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) stage_piece(buf, i);
+  };
+
+  f32x16 acc[3][TP][TQ];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+      for (int j = 0; j < TQ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[s][i][j][e] = 0.f;
+
+  if (gbeg < gend) stage(smem);
+  __syncthreads();
+  int cur = 0;
+  int pbase[TP], qbase[3][TQ];
+  {
+    const int g = lane >> 4, li = lane & 15, lq = li >> 2, lpp = li & 3, lh = g >> 1;
+    const int kq0 = 8 * lh + lq;
+#pragma unroll
+    for (int i = 0; i < TP; ++i) {
+      const int colb = (wp * WPR + i * 32 + 16 * (g & 1) + 4 * lpp) * 2;
+      pbase[i] = kq0 * RBP + (colb ^ (swz3<RBP>(kq0) << 4));
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) {
+        const int colb = (wq * (BQ / 2) + j * 32 + 16 * (g & 1) + 4 * lpp) * 2;
+        qbase[s][j] = 64 * RBP + (kq0 + s) * RBQ + (colb ^ (swz3<RBQ>(kq0 + s) << 4));
+      }
+  }
+  constexpr int P_KK = 16 * RBP, P_HI = 4 * RBP, Q_KK = 16 * RBQ, Q_HI = 4 * RBQ;
+  constexpr int NRD = 2 * (TP + 3 * TQ);
+  const unsigned smem_off = lds_off(smem);
+  const bool do_bias = pr.with_bias && tr == 0 && qt == 0 && wq == 0;
+  f32x16 accb[TP];
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+
+  for (int gi = gbeg; gi < gend; ++gi) {
+    if (gi + 1 < gend) stage(smem + (cur ^ 1) * STAGE);     // all pieces up front: spreading them between the MFMA groups lands the stage later and was 8 % slower
+    const unsigned Pl = smem_off + cur * STAGE;
+    bf16x4 fa[2][TP][2], fb[2][3][TQ][2];
+    auto issue = [&](int set, int kk) {
+#pragma unroll
+      for (int i = 0; i < TP; ++i) {
+        tr_issue(Pl + pbase[i] + kk * P_KK, fa[set][i][0]);
+        tr_issue(Pl + pbase[i] + kk * P_KK + P_HI, fa[set][i][1]);
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+          tr_issue(Pl + qbase[s][j] + kk * Q_KK, fb[set][s][j][0]);
+          tr_issue(Pl + qbase[s][j] + kk * Q_KK + Q_HI, fb[set][s][j][1]);
+        }
+    };
+    issue(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int set = kk & 1;
+      if (kk + 1 < 4) { issue(set ^ 1, kk + 1); lgkm_wait<NRD>(); } else { lgkm_wait<0>(); }
+#pragma unroll
+      for (int i = 0; i < TP; ++i) { touch(fa[set][i][0]); touch(fa[set][i][1]); }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) { touch(fb[set][s][j][0]); touch(fb[set][s][j][1]); }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 a[TP];
+#pragma unroll
+      for (int i = 0; i < TP; ++i) a[i] = join(fa[set][i][0], fa[set][i][1]);
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+          const bf16x8 b = join(fb[set][s][j][0], fb[set][s][j][1]);
+#pragma unroll
+          for (int i = 0; i < TP; ++i) acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[s][i][j], 0, 0, 0);
+        }
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < TP; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, accb[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const int half = lane >> 5, l31 = lane & 31;
+  float* base = pr.direct ? p.out : p.out + (long long)chunk * pr.slab_stride;
+  if (do_bias && l31 == 0) {
+    float* bb = pr.direct ? pr.bias : base + (long long)p.Cp * 9 * p.Cq;
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int prow = p0 + wp * WPR + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (pr.direct && pr.accumulate) bb[prow] += accb[i][e]; else bb[prow] = accb[i][e];
+      }
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) {
+        const int qc = q0 + wq * (BQ / 2) + j * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int prow = p0 + wp * WPR + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          float* dst = base + ((long long)prow * 9 + (tr * 3 + s)) * p.Cq + qc;
+          if (pr.direct && pr.accumulate) *dst += acc[s][i][j][e]; else *dst = acc[s][i][j][e];
+        }
+      }
+}
+
 // out[i] (=|+=) sum_slab partial[slab][i] for the n4w float4s of the weight gradient and, behind them in every
 // slab, the n4b float4s of the bias gradient.  Fixed order (four interleaved partial sums: loads in flight).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dw, float* db, long long n4w, long long n4b,
@@ -497,8 +733,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
   *outp = (s0 + s1) + (s2 + s3);
 }
 
-struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct, slabs; };
+struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct, slabs; int v3, segs_per_row, nseg, seg_per_chunk; };
 
+int g_tune_wgrad_rows = 1;     // 3x3 stride-1 layers on wide images: three taps of a filter row per block (wgrad3_kernel)
 int g_tune_wgrad_v2 = 1;       // dct_tune_set(DCT_TUNE_WGRAD_V2, 0): register-staged kernel
 int g_tune_wgrad_chunks = -1;  // >= 1 forces the number of pixel chunks
 
@@ -535,6 +772,31 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
   pl.chunks = (int)((M + ppc - 1) / ppc);
   pl.slabs = pl.chunks;
   pl.direct = (pl.v2 && pl.chunks == 1) ? 1 : 0;
+  pl.v3 = 0;
+  if (pl.v2 && g_tune_wgrad_rows && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil == 1 && p->w >= 48) {
+    // K-steps are runs of <= 64 pixels of one dy row: worth it when the runs are mostly full
+    const int segs = (p->w + 63) / 64;
+    if ((double)p->w / (segs * 64.0) >= 0.85) {
+      const long long nseg = (long long)p->n * p->h * segs;
+      // measured (tools/bench_conv.py --ab-wgrad): 64 x 64 tiles (4 waves, three blocks per CU) beat 128 x 64 and
+      // 128 x 128 (one 8-wave block per CU at 130 / 205 VGPRs) on every eligible layer, by 20-35 %
+      pl.bp = 64; pl.ptiles = p->c / 64; pl.bq = 64; pl.qtiles = q->c / 64;
+      const int tiles3 = pl.ptiles * pl.qtiles * 3;
+      const int target = 768;                                              // blocks: three per CU
+      long long ch = (target + tiles3 / 2) / tiles3;
+      if (ch > 256) ch = 256;
+      if (ch > nseg / 4) ch = nseg / 4;
+      while (ch > 1 && ch * per_chunk > (192ll << 20)) --ch;
+      if (g_tune_wgrad_chunks >= 1) ch = g_tune_wgrad_chunks;
+      if (ch < 1) ch = 1;
+      const long long spc = (nseg + ch - 1) / ch;
+      pl.v3 = 1;
+      pl.segs_per_row = segs; pl.nseg = (int)nseg; pl.seg_per_chunk = (int)spc;
+      pl.chunks = (int)((nseg + spc - 1) / spc);
+      pl.slabs = pl.chunks;
+      pl.direct = pl.chunks == 1 ? 1 : 0;
+    }
+  }
   return true;
 }
 
@@ -563,6 +825,21 @@ static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
     attr_set = true;
   }
   DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ, NW>), dim3(grid), dim3(NW * 64), lds, st, pr);
+}
+template <int BP, int BQ, int NW>
+static void launch_w3_t(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
+  constexpr size_t lds = 2 * (64 * (size_t)BP * 2 + 72 * (size_t)BQ * 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<BP, BQ, NW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW>), dim3(grid), dim3(NW * 64), lds, st, pr);
+}
+static void launch_w3(const Wgrad3Params& pr, const WPlan& pl, hipStream_t st) {
+  const unsigned grid = wgrid(pl, 3);
+  launch_w3_t<64, 64, 4>(pr, grid, st);          // the planner only picks 64 x 64 tiles for this kernel
 }
 static void launch_w2(const Wgrad2Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, pr.w.R * pr.w.S);
@@ -616,7 +893,14 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float
   wp.psN = p->sn; wp.psH = p->sh; wp.psW = p->sw; wp.qsN = q->sn; wp.qsH = q->sh; wp.qsW = q->sw;
   wp.chunks = pl.chunks; wp.pix_per_chunk = pl.ppc; wp.ptiles = pl.ptiles; wp.qtiles = pl.qtiles;
   hipStream_t st = (hipStream_t)stream;
-  if (pl.v2) {
+  if (pl.v3) {
+    Wgrad3Params pr;
+    pr.w = wp;
+    pr.segs_per_row = pl.segs_per_row; pr.nseg = pl.nseg; pr.seg_per_chunk = pl.seg_per_chunk;
+    pr.direct = pl.direct; pr.accumulate = d->accumulate;
+    pr.bias = db; pr.with_bias = db ? 1 : 0; pr.slab_stride = slab_stride;
+    launch_w3(pr, pl, st);
+  } else if (pl.v2) {
     Wgrad2Params pr;
     pr.w = wp;
     pr.dhw.d = p->h * p->w; pr.dhw.rcp = 1.0f / (float)pr.dhw.d;
@@ -638,5 +922,6 @@ int dct_tune_set_wgrad(int knob, int value) {
   if (knob == DCT_TUNE_WGRAD_V2) { g_tune_wgrad_v2 = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_CHUNKS) { g_tune_wgrad_chunks = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_WAVES8) { g_tune_wgrad_waves8 = value; return DCT_OK; }
+  if (knob == DCT_TUNE_WGRAD_ROWS) { g_tune_wgrad_rows = value; return DCT_OK; }
   return DCT_ERR_BAD_ARG;
 }

@@ -164,8 +164,12 @@ def test_convT2x2_fwd_scatter(ops, dtype, B, Cin, H, W, Cout):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [
     (2, 64, 20, 18, 128, 0), (2, 64, 20, 18, 64, 0), (1, 128, 14, 14, 128, 0),
-    (2, 128, 60, 60, 64, 0),      # many pixel chunks
+    (2, 128, 60, 60, 64, 0),      # many pixel chunks; bf16: filter-row kernel (wgrad3), one 58-pixel run per row
     (1, 64, 12, 12, 64, 1),       # padded conv
+    (2, 64, 34, 130, 64, 0),      # wgrad3: two full 64-pixel runs per row, 64 x 64 tile
+    (1, 128, 24, 124, 128, 0),    # wgrad3: runs of 64 + 58, 128 x 128 tile (8 waves)
+    (2, 64, 20, 62, 128, 1),      # wgrad3: padded conv -- the x strip starts outside the image
+    (1, 128, 12, 254, 64, 0),     # wgrad3: four runs per row (64, 64, 64, 60), 64 x 128 tile
 ])
 def test_conv2d_wgrad(ops, dtype, B, Cin, H, W, Cout, pad):
     g = torch.Generator().manual_seed(4)

@@ -112,18 +112,29 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--only", default="", help="comma-separated layer names")
+    ap.add_argument("--ab-wgrad", action="store_true", help="A/B the filter-row weight-gradient kernel (knob 8) against the per-tap kernel")
     ap.add_argument("--ab", action="store_true", help="A/B the shared-halo 3x3 kernel against the per-tap kernel, interleaved in one process")
     args = ap.parse_args()
     what = args.what.split(",")
     lib = _lib.load()
     only = set(args.only.split(",")) if args.only else None
     run(args.batch, args.reps, what, "default", only)
+    if args.ab_wgrad:
+        ab_wgrad(args, lib, only)
     if args.ab:
         for rnd in range(2):       # interleaved rounds in ONE process (devices / DVFS differ between runs)
             lib.dct_tune_set(7, 0)
             run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: per-tap kernel (v2) everywhere", only)
             lib.dct_tune_set(7, 1)
             run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: shared-halo kernel (v3) where eligible", only)
+
+def ab_wgrad(args, lib, only):
+    for rnd in range(2):
+        lib.dct_tune_set(8, 0)
+        run(args.batch, args.reps, ["wgrad"], f"round {rnd}: per-tap weight gradient (v2)", only)
+        lib.dct_tune_set(8, 1)
+        run(args.batch, args.reps, ["wgrad"], f"round {rnd}: filter-row weight gradient (v3) where eligible", only)
+
 
 if __name__ == "__main__":
     main()
