@@ -513,7 +513,8 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   static_assert(TP >= 1 && TQ >= 1, "tile/wave mismatch");
   extern __shared__ __attribute__((aligned(128))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: piece bookkeeping stays in SGPRs
   const int wp = wave >> 1, wq = wave & 1;
 
   const int tiles_per_chunk = p.ptiles * 3 * p.qtiles;
@@ -626,14 +627,12 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   constexpr int NRD = 2 * (TP + 3 * TQ);
   const unsigned smem_off = lds_off(smem);
   const bool do_bias = pr.with_bias && tr == 0 && qt == 0 && wq == 0;
-  f32x16 accb[TP];
+  // bias gradient = column sums of dy: a lane's dy fragment is 8 pixels of ONE channel (row l31 of the MFMA A operand),
+  // so the sum is 8 VALU adds per sub-step in one register (an MFMA against a ones fragment would pin 16 accumulators
+  // in every block of the launch and cost a wave per SIMD of occupancy)
+  float accb[TP];
 #pragma unroll
-  for (int i = 0; i < TP; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
-  bf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+  for (int i = 0; i < TP; ++i) accb[i] = 0.f;
 
   for (int gi = gbeg; gi < gend; ++gi) {
     if (gi + 1 < gend) stage(smem + (cur ^ 1) * STAGE);     // all pieces up front: spreading them between the MFMA groups lands the stage later and was 8 % slower
@@ -678,7 +677,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
         }
       if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < TP; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, accb[i], 0, 0, 0);
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) accb[i] += (float)a[i][e];
       }
     }
     __syncthreads();
@@ -687,15 +688,16 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
 
   const int half = lane >> 5, l31 = lane & 31;
   float* base = pr.direct ? p.out : p.out + (long long)chunk * pr.slab_stride;
-  if (do_bias && l31 == 0) {
+  if (do_bias) {
     float* bb = pr.direct ? pr.bias : base + (long long)p.Cp * 9 * p.Cq;
 #pragma unroll
-    for (int i = 0; i < TP; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int prow = p0 + wp * WPR + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (pr.direct && pr.accumulate) bb[prow] += accb[i][e]; else bb[prow] = accb[i][e];
+    for (int i = 0; i < TP; ++i) {
+      const float t = accb[i] + __shfl_xor(accb[i], 32, 64);       // the two 8-pixel halves of each sub-step
+      if (half == 0) {
+        const int prow = p0 + wp * WPR + i * 32 + l31;
+        if (pr.direct && pr.accumulate) bb[prow] += t; else bb[prow] = t;
       }
+    }
   }
 #pragma unroll
   for (int s = 0; s < 3; ++s)
@@ -778,11 +780,11 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
     const int segs = (p->w + 63) / 64;
     if ((double)p->w / (segs * 64.0) >= 0.85) {
       const long long nseg = (long long)p->n * p->h * segs;
-      // measured (tools/bench_conv.py --ab-wgrad): 64 x 64 tiles (4 waves, three blocks per CU) beat 128 x 64 and
+      // measured (tools/bench_conv.py --ab-wgrad): 64 x 64 tiles (4 waves, 113 registers: four waves per SIMD) beat 128 x 64 and
       // 128 x 128 (one 8-wave block per CU at 130 / 205 VGPRs) on every eligible layer, by 20-35 %
       pl.bp = 64; pl.ptiles = p->c / 64; pl.bq = 64; pl.qtiles = q->c / 64;
       const int tiles3 = pl.ptiles * pl.qtiles * 3;
-      const int target = 768;                                              // blocks: three per CU
+      const int target = 768;     // blocks; swept 384 / 512 / 640 / 768 / 1024 on the UNet layers: 768 is 10-25 % ahead of the rest
       long long ch = (target + tiles3 / 2) / tiles3;
       if (ch > 256) ch = 256;
       if (ch > nseg / 4) ch = nseg / 4;
