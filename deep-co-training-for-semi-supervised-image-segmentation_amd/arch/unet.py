@@ -125,6 +125,7 @@ class UNet(nn.Module):
         self._shadow_fresh = False
         self._pidx = {id(p): i for i, p in enumerate(self.flat_params.params)}
         self._packs: Dict[int, dict] = {}
+        self._pack_table = None
         self._pack_key = None
         self.external_dropout_masks: Optional[List[torch.Tensor]] = None  # parity replay hook
         self.last_dropout_masks: Optional[List[torch.Tensor]] = None
@@ -176,6 +177,7 @@ class UNet(nn.Module):
             if not self._shadow_fresh:          # weights changed outside the fused Adam (init, load, broadcast)
                 K.pack_weight(fp.flat, shadow, 1, 1, fp.total)
             self._shadow_fresh = False
+        jobs = []
         for conv in self._convs:
             if conv is self.final or conv is self.dec1.down.at(0):
                 continue  # stem and head read the fp32 masters directly
@@ -184,6 +186,7 @@ class UNet(nn.Module):
             if ent is None or ent["dev"] != dev or ent["dt"] != dt:
                 ent = {"dev": dev, "dt": dt}
                 self._packs[id(conv)] = ent
+                self._pack_table = None
                 n = w.numel()
                 if conv.transposed:
                     ent["fwd"] = torch.empty(n, dtype=dt, device=dev)                    # [(a,b,co)][ci]
@@ -191,11 +194,18 @@ class UNet(nn.Module):
                     ent["dgrad"] = torch.empty(n, dtype=dt, device=dev)                  # [ci][flip taps][co]
             ws = fp.shadow_dense(self._pidx[id(conv.weight)]) if use_shadow else w       # K-major image in dt
             if conv.transposed:
-                K.pack_weight(w, ent["fwd"], conv.cin, 4, conv.cout, transpose=2)
+                jobs.append((w, ent["fwd"], conv.cin, 4, conv.cout, 2, False))
                 ent["dgrad"] = ws                                                        # [ci][a][b][co] as stored
             else:
                 ent["fwd"] = ws                                                          # [co][r][s][ci] as stored
-                K.pack_weight(w, ent["dgrad"], conv.cout, conv.k * conv.k, conv.cin, transpose=1, flip_taps=True)
+                jobs.append((w, ent["dgrad"], conv.cout, conv.k * conv.k, conv.cin, 1, True))
+        # every transposed pack of the network in one launch (dct_pack_weights_batched); the job table holds device
+        # addresses, so it is rebuilt whenever the flat buffer or a pack was re-allocated
+        tkey = (fp.version, fp.flat.data_ptr(), dev, dt)
+        if self._pack_table is None or self._pack_table[0] != tkey:
+            self._pack_table = (tkey,) + K.pack_jobs_table(jobs, dev)
+        _, table, njobs, tiles = self._pack_table
+        K.pack_weights_batched(table, njobs, tiles, dt)
         self._pack_key = key
 
     # ------------------------------------------------------------------------------ forward

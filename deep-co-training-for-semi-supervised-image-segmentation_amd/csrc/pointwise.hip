@@ -102,6 +102,37 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* src, T
   }
 }
 
+// All transposed weight packs of a network in ONE launch: job j owns the 32 x 32 (p, q) tiles [tile_begin[j],
+// tile_begin[j+1]) of dst[q * dq + t' * dt + p] = src[p][t][q]  (t = flip ? T-1-t' : t').  A UNet has 21 such packs of
+// 2-20 us each per step; as one launch they run at HBM speed.
+struct PackJob { const float* src; void* dst; int P, T, Q, flip; long long dq, dt; int tile_begin, pad_; };
+template <typename T>
+__global__ __launch_bounds__(256) void pack_transpose_batched_kernel(const PackJob* jobs, int njobs) {
+  __shared__ float tile[32][33];
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].tile_begin) ++j;      // <= 32 jobs: a short uniform scan
+  const PackJob jb = jobs[j];
+  int rel = blockIdx.x - jb.tile_begin;
+  const int pt = jb.P / 32, qt = jb.Q / 32;
+  const int p0 = (rel % pt) * 32; rel /= pt;
+  const int q0 = (rel % qt) * 32;
+  const int t2 = rel / qt;
+  const int t = jb.flip ? jb.T - 1 - t2 : t2;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int pr = ly + 8 * k;
+    tile[pr][lx] = jb.src[((long long)(p0 + pr) * jb.T + t) * jb.Q + q0 + lx];
+  }
+  __syncthreads();
+  T* dst = reinterpret_cast<T*>(jb.dst);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int qr = ly + 8 * k;
+    dst[(long long)(q0 + qr) * jb.dq + (long long)t2 * jb.dt + p0 + lx] = from_f32<T>(tile[lx][qr]);
+  }
+}
+
 // ---- Cin = 1 stem --------------------------------------------------------------------------
 struct StemGeom { int R, S, stride, dil, pad_h, pad_w, relu, cout; };
 
@@ -550,6 +581,15 @@ extern "C" int dct_pack_weight(const float* src, void* dst, int P, int T_, int Q
   }
   if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, pack_kernel<bf16_t>, dim3(div_up(total, 256)), dim3(256), 0, st, src, (bf16_t*)dst, P, T_, Q, transpose, flip_taps);
   else if (dtype == DCT_F32) DCT_LAUNCH(DCT_PROF_POINTWISE, pack_kernel<float>, dim3(div_up(total, 256)), dim3(256), 0, st, src, (float*)dst, P, T_, Q, transpose, flip_taps);
+  else return DCT_ERR_BAD_ARG;
+  return dct_check_launch();
+}
+
+extern "C" int dct_pack_weights_batched(const void* jobs_dev, int njobs, int total_tiles, int dtype, dct_stream stream) {
+  if (!jobs_dev || njobs < 1 || total_tiles < 1) return DCT_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, pack_transpose_batched_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, st, (const PackJob*)jobs_dev, njobs);
+  else if (dtype == DCT_F32) DCT_LAUNCH(DCT_PROF_POINTWISE, pack_transpose_batched_kernel<float>, dim3(total_tiles), dim3(256), 0, st, (const PackJob*)jobs_dev, njobs);
   else return DCT_ERR_BAD_ARG;
   return dct_check_launch();
 }

@@ -70,6 +70,24 @@ def pack_weight(src_f32, dst, P, T, Q, transpose=False, flip_taps=False):
     return dst
 
 
+def pack_jobs_table(jobs, device):
+    """Device table for pack_weights_batched.  jobs: list of (src fp32 tensor, dst tensor, P, T, Q, mode, flip) with
+    mode 1 -> dst[Q][T'][P], mode 2 -> dst[T'][Q][P] (dct_pack_weight's transpose codes).  Returns (table, n, tiles)."""
+    import struct
+    buf, tiles = bytearray(), 0
+    for src, dst, P, T, Q, mode, flip in jobs:
+        assert P % 32 == 0 and Q % 32 == 0 and mode in (1, 2)
+        dq, dt = (T * P, P) if mode == 1 else (P, Q * P)
+        buf += struct.pack("<QQiiiiqqii", src.data_ptr(), dst.data_ptr(), P, T, Q, int(bool(flip)), dq, dt, tiles, 0)
+        tiles += (P // 32) * (Q // 32) * T
+    table = torch.frombuffer(bytes(buf), dtype=torch.uint8).clone().to(device)
+    return table, len(jobs), tiles
+
+
+def pack_weights_batched(table, njobs, tiles, dtype):
+    call("dct_pack_weights_batched", ptr(table), int(njobs), int(tiles), DTYPE_OF[dtype], stream())
+
+
 def conv_cin1_fwd(x, w, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=False):
     d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu)
     vx, vy = view(x), view(y)

@@ -99,6 +99,12 @@ size_t dct_bias_grad_workspace_bytes(const dct_view* dy);
  *   transpose == 2: dst[T'][Q][P]  (ConvTranspose2d forward pack for the scatter2x2 mode). */
 int dct_pack_weight(const float* src, void* dst, int P, int T, int Q, int transpose, int flip_taps,
                     int dtype, dct_stream stream);
+/* All transposed packs of a network in one launch.  jobs_dev: device array of njobs records
+ *   { const float* src; void* dst; int32 P, T, Q, flip; int64 dq, dt; int32 tile_begin, pad; }      (56 bytes)
+ * job j covers the 32 x 32 (p, q) tiles [tile_begin[j], tile_begin[j+1]) (P/32 * Q/32 * T of them; P, Q
+ * multiples of 32) of dst[q*dq + t'*dt + p] = src[p][t][q]: (dq, dt) = (T*P, P) is dct_pack_weight's
+ * transpose == 1, (P, Q*P) its transpose == 2.  total_tiles = tile_begin past the last job. */
+int dct_pack_weights_batched(const void* jobs_dev, int njobs, int total_tiles, int dtype, dct_stream stream);
 
 /* First layer, Cin = 1 (network.py:159 dec1 conv; enet.py:21 initial conv): direct conv.
  * x is fp32 [N,H,W,1]; w fp32 [Cout][R][S]; y in `dtype`. */
