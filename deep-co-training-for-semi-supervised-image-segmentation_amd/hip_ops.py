@@ -80,7 +80,7 @@ def pack_jobs_table(jobs, device):
         dq, dt = (T * P, P) if mode == 1 else (P, Q * P)
         buf += struct.pack("<QQiiiiqqii", src.data_ptr(), dst.data_ptr(), P, T, Q, int(bool(flip)), dq, dt, tiles, 0)
         tiles += (P // 32) * (Q // 32) * T
-    table = torch.frombuffer(bytes(buf), dtype=torch.uint8).clone().to(device)
+    table = torch.frombuffer(buf, dtype=torch.uint8).clone().to(device)
     return table, len(jobs), tiles
 
 
