@@ -491,6 +491,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad2_kernel(Wgrad2Params pr) {
 struct Wgrad3Params {
   WgradParams w;
   int segs_per_row, nseg, seg_per_chunk;
+  int pitch, nr, units_per_image;     // pitch > 0: narrow images -- a K-step packs nr image rows at a pitch of Wp + 2 rows
   int direct, accumulate, with_bias;
   float* bias;
   long long slab_stride;
@@ -500,7 +501,7 @@ template <int RB> __device__ __forceinline__ int swz3(int k) {       // in 16-B 
   return RB == 256 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2);
 }
 
-template <int BP, int BQ, int NW>
+template <int BP, int BQ, int NW, bool NARROW>
 __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   const WgradParams& p = pr.w;
   constexpr int RBP = BP * 2, RBQ = BQ * 2;
@@ -536,61 +537,60 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   const char* zero = reinterpret_cast<const char*>(g_wzero_page) + (lane & 7) * 16;
   const int psW = (int)p.psW, qsW = (int)p.qsW;
 
-  // per-lane staging constants: piece (wave + i * NW) is a dy piece (8 or 4 pixel rows) or an x piece
-  int krow[NPW], loff[NPW], ldst[NPW];
+  // per-lane staging constants: piece (wave + i * NW) is a dy piece (8 or 4 pixel rows) or an x piece.  LDS row k of a
+  // tile is pixel (rho, col) of the step: (0, k) for wide images (one run of a row per step), (k / pitch, k % pitch)
+  // for narrow ones (nr image rows per step, each followed by two gap rows so that tap s is still "row k + s").
+  int rho[NPW], col[NPW], loff[NPW], ldst[NPW];
   bool isP[NPW], live[NPW];
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
     const int piece = wave + i * NW;
     live[i] = piece < NPC;
     isP[i] = piece < NPCP;
+    const int k = isP[i] ? piece * RPIP + lane / CPRP : (piece - NPCP) * RPIQ + lane / CPRQ;
+    rho[i] = NARROW ? k / pr.pitch : 0;
+    col[i] = NARROW ? k - rho[i] * pr.pitch : k;
     if (isP[i]) {
-      const int k = piece * RPIP + lane / CPRP;
-      krow[i] = k;
-      loff[i] = k * psW * 2 + (((lane % CPRP) ^ swz3<RBP>(k)) * 16);
+      loff[i] = (rho[i] * (int)p.psH + col[i] * psW) * 2 + (((lane % CPRP) ^ swz3<RBP>(k)) * 16);
       ldst[i] = piece * 1024;
     } else {
-      const int k = (piece - NPCP) * RPIQ + lane / CPRQ;
-      krow[i] = k;
-      loff[i] = k * qsW * 2 + (((lane % CPRQ) ^ swz3<RBQ>(k)) * 16);
+      loff[i] = (rho[i] * (int)p.qsH + col[i] * qsW) * 2 + (((lane % CPRQ) ^ swz3<RBQ>(k)) * 16);
       ldst[i] = 64 * RBP + (piece - NPCP) * 1024;
     }
   }
-  // run (image n, row y, run xs) of the first segment; then incremental
-  int n, y, xs;
+  // (image, first dy row, first dy column) of the next step to stage: one decode here, then increments
+  int s_n, s_y, s_x;
   {
-    const int rows = gbeg / pr.segs_per_row;
-    xs = gbeg - rows * pr.segs_per_row;
-    n = rows / p.Hp;
-    y = rows - n * p.Hp;
+    s_n = gbeg / pr.units_per_image;
+    const int u = gbeg - s_n * pr.units_per_image;
+    if (NARROW) { s_y = u * pr.nr; s_x = 0; }
+    else { s_y = u / pr.segs_per_row; s_x = (u - s_y * pr.segs_per_row) * 64; }
   }
-  // A stage is issued piece by piece (stage_begin fixes the run, stage_piece(i) issues this wave's i-th piece) so that
-  // the main loop can spread the LDS-DMA issue stalls between the MFMA groups of a step.
-  int s_len = 0; bool s_rowok = false; int s_x0 = 0;
-  long long s_baseP = 0, s_baseQ = 0;
-  auto stage_begin = [&]() {
-    s_x0 = xs * 64;
-    s_len = min(64, p.Wp - s_x0);
-    const int iy = y + tr - p.pad_h;
-    s_rowok = (unsigned)iy < (unsigned)p.Hq;
-    s_baseP = ((long long)n * p.psN + (long long)y * p.psH + (long long)s_x0 * p.psW) * 2;
-    s_baseQ = ((long long)n * p.qsN + (long long)iy * p.qsH + (long long)(s_x0 - p.pad_w) * p.qsW) * 2;
-    if (++xs == pr.segs_per_row) { xs = 0; if (++y == p.Hp) { y = 0; ++n; } }
-  };
-  auto stage_piece = [&](char* buf, int i) {
-    if (!live[i]) return;
-    const char* src;
-    if (isP[i]) src = krow[i] < s_len ? Pb + s_baseP + loff[i] : zero;
-    else {
-      const int ix = s_x0 - p.pad_w + krow[i];
-      src = (s_rowok && krow[i] < s_len + 2 && (unsigned)ix < (unsigned)p.Wq) ? Qb + s_baseQ + loff[i] : zero;
-    }
-    __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(buf + ldst[i]), 16, 0, 0);
-  };
   auto stage = [&](char* buf) {
-    stage_begin();
+    const int n = s_n, ybase = s_y, x0 = s_x;
+    int len, nrows;
+    if (NARROW) {
+      len = p.Wp; nrows = min(pr.nr, p.Hp - ybase);
+      s_y += pr.nr;
+      if (s_y >= p.Hp) { s_y = 0; ++s_n; }
+    } else {
+      len = min(64, p.Wp - x0); nrows = 1;
+      s_x += 64;
+      if (s_x >= p.Wp) { s_x = 0; if (++s_y == p.Hp) { s_y = 0; ++s_n; } }
+    }
+    const int iy0 = ybase + tr - p.pad_h, ix0 = x0 - p.pad_w;
+    const long long baseP = ((long long)n * p.psN + (long long)ybase * p.psH + (long long)x0 * p.psW) * 2;
+    const long long baseQ = ((long long)n * p.qsN + (long long)iy0 * p.qsH + (long long)ix0 * p.qsW) * 2;
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) stage_piece(buf, i);
+    for (int i = 0; i < NPW; ++i) {
+      if (!live[i]) continue;
+      const char* src;
+      if (isP[i]) src = (rho[i] < nrows && col[i] < len) ? Pb + baseP + loff[i] : zero;
+      else
+        src = (rho[i] < nrows && col[i] < len + 2 && (unsigned)(iy0 + rho[i]) < (unsigned)p.Hq &&
+               (unsigned)(ix0 + col[i]) < (unsigned)p.Wq) ? Qb + baseQ + loff[i] : zero;
+      __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(buf + ldst[i]), 16, 0, 0);
+    }
   };
 
   f32x16 acc[3][TP][TQ];
@@ -735,8 +735,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
   *outp = (s0 + s1) + (s2 + s3);
 }
 
-struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct, slabs; int v3, segs_per_row, nseg, seg_per_chunk; };
+struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct, slabs; int v3, segs_per_row, nseg, seg_per_chunk, pitch, nr, units; };
 
+int g_tune_wgrad_rows_fill = 70;   // percent: minimum fill of the 64-row K-steps for the filter-row kernel
 int g_tune_wgrad_rows = 1;     // 3x3 stride-1 layers on wide images: three taps of a filter row per block (wgrad3_kernel)
 int g_tune_wgrad_v2 = 1;       // dct_tune_set(DCT_TUNE_WGRAD_V2, 0): register-staged kernel
 int g_tune_wgrad_chunks = -1;  // >= 1 forces the number of pixel chunks
@@ -775,13 +776,24 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
   pl.slabs = pl.chunks;
   pl.direct = (pl.v2 && pl.chunks == 1) ? 1 : 0;
   pl.v3 = 0;
-  if (pl.v2 && g_tune_wgrad_rows && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil == 1 && p->w >= 48) {
-    // K-steps are runs of <= 64 pixels of one dy row: worth it when the runs are mostly full
-    const int segs = (p->w + 63) / 64;
-    if ((double)p->w / (segs * 64.0) >= 0.85) {
-      const long long nseg = (long long)p->n * p->h * segs;
-      // measured (tools/bench_conv.py --ab-wgrad): 64 x 64 tiles (4 waves, 113 registers: four waves per SIMD) beat 128 x 64 and
-      // 128 x 128 (one 8-wave block per CU at 130 / 205 VGPRs) on every eligible layer, by 20-35 %
+  if (pl.v2 && g_tune_wgrad_rows && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil == 1) {
+    // K-steps of 64 LDS rows: wide images -- runs of <= 64 pixels of one dy row; narrow ones -- nr whole rows at a pitch
+    // of Wp + 2.  Worth it when the steps are mostly full (threshold measured with tools/bench_conv.py --ab-wgrad).
+    const int Wp = p->w;
+    int segs = 1, pitch = 0, nr = 1;
+    double fill;
+    long long units;
+    if (Wp > 64) { segs = (Wp + 63) / 64; fill = (double)Wp / (segs * 64.0); units = (long long)p->h * segs; }
+    else {
+      pitch = Wp + 2; nr = 66 / pitch; if (nr < 1) nr = 1;
+      const int steps = (p->h + nr - 1) / nr;
+      fill = (double)p->h * Wp / (steps * 64.0);
+      units = steps;
+    }
+    if (fill >= g_tune_wgrad_rows_fill * 0.01 && (long long)p->h * p->sh < (1ll << 29) && (long long)q->h * q->sh < (1ll << 29)) {
+      const long long nseg = (long long)p->n * units;
+      // measured (tools/bench_conv.py --ab-wgrad): 64 x 64 tiles (4 waves, 113 registers: four waves per SIMD) beat
+      // 128 x 64 and 128 x 128 (one 8-wave block per CU at 130 / 205 VGPRs) on every eligible layer, by 20-35 %
       pl.bp = 64; pl.ptiles = p->c / 64; pl.bq = 64; pl.qtiles = q->c / 64;
       const int tiles3 = pl.ptiles * pl.qtiles * 3;
       const int target = 768;     // blocks; swept 384 / 512 / 640 / 768 / 1024 on the UNet layers: 768 is 10-25 % ahead of the rest
@@ -794,6 +806,7 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
       const long long spc = (nseg + ch - 1) / ch;
       pl.v3 = 1;
       pl.segs_per_row = segs; pl.nseg = (int)nseg; pl.seg_per_chunk = (int)spc;
+      pl.pitch = pitch; pl.nr = nr; pl.units = (int)units;
       pl.chunks = (int)((nseg + spc - 1) / spc);
       pl.slabs = pl.chunks;
       pl.direct = pl.chunks == 1 ? 1 : 0;
@@ -828,20 +841,21 @@ static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
   }
   DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ, NW>), dim3(grid), dim3(NW * 64), lds, st, pr);
 }
-template <int BP, int BQ, int NW>
+template <int BP, int BQ, int NW, bool NARROW>
 static void launch_w3_t(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
   constexpr size_t lds = 2 * (64 * (size_t)BP * 2 + 72 * (size_t)BQ * 2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<BP, BQ, NW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<BP, BQ, NW, NARROW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW>), dim3(grid), dim3(NW * 64), lds, st, pr);
+  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW>), dim3(grid), dim3(NW * 64), lds, st, pr);
 }
 static void launch_w3(const Wgrad3Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, 3);
-  launch_w3_t<64, 64, 4>(pr, grid, st);          // the planner only picks 64 x 64 tiles for this kernel
+  // the planner only picks 64 x 64 tiles for this kernel
+  if (pr.pitch > 0) launch_w3_t<64, 64, 4, true>(pr, grid, st); else launch_w3_t<64, 64, 4, false>(pr, grid, st);
 }
 static void launch_w2(const Wgrad2Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, pr.w.R * pr.w.S);
@@ -899,6 +913,7 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float
     Wgrad3Params pr;
     pr.w = wp;
     pr.segs_per_row = pl.segs_per_row; pr.nseg = pl.nseg; pr.seg_per_chunk = pl.seg_per_chunk;
+    pr.pitch = pl.pitch; pr.nr = pl.nr; pr.units_per_image = pl.units;
     pr.direct = pl.direct; pr.accumulate = d->accumulate;
     pr.bias = db; pr.with_bias = db ? 1 : 0; pr.slab_stride = slab_stride;
     launch_w3(pr, pl, st);
@@ -925,5 +940,6 @@ int dct_tune_set_wgrad(int knob, int value) {
   if (knob == DCT_TUNE_WGRAD_CHUNKS) { g_tune_wgrad_chunks = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_WAVES8) { g_tune_wgrad_waves8 = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_ROWS) { g_tune_wgrad_rows = value; return DCT_OK; }
+  if (knob == DCT_TUNE_WGRAD_ROWS_FILL) { g_tune_wgrad_rows_fill = value; return DCT_OK; }
   return DCT_ERR_BAD_ARG;
 }

@@ -196,6 +196,35 @@ def test_conv2d_wgrad(ops, dtype, B, Cin, H, W, Cout, pad):
             close(db.cpu() - (oldb if acc else 0), bref, dtype, "wgrad+bias: db", rtol16=1e-2)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [
+    (2, 64, 29, 29, 64, 0),       # 27-wide dy: two image rows per K-step (pitch 29), odd row count -> a one-row last step
+    (2, 64, 16, 16, 128, 0),      # 14-wide: four rows per step
+    (1, 128, 13, 11, 64, 1),      # padded, 11-wide: five rows per step, strip starts outside the image
+    (3, 64, 27, 48, 64, 0),       # 46-wide: one row per step
+])
+def test_conv2d_wgrad_filter_row_kernel_narrow_images(ops, B, Cin, H, W, Cout, pad):
+    """wgrad3_kernel's packed-rows mode, forced also on layers the planner would leave to the per-tap kernel
+    (dct_tune_set(DCT_TUNE_WGRAD_ROWS_FILL, 30)); same reference as test_conv2d_wgrad."""
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(14)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    y = F.conv2d(x, w, padding=pad)
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    (ref,) = torch.autograd.grad(y, w, dy)
+    lib = _lib.load()
+    lib.dct_tune_set(9, 30)
+    try:
+        dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=DEV)
+        db = torch.full((Cout,), float("nan"), device=DEV)
+        ops.conv2d_wgrad(to_dev(dy, dtype), to_dev(x, dtype), dw, pad_h=pad, pad_w=pad, accumulate=False, db=db)
+    finally:
+        lib.dct_tune_set(9, 70)
+    close(dw.cpu(), ref.permute(0, 2, 3, 1), dtype, "filter-row wgrad, packed rows")
+    close(db.cpu(), dy.sum((0, 2, 3)), dtype, "filter-row wgrad, packed rows: db", rtol16=1e-2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_convT_wgrad_and_dgrad(ops, dtype):
     g = torch.Generator().manual_seed(5)

@@ -134,6 +134,9 @@ def ab_wgrad(args, lib, only):
         run(args.batch, args.reps, ["wgrad"], f"round {rnd}: per-tap weight gradient (v2)", only)
         lib.dct_tune_set(8, 1)
         run(args.batch, args.reps, ["wgrad"], f"round {rnd}: filter-row weight gradient (v3) where eligible", only)
+        lib.dct_tune_set(9, 60)
+        run(args.batch, args.reps, ["wgrad"], f"round {rnd}: v3 down to 60 % K-step fill", only)
+        lib.dct_tune_set(9, 70)
 
 
 if __name__ == "__main__":
