@@ -134,6 +134,7 @@ class UNet(nn.Module):
         self._drop_state: Optional[torch.Tensor] = None   # int64[1] on the device: Philox offset = calls << 40
         self.dropout_seed = 0x5DEECE66D
         self._debug: Optional[dict] = None   # tools/debug_unet_layers.py stashes backward intermediates here
+        self._grad_hook = None               # data parallelism: called with a bucket index as gradient ranges complete
         self.wgrad_side_stream = False       # opt-in: weight gradients on a second HIP stream (see _run_backward)
         self._wgrad_stream = None
 
@@ -240,6 +241,17 @@ class UNet(nn.Module):
         params = self.flat_params.params
         save = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         return _UNetFn.apply(self, save, x, *params)
+
+    def grad_bucket_ranges(self):
+        """[lo, hi) element ranges of the flat gradient buffer in the order the backward pass completes them:
+        decoder side ("enc*" + final), centre, encoder side ("dec*").  The flat buffer is in registration order
+        dec1..dec4, center, enc4..enc1, final, so each bucket is contiguous; the gradient exchange of a bucket can
+        start while the rest of the backward still runs (_grad_hook, ddp.FlatGradSync.begin_bucket)."""
+        fp = self.flat_params
+        first_center = self._pidx[id(self.center.at(0).weight)]
+        first_enc4 = self._pidx[id(self.enc4.up.at(0).weight)]
+        return [(fp.offsets[first_enc4], fp.total), (fp.offsets[first_center], fp.offsets[first_enc4]),
+                (0, fp.offsets[first_center])]
 
     def _side_stream(self, dev):
         if not self.wgrad_side_stream:
@@ -405,6 +417,9 @@ class UNet(nn.Module):
                 self._debug[f"de{lvl}b"], self._debug[f"de{lvl}a"], self._debug[f"dcat{lvl - 1}"] = deb, dea, dcat
             cat = A[f"cat{lvl}"]
             dcat = conv_bwd(u.at(0), cat, dea, new_like(cat), mask=cat, mask_channels=2 * co)
+        hook = self._grad_hook if need_dw else None
+        if hook is not None and side is None:
+            hook(0)                           # decoder-side gradients are complete
         # center (cat4: 512 convT channels + 512 skip channels)
         c = self.center
         p4 = A["p4"]
@@ -413,6 +428,8 @@ class UNet(nn.Module):
         dc2 = convT_bwd(c.at(5), c2d, dcat[..., :512], new_like(c2d), mask=c2d, mask_scale=ds)
         dc1 = conv_bwd(c.at(2), c1, dc2, new_like(c1), mask=c1)
         conv_bwd(c.at(0), p4, dc1, dp[4], accumulate=True)
+        if hook is not None and side is None:
+            hook(1)                           # centre gradients are complete
         # encoder
         dx = None
         for lvl in (4, 3, 2, 1):
@@ -431,6 +448,8 @@ class UNet(nn.Module):
                     dx = K.conv_cin1_dgrad(da, self._w(c0), torch.empty_like(A["x"]), pad_h=0, pad_w=0)
         if side is not None:
             cur.wait_stream(side)
+        elif hook is not None:
+            hook(2)                           # encoder-side gradients: the whole buffer is final
         return dx
 
 

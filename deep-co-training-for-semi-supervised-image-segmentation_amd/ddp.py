@@ -36,6 +36,8 @@ class FlatGradSync(object):
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self._pending: List = []
+        self._bucketed = set()      # models whose gradients already went out bucket by bucket this step
+        self.bucket_calls = 0
         self._avg = dist.get_backend(process_group) == "nccl"   # RCCL supports ReduceOp.AVG; gloo does not
         if broadcast_weights:
             self.broadcast_weights()
@@ -64,8 +66,24 @@ class FlatGradSync(object):
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), t
 
+    def begin_bucket(self, model_index: int, lo: int, hi: int):
+        """Start the all-reduce of elements [lo, hi) of one model's flat gradient buffer -- called from inside the
+        backward pass (net._grad_hook) as soon as that range is final, so the exchange of the decoder-side and
+        centre gradients overlaps the rest of the backward.  xGMI ring all-reduce of UNet's 124 MB is ~1.4 ms at 8
+        GPUs; only the last, smallest bucket (encoder side, 19 MB) is left exposed."""
+        flat = self.segmentators[model_index].torchnet.flat_params
+        if hi <= lo:
+            return
+        work, scale = self._reduce_tensor(flat.gflat[lo:hi], True)
+        self._pending.append((model_index, work, scale, None, None))
+        self._bucketed.add(model_index)
+        self.bucket_calls += 1
+
     def begin(self, model_index: int):
-        """Start the (asynchronous) all-reduce of one model's gradients."""
+        """Start the (asynchronous) all-reduce of one model's gradients (no-op when the backward pass already
+        sent every bucket)."""
+        if model_index in self._bucketed:
+            return
         net = self.segmentators[model_index].torchnet
         flat = getattr(net, "flat_params", None)
         if flat is not None and flat.grads_attached():
@@ -98,6 +116,10 @@ class FlatGradSync(object):
                     p.grad.copy_(buf[off:off + n].view_as(p.grad))
                     off += n
         self._pending = keep
+        if model_index is None:
+            self._bucketed.clear()
+        else:
+            self._bucketed.discard(model_index)
 
     def all_reduce(self):
         for i in range(len(self.segmentators)):

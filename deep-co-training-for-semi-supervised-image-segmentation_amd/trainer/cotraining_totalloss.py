@@ -376,8 +376,17 @@ class CoTrainer(Trainer):
 
         def backward_of(i):
             def run():
-                for tape, dl in passes[i]:
-                    nets[i].plan_backward(tape, dl, need_dx=False, need_dw=True)
+                # data parallelism: during the LAST backward pass of a model its gradient buckets go out as they
+                # complete (earlier passes only accumulate)
+                ranges = nets[i].grad_bucket_ranges() if (self.grad_sync is not None and hasattr(nets[i], "grad_bucket_ranges")) else None
+                for k, (tape, dl) in enumerate(passes[i]):
+                    if ranges is not None and k == len(passes[i]) - 1:
+                        nets[i]._grad_hook = lambda b, i=i, r=ranges: self.grad_sync.begin_bucket(i, r[b][0], r[b][1])
+                    try:
+                        nets[i].plan_backward(tape, dl, need_dx=False, need_dw=True)
+                    finally:
+                        if ranges is not None:
+                            nets[i]._grad_hook = None
                 passes[i].clear()
             return run
         self._finish_step([(i, backward_of(i)) for i in range(S)], streams)

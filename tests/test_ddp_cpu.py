@@ -115,3 +115,49 @@ def test_two_rank_gloo_step_equals_averaged_gradient_step(tmp_path):
         # gloo sums then scales, the hand average divides once: 1 ulp apart in g, which Adam's first step
         # (lr * g / (|g| + eps)) turns into <= 1e-5 on elements whose |g| is comparable to eps = 1e-8
         np.testing.assert_allclose(a, b.numpy(), rtol=0, atol=2e-5)
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import types
+    import torch.distributed as dist
+    from dct_amd import ddp
+    from dct_amd.arch.flat import FlatParams
+    ddp.init_from_env("gloo")
+    segs = []
+    for m in range(2):
+        net = torch.nn.Sequential(torch.nn.Linear(40, 30), torch.nn.Linear(30, 7))
+        net.flat_params = FlatParams(list(net.parameters()))
+        net.flat_params.ensure()
+        net.flat_params.ensure_grads()
+        net.flat_params.gflat.copy_(torch.arange(net.flat_params.total, dtype=torch.float32) * (rank + 1) + 10 * m)
+        segs.append(types.SimpleNamespace(torchnet=net))
+    sync = ddp.FlatGradSync(segs, broadcast_weights=False)
+    total = segs[0].torchnet.flat_params.total
+    cuts = [(total // 2, total), (total // 5, total // 2), (0, total // 5)]     # completion order of a backward pass
+    for lo, hi in cuts:
+        sync.begin_bucket(0, lo, hi)
+    sync.begin(0)                   # every bucket already went out: must not reduce a second time
+    sync.begin(1)                   # model 1: one whole-buffer exchange
+    for m in range(2):
+        sync.finish(m)
+    torch.save([s.torchnet.flat_params.gflat.clone() for s in segs], os.path.join(out, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_bucketed_exchange(tmp_path):
+    """FlatGradSync.begin_bucket (the in-backward exchange of UNet's gradient buckets): three slices of model 0 and the
+    whole buffer of model 1 end as the rank mean on both ranks, each element reduced exactly once."""
+    world, port = 2, _free_port()
+    out = str(tmp_path)
+    mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    g0 = torch.load(os.path.join(out, "g0.pt"), weights_only=False)
+    g1 = torch.load(os.path.join(out, "g1.pt"), weights_only=False)
+    for m in range(2):
+        n = g0[m].numel()
+        want = (torch.arange(n, dtype=torch.float32) * 1 + 10 * m + torch.arange(n, dtype=torch.float32) * 2 + 10 * m) / 2
+        assert torch.equal(g0[m], g1[m])
+        np.testing.assert_allclose(g0[m].numpy(), want.numpy(), rtol=1e-6)

@@ -179,6 +179,8 @@ def test_rccl_gradient_exchange_single_rank(tmp_path, golden):
             lb = [lab[i][0][0] for i in range(2)]
             tr._run_step([(lb[0][0], lb[0][1]), (lb[1][0], lb[1][1])], (unl[0][0][0], unl[0][0][1]), True, False)
             torch.cuda.synchronize()
+            if sync:        # UNet gradients go out in three buckets per model from inside the backward pass
+                assert tr.grad_sync.bucket_calls == 6
             res.append([torch.cat([p.detach().flatten() for p in s.torchnet.parameters()]).cpu() for s in tr.segmentators])
     finally:
         if created:
