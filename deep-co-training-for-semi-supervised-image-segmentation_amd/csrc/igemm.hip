@@ -16,6 +16,7 @@
 //
 // bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  f32: v_mfma_f32_32x32x2_f32 -- exact
 // fp32 FMA chains, used by the parity path.
+#include <algorithm>
 #include "dct_common.h"
 
 namespace {
@@ -780,6 +781,235 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Shared-halo kernel for SMALL images ("v3p"): the 128-pixel tile is PR whole output rows of one image, packed in LDS
+// at a pitch of Wo + 2 rows (pixel m = (m / Wo, m % Wo) sits at LDS row (m / Wo) * pitch + m % Wo + tap offset
+// r * pitch + s), so the halo of a 64-channel slice is (PR + 2) * (Wo + 2) <= 192 rows, staged once for nine taps.
+// These layers have few tiles (16 images x 1-7 tiles x Cout / 128), so the channel slices are split over blockIdx.z
+// and the fp32 partial tiles go to slabs folded by splitk_epilogue_kernel (fixed order, as v2's split-K).
+template <int BN, int NWM, int NWN>
+__global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, int PR, int tiles_per_img, int chunks_per_split) {
+  constexpr int NW = NWM * NWN;
+  constexpr int BM = 128, APIECES = 24, A_BYTES = APIECES * 1024;                  // <= 192 halo rows of 128 B
+  constexpr int B_BYTES = BN * 128, BPIECES = BN / 8;
+  constexpr int NPA = APIECES / NW, NPB = BPIECES / NW;
+  constexpr int WTN = BN / NWN, TN = WTN / 32;
+  static_assert(NWM == 4 && APIECES % NW == 0 && BPIECES % NW == 0 && TN >= 1, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  char* Abuf = smem;
+  char* Bbuf = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave / NWM, wm = wave % NWM;
+  const int img = blockIdx.x / tiles_per_img, ty = blockIdx.x - img * tiles_per_img;
+  const int y0 = ty * PR, n0 = blockIdx.y * BN;
+  const int pitch = p.Wo + 2, hrows = (PR + 2) * pitch;
+  const long long Ktot = 9ll * p.Cin;
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
+
+  long long aoff[NPA];
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    const int row = (wave + i * NW) * 8 + (lane >> 3);
+    aoff[i] = -1;
+    if (row < hrows) {
+      const int hy = row / pitch, hx = row - hy * pitch;
+      const int iy = y0 - p.pad_h + hy, ix = hx - p.pad_w;
+      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+        aoff[i] = img * p.xsN + iy * p.xsH + ix * p.xsW + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+    }
+  }
+  auto stageA = [&](char* buf, int c0) {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const char* src = aoff[i] >= 0 ? reinterpret_cast<const char*>(xb + aoff[i] + c0) : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + (wave + i * NW) * 1024), 16, 0, 0);
+    }
+  };
+  const bf16_t* wsrc[NPB];
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int row = (wave + i * NW) * 8 + (lane >> 3);
+    wsrc[i] = reinterpret_cast<const bf16_t*>(p.w) + (long long)(n0 + row) * Ktot + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+  }
+  auto stageB = [&](char* buf, int tap, int c0) {
+    const long long woff = (long long)tap * p.Cin + c0;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + woff), (lptr_t)(buf + (wave + i * NW) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int half = lane >> 5, l31 = lane & 31;
+  const int mpix = wm * 32 + l31;                              // pixel slot of this lane's fragment column
+  int rho0;
+  {
+    const int pr = mpix / p.Wo, pc = mpix - pr * p.Wo;
+    rho0 = pr < PR ? pr * pitch + pc : 0;                      // slots past the tile read row 0 (never stored)
+  }
+  const int aswz = (l31 >> 1) & 7;
+
+  const int nch = p.Cin / 64;
+  const int cbeg = blockIdx.z * chunks_per_split, cend = min(nch, cbeg + chunks_per_split);
+  const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
+  stageA(Abuf, cbeg * 64);
+  stageB(Bbuf, 0, cbeg * 64);
+  __syncthreads();
+  int ab = 0, bb = 0;
+  for (int c = cbeg; c < cend; ++c) {
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
+      else if (c + 1 < cend) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
+      if (t == 0 && c + 1 < cend) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
+      const int r = t / 3, s = t - 3 * r;
+      const int rho = rho0 + r * pitch + s;
+      const int pswz = (rho >> 1) & 7;
+      const unsigned Wl = smem_l + 2 * A_BYTES + bb * B_BYTES + (wn * WTN + l31) * 128 + ((half ^ aswz) * 16);
+      const unsigned Xl = smem_l + ab * A_BYTES + rho * 128 + ((half ^ pswz) * 16);
+      bf16x8 a[2][TN], b[2];
+      auto issue = [&](int set, int kk) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) rd128((Wl + i * 32 * 128) ^ (kk * 32), a[set][i]);
+        rd128(Xl ^ (kk * 32), b[set]);
+      };
+      issue(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int set = kk & 1;
+        if (kk + 1 < 4) { issue(set ^ 1, kk + 1); lgkm_wait3<TN + 1>(); } else { lgkm_wait3<0>(); }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) touch8(a[set][i]);
+        touch8(b[set]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][i], b[set], acc[i], 0, 0, 0);
+      }
+      __syncthreads();
+      bb ^= 1;
+    }
+    ab ^= 1;
+  }
+
+  // ---- epilogue: tile row m = pixel slot; row tables behind the tile
+  const int npix = PR * p.Wo;
+  if (p.partial) {
+    // split over channel slices: fp32 tile -> LDS -> whole slab rows (BN * 4 contiguous bytes) with 16-byte stores
+    constexpr int CPR4 = BN / 4;
+    char* tile = smem;                                   // BM * BN * 4 = 64 KiB of the 80 KiB
+    int* rowS = reinterpret_cast<int*>(smem + BM * BN * 4);
+    if (tid < BM) {
+      const int pr = tid / p.Wo, pc = tid - pr * p.Wo, oy = y0 + pr;
+      rowS[tid] = (tid < npix && oy < p.Ho) ? (img * p.Ho + oy) * p.Wo + pc : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cl = wn * WTN + i * 32 + 8 * q + 4 * half;
+        const int chunk = (cl >> 2) ^ (mpix & (CPR4 - 1));
+        *reinterpret_cast<f32x4*>(tile + mpix * (BN * 4) + chunk * 16) =
+            f32x4{acc[i][4 * q + 0], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+      }
+    __syncthreads();
+    constexpr int NCH4 = BM * CPR4 / (NW * 64);
+    float* slab = p.partial + (long long)blockIdx.z * p.M * p.N + n0;
+#pragma unroll
+    for (int t = 0; t < NCH4; ++t) {
+      const int id = t * (NW * 64) + tid;
+      const int row = id / CPR4, cc = id % CPR4;
+      const int mg = rowS[row];
+      if (mg < 0) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * (BN * 4) + ((cc ^ (row & (CPR4 - 1))) * 16));
+      *reinterpret_cast<f32x4*>(slab + (long long)mg * p.N + cc * 4) = v;
+    }
+    return;
+  }
+  constexpr int CPR = BN / 8;
+  char* tile = smem;
+  int* rowY = reinterpret_cast<int*>(smem + BM * BN * 2);
+  int* rowM = rowY + BM;
+  if (tid < BM) {
+    const int pr = tid / p.Wo, pc = tid - pr * p.Wo, oy = y0 + pr;
+    int oy_ = -1, om_ = -1;
+    if (tid < npix && oy < p.Ho) {
+      oy_ = (int)(img * p.ysN + oy * p.ysH + pc * p.ysW);
+      om_ = (int)(img * p.msN + oy * p.msH + pc * p.msW);
+    }
+    rowY[tid] = oy_; rowM[tid] = om_;
+  }
+  {
+    f32x4 bv[TN][4];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          bv[i][q] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WTN + i * 32 + 8 * q + 4 * half);
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cl = wn * WTN + i * 32 + 8 * q + 4 * half;
+        float v[4] = {acc[i][4 * q + 0] + bv[i][q][0], acc[i][4 * q + 1] + bv[i][q][1], acc[i][4 * q + 2] + bv[i][q][2],
+                      acc[i][4 * q + 3] + bv[i][q][3]};
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+        const int chunk = (cl >> 3) ^ (mpix & (CPR - 1));
+        *reinterpret_cast<bf16x4*>(tile + mpix * (BN * 2) + chunk * 16 + (cl & 4) * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NCH = BM * CPR / (NW * 64);
+  int yo[NCH];
+  bf16x8 mk[NCH], old[NCH];
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    const int id = t * (NW * 64) + tid;
+    const int row = id / CPR, co = n0 + (id % CPR) * 8;
+    yo[t] = rowY[row];
+    if (yo[t] >= 0) {
+      if (p.mask && co < p.mask_channels) mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
+      if (p.accumulate) old[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.y) + yo[t] + co);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    const int id = t * (NW * 64) + tid;
+    const int row = id / CPR, cc = id % CPR;
+    if (yo[t] < 0) continue;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
+    const int co = n0 + cc * 8;
+    if (p.mask && co < p.mask_channels) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
+    }
+    if (p.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
+    }
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
+  }
+}
+
 // Sum split-K partial slabs and apply the epilogue.  One thread per (pixel, 4 channels).
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmParams p, int splits) {
@@ -883,6 +1113,54 @@ static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images
   DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3_kernel<BN, 4, NWN, ABUFS>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
 }
 
+// Packed-rows shared-halo kernel (igemm3p_kernel) for small images: geometry and split over channel slices.
+struct PlanP { int use, PR, tiles_per_img, splits, cps; };
+int g_tune_igemm_packed = 1;     // 0: deep levels stay on the per-tap kernel
+static PlanP make_plan_p(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int N) {
+  PlanP pp = {0, 0, 0, 1, 0};
+  if (!g_tune_igemm_halo || !g_tune_igemm_packed || dtype != DCT_BF16 || d->R != 3 || d->S != 3 || d->stride != 1 || d->dil != 1 ||
+      d->scatter2x2 || x->c % 64 || N % 128 || y->w > 126)
+    return pp;
+  const int Wo = y->w, Ho = y->h;
+  int PR = 128 / Wo;
+  const int by_lds = 192 / (Wo + 2) - 2;
+  if (PR > by_lds) PR = by_lds;
+  if (PR > Ho) PR = Ho;
+  if (PR < 1) return pp;
+  const int tiles = (Ho + PR - 1) / PR;
+  // measured on the UNet deep levels (tools/bench_conv.py --ab-packed): +8-12 % where the tiles are >= 76 % full and every
+  // block keeps >= 4 channel slices (36 K-steps); shorter blocks or emptier tiles are level with or behind the per-tap kernel
+  if ((double)Ho * Wo / (tiles * 128.0) < 0.76) return pp;
+  const int nch = x->c / 64;
+  const long long blocks0 = (long long)y->n * tiles * (N / 128);
+  int splits = 1;
+  if (blocks0 < 400) {
+    splits = (int)((448 + blocks0 - 1) / blocks0);
+    if (splits > nch) splits = nch;
+    while (splits > 1 && nch / splits < 4) --splits;
+  }
+  if (nch / splits < 4 || blocks0 * splits < 256) return pp;
+  pp.cps = (nch + splits - 1) / splits;
+  pp.splits = (nch + pp.cps - 1) / pp.cps;
+  pp.use = 1; pp.PR = PR; pp.tiles_per_img = tiles;
+  return pp;
+}
+static void launch_v3p(const IgemmParams& p, const PlanP& pp, int images, hipStream_t st) {
+  constexpr size_t lds = 2 * (size_t)(24 * 1024) + 2 * (size_t)128 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3p_kernel<128, 4, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(images * pp.tiles_per_img), p.N / 128, pp.splits);
+  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3p_kernel<128, 4, 2>), grid, dim3(512), lds, st, p, pp.PR, pp.tiles_per_img, pp.cps);
+  if (pp.splits > 1) {
+    const long long work = (long long)p.M * (p.N / 4);
+    DCT_LAUNCH(DCT_PROF_IGEMM, (splitk_epilogue_kernel<bf16_t>), dim3(div_up(work, 256)), dim3(256), 0, st, p, pp.splits);
+  }
+}
+
 template <typename T>
 static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
   dim3 grid(div_up(p.M, pl.bm), p.N / pl.bn, pl.splits);
@@ -917,7 +1195,10 @@ extern "C" size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* 
   const int N = d->scatter2x2 ? 4 * y->c : y->c;
   Plan pl;
   if (!make_plan(x, y, d, dtype, M, N, pl)) return 0;
-  return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+  size_t need = pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+  const PlanP pp = make_plan_p(x, y, d, dtype, N);
+  if (pp.use && pp.splits > 1) need = std::max(need, (size_t)pp.splits * M * N * sizeof(float));
+  return need;
 }
 
 extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* bias, const dct_view* mask,
@@ -1004,6 +1285,22 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
       return dct_check_launch();
     }
   }
+  if (pl.v2 && g_tune_igemm_staged && (!bias || !((uintptr_t)bias & 15))) {
+    const PlanP pp = make_plan_p(x, y, d, dtype, p.N);
+    if (pp.use) {
+      const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
+                       (long long)y->n * y->sn < (1ll << 31);
+      const bool m16 = !mask || (!((uintptr_t)mask->ptr & 15) && mask->sw % 8 == 0 && mask->sh % 8 == 0 && mask->sn % 8 == 0 &&
+                                 p.mask_channels % 8 == 0 && (long long)mask->n * mask->sn < (1ll << 31));
+      const size_t need = pp.splits > 1 ? (size_t)pp.splits * p.M * p.N * sizeof(float) : 0;
+      if (y16 && m16 && (!need || (workspace && workspace_bytes >= need))) {
+        IgemmParams q = p;
+        q.partial = pp.splits > 1 ? (float*)workspace : nullptr;
+        launch_v3p(q, pp, y->n, st);
+        return dct_check_launch();
+      }
+    }
+  }
   return dtype == DCT_BF16 ? launch<bf16_t>(p, pl, st) : launch<float>(p, pl, st);
 }
 
@@ -1040,6 +1337,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_STAGED: g_tune_igemm_staged = value; return DCT_OK;
     case DCT_TUNE_IGEMM_WAVES8: g_tune_igemm_waves8 = value; return DCT_OK;
     case DCT_TUNE_IGEMM_HALO: g_tune_igemm_halo = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_PACKED: g_tune_igemm_packed = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }
 }

@@ -109,6 +109,9 @@ def test_conv2d_epilogue_mask_accumulate_views(ops, dtype):
     (4, 64, 100, 116, 64, 2),       # the same tile in data-gradient form
     (5, 128, 122, 90, 128, 2),      # data-gradient form: pad 2, halo outside the image reads the zero page; two slices
     (3, 192, 96, 96, 256, 0),       # three channel slices, two Cout tiles
+    (8, 512, 27, 27, 128, 0),       # small image: packed-rows kernel (5 rows of 25 per tile), two-way split over channel slices
+    (16, 256, 18, 16, 256, 2),      # packed rows, data-gradient form (pad 2), ragged last tile, unsplit
+    (16, 1024, 13, 13, 128, 0),     # packed rows: one 11 x 11 tile per image, four-way split
 ])
 def test_conv2d_3x3_shared_halo(ops, B, Cin, H, W, Cout, pad):
     from dct_amd import _lib

@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--only", default="", help="comma-separated layer names")
+    ap.add_argument("--ab-packed", action="store_true", help="A/B the packed-rows shared-halo kernel (knob 10) on the deep levels")
     ap.add_argument("--ab-wgrad", action="store_true", help="A/B the filter-row weight-gradient kernel (knob 8) against the per-tap kernel")
     ap.add_argument("--ab", action="store_true", help="A/B the shared-halo 3x3 kernel against the per-tap kernel, interleaved in one process")
     args = ap.parse_args()
@@ -121,6 +122,12 @@ def main():
     run(args.batch, args.reps, what, "default", only)
     if args.ab_wgrad:
         ab_wgrad(args, lib, only)
+    if args.ab_packed:
+        for rnd in range(2):
+            lib.dct_tune_set(10, 0)
+            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: per-tap kernel on the deep levels", only)
+            lib.dct_tune_set(10, 1)
+            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: packed-rows shared-halo kernel", only)
     if args.ab:
         for rnd in range(2):       # interleaved rounds in ONE process (devices / DVFS differ between runs)
             lib.dct_tune_set(7, 0)
