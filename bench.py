@@ -310,8 +310,8 @@ def main():
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             result["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(args.config),
-                "kernel": {"igemm": "igemm2_kernel + igemm3_kernel (conv fwd + data-grad implicit GEMM: per-tap and shared-halo tiles, incl. split-K epilogue)",
-                           "wgrad": "wgrad2_kernel (weight-grad GEMM, incl. fixed-order reduce)"}[dom],
+                "kernel": {"igemm": "igemm2_kernel + igemm3m_kernel (conv fwd + data-grad implicit GEMM: per-tap and shared-halo tiles, incl. split-K epilogue)",
+                           "wgrad": "wgrad2_kernel + wgrad3_kernel (weight-grad GEMM: per-tap and filter-row tiles, incl. fixed-order reduce)"}[dom],
                 "algorithmic_flops_per_step": flops[dom], "kernel_ms_per_step": per[dom]["ms_per_step"],
                 "avg_launch_us": 1e3 * per[dom]["ms_per_step"] / max(per[dom]["launches_per_step"], 1),
                 "algorithmic_flops_per_launch": flops[dom] / max(per[dom]["launches_per_step"], 1),

@@ -781,6 +781,205 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
 #endif
 }
 
+// igemm3_kernel on v_mfma_f32_16x16x32_bf16 (same FLOPs per cycle, same LDS traffic, 32-deep sub-steps): MI355X holds a
+// higher clock on this shape under load (MI355X_MICROARCH.md, DVFS item 7).  dct_tune_set(DCT_TUNE_IGEMM_MFMA16, 0/1).
+template <int BN, int NWM, int NWN, int ABUFS>
+__global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, int tiles_x, int tiles_y) {
+  constexpr int NW = NWM * NWN;
+  constexpr int TH = 8, TW = 16, BM = TH * TW, HW = TW + 2, HROWS = (TH + 2) * HW;   // 180 halo rows of 128 B
+  constexpr int APIECES = (HROWS + 7) / 8, A_BYTES = APIECES * 8 * 128;              // 23 pieces, 23552 B
+  constexpr int B_BYTES = BN * 128, BPIECES = BN / 8;
+  constexpr int NPA = (APIECES + NW - 1) / NW, NPB = BPIECES / NW;
+  constexpr int WTN = BN / NWN, TN = WTN / 32;
+  static_assert(NWM == 4 && BPIECES % NW == 0 && TN >= 1, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  char* Abuf = smem;                       // halo stage(s)
+  char* Bbuf = smem + ABUFS * A_BYTES;     // two weight stages
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / NWM, wm = wave % NWM;
+  int bx = blockIdx.x;
+  const int tx = bx % tiles_x; bx /= tiles_x;
+  const int ty = bx % tiles_y; const int img = bx / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * BN;
+  const long long Ktot = 9ll * p.Cin;
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
+
+  // halo staging: wave w issues pieces w, w + NW, ...; lane -> (row = piece * 8 + lane / 8, its swizzled source chunk)
+  long long aoff[NPA];
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    const int piece = wave + i * NW;
+    const int row = piece * 8 + (lane >> 3);
+    aoff[i] = -1;
+    if (piece < APIECES && row < HROWS) {
+      const int hy = row / HW, hx = row - hy * HW;
+      const int iy = y0 - p.pad_h + hy, ix = x0 - p.pad_w + hx;
+      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+        aoff[i] = img * p.xsN + iy * p.xsH + ix * p.xsW + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+    }
+  }
+  auto stageA = [&](char* buf, int c0) {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int piece = wave + i * NW;
+      if (piece < APIECES) {
+        const char* src = aoff[i] >= 0 ? reinterpret_cast<const char*>(xb + aoff[i] + c0) : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + piece * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // weight staging: piece = 8 cout rows
+  const bf16_t* wsrc[NPB];
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int row = (wave + i * NW) * 8 + (lane >> 3);
+    wsrc[i] = reinterpret_cast<const bf16_t*>(p.w) + (long long)(n0 + row) * Ktot + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+  }
+  auto stageB = [&](char* buf, int tap, int c0) {
+    const long long woff = (long long)tap * p.Cin + c0;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + woff), (lptr_t)(buf + (wave + i * NW) * 1024), 16, 0, 0);
+  };
+
+  constexpr int TR = WTN / 16;                 // 16-channel row blocks per wave
+  f32x4 acc[TR][2];
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // v_mfma_f32_16x16x32_bf16 fragments: lane l holds row / column l % 16 and the 16-byte K chunk l / 16 of a 32-deep
+  // sub-step.  Column block j of the wave's 32 pixels is patch row 2 * wm + j, columns 0..15 in lane order.
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int rho0 = (2 * wm) * HW + l15;
+  const int aswz = (l15 >> 1) & 7;
+
+  const int nch = p.Cin / 64;
+  const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
+  stageA(Abuf, 0);
+  stageB(Bbuf, 0, 0);
+  __syncthreads();
+  int ab = 0, bb = 0;
+  for (int c = 0; c < nch; ++c) {
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
+      else if (c + 1 < nch) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
+      if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
+      const int r = t / 3, s = t - 3 * r;
+      const int rho = rho0 + r * HW + s;                      // column block 0; block 1 is one patch row (HW LDS rows) further
+      const int pswz0 = (rho >> 1) & 7, pswz1 = ((rho + HW) >> 1) & 7;
+      const unsigned Wl = smem_l + ABUFS * A_BYTES + bb * B_BYTES + (wn * WTN + l15) * 128;
+      const unsigned Xl = smem_l + ab * A_BYTES + rho * 128;
+      bf16x8 a[2][TR], b[2][2];
+      auto issue = [&](int set, int k2) {                      // k2: 32-deep sub-step (chunks 4 * k2 + kq)
+        const int ch = 4 * k2 + kq;
+#pragma unroll
+        for (int i = 0; i < TR; ++i) rd128(Wl + i * 16 * 128 + ((ch ^ aswz) * 16), a[set][i]);
+        rd128(Xl + ((ch ^ pswz0) * 16), b[set][0]);
+        rd128(Xl + HW * 128 + ((ch ^ pswz1) * 16), b[set][1]);
+      };
+      issue(0, 0);
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int set = k2 & 1;
+        if (k2 + 1 < 2) { issue(set ^ 1, k2 + 1); lgkm_wait3<TR + 2>(); } else { lgkm_wait3<0>(); }
+#pragma unroll
+        for (int i = 0; i < TR; ++i) touch8(a[set][i]);
+        touch8(b[set][0]); touch8(b[set][1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TR; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[set][i], b[set][j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      bb ^= 1;
+    }
+    ab ^= 1;
+  }
+
+  // ---- epilogue (staged through LDS as in v2): tile row = patch pixel py * 16 + px
+  constexpr int CPR = BN / 8;
+  static_assert(BM * BN * 2 <= ABUFS * A_BYTES + (BN * 128 * 2 - BM * 8), "epilogue tile does not fit");
+  char* tile = smem;                                   // BM * BN * 2 bytes: the halo stage(s) and, if needed, the head of the weight stages
+  int* rowY = reinterpret_cast<int*>(smem + ABUFS * A_BYTES + 2 * B_BYTES - BM * 8);   // tail of the weight stages
+  int* rowM = rowY + BM;
+  if (tid < BM) {
+    const int oy = y0 + (tid >> 4), ox = x0 + (tid & 15);
+    int oy_ = -1, om_ = -1;
+    if (oy < p.Ho && ox < p.Wo) {
+      oy_ = (int)(img * p.ysN + oy * p.ysH + ox * p.ysW);
+      om_ = (int)(img * p.msN + oy * p.msH + ox * p.msW);
+    }
+    rowY[tid] = oy_; rowM[tid] = om_;
+  }
+  {
+    // accumulator (i, j): channels wn * WTN + 16 * i + 4 * kq + {0..3} of pixel (patch row 2 * wm + j, column l15)
+    f32x4 bv[TR];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int i = 0; i < TR; ++i) bv[i] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WTN + i * 16 + 4 * kq);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (2 * wm + j) * TW + l15;
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        const int cl = wn * WTN + i * 16 + 4 * kq;
+        float v[4] = {acc[i][j][0] + bv[i][0], acc[i][j][1] + bv[i][1], acc[i][j][2] + bv[i][2], acc[i][j][3] + bv[i][3]};
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+        const int chunk = (cl >> 3) ^ (row & (CPR - 1));
+        *reinterpret_cast<bf16x4*>(tile + row * (BN * 2) + chunk * 16 + (cl & 4) * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NCH = BM * CPR / (NW * 64);
+  // the mask / old-value loads of all NCH chunks go out together, then the stores
+  int yo[NCH];
+  bf16x8 mk[NCH], old[NCH];
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    const int id = t * (NW * 64) + tid;
+    const int row = id / CPR, co = n0 + (id % CPR) * 8;
+    yo[t] = rowY[row];
+    if (yo[t] >= 0) {
+      if (p.mask && co < p.mask_channels) mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
+      if (p.accumulate) old[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.y) + yo[t] + co);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    const int id = t * (NW * 64) + tid;
+    const int row = id / CPR, cc = id % CPR;
+    if (yo[t] < 0) continue;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
+    const int co = n0 + cc * 8;
+    if (p.mask && co < p.mask_channels) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
+    }
+    if (p.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
+    }
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Shared-halo kernel for SMALL images ("v3p"): the 128-pixel tile is PR whole output rows of one image, packed in LDS
 // at a pitch of Wo + 2 rows (pixel m = (m / Wo, m % Wo) sits at LDS row (m / Wo) * pitch + m % Wo + tap offset
@@ -1042,6 +1241,7 @@ int g_tune_igemm_split = -1;    // >= 1 forces the split-K factor
 int g_tune_igemm_waves8 = 1;    // 8 waves per tile (32 pixels x 64 channels each) instead of 4: an LDS-DMA piece costs ~100 issue
                                 // cycles, so halving the pieces per wave shortens every K-step (+4..15 % in-process A/B)
 int g_tune_igemm_staged = 1;    // 0: scattered 8-byte epilogue stores instead of the LDS-staged epilogue
+int g_tune_igemm_mfma16 = 1;    // shared-halo kernel on 16x16x32 MFMAs (igemm3m_kernel)
 int g_tune_igemm_halo_min_blocks = 400;
 int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3_kernel); 0: always v2
 
@@ -1110,12 +1310,22 @@ static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images
     attr_set = true;
   }
   const dim3 grid((unsigned)(images * tiles_y * tiles_x), p.N / BN, 1);
+  if (g_tune_igemm_mfma16) {
+    static bool attr16 = false;
+    if (!attr16) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3m_kernel<BN, 4, NWN, ABUFS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr16 = true;
+    }
+    DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 4, NWN, ABUFS>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
+    return;
+  }
   DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3_kernel<BN, 4, NWN, ABUFS>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
 }
 
 // Packed-rows shared-halo kernel (igemm3p_kernel) for small images: geometry and split over channel slices.
 struct PlanP { int use, PR, tiles_per_img, splits, cps; };
-int g_tune_igemm_packed = 1;     // 0: deep levels stay on the per-tap kernel
+int g_tune_igemm_packed = 0;     // 0: deep levels stay on the per-tap kernel
 static PlanP make_plan_p(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int N) {
   PlanP pp = {0, 0, 0, 1, 0};
   if (!g_tune_igemm_halo || !g_tune_igemm_packed || dtype != DCT_BF16 || d->R != 3 || d->S != 3 || d->stride != 1 || d->dil != 1 ||
@@ -1338,6 +1548,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_WAVES8: g_tune_igemm_waves8 = value; return DCT_OK;
     case DCT_TUNE_IGEMM_HALO: g_tune_igemm_halo = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED: g_tune_igemm_packed = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_MFMA16: g_tune_igemm_mfma16 = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }
 }

@@ -113,7 +113,22 @@ def test_conv2d_epilogue_mask_accumulate_views(ops, dtype):
     (16, 256, 18, 16, 256, 2),      # packed rows, data-gradient form (pad 2), ragged last tile, unsplit
     (16, 1024, 13, 13, 128, 0),     # packed rows: one 11 x 11 tile per image, four-way split
 ])
-def test_conv2d_3x3_shared_halo(ops, B, Cin, H, W, Cout, pad):
+@pytest.mark.parametrize("mfma16", [0, 1])
+def test_conv2d_3x3_shared_halo(ops, B, Cin, H, W, Cout, pad, mfma16):
+    from dct_amd import _lib
+    if mfma16 and H < 90:
+        pytest.skip("the 16x16x32 variant exists for the patch kernel only")
+    _lib.load().dct_tune_set(11, mfma16)
+    try:
+        _shared_halo_case(ops, B, Cin, H, W, Cout, pad)
+    finally:
+        _lib.load().dct_tune_set(11, _MFMA16_DEFAULT)
+
+
+_MFMA16_DEFAULT = 1
+
+
+def _shared_halo_case(ops, B, Cin, H, W, Cout, pad):
     from dct_amd import _lib
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(11)

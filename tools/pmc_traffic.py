@@ -18,8 +18,8 @@ def per_kernel(path, counter):
             if r["Counter_Name"] != counter:
                 continue
             name = r["Kernel_Name"]
-            key = ("igemm3" if "igemm3_kernel" in name else "igemm2" if "igemm2_kernel" in name
-                   else "wgrad2" if "wgrad2_kernel" in name else None)
+            key = ("igemm3" if "igemm3" in name else "igemm2" if "igemm2_kernel" in name
+                   else "wgrad3" if "wgrad3_kernel" in name else "wgrad2" if "wgrad2_kernel" in name else None)
             if key is None:
                 continue
             a = agg.setdefault(key, [0, 0.0])
