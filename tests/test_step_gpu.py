@@ -232,3 +232,54 @@ def test_three_view_step_vs_oracle(tmp_path, arch, H, pair):
         a = torch.cat([p.detach().flatten().cpu() for p in seg.torchnet.parameters()]).double()
         b = torch.cat([p.detach().flatten() for p in om.net.parameters()]).double()
         assert ((a - b).norm() / b.norm()).item() < 1e-3
+
+
+@pytest.mark.parametrize("arch,adv", [("unet", True), ("enet", False)])
+def test_graph_replay_equals_eager_step_sequence(tmp_path, arch, adv):
+    """trainer/step_graph.py: seven steps (two eager, the capture, four replays) with fresh batches every step, dropout on
+    (UNet), a learning-rate change and a loss-weight change on the way must leave exactly the weights, Adam moments and
+    step counts of seven eagerly launched steps -- i.e. nothing a step depends on was baked into the captured graph."""
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    C, B, H, n = 3, 2, (176 if arch == "unet" else 64), 7
+    res = []
+    for use_graph in (False, True):
+        segs = []
+        for seed in (11, 12):
+            torch.manual_seed(seed)
+            seg = Segmentator({"name": arch, "num_classes": C, "compute_dtype": torch.bfloat16},
+                              {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                              {"name": "StepLR", "step_size": 90, "gamma": 0.1})
+            segs.append(seg)
+        lab = [FakeLoader(batches(81 + i, n, B, H, C), B) for i in range(2)]
+        unl = FakeLoader(batches(91, n, B, H, C), B)
+        crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+        tr = CoTrainer(segs, lab, unl, unl, crit, max_epoch=1, save_dir=str(tmp_path), device=DEV, axises=[1, 2],
+                       cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                       adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                       adv_training_dict={"eplision": 0.03}, use_tqdm=False, steps_per_epoch=n)
+        tr.use_hip_graph = use_graph
+        for s in segs:
+            s.train()
+        sups = []
+        for k in range(n):
+            if k == 4:                          # a scheduler step between replays: lr and lambda_cot change
+                for s in segs:
+                    s.optimizer.param_groups[0]["lr"] = 3e-4
+                tr.cot_scheduler.max_value = 0.25
+            lb = [(lab[i][k][0][0], lab[i][k][0][1]) for i in range(2)]
+            out = tr._run_step(lb, (unl[k][0][0], unl[k][0][1]), True, adv, (0, 1) if adv else None)
+            sups.append([float(v) for v in out["sup"]])
+        torch.cuda.synchronize()
+        if use_graph:
+            assert tr._step_graphs is not None and tr._step_graphs.captures >= 1 and tr._step_graphs.replays >= 4
+        res.append(dict(
+            w=[torch.cat([p.detach().flatten() for p in s.torchnet.parameters()]).cpu() for s in segs],
+            m=[s.optimizer._m.cpu() for s in segs], steps=[s.optimizer._steps for s in segs],
+            dev_steps=[float(s.optimizer._dev_state[0]) for s in segs], sups=sups))
+    a, b = res
+    assert a["steps"] == b["steps"] == [n, n] and a["dev_steps"] == b["dev_steps"] == [float(n)] * 2
+    assert a["sups"] == b["sups"]
+    for x, y in zip(a["w"] + a["m"], b["w"] + b["m"]):
+        assert torch.equal(x, y)
