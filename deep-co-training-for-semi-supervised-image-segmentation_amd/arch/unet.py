@@ -227,12 +227,15 @@ class UNet(nn.Module):
         self._ensure_packs()
         return self._run_forward(x, save)
 
-    def plan_backward(self, tape, dlogits: torch.Tensor, need_dx: bool = False, need_dw: bool = True):
-        """dlogits: NHWC fp32 like the logits.  Parameter gradients accumulate into the flat gradient buffer
-        (attached as p.grad); returns d/dx as [B,1,H,W] when need_dx."""
+    supports_grad_overwrite = True
+
+    def plan_backward(self, tape, dlogits: torch.Tensor, need_dx: bool = False, need_dw: bool = True,
+                      overwrite: bool = False):
+        """dlogits: NHWC fp32 like the logits.  Parameter gradients accumulate into (``overwrite``: replace the
+        contents of) the flat gradient buffer (attached as p.grad); returns d/dx as [B,1,H,W] when need_dx."""
         if need_dw:
             self.flat_params.ensure_grads()
-        dx = self._run_backward(tape, dlogits, need_dx, need_dw)
+        dx = self._run_backward(tape, dlogits, need_dx, need_dw, overwrite=overwrite and need_dw)
         return dx.reshape(dx.shape[0], 1, dx.shape[1], dx.shape[2]) if dx is not None else None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -347,8 +350,11 @@ class UNet(nn.Module):
         A["drop_scale"] = drop_scale
         return logits, (A if save else None)
 
-    def _run_backward(self, A, dlogits: torch.Tensor, need_dx: bool, need_dw: bool):
-        """dlogits: fp32 NHWC [B,H,W,C].  Accumulates parameter grads in place; returns dx or None."""
+    def _run_backward(self, A, dlogits: torch.Tensor, need_dx: bool, need_dw: bool, overwrite: bool = False):
+        """dlogits: fp32 NHWC [B,H,W,C].  Accumulates parameter grads in place (``overwrite``: writes them -- every
+        parameter of the network receives a gradient in every backward pass, so the first pass of a step can replace
+        the zero fill of the 124 MB gradient buffer and the read-modify-write of the folds); returns dx or None."""
+        gacc = not overwrite
         dt, dev = self.compute_dtype, dlogits.device
         B = dlogits.shape[0]
         P = self._packs
@@ -378,10 +384,10 @@ class UNet(nn.Module):
             if need_dw:
                 with on_side(dy, x_in):
                     if dt == torch.bfloat16:     # bias gradient rides along in the weight-gradient launch
-                        K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=True, db=self._gb(conv))
+                        K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=gacc, db=self._gb(conv))
                     else:
-                        K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=True)
-                        K.bias_grad(dy, self._gb(conv), accumulate=True)
+                        K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=gacc)
+                        K.bias_grad(dy, self._gb(conv), accumulate=gacc)
             if dx_out is not None:
                 K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, pad_h=2, pad_w=2, mask=mask,
                          mask_channels=mask_channels, mask_scale=mask_scale, accumulate=accumulate)
@@ -390,8 +396,8 @@ class UNet(nn.Module):
         def convT_bwd(conv, x_in, dy, dx_out, mask, mask_scale=1.0):
             if need_dw:
                 with on_side(dy, x_in):
-                    K.conv2d_wgrad(x_in, dy, self._gw(conv), R=2, S=2, stride=2, accumulate=True)
-                    K.bias_grad(dy, self._gb(conv), accumulate=True)
+                    K.conv2d_wgrad(x_in, dy, self._gw(conv), R=2, S=2, stride=2, accumulate=gacc)
+                    K.bias_grad(dy, self._gb(conv), accumulate=gacc)
             K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, R=2, S=2, stride=2, mask=mask, mask_scale=mask_scale)
             return dx_out
 
@@ -401,7 +407,7 @@ class UNet(nn.Module):
         de1b = new_like(e1b)
         K.head_bwd(e1b, df, self._w(self.final), de1b,
                    self._gw(self.final) if need_dw else None, self._gb(self.final) if need_dw else None,
-                   relu_mask=True, accumulate=True)
+                   relu_mask=True, accumulate=gacc)
         de1a = conv_bwd(self.enc1.at(2), e1a, de1b, new_like(e1a), mask=e1a)
         cat = A["cat1"]
         dcat = conv_bwd(self.enc1.at(0), cat, de1a, new_like(cat), mask=cat, mask_channels=64)
@@ -443,7 +449,7 @@ class UNet(nn.Module):
                 c0 = blk.at(0)
                 if need_dw:
                     with on_side(da):
-                        K.conv_cin1_wgrad(A["x"], da, self._gw(c0), self._gb(c0), accumulate=True)
+                        K.conv_cin1_wgrad(A["x"], da, self._gw(c0), self._gb(c0), accumulate=gacc)
                 if need_dx:
                     dx = K.conv_cin1_dgrad(da, self._w(c0), torch.empty_like(A["x"]), pad_h=0, pad_w=0)
         if side is not None:

@@ -122,6 +122,8 @@ class CoTrainer(Trainer):
         self.batch_lab_unlab = True         # one B_l+B_u pass per batch-independent net (see _run_step_fused)
         self.model_streams = True           # one HIP stream per model in the fused step (see _streams)
         self._stream_pool = None
+        self.grad_overwrite = True          # nets that support it: first backward pass of a step writes the gradients (no zero fill)
+        self._overwrite_models = set()
         self.use_hip_graph = True           # replay the fused step from a captured HIP graph (trainer/step_graph.py)
         self._step_graphs = None
         self.last_step = None
@@ -235,6 +237,8 @@ class CoTrainer(Trainer):
         def on(i):
             return torch.cuda.stream(streams[i]) if streams is not None and i is not None else contextlib.nullcontext()
         for i, seg in enumerate(self.segmentators):
+            if i in self._overwrite_models:      # the first backward pass of this model writes every gradient element
+                continue
             with on(i):
                 seg.optimizer.zero_grad()
         for idx, call in backward_calls:
@@ -383,13 +387,23 @@ class CoTrainer(Trainer):
                     if ranges is not None and k == len(passes[i]) - 1:
                         nets[i]._grad_hook = lambda b, i=i, r=ranges: self.grad_sync.begin_bucket(i, r[b][0], r[b][1])
                     try:
-                        nets[i].plan_backward(tape, dl, need_dx=False, need_dw=True)
+                        if i in self._overwrite_models:
+                            nets[i].plan_backward(tape, dl, need_dx=False, need_dw=True, overwrite=(k == 0))
+                        else:
+                            nets[i].plan_backward(tape, dl, need_dx=False, need_dw=True)
                     finally:
                         if ranges is not None:
                             nets[i]._grad_hook = None
                 passes[i].clear()
             return run
-        self._finish_step([(i, backward_of(i)) for i in range(S)], streams)
+        # nets whose every parameter gets a gradient in every pass, with the flat gradient buffer already attached:
+        # the first pass overwrites instead of zero_grad + accumulate (the reference's zero_grad at :245 has the same effect)
+        self._overwrite_models = {i for i in range(S) if self.grad_overwrite and passes[i] and
+                                  getattr(nets[i], "supports_grad_overwrite", False) and nets[i].flat_params.grads_attached()}
+        try:
+            self._finish_step([(i, backward_of(i)) for i in range(S)], streams)
+        finally:
+            self._overwrite_models = set()
         join()
         return dict(sup=sup, jsd=jsd, adv=adv, preds=preds, unlab_probs=unlab_probs)
 
