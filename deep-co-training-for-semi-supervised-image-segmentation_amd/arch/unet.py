@@ -194,15 +194,17 @@ class UNet(nn.Module):
                 else:
                     ent["dgrad"] = torch.empty(n, dtype=dt, device=dev)                  # [ci][flip taps][co]
             ws = fp.shadow_dense(self._pidx[id(conv.weight)]) if use_shadow else w       # K-major image in dt
+            # the packs read the bf16 shadow when there is one (half the bytes of the fp32 masters, same values:
+            # both are round-to-nearest of the same fp32 weights)
             if conv.transposed:
-                jobs.append((w, ent["fwd"], conv.cin, 4, conv.cout, 2, False))
+                jobs.append((ws, ent["fwd"], conv.cin, 4, conv.cout, 2, False))
                 ent["dgrad"] = ws                                                        # [ci][a][b][co] as stored
             else:
                 ent["fwd"] = ws                                                          # [co][r][s][ci] as stored
-                jobs.append((w, ent["dgrad"], conv.cout, conv.k * conv.k, conv.cin, 1, True))
+                jobs.append((ws, ent["dgrad"], conv.cout, conv.k * conv.k, conv.cin, 1, True))
         # every transposed pack of the network in one launch (dct_pack_weights_batched); the job table holds device
         # addresses, so it is rebuilt whenever the flat buffer or a pack was re-allocated
-        tkey = (fp.version, fp.flat.data_ptr(), dev, dt)
+        tkey = (fp.version, fp.flat.data_ptr(), fp.shadow.data_ptr() if use_shadow else 0, dev, dt)
         if self._pack_table is None or self._pack_table[0] != tkey:
             self._pack_table = (tkey,) + K.pack_jobs_table(jobs, dev)
         _, table, njobs, tiles = self._pack_table

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* src, T
 // All transposed weight packs of a network in ONE launch: job j owns the 32 x 32 (p, q) tiles [tile_begin[j],
 // tile_begin[j+1]) of dst[q * dq + t' * dt + p] = src[p][t][q]  (t = flip ? T-1-t' : t').  A UNet has 21 such packs of
 // 2-20 us each per step; as one launch they run at HBM speed.
-struct PackJob { const float* src; void* dst; int P, T, Q, flip; long long dq, dt; int tile_begin, pad_; };
+struct PackJob { const void* src; void* dst; int P, T, Q, flip; long long dq, dt; int tile_begin, src_bf16; };
 template <typename T>
 __global__ __launch_bounds__(256) void pack_transpose_batched_kernel(const PackJob* jobs, int njobs) {
   __shared__ float tile[32][33];
@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void pack_transpose_batched_kernel(const PackJ
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int pr = ly + 8 * k;
-    tile[pr][lx] = jb.src[((long long)(p0 + pr) * jb.T + t) * jb.Q + q0 + lx];
+    const long long si = ((long long)(p0 + pr) * jb.T + t) * jb.Q + q0 + lx;
+    tile[pr][lx] = jb.src_bf16 ? (float)reinterpret_cast<const bf16_t*>(jb.src)[si] : reinterpret_cast<const float*>(jb.src)[si];
   }
   __syncthreads();
   T* dst = reinterpret_cast<T*>(jb.dst);

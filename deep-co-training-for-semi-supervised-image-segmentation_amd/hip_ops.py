@@ -71,14 +71,16 @@ def pack_weight(src_f32, dst, P, T, Q, transpose=False, flip_taps=False):
 
 
 def pack_jobs_table(jobs, device):
-    """Device table for pack_weights_batched.  jobs: list of (src fp32 tensor, dst tensor, P, T, Q, mode, flip) with
+    """Device table for pack_weights_batched.  jobs: list of (src fp32 or bf16 tensor, dst tensor, P, T, Q, mode, flip) with
     mode 1 -> dst[Q][T'][P], mode 2 -> dst[T'][Q][P] (dct_pack_weight's transpose codes).  Returns (table, n, tiles)."""
     import struct
     buf, tiles = bytearray(), 0
     for src, dst, P, T, Q, mode, flip in jobs:
         assert P % 32 == 0 and Q % 32 == 0 and mode in (1, 2)
         dq, dt = (T * P, P) if mode == 1 else (P, Q * P)
-        buf += struct.pack("<QQiiiiqqii", src.data_ptr(), dst.data_ptr(), P, T, Q, int(bool(flip)), dq, dt, tiles, 0)
+        assert src.dtype in (torch.float32, torch.bfloat16)
+        buf += struct.pack("<QQiiiiqqii", src.data_ptr(), dst.data_ptr(), P, T, Q, int(bool(flip)), dq, dt, tiles,
+                           int(src.dtype == torch.bfloat16))
         tiles += (P // 32) * (Q // 32) * T
     table = torch.frombuffer(buf, dtype=torch.uint8).clone().to(device)
     return table, len(jobs), tiles

@@ -100,7 +100,8 @@ size_t dct_bias_grad_workspace_bytes(const dct_view* dy);
 int dct_pack_weight(const float* src, void* dst, int P, int T, int Q, int transpose, int flip_taps,
                     int dtype, dct_stream stream);
 /* All transposed packs of a network in one launch.  jobs_dev: device array of njobs records
- *   { const float* src; void* dst; int32 P, T, Q, flip; int64 dq, dt; int32 tile_begin, pad; }      (56 bytes)
+ *   { const void* src; void* dst; int32 P, T, Q, flip; int64 dq, dt; int32 tile_begin, src_bf16; }  (56 bytes;
+ *     src is fp32, or the bf16 image of the same tensor when src_bf16 != 0)
  * job j covers the 32 x 32 (p, q) tiles [tile_begin[j], tile_begin[j+1]) (P/32 * Q/32 * T of them; P, Q
  * multiples of 32) of dst[q*dq + t'*dt + p] = src[p][t][q]: (dq, dt) = (T*P, P) is dct_pack_weight's
  * transpose == 1, (P, Q*P) its transpose == 2.  total_tiles = tile_begin past the last job. */
