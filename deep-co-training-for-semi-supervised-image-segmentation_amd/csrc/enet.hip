@@ -15,6 +15,8 @@
 // Activations are NHWC in `dtype` (bf16 or f32); all per-channel vectors and the math are fp32.
 #include "dct_common.h"
 
+int g_enet_wgrad_max_blocks = 1024;   // dct_tune_set(DCT_TUNE_ENET_WGRAD_BLOCKS, n); <= WG_MAX_BLOCKS
+
 namespace {
 
 // Element access through a view whose storage is `T` or, when its bit of the call's f32 mask is set, fp32
@@ -434,6 +436,7 @@ struct WgP {
   int ppb;
   int fm;                         // f32 mask: bit0 a, bit1 b
 };
+constexpr int WG_MAX_BLOCKS = 1024;
 constexpr int WG_PB = 32;          // pixels staged per round
 constexpr int WG_TPT = 2;          // 4x8 register tiles per thread (<= 512 tiles: E <= 16384)
 
@@ -709,7 +712,7 @@ extern "C" int dct_enet_tail_bwd(const dct_view* dout, const dct_view* out_mask,
 
 extern "C" size_t dct_enet_wgrad_workspace_bytes(const dct_view* a, const dct_view* b, const dct_conv_desc* d) {
   if (!a || !b || !d) return 0;
-  return (size_t)256 * a->c * d->R * d->S * b->c * sizeof(float);
+  return (size_t)WG_MAX_BLOCKS * a->c * d->R * d->S * b->c * sizeof(float);
 }
 
 extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const dct_view* b, const dct_enet_tf* tfb,
@@ -726,8 +729,10 @@ extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const d
   p.R = d->R; p.S = d->S; p.stride = d->stride; p.dil = d->dil; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
   p.fm = f32_mask;
   const long long P = (long long)a->n * a->h * a->w;
-  long long blocks = (P + 4 * WG_PB - 1) / (4 * WG_PB);
-  if (blocks > 256) blocks = 256;
+  // latency-bound (gather, transform, barrier, 32-pixel FMA round): several resident blocks per CU overlap each other's
+  // phases; every block keeps >= 2 rounds so the zero fill and the partial-tile write stay amortised
+  long long blocks = (P + 2 * WG_PB - 1) / (2 * WG_PB);
+  if (blocks > g_enet_wgrad_max_blocks) blocks = g_enet_wgrad_max_blocks;
   if (blocks < 1) blocks = 1;
   long long ppb = (P + blocks - 1) / blocks;
   ppb = (ppb + WG_PB - 1) / WG_PB * WG_PB;

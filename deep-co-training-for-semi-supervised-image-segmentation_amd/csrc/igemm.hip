@@ -1539,6 +1539,7 @@ extern "C" int dct_debug_stamps(unsigned long long* out16, int reset) {
 #endif
 
 int dct_tune_set_wgrad(int knob, int value);  // wgrad.hip
+extern int g_enet_wgrad_max_blocks;           // enet.hip
 
 extern "C" int dct_tune_set(int knob, int value) {
   switch (knob) {
@@ -1549,6 +1550,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_HALO: g_tune_igemm_halo = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED: g_tune_igemm_packed = value; return DCT_OK;
     case DCT_TUNE_IGEMM_MFMA16: g_tune_igemm_mfma16 = value; return DCT_OK;
+    case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }
 }
