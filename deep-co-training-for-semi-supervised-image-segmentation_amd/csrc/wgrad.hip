@@ -501,8 +501,11 @@ template <int RB> __device__ __forceinline__ int swz3(int k) {       // in 16-B 
   return RB == 256 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2);
 }
 
-template <int BP, int BQ, int NW, bool NARROW>
-__global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
+// G: wave groups per block.  Each group of NW waves is a complete copy of the tile machinery (own stages, own half of the
+// block's K-steps); the groups' accumulators are added through LDS before the slab is written.  Two groups halve the
+// number of slabs (written once, read once by the fold: 38 MB per layer at 768 four-wave blocks) at the same waves per CU.
+template <int BP, int BQ, int NW, bool NARROW, int G>
+__global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   const WgradParams& p = pr.w;
   constexpr int RBP = BP * 2, RBQ = BQ * 2;
   constexpr int CPRP = RBP / 16, CPRQ = RBQ / 16, RPIP = 64 / CPRP, RPIQ = 64 / CPRQ;
@@ -512,10 +515,12 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   constexpr int WPR = BP / (NW / 2), TP = WPR / 32, TQ = BQ / 64;
   constexpr int STAGE = 64 * RBP + QROWS * RBQ;
   static_assert(TP >= 1 && TQ >= 1, "tile/wave mismatch");
-  extern __shared__ __attribute__((aligned(128))) char smem[];
+  extern __shared__ __attribute__((aligned(128))) char smem_all[];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: piece bookkeeping stays in SGPRs
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: piece bookkeeping stays in SGPRs
+  const int grp = wave_all / NW, wave = wave_all % NW;
+  char* smem = smem_all + grp * (2 * STAGE);
   const int wp = wave >> 1, wq = wave & 1;
 
   const int tiles_per_chunk = p.ptiles * 3 * p.qtiles;
@@ -530,7 +535,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   const int tr = tile % 3;
   const int pt = tile / 3;
   const int p0 = pt * BP, q0 = qt * BQ;
-  const int gbeg = chunk * pr.seg_per_chunk, gend = min(pr.nseg, gbeg + pr.seg_per_chunk);
+  const int cbeg = chunk * pr.seg_per_chunk, cend = min(pr.nseg, cbeg + pr.seg_per_chunk);
+  const int per_group = (cend - cbeg + G - 1) / G;                   // K-steps of every group (the last may have fewer)
+  const int gbeg = min(cend, cbeg + grp * per_group), gend = min(cend, gbeg + per_group);
 
   const char* Pb = p.P + (long long)p0 * 2;
   const char* Qb = p.Q + (long long)q0 * 2;
@@ -634,8 +641,10 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
 #pragma unroll
   for (int i = 0; i < TP; ++i) accb[i] = 0.f;
 
-  for (int gi = gbeg; gi < gend; ++gi) {
-    if (gi + 1 < gend) stage(smem + (cur ^ 1) * STAGE);     // all pieces up front: spreading them between the MFMA groups lands the stage later and was 8 % slower
+  for (int it = 0; it < per_group; ++it) {
+    const int gi = gbeg + it;
+    if (gi + 1 < gend) stage(smem + (cur ^ 1) * STAGE);
+    if (gi < gend) {                    // wave-uniform: a group with one step fewer only keeps the barrier     // all pieces up front: spreading them between the MFMA groups lands the stage later and was 8 % slower
     const unsigned Pl = smem_off + cur * STAGE;
     bf16x4 fa[2][TP][2], fb[2][3][TQ][2];
     auto issue = [&](int set, int kk) {
@@ -682,8 +691,49 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
           for (int e = 0; e < 8; ++e) accb[i] += (float)a[i][e];
       }
     }
+    }
     __syncthreads();
     cur ^= 1;
+  }
+  if constexpr (G > 1) {
+    // fold the groups: group g > 0 parks its accumulators in LDS (lane-linear), group 0 adds them in order
+    float* fold = reinterpret_cast<float*>(smem_all);
+    constexpr int PER_WAVE = (3 * TP * TQ * 16 + TP) * 64;
+    static_assert((size_t)NW * PER_WAVE * 4 <= (size_t)G * 2 * STAGE, "fold buffer does not fit");
+#pragma unroll 1
+    for (int g = 1; g < G; ++g) {
+      if (grp == g) {
+        float* dstp = fold + wave * PER_WAVE + lane;
+        int o = 0;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < TQ; ++j)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) dstp[64 * (o++)] = acc[s][i][j][e];
+#pragma unroll
+        for (int i = 0; i < TP; ++i) dstp[64 * (o++)] = accb[i];
+      }
+      __syncthreads();
+      if (grp == 0) {
+        const float* srcp = fold + wave * PER_WAVE + lane;
+        int o = 0;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < TQ; ++j)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[s][i][j][e] += srcp[64 * (o++)];
+#pragma unroll
+        for (int i = 0; i < TP; ++i) accb[i] += srcp[64 * (o++)];
+      }
+      __syncthreads();
+    }
+    if (grp != 0) return;
   }
 
   const int half = lane >> 5, l31 = lane & 31;
@@ -735,8 +785,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
   *outp = (s0 + s1) + (s2 + s3);
 }
 
-struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct, slabs; int v3, segs_per_row, nseg, seg_per_chunk, pitch, nr, units; };
+struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct, slabs; int v3, segs_per_row, nseg, seg_per_chunk, pitch, nr, units, groups; };
 
+int g_tune_wgrad_groups = 2;       // wave groups per wgrad3 block (1 | 2)
 int g_tune_wgrad_rows_fill = 70;   // percent: minimum fill of the 64-row K-steps for the filter-row kernel
 int g_tune_wgrad_rows = 1;     // 3x3 stride-1 layers on wide images: three taps of a filter row per block (wgrad3_kernel)
 int g_tune_wgrad_v2 = 1;       // dct_tune_set(DCT_TUNE_WGRAD_V2, 0): register-staged kernel
@@ -796,10 +847,11 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
       // 128 x 64 and 128 x 128 (one 8-wave block per CU at 130 / 205 VGPRs) on every eligible layer, by 20-35 %
       pl.bp = 64; pl.ptiles = p->c / 64; pl.bq = 64; pl.qtiles = q->c / 64;
       const int tiles3 = pl.ptiles * pl.qtiles * 3;
-      const int target = 768;     // blocks; swept 384 / 512 / 640 / 768 / 1024 on the UNet layers: 768 is 10-25 % ahead of the rest
-      long long ch = (target + tiles3 / 2) / tiles3;
+      const int target = 768;     // 4-wave units; swept 384 / 512 / 640 / 768 / 1024 on the UNet layers: 768 is 10-25 % ahead of the rest
+      pl.groups = g_tune_wgrad_groups == 2 ? 2 : 1;     // four groups (one 16-wave block per CU) measured 0.7 % behind two     // two wave groups per block: half the slabs at the same waves per CU
+      long long ch = (target / pl.groups + tiles3 / 2) / tiles3;
       if (ch > 256) ch = 256;
-      if (ch > nseg / 4) ch = nseg / 4;
+      if (ch > nseg / (4 * pl.groups)) ch = nseg / (4 * pl.groups);
       while (ch > 1 && ch * per_chunk > (192ll << 20)) --ch;
       if (g_tune_wgrad_chunks >= 1) ch = g_tune_wgrad_chunks;
       if (ch < 1) ch = 1;
@@ -841,21 +893,23 @@ static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
   }
   DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ, NW>), dim3(grid), dim3(NW * 64), lds, st, pr);
 }
-template <int BP, int BQ, int NW, bool NARROW>
+template <int BP, int BQ, int NW, bool NARROW, int G>
 static void launch_w3_t(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
-  constexpr size_t lds = 2 * (64 * (size_t)BP * 2 + 72 * (size_t)BQ * 2);
+  constexpr size_t lds = G * 2 * (64 * (size_t)BP * 2 + 72 * (size_t)BQ * 2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<BP, BQ, NW, NARROW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<BP, BQ, NW, NARROW, G>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW>), dim3(grid), dim3(NW * 64), lds, st, pr);
+  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW, G>), dim3(grid), dim3(G * NW * 64), lds, st, pr);
 }
 static void launch_w3(const Wgrad3Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, 3);
   // the planner only picks 64 x 64 tiles for this kernel
-  if (pr.pitch > 0) launch_w3_t<64, 64, 4, true>(pr, grid, st); else launch_w3_t<64, 64, 4, false>(pr, grid, st);
+  if (pl.groups == 2) {
+    if (pr.pitch > 0) launch_w3_t<64, 64, 4, true, 2>(pr, grid, st); else launch_w3_t<64, 64, 4, false, 2>(pr, grid, st);
+  } else if (pr.pitch > 0) launch_w3_t<64, 64, 4, true, 1>(pr, grid, st); else launch_w3_t<64, 64, 4, false, 1>(pr, grid, st);
 }
 static void launch_w2(const Wgrad2Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, pr.w.R * pr.w.S);
@@ -941,5 +995,6 @@ int dct_tune_set_wgrad(int knob, int value) {
   if (knob == DCT_TUNE_WGRAD_WAVES8) { g_tune_wgrad_waves8 = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_ROWS) { g_tune_wgrad_rows = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_ROWS_FILL) { g_tune_wgrad_rows_fill = value; return DCT_OK; }
+  if (knob == DCT_TUNE_WGRAD_GROUPS) { g_tune_wgrad_groups = value; return DCT_OK; }
   return DCT_ERR_BAD_ARG;
 }
