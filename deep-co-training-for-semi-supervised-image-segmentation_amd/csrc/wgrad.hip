@@ -787,6 +787,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
 
 struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct, slabs; int v3, segs_per_row, nseg, seg_per_chunk, pitch, nr, units, groups; };
 
+int g_tune_wgrad_target = 384;     // block target of the per-tap kernel (slab bytes = blocks x 64 KiB).  In isolation ~1150 blocks is
+                                   // fastest; on the whole step (tools/ab_step.py --knob 14) 256-768 are level and 1.5 % ahead of 1150
+int g_tune_wgrad3_target = 768;    // same for the filter-row kernel, in 4-wave units
 int g_tune_wgrad_groups = 2;       // wave groups per wgrad3 block (1 | 2)
 int g_tune_wgrad_rows_fill = 70;   // percent: minimum fill of the 64-row K-steps for the filter-row kernel
 int g_tune_wgrad_rows = 1;     // 3x3 stride-1 layers on wide images: three taps of a filter row per block (wgrad3_kernel)
@@ -806,7 +809,7 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
   long long chunks;
   if (pl.v2) {
     // measured (tools/bench_conv.py chunk sweep): ~1150 blocks in total, at most 64 slabs to fold
-    chunks = (1150 + tiles / 2) / tiles;
+    chunks = (g_tune_wgrad_target + tiles / 2) / tiles;
     if (chunks > 64) chunks = 64;
     const long long max_by_pix = (M + 4 * bkp - 1) / (4 * bkp);      // >= 4 K-steps per chunk
     if (chunks > max_by_pix) chunks = max_by_pix;
@@ -847,7 +850,7 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
       // 128 x 64 and 128 x 128 (one 8-wave block per CU at 130 / 205 VGPRs) on every eligible layer, by 20-35 %
       pl.bp = 64; pl.ptiles = p->c / 64; pl.bq = 64; pl.qtiles = q->c / 64;
       const int tiles3 = pl.ptiles * pl.qtiles * 3;
-      const int target = 768;     // 4-wave units; swept 384 / 512 / 640 / 768 / 1024 on the UNet layers: 768 is 10-25 % ahead of the rest
+      const int target = g_tune_wgrad3_target;     // 4-wave units; swept 384 / 512 / 640 / 768 / 1024 on the UNet layers: 768 is 10-25 % ahead of the rest
       pl.groups = g_tune_wgrad_groups == 2 ? 2 : 1;     // four groups (one 16-wave block per CU) measured 0.7 % behind two     // two wave groups per block: half the slabs at the same waves per CU
       long long ch = (target / pl.groups + tiles3 / 2) / tiles3;
       if (ch > 256) ch = 256;
@@ -996,5 +999,7 @@ int dct_tune_set_wgrad(int knob, int value) {
   if (knob == DCT_TUNE_WGRAD_ROWS) { g_tune_wgrad_rows = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_ROWS_FILL) { g_tune_wgrad_rows_fill = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_GROUPS) { g_tune_wgrad_groups = value; return DCT_OK; }
+  if (knob == DCT_TUNE_WGRAD3_TARGET) { if (value < 64) return DCT_ERR_BAD_ARG; g_tune_wgrad3_target = value; return DCT_OK; }
+  if (knob == DCT_TUNE_WGRAD_TARGET) { if (value < 64) return DCT_ERR_BAD_ARG; g_tune_wgrad_target = value; return DCT_OK; }
   return DCT_ERR_BAD_ARG;
 }
