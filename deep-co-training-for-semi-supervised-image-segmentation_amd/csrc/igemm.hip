@@ -1237,6 +1237,7 @@ struct Plan {
 };
 
 int g_tune_igemm_v2 = 1;        // dct_tune_set(DCT_TUNE_IGEMM_V2, 0) forces the register-staged kernel
+int g_tune_igemm_split_target = 450;   // block target of a split layer (tiles < 200)
 int g_tune_igemm_split = -1;    // >= 1 forces the split-K factor
 int g_tune_igemm_waves8 = 1;    // 8 waves per tile (32 pixels x 64 channels each) instead of 4: an LDS-DMA piece costs ~100 issue
                                 // cycles, so halving the pieces per wave shortens every K-step (+4..15 % in-process A/B)
@@ -1272,7 +1273,7 @@ static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc*
     // (two resident blocks per CU interleave); below that ~450 blocks in total is the sweet spot, and each
     // split must keep >= 4 K-steps to amortise its prologue and its fp32 slab
     if (pl.tiles < 200) {
-      splits = (int)((450 + pl.tiles / 2) / pl.tiles);
+      splits = (int)((g_tune_igemm_split_target + pl.tiles / 2) / pl.tiles);
       if (splits > 8) splits = 8;
       while (splits > 1 && pl.kiters / splits < 4) --splits;
     }
@@ -1550,6 +1551,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_HALO: g_tune_igemm_halo = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED: g_tune_igemm_packed = value; return DCT_OK;
     case DCT_TUNE_IGEMM_MFMA16: g_tune_igemm_mfma16 = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_SPLIT_TARGET: if (value < 64) return DCT_ERR_BAD_ARG; g_tune_igemm_split_target = value; return DCT_OK;
     case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }
