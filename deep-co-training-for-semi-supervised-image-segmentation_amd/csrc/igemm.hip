@@ -35,6 +35,7 @@ struct IgemmParams {
   int kiters, kiters_per_split, cin_iters;
   int cout;  // real Cout (N/4 in scatter mode)
   int staged;  // v2: LDS-staged epilogue with 16-byte row stores (host-checked alignment / 32-bit offsets)
+  int xcd_tiles, xcd_total;  // v3m: XCD-aware 1-D tile order (0: plain 2-D grid)
 };
 
 template <typename T> struct Mfma;
@@ -798,10 +799,21 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / NWM, wm = wave % NWM;
-  int bx = blockIdx.x;
+  // XCD-aware tile order (knob DCT_TUNE_IGEMM_XCD): workgroups go round-robin over the 8 XCDs, each with its own L2.
+  // Tile t of a 1-D grid is given to XCD t % 8's (t / 8)-th slot, and an XCD's slots cover a CONTIGUOUS range of
+  // (patch, channel tile) pairs with the channel tile fastest: the N tiles of one patch and neighbouring patches
+  // (shared halo rows) read their input through the same L2.
+  int bx, ntile;
+  if (p.xcd_tiles > 0) {
+    const int per_xcd = p.xcd_tiles;                          // ceil(total tiles / 8)
+    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int nt = p.N / BN;
+    if ((blockIdx.x >> 3) >= per_xcd || t >= p.xcd_total) return;
+    bx = t / nt; ntile = t - bx * nt;
+  } else { bx = blockIdx.x; ntile = blockIdx.y; }
   const int tx = bx % tiles_x; bx /= tiles_x;
   const int ty = bx % tiles_y; const int img = bx / tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * BN;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = ntile * BN;
   const long long Ktot = 9ll * p.Cin;
   const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
   const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
@@ -1242,6 +1254,7 @@ int g_tune_igemm_split = -1;    // >= 1 forces the split-K factor
 int g_tune_igemm_waves8 = 1;    // 8 waves per tile (32 pixels x 64 channels each) instead of 4: an LDS-DMA piece costs ~100 issue
                                 // cycles, so halving the pieces per wave shortens every K-step (+4..15 % in-process A/B)
 int g_tune_igemm_staged = 1;    // 0: scattered 8-byte epilogue stores instead of the LDS-staged epilogue
+int g_tune_igemm_xcd = 0;       // XCD-aware tile order of the shared-halo kernel
 int g_tune_igemm_mfma16 = 1;    // shared-halo kernel on 16x16x32 MFMAs (igemm3m_kernel)
 int g_tune_igemm_halo_min_blocks = 400;
 int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3_kernel); 0: always v2
@@ -1312,13 +1325,20 @@ static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images
   }
   const dim3 grid((unsigned)(images * tiles_y * tiles_x), p.N / BN, 1);
   if (g_tune_igemm_mfma16) {
+    IgemmParams q = p;
+    dim3 g1 = grid;
+    if (g_tune_igemm_xcd) {
+      q.xcd_total = (int)(grid.x * grid.y);
+      q.xcd_tiles = (q.xcd_total + 7) / 8;
+      g1 = dim3((unsigned)(q.xcd_tiles * 8), 1, 1);
+    }
     static bool attr16 = false;
     if (!attr16) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3m_kernel<BN, 4, NWN, ABUFS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr16 = true;
     }
-    DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 4, NWN, ABUFS>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
+    DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 4, NWN, ABUFS>), g1, dim3(4 * NWN * 64), lds, st, q, tiles_x, tiles_y);
     return;
   }
   DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3_kernel<BN, 4, NWN, ABUFS>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
@@ -1463,6 +1483,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   p.cin_iters = x->c / pl.bk;
   p.partial = nullptr;
   p.staged = 0;
+  p.xcd_tiles = 0; p.xcd_total = 0;
   if (pl.v2 && pl.splits == 1 && !d->accumulate && g_tune_igemm_staged) {
     const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
                      (long long)y->n * y->sn < (1ll << 31);
@@ -1551,6 +1572,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_HALO: g_tune_igemm_halo = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED: g_tune_igemm_packed = value; return DCT_OK;
     case DCT_TUNE_IGEMM_MFMA16: g_tune_igemm_mfma16 = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_XCD: g_tune_igemm_xcd = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT_TARGET: if (value < 64) return DCT_ERR_BAD_ARG; g_tune_igemm_split_target = value; return DCT_OK;
     case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);

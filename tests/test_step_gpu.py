@@ -283,3 +283,42 @@ def test_graph_replay_equals_eager_step_sequence(tmp_path, arch, adv):
     assert a["sups"] == b["sups"]
     for x, y in zip(a["w"] + a["m"], b["w"] + b["m"]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("H,B_l,B_u,C", [(200, 3, 5, 2), (176, 1, 2, 4), (264, 2, 2, 3)])
+def test_unet_bf16_step_odd_shapes(tmp_path, H, B_l, B_u, C):
+    """Planner robustness: image sizes / batch sizes other than the benchmark's (GM 200 x 200, the 176 minimum, a
+    non-multiple-of-16 size; ragged patches, runs and tiles everywhere): five bf16 steps (eager, capture, replays) stay
+    finite and step 0's losses match the fp32 kernels on the same weights to bf16 accuracy."""
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    n = 5
+    first = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        segs = []
+        for seed in (31, 32):
+            torch.manual_seed(seed)
+            segs.append(Segmentator({"name": "unet", "num_classes": C, "compute_dtype": dtype, "dropout_p": 0.0},
+                                    {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                                    {"name": "StepLR", "step_size": 90, "gamma": 0.1}))
+        lab = [FakeLoader(batches(51 + i, n, B_l, H, C), B_l) for i in range(2)]
+        unl = FakeLoader(batches(61, n, B_u, H, C), B_u)
+        crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+        tr = CoTrainer(segs, lab, unl, unl, crit, max_epoch=1, save_dir=str(tmp_path), device=DEV, axises=list(range(1, C)),
+                       cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                       adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                       adv_training_dict={"eplision": 0.03}, use_tqdm=False, steps_per_epoch=n)
+        for s in segs:
+            s.train()
+        steps = n if dtype == torch.bfloat16 else 1
+        for k in range(steps):
+            lb = [(lab[i][k][0][0], lab[i][k][0][1]) for i in range(2)]
+            out = tr._run_step(lb, (unl[k][0][0], unl[k][0][1]), True, True, (0, 1))
+            vals = [float(v) for v in out["sup"]] + [float(out["jsd"]), float(out["adv"])]
+            assert all(np.isfinite(v) for v in vals), (dtype, k, vals)
+            if k == 0:
+                first[dtype] = vals
+    a, b = first[torch.float32], first[torch.bfloat16]
+    np.testing.assert_allclose(b[:2], a[:2], rtol=2e-2)              # supervised losses
+    np.testing.assert_allclose(b[2], a[2], rtol=0.25, atol=1e-7)      # JSD of two near-uniform predictions: tiny, relative noise is large
