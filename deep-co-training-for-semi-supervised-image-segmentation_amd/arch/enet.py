@@ -371,11 +371,7 @@ class Enet(nn.Module):
         dg = self._g(rec.bn.weight) if need_dw else None
         db = self._g(rec.bn.bias) if need_dw else None
         ds = self._g(rec.act.weight) if (need_dw and isinstance(rec.act, _PReLU)) else None
-        if isinstance(rec.act, _PReLU) and ds is None:
-            ds = torch.zeros(c, dtype=torch.float32, device=dev)
-        if dg is None:
-            dg = torch.zeros(c, dtype=torch.float32, device=dev)
-            db = torch.zeros(c, dtype=torch.float32, device=dev)
+        # FGSM pass (need_dw False): the finalize kernel skips null parameter gradients -- no throw-away zero buffers
         K.enet_bn_bwd(rec.raw, g, g_mask, rec.tf, rec.mean, rec.invstd, dg, db, ds, scratch, draw, training=self._tape_training)
         return draw
 
