@@ -21,7 +21,8 @@ from dct_amd import _lib  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--knob", type=int, required=True)
+    ap.add_argument("--knob", type=int, default=-1)
+    ap.add_argument("--attr", default="", help="toggle a boolean CoTrainer attribute (a = False, b = True) instead of a library knob")
     ap.add_argument("--a", type=int, default=0)
     ap.add_argument("--b", type=int, default=1)
     ap.add_argument("--config", default="cfg2")
@@ -43,7 +44,10 @@ def main():
         return tr._run_step(lb, ub, True, cfg["train_adv"], (0, 1) if cfg["train_adv"] else None)
 
     def arm(v):
-        lib.dct_tune_set(args.knob, v)
+        if args.attr:
+            setattr(tr, args.attr, bool(v))
+        else:
+            lib.dct_tune_set(args.knob, v)
         for i in range(3):
             one_step(i)
         torch.cuda.synchronize()
