@@ -119,10 +119,12 @@ def test_conv2d_3x3_shared_halo(ops, B, Cin, H, W, Cout, pad, mfma16):
     if mfma16 and H < 90:
         pytest.skip("the 16x16x32 variant exists for the patch kernel only")
     _lib.load().dct_tune_set(11, mfma16)
+    _lib.load().dct_tune_set(10, 1)          # small images: the packed-rows kernel (off by default) is what these cases test
     try:
         _shared_halo_case(ops, B, Cin, H, W, Cout, pad)
     finally:
         _lib.load().dct_tune_set(11, _MFMA16_DEFAULT)
+        _lib.load().dct_tune_set(10, 0)
 
 
 _MFMA16_DEFAULT = 1
