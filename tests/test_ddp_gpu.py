@@ -1,0 +1,80 @@
+"""Two data-parallel ranks on ONE GPU (both processes on cuda:0, torch.distributed over gloo, which moves CUDA tensors
+through the host): the multi-rank control flow of the fused step on the real kernels -- weight broadcast, per-model
+streams, gradient buckets handed to FlatGradSync.begin_bucket from inside the backward pass, per-model wait, fused Adam.
+(The RCCL transport itself needs one GPU per rank; tests/test_step_gpu.py covers it single-rank.)"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _trainer(tmp, rank, with_sync):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import FakeLoader, batches
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    C, H, B, n = 3, 176, 1, 3
+    segs = []
+    for seed in (5 + 10 * rank, 6 + 10 * rank):      # ranks start from DIFFERENT weights: the broadcast must equalise them
+        torch.manual_seed(seed)
+        segs.append(Segmentator({"name": "unet", "num_classes": C, "compute_dtype": torch.bfloat16, "dropout_p": 0.0},
+                                {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                                {"name": "StepLR", "step_size": 90, "gamma": 0.1}))
+    lab = [FakeLoader(batches(100 * rank + 31 + i, n, B, H, C), B) for i in range(2)]
+    unl = FakeLoader(batches(100 * rank + 41, n, B, H, C), B)
+    crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tr = CoTrainer(segs, lab, unl, unl, crit, max_epoch=1, save_dir=tmp, device="cuda:0", axises=[1, 2],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False, steps_per_epoch=n)
+    for s in segs:
+        s.train()
+    if with_sync:
+        from dct_amd.ddp import FlatGradSync
+        tr.grad_sync = FlatGradSync(segs)
+    return tr, lab, unl, n
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    tr, lab, unl, n = _trainer(os.path.join(out, f"r{rank}"), rank, True)
+    for k in range(n):
+        lb = [(lab[i][k][0][0], lab[i][k][0][1]) for i in range(2)]
+        o = tr._run_step(lb, (unl[k][0][0], unl[k][0][1]), True, True, (0, 1))
+        assert all(torch.isfinite(v) for v in o["sup"])
+    torch.cuda.synchronize()
+    w = [torch.cat([p.detach().flatten() for p in s.torchnet.parameters()]).cpu() for s in tr.segmentators]
+    torch.save(dict(w=w, buckets=tr.grad_sync.bucket_calls), os.path.join(out, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_one_gpu_fused_step_stays_in_sync(tmp_path):
+    world, port, out = 2, _free_port(), str(tmp_path)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(out, "w0.pt"), weights_only=False)
+    r1 = torch.load(os.path.join(out, "w1.pt"), weights_only=False)
+    assert r0["buckets"] == r1["buckets"] == 3 * 2 * 3          # 3 buckets x 2 models x 3 steps, from inside the backward
+    for a, b in zip(r0["w"], r1["w"]):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)                                  # same start (broadcast) + same averaged gradients
