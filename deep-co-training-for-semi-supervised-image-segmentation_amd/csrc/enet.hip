@@ -13,8 +13,10 @@
 //   * the bottleneck tail relu(main + act(bn(raw))) also does the 2x2 max-pool-with-indices /
 //     max-unpool / zero-channel-pad of the down- and up-sampling bottlenecks.
 // Activations are NHWC in `dtype` (bf16 or f32); all per-channel vectors and the math are fp32.
+#include <algorithm>
 #include "dct_common.h"
 
+int g_enet_wgrad_slices = 1;          // 0: one pixel slice per round whatever the tile count
 int g_enet_wgrad_max_blocks = 1024;   // dct_tune_set(DCT_TUNE_ENET_WGRAD_BLOCKS, n); <= WG_MAX_BLOCKS
 
 namespace {
@@ -443,7 +445,10 @@ constexpr int WG_TPT = 2;          // 4x8 register tiles per thread (<= 512 tile
 // Register-tiled: the [Ca] x [taps*Cb] gradient is cut into 4 x 8 tiles, a thread owns up to two of them
 // and per staged pixel reads 4 + 8 operands (three 16-B LDS reads) for 32 FMAs.  LDS rows are padded to
 // multiples of 4 / 8 floats and zero-filled, so ragged channel counts (3, 13, 14) need no branches.
-template <typename T>
+// SL pixel slices: when the gradient has <= 256 / SL register tiles, SL thread groups each take 32 / SL of a round's pixels
+// for every tile and their accumulators are added through LDS at the end -- otherwise most of the block idles in the FMA
+// phase (a 16 x 16 x 9 gradient has 72 tiles).
+template <typename T, int SL>
 __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, int E) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Ca = p.a.c, Cb = p.b.c, taps = p.R * p.S;
@@ -455,11 +460,15 @@ __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, 
   __shared__ int pixn[WG_PB], pixy[WG_PB], pixx[WG_PB];
   const long long P = (long long)p.a.n * p.a.h * p.a.w;
   const long long pbeg = (long long)blockIdx.x * p.ppb, pend = min(P, pbeg + p.ppb);
-  int to[WG_TPT], tk[WG_TPT];
-  float acc[WG_TPT][4][8];
+  constexpr int TPB = 256 / SL;               // tiles a slice group can own
+  constexpr int NT = SL == 1 ? WG_TPT : 1;    // tiles per thread
+  constexpr int QS = WG_PB / SL;              // pixels of a round per slice
+  const int slice = SL == 1 ? 0 : (int)threadIdx.x / TPB, tl = SL == 1 ? (int)threadIdx.x : (int)threadIdx.x % TPB;
+  int to[NT], tk[NT];
+  float acc[NT][4][8];
 #pragma unroll
-  for (int j = 0; j < WG_TPT; ++j) {
-    const int t = min(j * 256 + (int)threadIdx.x, ntiles - 1);
+  for (int j = 0; j < NT; ++j) {
+    const int t = min(j * 256 + tl, ntiles - 1);
     to[j] = (t / KT) * 4; tk[j] = (t % KT) * 8;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -490,10 +499,11 @@ __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, 
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < WG_TPT; ++j) {
-      if (j * 256 < ntiles) {      // block-uniform
+    for (int j = 0; j < NT; ++j) {
+      if (SL > 1 ? tl < ntiles : j * 256 < ntiles) {
 #pragma unroll 8
-        for (int q = 0; q < WG_PB; ++q) {
+        for (int qq = 0; qq < QS; ++qq) {
+          const int q = slice * QS + qq;
           const f32x4 av = *reinterpret_cast<const f32x4*>(As + q * CaP + to[j]);
           const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + q * kbP + tk[j]);
           const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs + q * kbP + tk[j] + 4);
@@ -509,9 +519,33 @@ __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, 
       }
     }
   }
+  if constexpr (SL > 1) {
+    // fold the slices in fixed order through LDS: [slice][tile][32]
+    __syncthreads();
+    float* fold = sm;
+    if (slice > 0 && tl < ntiles) {
+      float* d = fold + ((slice - 1) * TPB + tl) * 32;
 #pragma unroll
-  for (int j = 0; j < WG_TPT; ++j) {
-    const int t = j * 256 + threadIdx.x;
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) d[a * 8 + b] = acc[0][a][b];
+    }
+    __syncthreads();
+    if (slice == 0 && tl < ntiles) {
+#pragma unroll 1
+      for (int s2 = 1; s2 < SL; ++s2) {
+        const float* d = fold + ((s2 - 1) * TPB + tl) * 32;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 8; ++b) acc[0][a][b] += d[a * 8 + b];
+      }
+    }
+    if (slice != 0) return;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = j * 256 + tl;
     if (t < ntiles) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -722,7 +756,10 @@ extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const d
   const int E = a->c * d->R * d->S * b->c;
   const int CaP = (a->c + 3) & ~3, kbP = (d->R * d->S * b->c + 7) & ~7;
   if ((CaP / 4) * (kbP / 8) > 256 * WG_TPT) return DCT_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)WG_PB * (CaP + kbP) * sizeof(float);
+  const int ntiles = (CaP / 4) * (kbP / 8);
+  const int SL = !g_enet_wgrad_slices ? 1 : ntiles <= 64 ? 4 : ntiles <= 128 ? 2 : 1;       // pixel slices per round (see the kernel)
+  size_t lds = (size_t)WG_PB * (CaP + kbP) * sizeof(float);
+  if (SL > 1) lds = std::max(lds, (size_t)(SL - 1) * (256 / SL) * 32 * sizeof(float));
   if (lds > 64 * 1024) return DCT_ERR_UNSUPPORTED;
   WgP p;
   p.a = to_view(a); p.b = to_view(b); p.tfa = to_tf(tfa); p.tfb = to_tf(tfb);
@@ -740,7 +777,9 @@ extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const d
   const int nb = (int)((P + ppb - 1) / ppb);
   if (!workspace || workspace_bytes < (size_t)nb * E * sizeof(float)) return DCT_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_wgrad_kernel<T>, dim3(nb), dim3(256), lds, st, p, (float*)workspace, E));
+  if (SL == 4) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_wgrad_kernel<T, 4>), dim3(nb), dim3(256), lds, st, p, (float*)workspace, E));
+  else if (SL == 2) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_wgrad_kernel<T, 2>), dim3(nb), dim3(256), lds, st, p, (float*)workspace, E));
+  else ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_wgrad_kernel<T, 1>), dim3(nb), dim3(256), lds, st, p, (float*)workspace, E));
   DCT_LAUNCH(DCT_PROF_OTHER, enet_wgrad_reduce_kernel, dim3(div_up(E, 16)), dim3(256), 0, st, (const float*)workspace, dw, E, nb);
   return dct_check_launch();
 }
