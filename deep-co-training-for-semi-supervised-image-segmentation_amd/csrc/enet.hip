@@ -16,6 +16,7 @@
 #include <algorithm>
 #include "dct_common.h"
 
+int g_enet_reduce_ppt = 8;           // pixels per thread of a per-channel reduction (sets the number of partial rows)
 int g_enet_wgrad_slices = 1;          // 0: one pixel slice per round whatever the tile count
 int g_enet_wgrad_max_blocks = 1024;   // dct_tune_set(DCT_TUNE_ENET_WGRAD_BLOCKS, n); <= WG_MAX_BLOCKS
 
@@ -583,7 +584,9 @@ static inline int red_plan(long long P, int C, int& ppb) {
   int CP = 1;
   while (CP < C) CP <<= 1;
   const int rows = 256 / CP;
-  long long blocks = (P + 16ll * rows - 1) / (16ll * rows);
+  // g_enet_reduce_ppt pixels per thread.  Swept on cfg4 (graph replay): 4 / 8 / 16 / 32 / 64 -> 50.0 / 49.8 / 50.5 / 53.9 /
+  // 65.4 ms per step: the reductions want parallelism, the longer fold of the single-block finalize costs less
+  long long blocks = (P + (long long)g_enet_reduce_ppt * rows - 1) / ((long long)g_enet_reduce_ppt * rows);
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   ppb = (int)((P + blocks - 1) / blocks);
