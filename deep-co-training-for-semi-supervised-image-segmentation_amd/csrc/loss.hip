@@ -372,17 +372,18 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 }
 // state (nullable): device-resident {step count t, learning rate, table base, table length} (doubles).  When given,
 // the step-dependent scalars come from device memory so that a captured HIP graph of the step needs no per-step
-// host value: table[2*(t-base-1)] = {step_size, bc2_sqrt} as the HOST computed them for step t (bit-identical to the
-// scalar-argument path); outside the table they are formed here in double.
+// host value: table[2*(t-base-1)] = {1 - beta1^t, sqrt(1 - beta2^t)} as the HOST computed them (doubles; the step size
+// lr / bc1 is then the same correctly rounded division the host does: bit-identical to the scalar-argument path, and a
+// learning-rate change touches only state[1]); outside the table they are formed here in double.
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float step_size,
                                                     float bc2s, float omb1, float b2, float omb2, float eps, float wd, bf16_t* shadow,
-                                                    const double* state, const float* table, double beta1, double beta2) {
+                                                    const double* state, const double* table, double beta1, double beta2) {
   if (state) {
     const double t = state[0], lr = state[1];
     const long long idx = (long long)t - (long long)state[2] - 1;
     if (table && idx >= 0 && idx < (long long)state[3]) {
-      step_size = table[2 * idx];
-      bc2s = table[2 * idx + 1];
+      step_size = (float)(lr / table[2 * idx]);        // the division the host does (lr / bc1 in double, then fp32)
+      bc2s = (float)table[2 * idx + 1];
     } else {
       step_size = (float)(lr / (1.0 - pow(beta1, t)));
       bc2s = (float)sqrt(1.0 - pow(beta2, t));
@@ -598,12 +599,12 @@ extern "C" int dct_adam_flat(float* p, const float* g, float* m, float* v, int64
   if (bf16_shadow && ((uintptr_t)bf16_shadow & 7)) return DCT_ERR_UNSUPPORTED;
   DCT_LAUNCH(DCT_PROF_ADAM, adam_kernel, dim3(wide_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
              step_size, bc2_sqrt, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, (bf16_t*)bf16_shadow,
-             (const double*)nullptr, (const float*)nullptr, beta1, beta2);
+             (const double*)nullptr, (const double*)nullptr, beta1, beta2);
   return dct_check_launch();
 }
 
 extern "C" int dct_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, double* state,
-                                 const float* table, double beta1, double beta2, float eps, float weight_decay,
+                                 const double* table, double beta1, double beta2, float eps, float weight_decay,
                                  void* bf16_shadow, dct_stream stream) {
   if (!p || !g || !m || !v || !state || n < 1) return DCT_ERR_BAD_ARG;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return DCT_ERR_UNSUPPORTED;

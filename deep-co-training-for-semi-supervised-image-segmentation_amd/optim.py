@@ -51,18 +51,21 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _ensure_dev_state(self, dev, lr):
         """Device state of dct_adam_flat_dev: {t, lr, table base, table length} + the table of host-computed
-        {lr / (1 - beta1^t), sqrt(1 - beta2^t)} for the next TABLE_STEPS steps (python doubles rounded to fp32,
-        exactly what torch.optim.Adam hands its kernels).  Rebuilt when the table runs out, the learning rate
-        changes or the moments were re-imported -- a few small copies every TABLE_STEPS steps, never inside a
-        captured graph."""
+        {1 - beta1^t, sqrt(1 - beta2^t)} (python doubles) for the next TABLE_STEPS steps; the kernel forms
+        lr / (1 - beta1^t) in double and rounds to fp32 -- exactly what torch.optim.Adam hands its kernels.  The table is
+        rebuilt when it runs out or the moments were re-imported; a learning-rate change is one async fill of state[1]
+        (a per-step schedule costs nothing more).  Never inside a captured graph."""
         lr = float(lr)
         fresh = self._dev_state is None or self._dev_state.device != dev
-        if not fresh and lr == self._dev_lr and self._steps + 1 <= self._table_base + self.TABLE_STEPS:
+        if not fresh and self._steps + 1 <= self._table_base + self.TABLE_STEPS:
+            if lr != self._dev_lr:
+                self._dev_state[1:2].fill_(lr)
+                self._dev_lr = lr
             return self._dev_state
         b1, b2 = self.param_groups[0]["betas"]
         base = self._steps
-        rows = [(lr / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t)) for t in range(base + 1, base + 1 + self.TABLE_STEPS)]
-        table = torch.tensor(rows, dtype=torch.float32)
+        rows = [(1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)) for t in range(base + 1, base + 1 + self.TABLE_STEPS)]
+        table = torch.tensor(rows, dtype=torch.float64)
         state = torch.tensor([float(self._steps), lr, float(base), float(self.TABLE_STEPS)], dtype=torch.float64)
         if fresh:
             self._dev_state, self._dev_table = state.to(dev), table.to(dev)

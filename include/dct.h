@@ -223,14 +223,14 @@ int dct_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float
                   float bc2_sqrt, double beta1, double beta2, float eps, float weight_decay,
                   void* bf16_shadow, dct_stream stream);
 /* Same update with the step-dependent scalars in device memory: state = {step count t, learning rate,
- * table base, table length} (four doubles), table (nullable) = {step_size, bc2_sqrt} float pairs the host
- * computed for steps base+1 .. base+length.  Stream-ordered: t += 1, then the pair for step t is read from
+ * table base, table length} (four doubles), table (nullable) = {1 - beta1^t, sqrt(1 - beta2^t)} double pairs the
+ * host computed for steps t = base+1 .. base+length.  Stream-ordered: t += 1, then the pair for step t is read from
  * the table (bit-identical to dct_adam_flat with the same host scalars); outside the table it is formed on
  * the device in double: step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t).  No per-step host
  * scalar, so the launch can be replayed from a captured HIP graph (torch.optim.Adam's `capturable` mode is
  * the reference-side analogue). */
 int dct_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, double* state,
-                      const float* table, double beta1, double beta2, float eps, float weight_decay,
+                      const double* table, double beta1, double beta2, float eps, float weight_decay,
                       void* bf16_shadow, dct_stream stream);
 
 /* ---- K2/K3/K4/K6/K7/K8: Enet layers (arch/enet.py:8-243) -------------------------------------
