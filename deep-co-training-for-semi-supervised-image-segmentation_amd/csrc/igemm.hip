@@ -1256,6 +1256,7 @@ int g_tune_igemm_waves8 = 1;    // 8 waves per tile (32 pixels x 64 channels eac
 int g_tune_igemm_staged = 1;    // 0: scattered 8-byte epilogue stores instead of the LDS-staged epilogue
 int g_tune_igemm_xcd = 0;       // XCD-aware tile order of the shared-halo kernel
 int g_tune_igemm_mfma16 = 1;    // shared-halo kernel on 16x16x32 MFMAs (igemm3m_kernel)
+int g_tune_igemm_halo_cover = 75;      // percent of the image the 8 x 16 patches must cover
 int g_tune_igemm_halo_min_blocks = 400;
 int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3_kernel); 0: always v2
 
@@ -1510,7 +1511,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     const long long blocks = (long long)y->n * tiles_y * tiles_x * (p.N / bn);
     const double cover = (double)p.Ho * p.Wo / ((double)tiles_y * 8 * tiles_x * 16);
     // measured (tools/bench_conv.py --ab): the 64-channel tile only pays with a single channel slice (four blocks per CU)
-    if (y16 && m16 && cover >= 0.75 && blocks >= g_tune_igemm_halo_min_blocks && (bn == 128 || x->c == 64)) {
+    if (y16 && m16 && cover >= g_tune_igemm_halo_cover * 0.01 && blocks >= g_tune_igemm_halo_min_blocks && (bn == 128 || x->c == 64)) {
       if (bn == 128) {
         if (x->c == 64) launch_v3<128, 2, 1>(p, tiles_x, tiles_y, y->n, st); else launch_v3<128, 2, 2>(p, tiles_x, tiles_y, y->n, st);
       } else launch_v3<64, 1, 1>(p, tiles_x, tiles_y, y->n, st);
@@ -1574,6 +1575,8 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_PACKED: g_tune_igemm_packed = value; return DCT_OK;
     case DCT_TUNE_IGEMM_MFMA16: g_tune_igemm_mfma16 = value; return DCT_OK;
     case DCT_TUNE_IGEMM_XCD: g_tune_igemm_xcd = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_HALO_MIN_BLOCKS: g_tune_igemm_halo_min_blocks = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_HALO_COVER: g_tune_igemm_halo_cover = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT_TARGET: if (value < 64) return DCT_ERR_BAD_ARG; g_tune_igemm_split_target = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_PPT: if (value < 1 || value > 4096) return DCT_ERR_BAD_ARG; g_enet_reduce_ppt = value; return DCT_OK;
     case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;

@@ -334,7 +334,9 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
        DCT_TUNE_WGRAD3_TARGET = 15,
        DCT_TUNE_IGEMM_SPLIT_TARGET = 16,
        DCT_TUNE_IGEMM_XCD = 17,
-       DCT_TUNE_ENET_REDUCE_PPT = 18 };  /* pixels per thread of an Enet per-channel reduction (default: see enet.hip) */  /* 1: XCD-aware tile order in the shared-halo kernel (level with the plain 2-D grid on the step: default 0) */  /* >= 64 (default 450): block target of a split-K conv layer */  /* >= 64: block target (4-wave units) of the filter-row weight-gradient kernel */  /* >= 64 (default: see wgrad.hip): block target of the per-tap weight-gradient kernel */  /* 1 | 2 (default 2): wave groups per block of the filter-row weight-gradient kernel */  /* 1..1024 (default 1024): cap on the pixel chunks (blocks) of dct_enet_wgrad */  /* 1: shared-halo kernel on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (default: see igemm.hip) */  /* 1 (default): packed-rows shared-halo kernel for 3x3 stride-1 layers on small images; 0: v2 *//* percent (default 70): minimum fill of that kernel's 64-pixel K-steps */
+       DCT_TUNE_ENET_REDUCE_PPT = 18,
+       DCT_TUNE_IGEMM_HALO_MIN_BLOCKS = 19,  /* default 400: fewest blocks for which the shared-halo patch kernel is taken */
+       DCT_TUNE_IGEMM_HALO_COVER = 20 };     /* percent (default 75): least image cover of its 8 x 16 patches */  /* pixels per thread of an Enet per-channel reduction (default: see enet.hip) */  /* 1: XCD-aware tile order in the shared-halo kernel (level with the plain 2-D grid on the step: default 0) */  /* >= 64 (default 450): block target of a split-K conv layer */  /* >= 64: block target (4-wave units) of the filter-row weight-gradient kernel */  /* >= 64 (default: see wgrad.hip): block target of the per-tap weight-gradient kernel */  /* 1 | 2 (default 2): wave groups per block of the filter-row weight-gradient kernel */  /* 1..1024 (default 1024): cap on the pixel chunks (blocks) of dct_enet_wgrad */  /* 1: shared-halo kernel on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (default: see igemm.hip) */  /* 1 (default): packed-rows shared-halo kernel for 3x3 stride-1 layers on small images; 0: v2 *//* percent (default 70): minimum fill of that kernel's 64-pixel K-steps */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 
