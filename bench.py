@@ -95,7 +95,7 @@ def make_trainer(cfg, dtype, device, rank, world, grad_sync_factory, n_batches=4
     from dct_amd.loss import get_loss_fn
     from dct_amd.models import Segmentator
     from dct_amd.trainer import CoTrainer
-    from helpers import FakeLoader
+    from helpers import FakeLoader, blob_batches
     S, C, H = cfg["S"], cfg["C"], cfg["H"]
     torch.manual_seed(1234)        # identical initial weights on every rank
     segs = [Segmentator({"name": cfg["arch"], "num_classes": C, "compute_dtype": dtype},
@@ -103,13 +103,9 @@ def make_trainer(cfg, dtype, device, rank, world, grad_sync_factory, n_batches=4
                         {"name": "StepLR", "step_size": 90, "gamma": 0.1}) for _ in range(S)]
 
     def dev_batches(seed, B):
-        g = torch.Generator().manual_seed(seed)
-        out = []
-        for i in range(n_batches):
-            img = torch.rand(B, 1, H, H, generator=g).to(device)
-            gt = torch.randint(0, C, (B, 1, H, H), generator=g).to(device)
-            out.append([[img, gt], None, [f"r{rank}_{seed}_{i}_{j}" for j in range(B)]])
-        return out
+        # blob-structured slices (tests/helpers.py): the nets learn them, so the timed steps run on the operand statistics
+        # of a network that is training (i.i.d. random labels drive it to the trivial uniform predictor)
+        return [[[b[0][0].to(device), b[0][1].to(device)], None, b[2]] for b in blob_batches(seed, n_batches, B, H, C)]
 
     base = 1234 + 1000 * rank      # reference default seed (config/ACDC_config_cotraing.yaml:79) + rank
     lab = [FakeLoader(dev_batches(base + 1 + i, cfg["B_l"]), cfg["B_l"]) for i in range(S)]
@@ -120,10 +116,8 @@ def make_trainer(cfg, dtype, device, rank, world, grad_sync_factory, n_batches=4
                    cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
                    adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
                    adv_training_dict={"eplision": 0.03}, use_tqdm=False)
-    for i, s in enumerate(segs):
+    for s in segs:
         s.train()
-        if hasattr(s.torchnet, "dropout_seed"):
-            s.torchnet.dropout_seed += 7919 * (rank * S + i)
     if world > 1:
         tr.grad_sync = grad_sync_factory(segs)
     return tr, lab, unl
@@ -147,19 +141,20 @@ def host_cores() -> int:
 
 def cpu_baseline(cfg, seconds_budget=25.0):
     """The oracle's step (fp32, ATen CPU kernels = what the reference executes) on a bounded sample:
-    bs 1+1, one warm-up step, then as many timed steps as fit the budget (at least one)."""
+    the configuration's own batch (cfg2: 8+8 = 24 images per step), one warm-up step, then as many timed steps as fit the
+    budget (at least one)."""
     import oracle
+    from helpers import blob_batches
     S, C, H = cfg["S"], cfg["C"], cfg["H"]
-    B = 1
+    B_l, B_u = cfg["B_l"], cfg["B_u"]
     threads = host_cores()
     torch.set_num_threads(threads)
     models = []
     for s in range(S):
         torch.manual_seed(100 + s)
         models.append(oracle.OracleModel.make(oracle.build_net(cfg["arch"], C).train()))
-    g = torch.Generator().manual_seed(5)
-    lab = [(torch.rand(B, 1, H, H, generator=g), torch.randint(0, C, (B, 1, H, H), generator=g)) for _ in range(S)]
-    unl = torch.rand(B, 1, H, H, generator=g)
+    lab = [tuple(blob_batches(5 + s, 1, B_l, H, C)[0][0]) for s in range(S)]
+    unl = blob_batches(99, 1, B_u, H, C)[0][0][0]
 
     def step():
         oracle.cotrain_step(models, lab, unl, True, cfg["train_adv"], lam_cot=0.5, lam_adv=0.05, eps=0.03)
@@ -172,19 +167,18 @@ def cpu_baseline(cfg, seconds_budget=25.0):
         step()
         n += 1
     dt = (time.perf_counter() - t0) / n
-    imgs = S * B + B
-    imgs_note = ""
+    imgs = S * B_l + B_u
     return {"value": imgs / dt, "unit": "imgs/sec", "cores": threads, "kind": "port",
             "sample": f"oracle (PyTorch-CPU fp32 restatement of the reference step) {S}x{cfg['arch']} {H}x{H} C={C}, "
-                      f"bs {B}+{B} ({imgs} imgs/step), {n} timed steps after 1 warm-up, {dt:.2f} s/step, "
+                      f"bs {B_l}+{B_u} ({imgs} imgs/step, the benchmarked batch), {n} timed steps after 1 warm-up, {dt:.2f} s/step, "
                       f"{threads} threads"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -255,6 +249,40 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # The step with the in-step meters on (SURVEY.md 8d asks for it separately): what _train_loop adds around _run_step --
+    # DiceMeter.add on the labeled and unlabeled predictions, the loss meters, and the progress read-out every 10 steps.
+    meters_ms = None
+    if rank == 0 and world == 1:
+        from dct_amd.metrics import AverageValueMeter, DiceMeter
+        axes = list(range(1, cfg["C"]))
+        dm = [DiceMeter(report_axises=axes, method='2d', C=cfg["C"]) for _ in range(2 * S)]
+        lm = [AverageValueMeter() for _ in range(S)]
+        nm = min(args.steps, 20)
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        for i in range(nm):
+            o = one_step(args.warmup + args.steps + i)
+            lb_gt = [lab[m][(args.warmup + args.steps + i) % nb][0][1] for m in range(S)]
+            ub_gt = unl[(args.warmup + args.steps + i) % nb][0][1]
+            for m in range(S):
+                dm[m].add(o["preds"][m], lb_gt[m])
+                dm[S + m].add(o["unlab_probs"][m], ub_gt)
+                lm[m].add(o["sup"][m])
+            if i % 10 == 0 or i == nm - 1:
+                [float(d.value()[0][0]) for d in dm[:S]]
+        torch.cuda.synchronize()
+        meters_ms = 1e3 * (time.perf_counter() - tm) / nm
+    # Operand statistics of the timed network (MI355X_MICROARCH.md, DVFS give-back: zero / trivial operands clock higher):
+    # fraction of exactly-zero activations at every conv output of model 0 on the next batch.
+    operand_stats = None
+    if rank == 0 and cfg["arch"] == "unet":
+        net0 = tr.segmentators[0].torchnet
+        _, tape = net0.plan_forward(torch.cat((lab[0][0][0][0], unl[0][0][0]), dim=0), True)
+        torch.cuda.synchronize()
+        keys = ["a1", "d1", "a2", "d2", "a3", "d3", "a4", "d4", "c1", "c2", "e4a", "e4b", "e3a", "e3b", "e2a", "e2b", "e1a", "e1b"]
+        operand_stats = {"zero_fraction_of_bf16_activations": {k: round(float((tape[k] == 0).float().mean()), 4) for k in keys if k in tape},
+                         "note": "ReLU outputs (d4 / c2 include dropout p=0.5); ~0.5 is what a trained ReLU net carries"}
+        del tape
     # Roofline leg: the SAME K steps once more with every launch bracketed by HIP events on its
     # stream (kept out of the timed region above: ~1200 event records per step would cost the
     # step ~25 % and `value` must be the unperturbed rate).
@@ -292,9 +320,14 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.config}: {cfg['desc']}", "imgs_per_step_per_gpu": imgs_per_step,
                    "global_batch": f"{cfg['B_l'] * world}+{cfg['B_u'] * world}", "parallelism": f"dp{world}",
-                   "weights": "random init (xavier_normal), reference architecture"},
+                   "weights": "random init (xavier_normal), reference architecture; trained for the setup + warm-up steps on "
+                              "blob-structured synthetic slices (tests/helpers.py::blob_batches)"},
         "losses_last_step": losses,
     }
+    if meters_ms is not None:
+        result["ms_per_step_with_meters"] = meters_ms
+    if operand_stats is not None:
+        result["operand_stats"] = operand_stats
     if rank == 0:
         if prof is not None and cfg["arch"] == "unet":
             gemm_f, small_f = unet_conv_flops(cfg["H"], cfg["H"], cfg["C"])

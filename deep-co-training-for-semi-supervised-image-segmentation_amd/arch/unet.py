@@ -130,9 +130,13 @@ class UNet(nn.Module):
         self.external_dropout_masks: Optional[List[torch.Tensor]] = None  # parity replay hook
         self.last_dropout_masks: Optional[List[torch.Tensor]] = None
         self.record_dropout_masks = False
+        self.dropout_mask_log: List[List[torch.Tensor]] = []   # with record_dropout_masks: one entry per forward (the caller clears it)
         self._drop_calls = 0                  # host mirror of the device call counter below
         self._drop_state: Optional[torch.Tensor] = None   # int64[1] on the device: Philox offset = calls << 40
-        self.dropout_seed = 0x5DEECE66D
+        # Philox seed of the two dropout sites: drawn from torch's global generator at construction, so a user seed
+        # (torch.manual_seed / fix_all_seed) controls it and co-trained models get decorrelated masks (the reference
+        # draws every mask from that generator: network.py:165,210).  ddp.FlatGradSync mixes the rank in.
+        self.dropout_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         self._debug: Optional[dict] = None   # tools/debug_unet_layers.py stashes backward intermediates here
         self._grad_hook = None               # data parallelism: called with a bucket index as gradient ranges complete
         self.wgrad_side_stream = False       # opt-in: weight gradients on a second HIP stream (see _run_backward)
@@ -348,6 +352,7 @@ class UNet(nn.Module):
         A["fshape"] = (h - 4, w - 4)
         if masks_out is not None:
             self.last_dropout_masks = masks_out
+            self.dropout_mask_log.append(masks_out)
         drop_scale = 1.0 / (1.0 - self.dropout_p) if (training or self.external_dropout_masks is not None) else 1.0
         A["drop_scale"] = drop_scale
         return logits, (A if save else None)

@@ -41,6 +41,12 @@ class FlatGradSync(object):
         self._avg = dist.get_backend(process_group) == "nccl"   # RCCL supports ReduceOp.AVG; gloo does not
         if broadcast_weights:
             self.broadcast_weights()
+        # decorrelate the ranks' dropout masks (same torch seed on every rank gives every rank the same Philox seed)
+        for seg in self.segmentators:
+            net = seg.torchnet
+            if hasattr(net, "dropout_seed") and not getattr(net, "_rank_mixed", False):
+                net.dropout_seed = (int(net.dropout_seed) + 0x9E3779B97F4A7C15 * (self.rank + 1) * int(self.rank > 0)) & ((1 << 62) - 1)
+                net._rank_mixed = True
 
     # -- weights: rank 0's initialisation everywhere ---------------------------------------------
     @torch.no_grad()

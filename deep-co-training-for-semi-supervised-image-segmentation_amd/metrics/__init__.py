@@ -20,9 +20,13 @@ class DiceMeter(object):
         self.report_axis = report_axises
         self.diceLog = []
         self.C = C
+        self._acc = None        # float64 [2, C + 1] on the device: running sum / sum of squares per class and of the report mean
+        self._n = 0
 
     def reset(self):
         self.diceLog = []
+        self._acc = None
+        self._n = 0
 
     def add(self, pred_logit: torch.Tensor, gt: torch.Tensor, smooth: float = 1e-8):
         """pred_logit [B,C,H,W] (logits or probabilities: only the argmax matters, dice_meter.py:28-32),
@@ -41,6 +45,13 @@ class DiceMeter(object):
             inter, ps, gs = inter.sum(0, keepdim=True), ps.sum(0, keepdim=True), gs.sum(0, keepdim=True)
         dice = (2 * inter.float() + smooth) / ((ps + gs).float() + smooth)
         self.diceLog.append(dice)
+        # running moments, so that value() (called 4 S times per reported step, cotraining_totalloss.py:251-264) costs O(1)
+        # instead of a torch.cat over the whole history
+        rep = dice.mean(1, keepdim=True) if self.report_axis == 'all' else dice[:, self.report_axis].mean(1, keepdim=True)
+        row = torch.cat((dice, rep), dim=1).double()
+        upd = torch.stack((row.sum(0), (row * row).sum(0)))
+        self._acc = upd if self._acc is None else self._acc + upd
+        self._n += dice.shape[0]
 
     @property
     def log(self):
@@ -51,11 +62,15 @@ class DiceMeter(object):
         return log
 
     def value(self, **kwargs):
-        log = self.log
-        means = log.mean(0)
-        stds = log.std(0)
-        report_means = log.mean(1) if self.report_axis == 'all' else log[:, self.report_axis].mean(1)
-        return (report_means.mean(), report_means.std()), (means, stds)
+        if self._acc is None:               # nothing added yet: the reference reports over one row of zeros
+            log = self.log
+            report_means = log.mean(1) if self.report_axis == 'all' else log[:, self.report_axis].mean(1)
+            return (report_means.mean(), report_means.std()), (log.mean(0), log.std(0))
+        n = self._n
+        mean = self._acc[0] / n
+        var = (self._acc[1] - n * mean * mean).clamp_min(0.0) / (n - 1) if n > 1 else torch.full_like(mean, float('nan'))
+        mean, std = mean.float(), var.sqrt().float()
+        return (mean[-1], std[-1]), (mean[:-1], std[:-1])
 
     def detailed_summary(self) -> dict:
         _, (means, _) = self.value()

@@ -30,6 +30,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._m = None
         self._v = None
         self._steps = 0
+        self._import_steps = False
         self._flat_version = -1
         self._on_step = on_step
         # {step count, lr} as float64[2] ON THE DEVICE: the kernel forms the bias corrections itself
@@ -104,12 +105,16 @@ class FusedAdam(torch.optim.Optimizer):
         m = torch.zeros(f.total, dtype=torch.float32, device=dev)
         v = torch.zeros(f.total, dtype=torch.float32, device=dev)
         steps = self._steps
+        if self._import_steps:          # load_state_dict: the loaded moments come with THEIR step count (torch.optim.Adam
+            steps = 0                   # takes the loaded one too); one flat kernel = one count, the largest loaded
         for p, off in zip(f.params, f.offsets):
             st = self.state.get(p)
             if st and "exp_avg" in st:
                 m.as_strided(p.shape, p.stride(), off).copy_(st["exp_avg"])
                 v.as_strided(p.shape, p.stride(), off).copy_(st["exp_avg_sq"])
-                steps = max(steps, int(float(st.get("step", 0))))
+                if self._import_steps:
+                    steps = max(steps, int(float(st.get("step", 0))))
+        self._import_steps = False
         self._m, self._v, self._steps = m, v, steps
         self._dev_state = None
         self._state_views()
@@ -139,6 +144,10 @@ class FusedAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._m = None  # force re-import of the loaded per-parameter moments
+        self._import_steps = True
+        self._dev_state = None
+        steps = [int(float(st.get("step", 0))) for st in self.state.values() if isinstance(st, dict)]
+        self._steps = max(steps) if steps else 0
 
     def state_dict(self):
         if self._m is not None:

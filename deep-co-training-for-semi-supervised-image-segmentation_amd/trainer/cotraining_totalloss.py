@@ -200,12 +200,21 @@ class CoTrainer(Trainer):
         dict(sup=[Tensor], jsd=Tensor|0, adv=Tensor|0, preds=[Tensor], unlab_probs=[Tensor])."""
         if train_adv and adv_choice is None:
             adv_choice = self._draw_adv_choice()
-        lab = [(img.to(self.device), gt.to(self.device)) for img, gt in lab_batches]
+        # the kernels take raw pointers: images fp32, labels int64, both dense (a loader may hand over uint8 labels or
+        # half images; the reference's modules would cast or raise, the C ABI would reinterpret the bytes)
+        def _img(t):
+            return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+        def _gt(t):
+            return t.to(device=self.device, dtype=torch.int64).contiguous()
+        lab = [(_img(img), _gt(gt)) for img, gt in lab_batches]
         unl = None
         if unlab_batch is not None and (train_jsd or train_adv):
-            unl = (unlab_batch[0].to(self.device), unlab_batch[1].to(self.device) if unlab_batch[1] is not None else None)
+            unl = (_img(unlab_batch[0]), _gt(unlab_batch[1]) if unlab_batch[1] is not None else None)
         if self._fused_ok():
-            if self.use_hip_graph and self.grad_sync is None and all(s.torchnet.training for s in self.segmentators):
+            # replay needs every per-step scalar on the device: only the fused Adam keeps its step count / lr there
+            graphable = all(hasattr(s.optimizer, "refresh_lr") and hasattr(s.optimizer, "_steps") for s in self.segmentators)
+            if self.use_hip_graph and graphable and self.grad_sync is None and all(s.torchnet.training for s in self.segmentators):
                 if self._step_graphs is None:
                     from .step_graph import StepGraphCache
                     self._step_graphs = StepGraphCache(self)

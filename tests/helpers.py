@@ -34,3 +34,43 @@ def batches(seed, n, B, H, C, W=None):
 def digest(t):
     t = t.detach().double().flatten().cpu()
     return np.array([t.sum().item(), t.abs().sum().item(), t.norm().item(), t.abs().max().item()])
+
+
+def blob_batches(seed, n, B, H, C, W=None, noise=0.08):
+    """Blob-structured synthetic slices ("blob-structured labels optional for DSC sanity"): background 0 plus
+    one to three random ellipses per foreground class; the image is a class-dependent grey level plus smooth noise, in
+    [0, 1] -- learnable by a segmentation net, unlike i.i.d. random labels, so losses fall and Dice rises within tens of
+    steps.  Same batch format as ``batches``."""
+    W = W or H
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    levels = torch.linspace(0.15, 0.85, C)
+    out = []
+    for i in range(n):
+        gt = torch.zeros(B, H, W, dtype=torch.int64)
+        for b in range(B):
+            for c in range(1, C):
+                for _ in range(int(torch.randint(1, 4, (1,), generator=g))):
+                    cy, cx = (torch.rand(2, generator=g) * torch.tensor([H, W]) * 0.8 + torch.tensor([H, W]) * 0.1).tolist()
+                    ry, rx = (torch.rand(2, generator=g) * (min(H, W) / 5 - min(H, W) / 16) + min(H, W) / 16).tolist()
+                    gt[b][((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = c
+        img = levels[gt] + noise * torch.randn(B, H, W, generator=g)
+        # 3x3 box blur: soft edges, spatially correlated noise
+        img = torch.nn.functional.avg_pool2d(img.unsqueeze(1), 3, stride=1, padding=1, count_include_pad=False)
+        img = img.clamp_(0.0, 1.0)
+        out.append([[img.contiguous(), gt.unsqueeze(1).contiguous()], None, [f"blob{seed}_{i}_{j}" for j in range(B)]])
+    return out
+
+
+class MaskReplayNet(torch.nn.Module):
+    """Oracle UNet wrapper: each forward pops the next recorded pair of dropout masks (GPU Philox masks cannot equal CPU
+    masks, so parity runs replay the masks the HIP network drew)."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+        self.queue = []
+
+    def forward(self, x):
+        masks = self.queue.pop(0) if self.queue else None
+        return self.net(x, dropout_masks=masks) if masks is not None else self.net(x)

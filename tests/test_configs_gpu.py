@@ -1,0 +1,247 @@
+"""BASELINE.json's configurations as they are benchmarked, held to the CPU oracle at full size ("next" 2):
+
+* cfg1  S = 1, cross-entropy only (no JSD, no FGSM) through both ``_run_step`` paths.  The reference ``unet`` cannot run at
+        64 x 64 (valid convolutions: H >= 176), so cfg1's "4x1x64x64, 2-class" plumbing case runs ``enet``
+        at 64 x 64 and ``unet`` at its 176 x 176 minimum -- never a padded UNet.
+* cfg2 / cfg3  exactly what ``bench.py`` times: ``bench.make_trainer`` (2 x UNet, 8 + 8 images of 256 x 256, C = 4, dropout
+        on, one HIP stream per model, labeled + unlabeled batch in one pass, HIP-graph replay after two eager steps), four
+        steps against ``oracle.cotrain_step`` on the same weights, batches and (replayed) dropout masks: losses of every
+        step, logits of step 0, per-tensor weight displacement after the last step; bf16 (the benchmarked mode) and fp32.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+from helpers import FakeLoader, MaskReplayNet, batches, blob_batches  # noqa: E402
+
+DEV = "cuda:0"
+REPORT = bool(os.environ.get("DCT_PARITY_REPORT"))
+
+
+def _say(*a):
+    if REPORT:
+        print(*a, flush=True)
+
+
+def _crit():
+    from dct_amd.loss import get_loss_fn
+    return {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+
+
+def _cotrainer(tmp_path, segs, lab, unl, C, n):
+    from dct_amd.trainer import CoTrainer
+    return CoTrainer(segs, lab, unl, unl, _crit(), max_epoch=1, save_dir=str(tmp_path), device=DEV, axises=list(range(1, C)),
+                     cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                     adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                     adv_training_dict={"eplision": 0.03}, use_tqdm=False, steps_per_epoch=n)
+
+
+# ------------------------------------------------------------------------------------------------ cfg1
+@pytest.mark.parametrize("arch,H", [("enet", 64), ("unet", 176)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_cfg1_single_model_supervised_only(tmp_path, arch, H, fused):
+    """BASELINE configs[0]: one model, fully supervised CE, batch 4, 2 classes.  Five steps (two eager, the capture, two
+    replays on the fused path) against the oracle's step with S = 1, train_jsd = train_adv = False."""
+    from dct_amd import ModelMode
+    from dct_amd.models import Segmentator
+    C, B, n = 2, 4, 5
+    torch.manual_seed(3)
+    onet = oracle.build_net(arch, C, **({"dropout_p": 0.0} if arch == "unet" else {})).train()
+    arch_dict = {"name": arch, "num_classes": C, "compute_dtype": torch.float32}
+    if arch == "unet":
+        arch_dict["dropout_p"] = 0.0
+    seg = Segmentator(arch_dict, {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4}, {"name": "StepLR", "step_size": 90, "gamma": 0.1})
+    seg.torchnet.load_state_dict(onet.state_dict())
+    om = oracle.OracleModel.make(onet)
+    lab = [FakeLoader(blob_batches(17, n, B, H, C), B)]
+    unl = FakeLoader(batches(18, n, B, H, C), B)
+    tr = _cotrainer(tmp_path, [seg], lab, unl, C, n)
+    assert tr._fused_ok()
+    if not fused:
+        tr._fused_ok = lambda: False
+    seg.train()
+    for k in range(n):
+        img, gt = lab[0][k][0]
+        out = tr._run_step([(img, gt)], None, False, False)
+        ref = oracle.cotrain_step([om], [(img, gt)], None, False, False)
+        assert out["jsd"] == 0 and out["adv"] == 0 and len(out["sup"]) == 1 and out["unlab_probs"] == []
+        tol = 2e-5 if k == 0 else (1e-2 if arch == "enet" else 2e-3)     # later steps inherit Adam's sign-like first update
+        np.testing.assert_allclose(out["sup"][0].item(), ref["sup"][0].item(), rtol=tol)
+        if k == 0:
+            np.testing.assert_allclose(out["preds"][0].cpu().numpy(), ref["preds"][0].numpy(), rtol=0, atol=2e-5 * ref["preds"][0].abs().max().item())
+    if fused:
+        assert tr._step_graphs is not None and tr._step_graphs.replays >= 2
+    a = torch.cat([p.detach().flatten().cpu() for p in seg.torchnet.parameters()]).double()
+    b = torch.cat([p.detach().flatten() for p in onet.parameters()]).double()
+    assert ((a - b).norm() / b.norm()).item() < (2e-2 if arch == "enet" else 2e-3)
+    # the epoch loop with the same switches (what train_ACDC_cotraining.py runs for a fully-supervised baseline)
+    d_lab, d_unl = tr._train_loop(lab, unl, epoch=0, mode=ModelMode.TRAIN, save=False, train_jsd=False, train_adv=False)
+    assert d_lab.shape == (1, C, 2) and torch.isfinite(d_lab).all()
+
+
+# ------------------------------------------------------------------------------------------------ cfg2 / cfg3 as benchmarked
+def _oracle_models(tr, dropout_p):
+    oms = []
+    for seg in tr.segmentators:
+        onet = oracle.build_net("unet", tr.C, dropout_p=dropout_p).train()
+        onet.load_state_dict({k: v.detach().cpu() for k, v in seg.torchnet.state_dict().items()})
+        oms.append(oracle.OracleModel.make(MaskReplayNet(onet)))
+    return oms
+
+
+def _nchw_mask(m):
+    return m.permute(0, 3, 1, 2).float().cpu()
+
+
+@pytest.mark.parametrize("config,dtype", [("cfg2", "bf16"), ("cfg3", "bf16"), ("cfg2", "f32")])
+def test_bench_path_full_size_vs_oracle(config, dtype):
+    import bench
+    cfg = bench.CONFIGS[config]
+    tdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
+    n = 4
+    tr, lab, unl = bench.make_trainer(cfg, tdtype, torch.device(DEV), 0, 1, None, n_batches=n)
+    assert tr._fused_ok() and tr.use_hip_graph and tr.model_streams and tr.batch_lab_unlab
+    S, B_l, adv = cfg["S"], cfg["B_l"], cfg["train_adv"]
+    nets = [s.torchnet for s in tr.segmentators]
+    assert all(net.dropout_p == 0.5 and net.training for net in nets)
+    for net in nets:
+        net.record_dropout_masks = True
+    oms = _oracle_models(tr, 0.5)
+    w0 = [{k: v.detach().cpu().clone() for k, v in net.state_dict().items()} for net in nets]
+    bf = dtype == "bf16"
+    for k in range(n):
+        lb = [(lab[m][k][0][0], lab[m][k][0][1]) for m in range(S)]
+        ub = (unl[k][0][0], unl[k][0][1])
+        graphs = tr._step_graphs
+        replay = graphs is not None and graphs.captures > 0
+        if not replay:
+            for net in nets:
+                net.dropout_mask_log.clear()
+        out = tr._run_step(lb, ub, True, adv, (0, 1) if adv else None)
+        torch.cuda.synchronize()
+        # the masks this step drew (static buffers of the captured graph once it replays) -> the oracle's forwards, in its order:
+        # labeled pass, unlabeled pass [, third pass: FGSM forward of model b / adversarial forward of model a]
+        for m, net in enumerate(nets):
+            log = net.dropout_mask_log
+            assert len(log) == (2 if adv else 1)
+            joint = [_nchw_mask(t) for t in log[0]]
+            q = [[t[:B_l] for t in joint], [t[B_l:] for t in joint]]
+            if adv:
+                q.append([_nchw_mask(t) for t in log[1]])
+            oms[m].net.queue = q
+        ref = oracle.cotrain_step(oms, [(a.cpu(), b.cpu()) for a, b in lb], ub[0].cpu(), True, adv, lam_cot=0.5, lam_adv=0.05, eps=0.03)
+        assert all(len(om.net.queue) == 0 for om in oms)
+        sup, rsup = [float(v) for v in out["sup"]], [float(v) for v in ref["sup"]]
+        jsd, rjsd = float(out["jsd"]), float(ref["jsd"])
+        _say(config, dtype, "step", k, "replay" if replay else "eager", "sup", sup, rsup, "jsd", jsd, rjsd,
+             "adv", float(out["adv"]) if adv else None, float(ref["adv"]) if adv else None)
+        # bf16 activations carry ~2^-8 relative rounding per layer; from step 1 on both sides also carry Adam's sign-like first
+        # updates of near-zero gradient elements.  fp32: kernels vs ATen on the same weights.
+        tol_sup = (1e-2 if k == 0 else 3e-2) if bf else (2e-5 if k == 0 else 2e-3)
+        np.testing.assert_allclose(sup, rsup, rtol=tol_sup)
+        np.testing.assert_allclose(jsd, rjsd, rtol=(0.15 if bf else (1e-4 if k == 0 else 2e-2)), atol=1e-6)
+        if adv:
+            np.testing.assert_allclose(float(out["adv"]), float(ref["adv"]), rtol=(0.25 if bf else 5e-2), atol=1e-6)
+        if k == 0:
+            for m in range(S):
+                a, b = out["preds"][m].float().cpu(), ref["preds"][m]
+                err = ((a - b).abs().max() / b.abs().max()).item()
+                _say("  logits model", m, "max-rel err", err)
+                assert err < (4e-2 if bf else 1e-5)
+    if tr._step_graphs is not None:
+        assert tr._step_graphs.captures == 1 and tr._step_graphs.replays == n - 2
+    # weights after n steps: displacement from the initial weights, per tensor, HIP vs oracle
+    for m, net in enumerate(nets):
+        sd = net.state_dict()
+        osd = oms[m].net.net.state_dict()
+        worst_cos, worst_rel = 1.0, 0.0
+        for name, w_init in w0[m].items():
+            d_hip = (sd[name].detach().cpu() - w_init).double().flatten()
+            d_ref = (osd[name] - w_init).double().flatten()
+            cos = float(d_hip @ d_ref / (d_hip.norm() * d_ref.norm() + 1e-30))
+            rel = float((sd[name].detach().cpu().double().flatten() - osd[name].double().flatten()).norm() / osd[name].double().norm())
+            _say("  model", m, name, "numel", d_ref.numel(), "cos(delta)", round(cos, 4), "rel(w)", rel)
+            if d_ref.numel() >= 4096:
+                worst_cos = min(worst_cos, cos)
+            worst_rel = max(worst_rel, rel)
+            # every element moved at most n * lr (Adam) on both sides
+            assert float(d_hip.abs().max()) <= 1.05 * n * 1e-3 + 1e-7
+        _say(" model", m, "worst cos", worst_cos, "worst rel", worst_rel)
+        assert worst_cos > (0.5 if bf else 0.98)
+        assert worst_rel < (2e-2 if bf else 2e-3)
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r1
+def test_fused_step_with_a_stock_torch_optimizer(tmp_path):
+    """optim_dict names any torch.optim class (models/segmentators.py:37-43).  With SGD the fused step must stay eager (no
+    graph: torch's optimizers keep lr / step on the host) and match the oracle's SGD step."""
+    from dct_amd.models import Segmentator
+    C, B, H, n = 3, 2, 176, 4
+    segs, oms = [], []
+    for seed in (41, 42):
+        torch.manual_seed(seed)
+        onet = oracle.build_net("unet", C, dropout_p=0.0).train()
+        seg = Segmentator({"name": "unet", "num_classes": C, "compute_dtype": torch.float32, "dropout_p": 0.0},
+                          {"name": "SGD", "lr": 1e-2, "momentum": 0.9}, {"name": "StepLR", "step_size": 90, "gamma": 0.1})
+        assert type(seg.optimizer) is torch.optim.SGD
+        seg.torchnet.load_state_dict(onet.state_dict())
+        segs.append(seg)
+        oms.append(oracle.OracleModel(onet, torch.optim.SGD(onet.parameters(), lr=1e-2, momentum=0.9)))
+    lab = [FakeLoader(batches(51 + i, n, B, H, C), B) for i in range(2)]
+    unl = FakeLoader(batches(61, n, B, H, C), B)
+    tr = _cotrainer(tmp_path, segs, lab, unl, C, n)
+    for s in segs:
+        s.train()
+    for k in range(n):
+        lb = [(lab[i][k][0][0], lab[i][k][0][1]) for i in range(2)]
+        out = tr._run_step(lb, (unl[k][0][0], unl[k][0][1]), True, False)
+        ref = oracle.cotrain_step(oms, lb, unl[k][0][0], True, False, lam_cot=0.5)
+        np.testing.assert_allclose([float(v) for v in out["sup"]], [float(v) for v in ref["sup"]], rtol=1e-4)
+    assert tr._step_graphs is None or tr._step_graphs.captures == 0
+    for seg, om in zip(segs, oms):
+        a = torch.cat([p.detach().flatten().cpu() for p in seg.torchnet.parameters()]).double()
+        b = torch.cat([p.detach().flatten() for p in om.net.parameters()]).double()
+        assert ((a - b).norm() / b.norm()).item() < 1e-4
+
+
+def test_cotrained_models_draw_different_dropout_masks():
+    from dct_amd.arch import get_arch
+    torch.manual_seed(5)
+    nets = [get_arch("unet", {"num_classes": 4}).to(DEV).train() for _ in range(2)]
+    x = torch.rand(2, 1, 176, 176, device=DEV)
+    masks = []
+    for net in nets:
+        net.record_dropout_masks = True
+        net.plan_forward(x, False)
+        masks.append([m.clone() for m in net.last_dropout_masks])
+    for a, b in zip(*masks):
+        agree = (a == b).float().mean().item()
+        assert 0.45 < agree < 0.55          # independent Bernoulli(0.5) masks agree on half the elements
+
+
+@pytest.mark.parametrize("method,axes", [("2d", [1, 2, 3]), ("3d", "all")])
+def test_dice_meter_running_moments_equal_the_history_formulas(method, axes):
+    """DiceMeter.value() from running sums (O(1) per call) == the reference's formulas over the concatenated history
+    (metrics/dice_meter.py:61-74): per-class mean / unbiased std, and mean / std of the per-row report mean."""
+    from dct_amd.metrics import DiceMeter
+    g = torch.Generator().manual_seed(3)
+    m = DiceMeter(method=method, report_axises=axes, C=4)
+    rows = []
+    for k in range(7):
+        pred = torch.randn(3, 4, 32, 32, generator=g)
+        gt = torch.randint(0, 4, (3, 1, 32, 32), generator=g)
+        m.add(pred.to(DEV), gt.to(DEV))
+        rows.append(oracle.dice_2d(pred, gt) if method == "2d" else oracle.dice_3d(pred, gt).unsqueeze(0))
+    log = torch.cat(rows)
+    rep = log.mean(1) if axes == "all" else log[:, axes].mean(1)
+    (rm, rs), (cm, cs) = m.value()
+    np.testing.assert_allclose(cm.cpu().numpy(), log.mean(0).numpy(), rtol=1e-5)
+    np.testing.assert_allclose(cs.cpu().numpy(), log.std(0).numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(float(rm), float(rep.mean()), rtol=1e-5)
+    np.testing.assert_allclose(float(rs), float(rep.std()), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(m.log.cpu().numpy(), log.numpy(), rtol=1e-5)

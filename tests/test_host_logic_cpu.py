@@ -277,3 +277,56 @@ def test_flat_params_survive_reallocation():
     sd = oracle.build_net("unet", 2).state_dict()
     net.load_state_dict(sd)
     assert fp.is_flat() and torch.equal(net.final.weight.detach(), sd["final.weight"])
+
+
+def test_dropout_seed_follows_torch_seed_and_differs_between_models():
+    """co-trained models must not share dropout masks; a user seed controls them."""
+    from dct_amd.arch import get_arch
+    torch.manual_seed(7)
+    a, b = get_arch("unet", {"num_classes": 4}), get_arch("unet", {"num_classes": 4})
+    torch.manual_seed(7)
+    c = get_arch("unet", {"num_classes": 4})
+    assert a.dropout_seed != b.dropout_seed
+    assert a.dropout_seed == c.dropout_seed
+    assert 0 <= a.dropout_seed < 2 ** 62
+
+
+def test_fused_adam_load_state_dict_takes_the_loaded_step():
+    """restoring a checkpoint into an optimizer that already stepped further must take the loaded step count
+    (torch.optim.Adam does), not the larger one."""
+    from dct_amd.arch import get_arch
+    from dct_amd.optim import FusedAdam
+    net = get_arch("enet", {"num_classes": 2})
+    opt = FusedAdam(net.parameters(), flat=net.flat_params, lr=1e-3)
+    opt._ensure_state()
+    opt._steps = 5
+    sd = copy.deepcopy(opt.state_dict())
+    assert all(int(float(st["step"])) == 5 for st in sd["state"].values())
+    opt._steps = 40                       # trained on ...
+    opt._state_views()
+    opt.load_state_dict(sd)               # ... then restored
+    opt._ensure_state()
+    assert opt._steps == 5
+    assert all(int(float(st["step"])) == 5 for st in opt.state_dict()["state"].values())
+
+
+def test_run_step_normalises_loader_dtypes(tmp_path, monkeypatch):
+    """uint8 / int32 labels and double images from a loader are cast once at the step boundary."""
+    tr, lab, unl = _make_trainer(tmp_path, monkeypatch, "enet", 2, 16, 2, 1)
+    for s in tr.segmentators:
+        s.train()
+    lb = []
+    for i in range(2):
+        img, gt = lab[i][0][0]
+        lb.append((img.double(), gt.to(torch.uint8)))
+    seen = {}
+    orig = tr._run_step_generic
+
+    def spy(lab_, unl_, *a):
+        seen["lab"] = [(x.dtype, y.dtype, x.is_contiguous()) for x, y in lab_]
+        seen["unl"] = unl_[0].dtype
+        return orig(lab_, unl_, *a)
+    tr._run_step_generic = spy
+    out = tr._run_step(lb, (unl[0][0][0].half(), unl[0][0][1].int()), True, False)
+    assert seen["lab"] == [(torch.float32, torch.int64, True)] * 2 and seen["unl"] == torch.float32
+    assert all(torch.isfinite(s) for s in out["sup"])
