@@ -180,7 +180,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
+    ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"],
+                    help="N > 1: gradients travel as bf16 on the xGMI ring (half the bytes); default fp32, as the reference's sums are")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight gradients on a second stream per model (eager only)")
@@ -206,11 +208,11 @@ def main():
 
     from dct_amd import _lib
     cfg = CONFIGS[args.config]
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[args.dtype]
 
     def sync_factory(segs):
         from dct_amd.ddp import FlatGradSync
-        return FlatGradSync(segs)
+        return FlatGradSync(segs, compress=None if args.grad_compress == "none" else args.grad_compress, measure=True)
 
     tr, lab, unl = make_trainer(cfg, dtype, device, rank, world, sync_factory)
     S = cfg["S"]
@@ -239,6 +241,8 @@ def main():
         one_step(i)
     torch.cuda.synchronize()
     if world > 1:
+        tr.grad_sync.exposed_ms(reset=True)
+        tr.grad_sync.exchanged_bytes = 0
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -249,6 +253,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    exchange = None
+    if world > 1:
+        ex = torch.tensor([tr.grad_sync.exposed_ms(reset=True) / args.steps], dtype=torch.float64, device=device)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        exchange = {"exposed_allreduce_ms_per_step_max_over_ranks": float(ex.item()),
+                    "bytes_per_step_per_rank": tr.grad_sync.exchanged_bytes / args.steps,
+                    "wire_dtype": "bf16" if args.grad_compress == "bf16" else "f32",
+                    "mode": "two captured graphs around one eager all-reduce per model" if tr._step_graphs is not None and tr._step_graphs.captures
+                    else "eager launches, bucketed all-reduce from inside the backward pass"}
     # The step with the in-step meters on (SURVEY.md 8d asks for it separately): what _train_loop adds around _run_step --
     # DiceMeter.add on the labeled and unlabeled predictions, the loss meters, and the progress read-out every 10 steps.
     meters_ms = None
@@ -324,6 +337,8 @@ def main():
                               "blob-structured synthetic slices (tests/helpers.py::blob_batches)"},
         "losses_last_step": losses,
     }
+    if exchange is not None:
+        result["gradient_exchange"] = exchange
     if meters_ms is not None:
         result["ms_per_step_with_meters"] = meters_ms
     if operand_stats is not None:
@@ -358,7 +373,7 @@ def main():
             # Enet: HBM bound.  Algorithmic bytes = conv in+out activation elements x 2 B (bf16) x 3 (fwd, dgrad, wgrad)
             # per training image-pass; the FGSM generator pass counts fwd + dgrad (x 2).
             elems = ENET_ACT_ELEMS[cfg["H"]]
-            esz = 2 if args.dtype == "bf16" else 4
+            esz = 4 if args.dtype == "f32" else 2
             passes = S * (cfg["B_l"] + cfg["B_u"])
             fgsm_imgs = (cfg["B_l"] + cfg["B_u"]) if cfg["train_adv"] else 0
             alg_bytes = elems * esz * (3 * passes + (2 + 3) * fgsm_imgs)

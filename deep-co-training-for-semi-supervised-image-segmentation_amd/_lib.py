@@ -14,9 +14,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdct_hip.so")
 
-F32, BF16 = 0, 1
-DTYPE_OF = {torch.float32: F32, torch.bfloat16: BF16}
-TORCH_OF = {F32: torch.float32, BF16: torch.bfloat16}
+F32, BF16, F16 = 0, 1, 2
+DTYPE_OF = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+TORCH_OF = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 PROF_CLASSES = ("igemm", "wgrad", "pointwise", "loss", "adam", "other")
 
 
@@ -102,8 +102,8 @@ SIGNATURES = {
     "dct_kl_logits_bwd": (_i, [_P, _P, _i64, _i, _f, _P, _f, _P, _i, _P]),
     "dct_argmax": (_i, [_P, _P, _i64, _i, _P]),
     "dct_fgsm_step": (_i, [_P, _P, _f, _P, _P, _i64, _P]),
-    "dct_adam_flat": (_i, [_P, _P, _P, _P, _i64, _f, _f, C.c_double, C.c_double, _f, _f, _P, _P]),
-    "dct_adam_flat_dev": (_i, [_P, _P, _P, _P, _i64, _P, _P, C.c_double, C.c_double, _f, _f, _P, _P]),
+    "dct_adam_flat": (_i, [_P, _P, _P, _P, _i64, _f, _f, C.c_double, C.c_double, _f, _f, _f, _P, _P]),
+    "dct_adam_flat_dev": (_i, [_P, _P, _P, _P, _i64, _P, _P, C.c_double, C.c_double, _f, _f, _f, _P, _P]),
     "dct_enet_conv": (_i, [_VP, _P, _P, _TP, _VP, _DP, _i, _i, _i, _i, _VP, _VP, _i, _i, _P]),
     "dct_enet_reduce_workspace_bytes": (_sz, [_i]),
     "dct_enet_bn_fwd_stats": (_i, [_VP, _P, _P, _f, _f, _P, _P, _i, _P, _P, _P, _P, _i, _i, _P, _sz, _P]),
@@ -113,6 +113,9 @@ SIGNATURES = {
     "dct_enet_tail_bwd": (_i, [_VP, _VP, _P, _i, _i, _i, _VP, _i, _i, _P]),
     "dct_enet_wgrad_workspace_bytes": (_sz, [_VP, _VP, _DP]),
     "dct_enet_wgrad": (_i, [_VP, _TP, _VP, _TP, _P, _DP, _i, _i, _P, _sz, _P]),
+    "dct_bn_workspace_bytes": (_sz, [_i]),
+    "dct_bn_fwd": (_i, [_VP, _P, _P, _f, _f, _P, _P, _i, _P, _P, _P, _P, _VP, _i, _i, _P, _sz, _P]),
+    "dct_bn_bwd": (_i, [_VP, _VP, _P, _P, _P, _P, _P, _P, _i, _P, _i, _i, _VP, _i, _P, _sz, _P]),
     "dct_dice_counts": (_i, [_P, _P, _i, _i64, _i, _P, _P, _P, _P]),
     "dct_tune_set": (_i, [_i, _i]),
     "dct_prof_enable": (_i, [_i]),

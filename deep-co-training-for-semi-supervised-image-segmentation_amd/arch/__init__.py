@@ -1,14 +1,14 @@
 """Architecture registry for the hot path (reference: generalframework/arch/__init__.py:17-81).
 
-Only the two networks the co-training scripts use are provided, as HIP execution plans:
-``unet`` (arch/network.py:196-240) and ``enet`` (arch/enet.py:234-243)."""
+Only the networks the co-training scripts use are provided, as HIP execution plans:
+``unet`` (arch/network.py:196-240), ``unet_bn`` (:243-290) and ``enet`` (arch/enet.py:234-243)."""
 from __future__ import annotations
 
 import torch
 from torch import nn
 
 from .enet import Enet
-from .unet import UNet, _ConvP
+from .unet import UNet, UNet_bn, _ConvP
 
 __all__ = ['weights_init', 'get_arch', 'ARCH_CALLABLES']
 
@@ -22,6 +22,7 @@ def _register_arch(arch, callable, alias=None):
 
 
 _register_arch('unet', UNet)
+_register_arch('unet_bn', UNet_bn)
 _register_arch('enet', Enet)
 
 

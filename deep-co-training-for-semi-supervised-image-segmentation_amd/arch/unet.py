@@ -86,8 +86,23 @@ class _ConvTP(_ConvP):
             self.bias.uniform_(-bound, bound)
 
 
+class _BNP(nn.Module):
+    """nn.BatchNorm2d(c) parameters and buffers (eps 1e-5, momentum 0.1: torch defaults, as network.py:138,181 use)."""
+    is_dct_batchnorm = True
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
 class UNet(nn.Module):
-    """Drop-in for the reference ``UNet(in_channels=1, num_classes=2)`` (network.py:196).
+    """Drop-in for the reference ``UNet(in_channels=1, num_classes=2)`` (network.py:196) and, with ``batchnorm=True``
+    (class ``UNet_bn`` below), for ``UNet_bn`` (network.py:243-290).
 
     ``compute_dtype``: torch.bfloat16 (MFMA bf16, fp32 accumulate) or torch.float32
     (v_mfma_f32_32x32x2_f32; the parity mode).  ``dropout_p`` is the p of the two
@@ -96,27 +111,61 @@ class UNet(nn.Module):
     batch_independent = True   # no BatchNorm: samples of a batch never interact
 
     def __init__(self, in_channels: int = 1, num_classes: int = 2, compute_dtype=torch.bfloat16,
-                 dropout_p: float = 0.5):
+                 dropout_p: float = 0.5, batchnorm: bool = False):
         super().__init__()
+        self.batchnorm = bool(batchnorm)
+        if self.batchnorm:
+            self.batch_independent = False     # batch statistics couple the samples of a pass
         if in_channels != 1:
             raise ValueError("dct_amd UNet: the hot path is single-channel slices (in_channels=1)")
         if not 2 <= num_classes <= 8:
             raise ValueError("dct_amd UNet: 2 <= num_classes <= 8")
+        if compute_dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("dct_amd UNet: compute_dtype is torch.bfloat16 (MFMA bf16) or torch.float32; fp16 is an Enet mode")
         self.num_classes = num_classes
         self.compute_dtype = compute_dtype
         self.dropout_p = float(dropout_p)
         cin = in_channels
+        bn = self.batchnorm
+        # Sequential indices of the reference modules (they are the state_dict keys): UNetDec / UNetDec_bn (network.py:153-193),
+        # centre (:204-212 / :251-261), UNetEnc / UNetEnc_bn (:115-150), enc1 (:216-221 / :265-271).  The plan addresses the
+        # layers by role through self._roles: (first conv, its BatchNorm or None, second conv, its BatchNorm or None[, convT]).
+        self._roles: Dict[str, tuple] = {}
         for lvl, width in enumerate(_WIDTHS, start=1):
             blk = _Holder()
-            blk.down = _Slots({0: _ConvP(cin, width, 3), 2: _ConvP(width, width, 3)})
+            if bn:
+                blk.down = _Slots({0: _ConvP(cin, width, 3), 1: _BNP(width), 3: _ConvP(width, width, 3)})
+                self._roles[f"dec{lvl}"] = (blk.down.at(0), blk.down.at(1), blk.down.at(3), None)
+            else:
+                blk.down = _Slots({0: _ConvP(cin, width, 3), 2: _ConvP(width, width, 3)})
+                self._roles[f"dec{lvl}"] = (blk.down.at(0), None, blk.down.at(2), None)
             setattr(self, f"dec{lvl}", blk)
             cin = width
-        self.center = _Slots({0: _ConvP(512, 1024, 3), 2: _ConvP(1024, 1024, 3), 5: _ConvTP(1024, 512)})
+        if bn:
+            self.center = _Slots({0: _ConvP(512, 1024, 3), 1: _BNP(1024), 3: _ConvP(1024, 1024, 3), 4: _BNP(1024), 7: _ConvTP(1024, 512)})
+            c = self.center
+            self._roles["center"] = (c.at(0), c.at(1), c.at(3), c.at(4), c.at(7))
+        else:
+            self.center = _Slots({0: _ConvP(512, 1024, 3), 2: _ConvP(1024, 1024, 3), 5: _ConvTP(1024, 512)})
+            c = self.center
+            self._roles["center"] = (c.at(0), None, c.at(2), None, c.at(5))
         for lvl, (ci, feat, co) in {4: (1024, 512, 256), 3: (512, 256, 128), 2: (256, 128, 64)}.items():
             blk = _Holder()
-            blk.up = _Slots({0: _ConvP(ci, feat, 3), 2: _ConvP(feat, feat, 3), 4: _ConvTP(feat, co)})
+            if bn:
+                blk.up = _Slots({0: _ConvP(ci, feat, 3), 1: _BNP(feat), 3: _ConvP(feat, feat, 3), 4: _BNP(feat), 6: _ConvTP(feat, co)})
+                u = blk.up
+                self._roles[f"enc{lvl}"] = (u.at(0), u.at(1), u.at(3), u.at(4), u.at(6))
+            else:
+                blk.up = _Slots({0: _ConvP(ci, feat, 3), 2: _ConvP(feat, feat, 3), 4: _ConvTP(feat, co)})
+                u = blk.up
+                self._roles[f"enc{lvl}"] = (u.at(0), None, u.at(2), None, u.at(4))
             setattr(self, f"enc{lvl}", blk)
-        self.enc1 = _Slots({0: _ConvP(128, 64, 3), 2: _ConvP(64, 64, 3)})
+        if bn:
+            self.enc1 = _Slots({0: _ConvP(128, 64, 3), 1: _BNP(64), 3: _ConvP(64, 64, 3)})
+            self._roles["enc1"] = (self.enc1.at(0), self.enc1.at(1), self.enc1.at(3), None)
+        else:
+            self.enc1 = _Slots({0: _ConvP(128, 64, 3), 2: _ConvP(64, 64, 3)})
+            self._roles["enc1"] = (self.enc1.at(0), None, self.enc1.at(2), None)
         self.final = _ConvP(64, num_classes, 1)
 
         self._convs: List[_ConvP] = [m for m in self.modules() if isinstance(m, _ConvP)]
@@ -184,7 +233,7 @@ class UNet(nn.Module):
             self._shadow_fresh = False
         jobs = []
         for conv in self._convs:
-            if conv is self.final or conv is self.dec1.down.at(0):
+            if conv is self.final or conv is self._roles["dec1"][0]:
                 continue  # stem and head read the fp32 masters directly
             w = self._w(conv)
             ent = self._packs.get(id(conv))
@@ -257,8 +306,8 @@ class UNet(nn.Module):
         dec1..dec4, center, enc4..enc1, final, so each bucket is contiguous; the gradient exchange of a bucket can
         start while the rest of the backward still runs (_grad_hook, ddp.FlatGradSync.begin_bucket)."""
         fp = self.flat_params
-        first_center = self._pidx[id(self.center.at(0).weight)]
-        first_enc4 = self._pidx[id(self.enc4.up.at(0).weight)]
+        first_center = self._pidx[id(self._roles["center"][0].weight)]
+        first_enc4 = self._pidx[id(self._roles["enc4"][0].weight)]
         return [(fp.offsets[first_enc4], fp.total), (fp.offsets[first_center], fp.offsets[first_enc4]),
                 (0, fp.offsets[first_center])]
 
@@ -279,9 +328,20 @@ class UNet(nn.Module):
         def new(h, w, c, dtype=dt):
             return torch.empty(B, h, w, c, dtype=dtype, device=dev)
 
-        def conv3(src, conv, dst):
-            K.conv2d(src, P[id(conv)]["fwd"], conv.bias, dst, relu=True)
-            return dst
+        bn_recs: Dict[str, tuple] = {}
+
+        def bn_relu(raw, bn, name):
+            """nn.BatchNorm2d + ReLU of unet_bn: statistics of the raw conv output -> y = relu(scale * raw + shift)."""
+            vec = torch.empty(4, bn.num_features, dtype=torch.float32, device=dev)
+            y = torch.empty_like(raw)
+            K.bn_fwd(raw, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                     self.training, vec[0], vec[1], vec[2], vec[3], y=y, relu=True)
+            bn_recs[name] = (raw, vec, bn)
+            return y
+
+        def conv3(src, conv, dst, bn=None, name=None):
+            K.conv2d(src, P[id(conv)]["fwd"], conv.bias, dst, relu=bn is None)
+            return dst if bn is None else bn_relu(dst, bn, name)
 
         xs = x.detach().to(torch.float32).reshape(B, H, W, 1)
         if not xs.is_contiguous():
@@ -311,43 +371,46 @@ class UNet(nn.Module):
         h, w = H, W
         src = xs
         for lvl, width in enumerate(_WIDTHS, start=1):
-            blk = getattr(self, f"dec{lvl}").down
+            ca, bna, cb, _ = self._roles[f"dec{lvl}"]
             a = new(h - 2, w - 2, width)
             if lvl == 1:
-                c0 = blk.at(0)
-                K.conv_cin1_fwd(xs, self._w(c0), c0.bias, a, relu=True)
+                K.conv_cin1_fwd(xs, self._w(ca), ca.bias, a, relu=bna is None)
+                if bna is not None:
+                    a = bn_relu(a, bna, "a1")
             else:
-                conv3(src, blk.at(0), a)
-            d = conv3(a, blk.at(2), new(h - 4, w - 4, width))
+                a = conv3(src, ca, a, bna, f"a{lvl}")
+            d = conv3(a, cb, new(h - 4, w - 4, width))
             dd = dropout(d, 0) if lvl == 4 else d
             h, w = (h - 4 + 1) // 2, (w - 4 + 1) // 2
             p = K.maxpool_fwd(dd, new(h, w, width))
             A[f"a{lvl}"], A[f"d{lvl}"], A[f"p{lvl}"] = a, dd, p
             src = p
         # center
-        c = self.center
-        c1 = conv3(src, c.at(0), new(h - 2, w - 2, 1024))
-        c2 = conv3(c1, c.at(2), new(h - 4, w - 4, 1024))
+        ca, bna, cb, bnb, ct = self._roles["center"]
+        c1 = conv3(src, ca, new(h - 2, w - 2, 1024), bna, "c1")
+        c2 = conv3(c1, cb, new(h - 4, w - 4, 1024), bnb, "c2")
         c2d = dropout(c2, 1)
         h, w = 2 * (h - 4), 2 * (w - 4)
         cat = new(h, w, 1024)
-        K.conv2d(c2d, P[id(c.at(5))]["fwd"], c.at(5).bias, cat[..., :512], R=1, S=1, relu=True, scatter2x2=True)
+        K.conv2d(c2d, P[id(ct)]["fwd"], ct.bias, cat[..., :512], R=1, S=1, relu=True, scatter2x2=True)
         K.bilinear_fwd(A["p4"], cat[..., 512:])
         A["c1"], A["c2"], A["cat4"] = c1, c2d, cat
         # decoder ("enc")
         for lvl, feat, co in ((4, 512, 256), (3, 256, 128), (2, 128, 64)):
-            u = getattr(self, f"enc{lvl}").up
-            ea = conv3(cat, u.at(0), new(h - 2, w - 2, feat))
-            eb = conv3(ea, u.at(2), new(h - 4, w - 4, feat))
+            ca, bna, cb, bnb, ct = self._roles[f"enc{lvl}"]
+            ea = conv3(cat, ca, new(h - 2, w - 2, feat), bna, f"e{lvl}a")
+            eb = conv3(ea, cb, new(h - 4, w - 4, feat), bnb, f"e{lvl}b")
             h, w = 2 * (h - 4), 2 * (w - 4)
             cat = new(h, w, 2 * co)
-            K.conv2d(eb, P[id(u.at(4))]["fwd"], u.at(4).bias, cat[..., :co], R=1, S=1, relu=True, scatter2x2=True)
+            K.conv2d(eb, P[id(ct)]["fwd"], ct.bias, cat[..., :co], R=1, S=1, relu=True, scatter2x2=True)
             K.bilinear_fwd(A[f"p{lvl - 1}"], cat[..., co:])
             A[f"e{lvl}a"], A[f"e{lvl}b"], A[f"cat{lvl - 1}"] = ea, eb, cat
-        e1a = conv3(cat, self.enc1.at(0), new(h - 2, w - 2, 64))
-        e1b = conv3(e1a, self.enc1.at(2), new(h - 4, w - 4, 64))
+        ca, bna, cb, _ = self._roles["enc1"]
+        e1a = conv3(cat, ca, new(h - 2, w - 2, 64), bna, "e1a")
+        e1b = conv3(e1a, cb, new(h - 4, w - 4, 64))
         f = K.head_fwd(e1b, self._w(self.final), self.final.bias, new(h - 4, w - 4, self.num_classes, torch.float32))
         logits = K.bilinear_fwd(f, new(H, W, self.num_classes, torch.float32))
+        A["bn"], A["bn_training"] = bn_recs, bool(self.training)
         A["e1a"], A["e1b"] = e1a, e1b
         A["fshape"] = (h - 4, w - 4)
         if masks_out is not None:
@@ -408,6 +471,19 @@ class UNet(nn.Module):
             K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, R=2, S=2, stride=2, mask=mask, mask_scale=mask_scale)
             return dx_out
 
+        def bn_back(name, g):
+            """g: gradient wrt the ReLU output of a BatchNorm'd conv -> gradient wrt the raw conv output (in place)."""
+            rec = A["bn"].get(name)
+            if rec is None:
+                return g
+            raw, vec, bn = rec
+            c1c2 = torch.empty(2 * bn.num_features, dtype=torch.float32, device=dev)
+            K.bn_bwd(raw, g, vec[0], vec[1], vec[2], vec[3],
+                     self.flat_params.grad_dense(self._pidx[id(bn.weight)]) if need_dw else None,
+                     self.flat_params.grad_dense(self._pidx[id(bn.bias)]) if need_dw else None,
+                     c1c2, g, training=A["bn_training"], relu=True, accumulate=gacc)
+            return g
+
         fh, fw = A["fshape"]
         df = K.bilinear_bwd(dlogits, torch.empty(B, fh, fw, C, dtype=torch.float32, device=dev))
         e1b, e1a = A["e1b"], A["e1a"]
@@ -415,45 +491,46 @@ class UNet(nn.Module):
         K.head_bwd(e1b, df, self._w(self.final), de1b,
                    self._gw(self.final) if need_dw else None, self._gb(self.final) if need_dw else None,
                    relu_mask=True, accumulate=gacc)
-        de1a = conv_bwd(self.enc1.at(2), e1a, de1b, new_like(e1a), mask=e1a)
+        ca, _, cb, _ = self._roles["enc1"]
+        de1a = bn_back("e1a", conv_bwd(cb, e1a, de1b, new_like(e1a), mask=e1a))
         cat = A["cat1"]
-        dcat = conv_bwd(self.enc1.at(0), cat, de1a, new_like(cat), mask=cat, mask_channels=64)
+        dcat = conv_bwd(ca, cat, de1a, new_like(cat), mask=cat, mask_channels=64)
         dp: Dict[int, torch.Tensor] = {}
         for lvl, co in ((2, 64), (3, 128), (4, 256)):
-            u = getattr(self, f"enc{lvl}").up
+            ca, _, cb, _, ct = self._roles[f"enc{lvl}"]
             ea, eb = A[f"e{lvl}a"], A[f"e{lvl}b"]
             p = A[f"p{lvl - 1}"]
             dp[lvl - 1] = K.bilinear_bwd(dcat[..., co:], new_like(p))
-            deb = convT_bwd(u.at(4), eb, dcat[..., :co], new_like(eb), mask=eb)
-            dea = conv_bwd(u.at(2), ea, deb, new_like(ea), mask=ea)
+            deb = bn_back(f"e{lvl}b", convT_bwd(ct, eb, dcat[..., :co], new_like(eb), mask=eb))
+            dea = bn_back(f"e{lvl}a", conv_bwd(cb, ea, deb, new_like(ea), mask=ea))
             if self._debug is not None:
                 self._debug[f"de{lvl}b"], self._debug[f"de{lvl}a"], self._debug[f"dcat{lvl - 1}"] = deb, dea, dcat
             cat = A[f"cat{lvl}"]
-            dcat = conv_bwd(u.at(0), cat, dea, new_like(cat), mask=cat, mask_channels=2 * co)
+            dcat = conv_bwd(ca, cat, dea, new_like(cat), mask=cat, mask_channels=2 * co)
         hook = self._grad_hook if need_dw else None
         if hook is not None and side is None:
             hook(0)                           # decoder-side gradients are complete
         # center (cat4: 512 convT channels + 512 skip channels)
-        c = self.center
+        ca, _, cb, _, ct = self._roles["center"]
         p4 = A["p4"]
         dp[4] = K.bilinear_bwd(dcat[..., 512:], new_like(p4))
         c2d, c1 = A["c2"], A["c1"]
-        dc2 = convT_bwd(c.at(5), c2d, dcat[..., :512], new_like(c2d), mask=c2d, mask_scale=ds)
-        dc1 = conv_bwd(c.at(2), c1, dc2, new_like(c1), mask=c1)
-        conv_bwd(c.at(0), p4, dc1, dp[4], accumulate=True)
+        dc2 = bn_back("c2", convT_bwd(ct, c2d, dcat[..., :512], new_like(c2d), mask=c2d, mask_scale=ds))
+        dc1 = bn_back("c1", conv_bwd(cb, c1, dc2, new_like(c1), mask=c1))
+        conv_bwd(ca, p4, dc1, dp[4], accumulate=True)
         if hook is not None and side is None:
             hook(1)                           # centre gradients are complete
         # encoder
         dx = None
         for lvl in (4, 3, 2, 1):
-            blk = getattr(self, f"dec{lvl}").down
+            ca, _, cb, _ = self._roles[f"dec{lvl}"]
             a, d = A[f"a{lvl}"], A[f"d{lvl}"]
             dd = K.maxpool_bwd(d, dp[lvl], new_like(d), relu_mask=True, scale=ds if lvl == 4 else 1.0)
-            da = conv_bwd(blk.at(2), a, dd, new_like(a), mask=a)
+            da = bn_back(f"a{lvl}", conv_bwd(cb, a, dd, new_like(a), mask=a))
             if lvl > 1:
-                conv_bwd(blk.at(0), A[f"p{lvl - 1}"], da, dp[lvl - 1], accumulate=True)
+                conv_bwd(ca, A[f"p{lvl - 1}"], da, dp[lvl - 1], accumulate=True)
             else:
-                c0 = blk.at(0)
+                c0 = ca
                 if need_dw:
                     with on_side(da):
                         K.conv_cin1_wgrad(A["x"], da, self._gw(c0), self._gb(c0), accumulate=gacc)
@@ -464,6 +541,15 @@ class UNet(nn.Module):
         elif hook is not None:
             hook(2)                           # encoder-side gradients: the whole buffer is final
         return dx
+
+
+class UNet_bn(UNet):
+    """Drop-in for the reference ``UNet_bn`` (network.py:243-290; registry name ``unet_bn``): BatchNorm2d + ReLU after the
+    first convolution of every encoder block and of ``enc1``, and after both convolutions of the centre and of the three
+    decoder blocks.  Same plan as ``UNet`` with one statistics + one apply pass per BatchNorm (csrc/bn.hip)."""
+
+    def __init__(self, in_channels: int = 1, num_classes: int = 2, compute_dtype=torch.bfloat16, dropout_p: float = 0.5):
+        super().__init__(in_channels, num_classes, compute_dtype, dropout_p, batchnorm=True)
 
 
 class _UNetFn(torch.autograd.Function):

@@ -8,6 +8,9 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -17,12 +20,20 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 template <typename T> struct dct_type_of;
 template <> struct dct_type_of<float> { static constexpr int id = DCT_F32; };
 template <> struct dct_type_of<bf16_t> { static constexpr int id = DCT_BF16; };
+template <> struct dct_type_of<f16_t> { static constexpr int id = DCT_F16; };
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
+// 8 consecutive 16-bit elements as one 16-byte load
+template <typename T> struct vec8_of;
+template <> struct vec8_of<bf16_t> { typedef bf16x8 type; };
+template <> struct vec8_of<f16_t> { typedef f16x8 type; };
+template <> struct vec8_of<float> { typedef f16x8 type; };   // never used for loads of fp32 data (sizeof(T) == 4 paths branch first)
 
 // Device-side copy of a dct_view (kernel argument).
 struct View {

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void enet_conv_kernel(ConvP p) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.x.ptr) + xo + i + 4);
             v8[0] = a[0]; v8[1] = a[1]; v8[2] = a[2]; v8[3] = a[3]; v8[4] = b[0]; v8[5] = b[1]; v8[6] = b[2]; v8[7] = b[3];
           } else {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.x.ptr) + xo + i);
+            typedef typename vec8_of<T>::type V8;
+            const V8 a = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.x.ptr) + xo + i);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v8[k] = (float)a[k];
           }
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(256) void enet_wgrad_reduce_kernel(const float* par
   }
 }
 
-static inline bool ok_dtype(int d) { return d == DCT_F32 || d == DCT_BF16; }
+static inline bool ok_dtype(int d) { return d == DCT_F32 || d == DCT_BF16 || d == DCT_F16; }
 static inline int red_plan(long long P, int C, int& ppb) {
   int CP = 1;
   while (CP < C) CP <<= 1;
@@ -595,7 +596,8 @@ static inline int red_plan(long long P, int C, int& ppb) {
 
 }  // namespace
 
-#define ENET_T(dtype, ...) do { if ((dtype) == DCT_BF16) { using T = bf16_t; __VA_ARGS__; } else { using T = float; __VA_ARGS__; } } while (0)
+#define ENET_T(dtype, ...) do { if ((dtype) == DCT_BF16) { using T = bf16_t; __VA_ARGS__; } else if ((dtype) == DCT_F16) { using T = f16_t; __VA_ARGS__; } \
+                               else { using T = float; __VA_ARGS__; } } while (0)
 
 extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
                              const dct_view* y, const dct_conv_desc* d, int transposed,
@@ -623,7 +625,7 @@ extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bia
   p.G = Gp;
   p.fm = f32_mask;
   {
-    const int xbytes = ((f32_mask & 1) || dtype == DCT_F32) ? 4 : 2;
+    const int xbytes = ((f32_mask & 1) || dtype == DCT_F32) ? 4 : 2;   // bf16 and f16 are both 2 bytes
     p.vec = (x->c % 8 == 0 && x->sw % 8 == 0 && x->sh % 8 == 0 && x->sn % 8 == 0 && ((uintptr_t)x->ptr % (8 * xbytes)) == 0) ? 1 : 0;
   }
   const size_t lds = (size_t)d->R * d->S * x->c * Gp * 8 * sizeof(float);

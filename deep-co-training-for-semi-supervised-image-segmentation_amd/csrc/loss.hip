@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256) void fgsm_kernel(const float* x, const float* 
 }
 
 // omb1/omb2 = 1-beta computed in double on the host, as torch does (float(1-0.999) != 1.f-0.999f)
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float step_size, float bc2s, float omb1, float b2, float omb2, float eps, float wd) {
-  g = fmaf(wd, p, g);
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float step_size, float bc2s, float omb1, float b2, float omb2, float eps, float wd, float gs) {
+  g = fmaf(wd, p, g * gs);                      // gs: 1, or the inverse power-of-two loss scale of an fp16 step (exact)
   m = m + (g - m) * omb1;                       // exp_avg.lerp_(grad, 1-b1)
   v = v * b2 + omb2 * g * g;                    // mul_(b2).addcmul_(g, g, 1-b2)
   const float denom = sqrtf(v) / bc2s + eps;
@@ -376,7 +376,7 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 // lr / bc1 is then the same correctly rounded division the host does: bit-identical to the scalar-argument path, and a
 // learning-rate change touches only state[1]); outside the table they are formed here in double.
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float step_size,
-                                                    float bc2s, float omb1, float b2, float omb2, float eps, float wd, bf16_t* shadow,
+                                                    float bc2s, float omb1, float b2, float omb2, float eps, float wd, float gs, bf16_t* shadow,
                                                     const double* state, const double* table, double beta1, double beta2) {
   if (state) {
     const double t = state[0], lr = state[1];
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float pp = pv[k], mm = mv[k], v2 = vv[k];
-      adam1(pp, gv[k], mm, v2, step_size, bc2s, omb1, b2, omb2, eps, wd);
+      adam1(pp, gv[k], mm, v2, step_size, bc2s, omb1, b2, omb2, eps, wd, gs);
       pv[k] = pp; mv[k] = mm; vv[k] = v2;
     }
     reinterpret_cast<f32x4*>(p)[i] = pv; reinterpret_cast<f32x4*>(m)[i] = mv; reinterpret_cast<f32x4*>(v)[i] = vv;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long long i = n4 * 4 + threadIdx.x;
     float pp = p[i], mm = m[i], v2 = v[i];
-    adam1(pp, g[i], mm, v2, step_size, bc2s, omb1, b2, omb2, eps, wd);
+    adam1(pp, g[i], mm, v2, step_size, bc2s, omb1, b2, omb2, eps, wd, gs);
     p[i] = pp; m[i] = mm; v[i] = v2;
     if (shadow) shadow[i] = (bf16_t)pp;
   }
@@ -592,19 +592,19 @@ extern "C" int dct_fgsm_step(const float* x, const float* g, float eps, float* x
 }
 
 extern "C" int dct_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float step_size,
-                             float bc2_sqrt, double beta1, double beta2, float eps, float weight_decay,
+                             float bc2_sqrt, double beta1, double beta2, float eps, float weight_decay, float grad_scale,
                              void* bf16_shadow, dct_stream stream) {
   if (!p || !g || !m || !v || n < 1) return DCT_ERR_BAD_ARG;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return DCT_ERR_UNSUPPORTED;
   if (bf16_shadow && ((uintptr_t)bf16_shadow & 7)) return DCT_ERR_UNSUPPORTED;
   DCT_LAUNCH(DCT_PROF_ADAM, adam_kernel, dim3(wide_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
-             step_size, bc2_sqrt, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, (bf16_t*)bf16_shadow,
+             step_size, bc2_sqrt, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, grad_scale, (bf16_t*)bf16_shadow,
              (const double*)nullptr, (const double*)nullptr, beta1, beta2);
   return dct_check_launch();
 }
 
 extern "C" int dct_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, double* state,
-                                 const double* table, double beta1, double beta2, float eps, float weight_decay,
+                                 const double* table, double beta1, double beta2, float eps, float weight_decay, float grad_scale,
                                  void* bf16_shadow, dct_stream stream) {
   if (!p || !g || !m || !v || !state || n < 1) return DCT_ERR_BAD_ARG;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return DCT_ERR_UNSUPPORTED;
@@ -612,7 +612,7 @@ extern "C" int dct_adam_flat_dev(float* p, const float* g, float* m, float* v, i
   if ((uintptr_t)state & 7) return DCT_ERR_UNSUPPORTED;
   DCT_LAUNCH(DCT_PROF_ADAM, adam_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
   DCT_LAUNCH(DCT_PROF_ADAM, adam_kernel, dim3(wide_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
-             0.f, 1.f, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, (bf16_t*)bf16_shadow,
+             0.f, 1.f, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, grad_scale, (bf16_t*)bf16_shadow,
              (const double*)state, table, beta1, beta2);
   return dct_check_launch();
 }

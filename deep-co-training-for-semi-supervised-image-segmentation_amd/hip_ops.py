@@ -296,16 +296,16 @@ def fgsm_step(x, g, eps, want_noise=True):
     return xa, noise
 
 
-def adam_flat(p, g, m, v, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, bf16_shadow=None):
+def adam_flat(p, g, m, v, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, bf16_shadow=None, grad_scale=1.0):
     call("dct_adam_flat", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(step_size), float(bc2_sqrt), float(beta1),
-         float(beta2), float(eps), float(weight_decay), ptr(bf16_shadow), stream())
+         float(beta2), float(eps), float(weight_decay), float(grad_scale), ptr(bf16_shadow), stream())
 
 
-def adam_flat_dev(p, g, m, v, state, table, beta1, beta2, eps, weight_decay, bf16_shadow=None):
+def adam_flat_dev(p, g, m, v, state, table, beta1, beta2, eps, weight_decay, bf16_shadow=None, grad_scale=1.0):
     """Adam with {step count, lr, table base, table length} in the float64[4] device tensor ``state`` and the
     host-computed {step_size, bc2_sqrt} pairs in the float32 device tensor ``table`` (dct_adam_flat_dev)."""
     call("dct_adam_flat_dev", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(state), ptr(table), float(beta1), float(beta2),
-         float(eps), float(weight_decay), ptr(bf16_shadow), stream())
+         float(eps), float(weight_decay), float(grad_scale), ptr(bf16_shadow), stream())
     return p
 
 
@@ -354,16 +354,18 @@ def _enet_ws(device, nbytes):
 
 
 def _mixed(*ts):
-    """(dtype code T, f32 mask) of a call whose view arguments are ``ts`` (None = absent): T is bf16 when any
-    view is bf16, and bit k of the mask marks view k as fp32 storage."""
-    any_bf16 = any(t is not None and t.dtype == torch.bfloat16 for t in ts)
+    """(dtype code T, f32 mask) of a call whose view arguments are ``ts`` (None = absent): T is bf16 / f16 when any
+    view is, and bit k of the mask marks view k as fp32 storage."""
+    low = [t.dtype for t in ts if t is not None and t.dtype in (torch.bfloat16, torch.float16)]
+    if len(set(low)) > 1:
+        raise RuntimeError("dct_amd: bf16 and f16 views in one Enet call")
     mask = 0
     for k, t in enumerate(ts):
         if t is not None and t.dtype == torch.float32:
             mask |= 1 << k
-        elif t is not None and t.dtype != torch.bfloat16:
+        elif t is not None and t.dtype not in (torch.bfloat16, torch.float16):
             raise RuntimeError(f"dct_amd: unsupported dtype {t.dtype}")
-    return (BF16 if any_bf16 else F32), mask
+    return (DTYPE_OF[low[0]] if low else F32), mask
 
 
 def enet_conv(x, w, bias, tf, y, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, transposed=False, ws=(0, 0, 0),
@@ -398,6 +400,25 @@ def enet_bn_bwd(raw, g, g_mask, tf, mean, invstd, dgamma, dbeta, dslope, c1c2, d
     call("dct_enet_bn_bwd", C.byref(vr), C.byref(vg), C.byref(vm) if vm is not None else None,
          ptr(tf.scale), ptr(tf.shift), ptr(tf.slope), int(act), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(dslope),
          ptr(c1c2), int(training), C.byref(vd), fm, dt, ptr(ws), ws.numel(), stream())
+    return draw
+
+
+def bn_fwd(raw, gamma, beta, eps, momentum, running_mean, running_var, training, scale, shift, mean, invstd, y=None, relu=True):
+    """Wide-channel BatchNorm2d (+ReLU) forward of unet_bn: statistics -> scale/shift (+ running statistics) -> y."""
+    vr = view(raw)
+    vy = view(y) if y is not None else None
+    ws = _enet_ws(raw.device, _lib.load().dct_bn_workspace_bytes(raw.shape[3]))
+    call("dct_bn_fwd", C.byref(vr), ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(running_mean), ptr(running_var),
+         int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), C.byref(vy) if vy is not None else None, int(relu),
+         _dt(raw), ptr(ws), ws.numel(), stream())
+    return y
+
+
+def bn_bwd(raw, g, scale, shift, mean, invstd, dgamma, dbeta, c1c2, draw, training=True, relu=True, accumulate=True):
+    vr, vg, vd = view(raw), view(g), view(draw)
+    ws = _enet_ws(raw.device, _lib.load().dct_bn_workspace_bytes(raw.shape[3]))
+    call("dct_bn_bwd", C.byref(vr), C.byref(vg), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
+         int(accumulate), ptr(c1c2), int(training), int(relu), C.byref(vd), _dt(raw), ptr(ws), ws.numel(), stream())
     return draw
 
 

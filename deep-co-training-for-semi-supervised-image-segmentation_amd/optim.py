@@ -33,6 +33,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._import_steps = False
         self._flat_version = -1
         self._on_step = on_step
+        self.grad_scale = 1.0       # multiplies the gradients inside the update: the inverse loss scale of an fp16 step
         # {step count, lr} as float64[2] ON THE DEVICE: the kernel forms the bias corrections itself
         # (dct_adam_flat_dev), so step() has no per-step host scalar and can be replayed from a HIP graph.
         self._dev_state = None
@@ -133,7 +134,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._steps += 1                    # the kernel increments the device copy in stream order
         shadow = f.ensure_shadow() if f.want_shadow else None
         hip_ops.adam_flat_dev(f.flat, f.gflat, self._m, self._v, state, self._dev_table, b1, b2, g["eps"],
-                              g["weight_decay"], bf16_shadow=shadow)
+                              g["weight_decay"], bf16_shadow=shadow, grad_scale=self.grad_scale)
         if self._on_step is not None:
             try:
                 self._on_step(shadow_fresh=shadow is not None)

@@ -127,6 +127,10 @@ class CoTrainer(Trainer):
         self.use_hip_graph = True           # replay the fused step from a captured HIP graph (trainer/step_graph.py)
         self._step_graphs = None
         self.last_step = None
+        self.force_loss_scale = None        # tests: a power of two applied to every loss gradient and divided out by the optimizers
+        self._defer_optimizer = False       # segmented capture: _finish_step stops after the backward passes (see _optimizer_phase)
+        self.ddp_segmented_graph = True     # data parallelism, nets without gradient buckets (Enet): replay [forward + backward] and
+                                            # [optimizers] as two captured graphs around one eager all-reduce per model
 
     def to(self, device: torch.device):
         [segmentator.to(device) for segmentator in self.segmentators]
@@ -214,7 +218,14 @@ class CoTrainer(Trainer):
         if self._fused_ok():
             # replay needs every per-step scalar on the device: only the fused Adam keeps its step count / lr there
             graphable = all(hasattr(s.optimizer, "refresh_lr") and hasattr(s.optimizer, "_steps") for s in self.segmentators)
-            if self.use_hip_graph and graphable and self.grad_sync is None and all(s.torchnet.training for s in self.segmentators):
+            # data parallelism: networks that hand out gradient buckets from inside their backward pass (UNet: 124 MB per model,
+            # the exchange must overlap the backward) stay eager -- their eager step is within 3 % of the replayed one; networks
+            # without (Enet: 1.45 MB per model, ~2500 launches per model-step, host-bound when eager) replay two graphs around
+            # one eager all-reduce per model
+            segmented = (self.grad_sync is not None and self.ddp_segmented_graph and
+                         not any(hasattr(s.torchnet, "grad_bucket_ranges") for s in self.segmentators))
+            if self.use_hip_graph and graphable and (self.grad_sync is None or segmented) and \
+                    all(s.torchnet.training for s in self.segmentators):
                 if self._step_graphs is None:
                     from .step_graph import StepGraphCache
                     self._step_graphs = StepGraphCache(self)
@@ -255,12 +266,27 @@ class CoTrainer(Trainer):
                 call()
                 if self.grad_sync is not None and idx is not None:
                     self.grad_sync.begin(idx)
+        if self._defer_optimizer:
+            return
         if self.grad_sync is not None and any(idx is None for idx, _ in backward_calls):
             self.grad_sync.all_reduce()
+        self._optimizer_phase(streams)
+
+    def _optimizer_phase(self, streams=None):
+        """[wait for model i's gradient exchange] -> optimizer step (:248), per model on its stream."""
+        def on(i):
+            return torch.cuda.stream(streams[i]) if streams is not None else contextlib.nullcontext()
+        unscale = getattr(self, "_grad_unscale", 1.0)
         for i, seg in enumerate(self.segmentators):
             with on(i):
                 if self.grad_sync is not None:
                     self.grad_sync.finish(i)     # model i's all-reduce only: later ones overlap this Adam launch
+                if hasattr(seg.optimizer, "grad_scale"):
+                    seg.optimizer.grad_scale = unscale          # fused Adam: folded into the update
+                elif unscale != 1.0:
+                    flat = getattr(seg.torchnet, "flat_params", None)
+                    if flat is not None and flat.grads_attached():
+                        flat.gflat.mul_(unscale)
                 seg.optimizer.step()
 
     def _run_step_generic(self, lab, unl, train_jsd, train_adv, adv_choice) -> dict:
@@ -282,6 +308,7 @@ class CoTrainer(Trainer):
             advLoss = self._adv_from_batches((self.segmentators[a], self.segmentators[b]), lab[b], unl[0],
                                              **self.adv_training_dict)
         totalLoss = supervisedLoss + self.cot_scheduler.value * jsdLoss + self.adv_scheduler.value * advLoss
+        self._grad_unscale = 1.0
         self._finish_step([(None, totalLoss.backward)])
         return dict(sup=sup, jsd=jsdLoss.detach() if train_jsd else 0, adv=advLoss.detach() if train_adv else 0,
                     preds=preds, unlab_probs=[p.detach() for p in unlab_preds])
@@ -296,8 +323,17 @@ class CoTrainer(Trainer):
         nets = [s.torchnet for s in self.segmentators]
         ignore = self.criterions['sup'].ignore_index
         lam_cot, lam_adv = float(self.cot_scheduler.value), float(self.adv_scheduler.value)
-        g_cot = dict(gscale=lam_dev[0:1], gmul=1.0) if lam_dev is not None else dict(gmul=lam_cot)
-        g_adv = dict(gscale=lam_dev[1:2], gmul=1.0) if lam_dev is not None else dict(gmul=lam_adv)
+        # fp16 networks: per-pixel gradients of a mean over ~1e6 pixels sit in half's subnormal range, so every loss
+        # gradient is scaled by a power of two (>= the pixel count of a labeled batch) and the optimizers divide it out again
+        # (include/dct.h, DCT_F16).  1.0 -- and bit-identical arithmetic -- for bf16 / fp32 networks.
+        gs = 1.0
+        if self.force_loss_scale is not None:
+            gs = float(self.force_loss_scale)
+        elif any(getattr(n, "compute_dtype", None) == torch.float16 for n in nets):
+            gs = float(2 ** min(24, max(10, (lab[0][0].shape[0] * lab[0][0].shape[2] * lab[0][0].shape[3] - 1).bit_length())))
+        g_cot = dict(gscale=lam_dev[0:1], gmul=gs) if lam_dev is not None else dict(gmul=lam_cot * gs)
+        g_adv = dict(gscale=lam_dev[1:2], gmul=gs) if lam_dev is not None else dict(gmul=lam_adv * gs)
+        self._grad_unscale, self._loss_scale = 1.0 / gs, gs
         passes: List[List[Tuple[object, Tensor]]] = [[] for _ in range(S)]     # per model: (tape, dlogits) to back-propagate
         sup, preds = [], []
         # Networks whose samples do not interact (UNet: no BatchNorm) run the labeled and the
@@ -339,7 +375,7 @@ class CoTrainer(Trainer):
                     passes[i].append((tape, dl_out))
                 t = gt.reshape(-1)
                 out = K.ce_fwd(lp, t, C, ignore)
-                K.ce_bwd(lp, t, C, out[1:2], dl_out, ignore_index=ignore)
+                K.ce_bwd(lp, t, C, out[1:2], dl_out, gmul=gs, ignore_index=ignore)
                 sup.append(out[0])
                 preds.append(_nchw(lp))
         jsd, unlab_probs = 0, []
@@ -428,7 +464,8 @@ class CoTrainer(Trainer):
             pseudo = K.argmax(lp, C)
             t = torch.cat((t, pseudo[t.numel():]))
         out = K.ce_fwd(lp, t, C, ignore)
-        dl = K.ce_bwd(lp, t, C, out[1:2], torch.empty_like(lp), ignore_index=ignore)
+        # only the sign of the input gradient is used: the (power-of-two) scale keeps it out of half's subnormals
+        dl = K.ce_bwd(lp, t, C, out[1:2], torch.empty_like(lp), gmul=getattr(self, "_loss_scale", 1.0), ignore_index=ignore)
         gx = net.plan_backward(tape, dl, need_dx=True, need_dw=False)
         x_adv, noise = K.fgsm_step(x.detach().contiguous(), gx.contiguous(), eps)
         return x_adv, noise, lp

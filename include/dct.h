@@ -13,7 +13,12 @@
  *     of a concat buffer and interior windows of padded buffers are plain views);
  *   - every launch goes to the hipStream_t passed in (void* here: no HIP headers needed);
  *   - return 0 on success, negative dct_status on failure; no exceptions cross the ABI;
- *   - no global mutable state: re-entrant from any thread.
+ *   - the compute entry points keep no state between calls and are re-entrant from any thread.  The ONLY process-global
+ *     mutable state is diagnostic: the A/B tuning knobs (dct_tune_set, defaults = the shipped configuration; read at
+ *     launch time, so set them between launches from one thread) and the per-class event timing (dct_prof_enable /
+ *     dct_prof_read).  SURVEY.md 8b sketched a `dct_init(device)` handle; it was dropped on purpose: every launch
+ *     already names its device through the stream it is given and the pointers it receives, and nothing else (no
+ *     allocation, no cached workspace, no per-device table) would live in such a handle.
  */
 #ifndef DCT_H_
 #define DCT_H_
@@ -33,7 +38,12 @@ typedef enum dct_status {
   DCT_ERR_WORKSPACE = -4     /* workspace too small */
 } dct_status;
 
-typedef enum dct_dtype { DCT_F32 = 0, DCT_BF16 = 1 } dct_dtype;
+/* DCT_F16 (IEEE half, BASELINE configs[4] "fp16"): storage type of the Enet kernels' activations and activation gradients
+ * (dct_enet_*), with fp32 raw conv outputs / statistics / parameters exactly as in bf16 mode.  Half's 5-bit exponent cannot
+ * hold per-pixel loss gradients of a mean over ~1e6 pixels, so the host scales the loss gradients by a power of two (the
+ * `gmul` argument of the loss backward kernels) and the optimizer divides it out (`grad_scale` of dct_adam_flat*): exact,
+ * because a power-of-two factor commutes with every rounding on the way.  The MFMA UNet kernels take F32 / BF16 only. */
+typedef enum dct_dtype { DCT_F32 = 0, DCT_BF16 = 1, DCT_F16 = 2 } dct_dtype;
 
 /* NHWC strided view; strides in ELEMENTS of the view's dtype; channel stride is 1. */
 typedef struct dct_view {
@@ -215,12 +225,13 @@ int dct_fgsm_step(const float* x, const float* g, float eps, float* x_adv, float
                   dct_stream stream);
 
 /* ---- K12: Adam over one flat fp32 buffer (torch.optim.Adam, segmentators.py:41; step :248) --
- * g' = g + wd*p; m = m + (g'-m)*(1-b1); v = v*b2 + (1-b2)*g'^2;
+ * g' = grad_scale*g + wd*p; m = m + (g'-m)*(1-b1); v = v*b2 + (1-b2)*g'^2;   (grad_scale: 1, or the inverse of the
+ * power-of-two loss-gradient scale of an fp16 step)
  * p -= step_size * m / (sqrt(v)/bc2_sqrt + eps)     (host passes step_size = lr/bc1, bc2_sqrt;
  * betas are doubles so that 1-beta is formed in double and then rounded, as torch does)
  * bf16_shadow (nullable): also writes the updated p rounded to bf16 at the same index. */
 int dct_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float step_size,
-                  float bc2_sqrt, double beta1, double beta2, float eps, float weight_decay,
+                  float bc2_sqrt, double beta1, double beta2, float eps, float weight_decay, float grad_scale,
                   void* bf16_shadow, dct_stream stream);
 /* Same update with the step-dependent scalars in device memory: state = {step count t, learning rate,
  * table base, table length} (four doubles), table (nullable) = {1 - beta1^t, sqrt(1 - beta2^t)} double pairs the
@@ -230,7 +241,7 @@ int dct_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float
  * scalar, so the launch can be replayed from a captured HIP graph (torch.optim.Adam's `capturable` mode is
  * the reference-side analogue). */
 int dct_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, double* state,
-                      const double* table, double beta1, double beta2, float eps, float weight_decay,
+                      const double* table, double beta1, double beta2, float eps, float weight_decay, float grad_scale,
                       void* bf16_shadow, dct_stream stream);
 
 /* ---- K2/K3/K4/K6/K7/K8: Enet layers (arch/enet.py:8-243) -------------------------------------
@@ -303,6 +314,23 @@ int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const dct_view* b,
                    float* dw, const dct_conv_desc* d, int f32_mask, int dtype,
                    void* workspace, size_t workspace_bytes, dct_stream stream);
 
+/* ---- K6 for the BatchNorm'd UNet: nn.BatchNorm2d(C) + ReLU (arch/network.py:138-146,181-183,243-290) -------------------
+ * C a power of two, 8 <= C <= 2048; dense-channel NHWC views with 16-byte aligned rows.  Forward: batch statistics of `raw`
+ * (training; double accumulation, fixed-order fold; running statistics updated with the unbiased variance) or the running
+ * statistics (eval) -> scale = gamma * invstd, shift = beta - mean * scale, save_mean / save_invstd (nullable), and
+ * y = relu?(scale * raw + shift) when y != NULL.  Backward: g = gradient wrt y;
+ * dgamma / dbeta (= | +=, nullable) and draw = scale * (dz - mean(dz) - xhat * mean(dz * xhat)), dz = g * [y > 0] when relu
+ * (eval mode: draw = scale * dz).  c1c2: 2 * C floats of scratch. */
+size_t dct_bn_workspace_bytes(int channels);
+int dct_bn_fwd(const dct_view* raw, const float* gamma, const float* beta, float eps, float momentum,
+               float* running_mean, float* running_var, int training,
+               float* scale, float* shift, float* save_mean, float* save_invstd,
+               const dct_view* y, int relu, int dtype, void* workspace, size_t workspace_bytes, dct_stream stream);
+int dct_bn_bwd(const dct_view* raw, const dct_view* g, const float* scale, const float* shift,
+               const float* mean, const float* invstd, float* dgamma, float* dbeta, int accumulate,
+               float* c1c2, int training, int relu, const dct_view* draw, int dtype,
+               void* workspace, size_t workspace_bytes, dct_stream stream);
+
 /* ---- Dice accumulation on device (metrics/dice_meter.py:12-83) ----------------------------
  * inter[b][c], psum[b][c], gsum[b][c] (int32, zeroed by caller) from logits argmax vs gt. */
 int dct_dice_counts(const float* logits, const int64_t* gt, int B, int64_t pixels_per_image, int C,
@@ -325,18 +353,18 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
        DCT_TUNE_WGRAD_WAVES8 = 6,  /* 1 (default): 8 waves on the 128x128 weight-gradient tile; 0: 4 waves */
        DCT_TUNE_IGEMM_HALO = 7,    /* 1 (default): shared-halo kernel for 3x3 stride-1 layers on large images; 0: v2 everywhere */
        DCT_TUNE_WGRAD_ROWS = 8,    /* 1 (default): filter-row weight-gradient kernel (three taps share the x strip); 0: v2 */
-       DCT_TUNE_WGRAD_ROWS_FILL = 9,
-       DCT_TUNE_IGEMM_PACKED = 10,
-       DCT_TUNE_IGEMM_MFMA16 = 11,
-       DCT_TUNE_ENET_WGRAD_BLOCKS = 12,
-       DCT_TUNE_WGRAD_GROUPS = 13,
-       DCT_TUNE_WGRAD_TARGET = 14,
-       DCT_TUNE_WGRAD3_TARGET = 15,
-       DCT_TUNE_IGEMM_SPLIT_TARGET = 16,
-       DCT_TUNE_IGEMM_XCD = 17,
-       DCT_TUNE_ENET_REDUCE_PPT = 18,
+       DCT_TUNE_WGRAD_ROWS_FILL = 9,   /* percent (default 70): minimum fill of the filter-row kernel's 64-pixel K-steps */
+       DCT_TUNE_IGEMM_PACKED = 10,     /* 1: packed-rows shared-halo kernel for 3x3 stride-1 layers on small images (default 0: per-tap) */
+       DCT_TUNE_IGEMM_MFMA16 = 11,     /* 1 (default): shared-halo kernel on v_mfma_f32_16x16x32_bf16; 0: 32x32x16 */
+       DCT_TUNE_ENET_WGRAD_BLOCKS = 12,/* 1..1024 (default 1024): cap on the pixel chunks (blocks) of dct_enet_wgrad */
+       DCT_TUNE_WGRAD_GROUPS = 13,     /* 1 | 2 (default 2): wave groups per block of the filter-row weight-gradient kernel */
+       DCT_TUNE_WGRAD_TARGET = 14,     /* >= 64 (default: see wgrad.hip): block target of the per-tap weight-gradient kernel */
+       DCT_TUNE_WGRAD3_TARGET = 15,    /* >= 64: block target (4-wave units) of the filter-row weight-gradient kernel */
+       DCT_TUNE_IGEMM_SPLIT_TARGET = 16, /* >= 64 (default 450): block target of a split-K conv layer */
+       DCT_TUNE_IGEMM_XCD = 17,        /* 1: XCD-aware tile order in the shared-halo kernel (default 0: level on the step) */
+       DCT_TUNE_ENET_REDUCE_PPT = 18,  /* pixels per thread of an Enet per-channel reduction (default: see enet.hip) */
        DCT_TUNE_IGEMM_HALO_MIN_BLOCKS = 19,  /* default 400: fewest blocks for which the shared-halo patch kernel is taken */
-       DCT_TUNE_IGEMM_HALO_COVER = 20 };     /* percent (default 75): least image cover of its 8 x 16 patches */  /* pixels per thread of an Enet per-channel reduction (default: see enet.hip) */  /* 1: XCD-aware tile order in the shared-halo kernel (level with the plain 2-D grid on the step: default 0) */  /* >= 64 (default 450): block target of a split-K conv layer */  /* >= 64: block target (4-wave units) of the filter-row weight-gradient kernel */  /* >= 64 (default: see wgrad.hip): block target of the per-tap weight-gradient kernel */  /* 1 | 2 (default 2): wave groups per block of the filter-row weight-gradient kernel */  /* 1..1024 (default 1024): cap on the pixel chunks (blocks) of dct_enet_wgrad */  /* 1: shared-halo kernel on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (default: see igemm.hip) */  /* 1 (default): packed-rows shared-halo kernel for 3x3 stride-1 layers on small images; 0: v2 *//* percent (default 70): minimum fill of that kernel's 64-pixel K-steps */
+       DCT_TUNE_IGEMM_HALO_COVER = 20 };     /* percent (default 75): least image cover of its 8 x 16 patches */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 

@@ -23,3 +23,4 @@ from .adam import adam_reference_step  # noqa: F401
 from .schedule import ramp_value  # noqa: F401
 from .dice import dice_2d, dice_3d  # noqa: F401
 from .step import OracleModel, cotrain_step  # noqa: F401
+from .ensemble import soft_vote, hard_vote  # noqa: F401

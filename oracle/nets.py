@@ -1,6 +1,7 @@
 """fp32 CPU restatement of the two networks on the hot path (TEST INFRASTRUCTURE ONLY).
 
-UNet  restates /root/reference/generalframework/arch/network.py:115-130,153-171,196-240
+UNet  restates /root/reference/generalframework/arch/network.py:115-130,153-171,196-240 and, with ``batchnorm=True``
+      (``build_net("unet_bn")``), UNet_bn / UNetDec_bn / UNetEnc_bn (:132-150,173-193,243-290)
 Enet  restates /root/reference/generalframework/arch/enet.py:8-30,33-152,167-243
 init  restates /root/reference/generalframework/arch/__init__.py:60-81
 
@@ -52,24 +53,48 @@ class UNet(nn.Module):
 
     WIDTHS = (64, 128, 256, 512)
 
-    def __init__(self, in_channels: int = 1, num_classes: int = 2, dropout_p: float = 0.5):
+    def __init__(self, in_channels: int = 1, num_classes: int = 2, dropout_p: float = 0.5, batchnorm: bool = False):
         super().__init__()
         self.dropout_p = float(dropout_p)
+        self.batchnorm = bool(batchnorm)
+        # Slot numbers are the reference's nn.Sequential positions (= state_dict keys).  Per block: (first conv, its
+        # BatchNorm or None, second conv, its BatchNorm or None, transposed conv or None).
+        if batchnorm:       # UNetDec_bn: BN after the first conv only; centre / UNetEnc_bn: after both; enc1: after the first
+            DEC, CEN, ENC, E1 = (0, 1, 3, None, None), (0, 1, 3, 4, 7), (0, 1, 3, 4, 6), (0, 1, 3, None, None)
+        else:
+            DEC, CEN, ENC, E1 = (0, None, 2, None, None), (0, None, 2, None, 5), (0, None, 2, None, 4), (0, None, 2, None, None)
+        self._idx = dict(dec=DEC, center=CEN, enc=ENC, enc1=E1)
+
+        def block(idx, cin, feat, cout=None):
+            layers = {idx[0]: nn.Conv2d(cin, feat, 3), idx[2]: nn.Conv2d(feat, feat, 3)}
+            if idx[1] is not None:
+                layers[idx[1]] = nn.BatchNorm2d(feat)
+            if idx[3] is not None:
+                layers[idx[3]] = nn.BatchNorm2d(feat)
+            if idx[4] is not None:
+                layers[idx[4]] = nn.ConvTranspose2d(feat, cout, 2, stride=2)
+            return _Slots(dict(sorted(layers.items())))
         cin = in_channels
         for lvl, width in enumerate(self.WIDTHS, start=1):
             blk = _Holder()
-            blk.down = _Slots({0: nn.Conv2d(cin, width, 3), 2: nn.Conv2d(width, width, 3)})
+            blk.down = block(DEC, cin, width)
             setattr(self, f"dec{lvl}", blk)
             cin = width
-        self.center = _Slots({0: nn.Conv2d(512, 1024, 3), 2: nn.Conv2d(1024, 1024, 3),
-                              5: nn.ConvTranspose2d(1024, 512, 2, stride=2)})
+        self.center = block(CEN, 512, 1024, 512)
         for lvl, (cin, feat, cout) in {4: (1024, 512, 256), 3: (512, 256, 128), 2: (256, 128, 64)}.items():
             blk = _Holder()
-            blk.up = _Slots({0: nn.Conv2d(cin, feat, 3), 2: nn.Conv2d(feat, feat, 3),
-                             4: nn.ConvTranspose2d(feat, cout, 2, stride=2)})
+            blk.up = block(ENC, cin, feat, cout)
             setattr(self, f"enc{lvl}", blk)
-        self.enc1 = _Slots({0: nn.Conv2d(128, 64, 3), 2: nn.Conv2d(64, 64, 3)})
+        self.enc1 = block(E1, 128, 64)
         self.final = nn.Conv2d(64, num_classes, 1)
+
+    @staticmethod
+    def _conv_act(slots, idx, which, h):
+        """conv `which` (0: first, 1: second) of a block, its BatchNorm when the variant has one, ReLU."""
+        h = slots.at(idx[2 * which])(h)
+        if idx[2 * which + 1] is not None:
+            h = slots.at(idx[2 * which + 1])(h)
+        return F.relu(h)
 
     def _drop(self, x, which: int, masks):
         if masks is not None:
@@ -82,10 +107,11 @@ class UNet(nn.Module):
                 taps: Optional[dict] = None) -> torch.Tensor:
         skips = []
         h = x
+        I = self._idx
         for lvl in (1, 2, 3, 4):
             d = getattr(self, f"dec{lvl}").down
-            h = F.relu(d.at(0)(h))
-            h = F.relu(d.at(2)(h))
+            h = self._conv_act(d, I["dec"], 0, h)
+            h = self._conv_act(d, I["dec"], 1, h)
             if lvl == 4:
                 h = self._drop(h, 0, dropout_masks)
             h = F.max_pool2d(h, 2, stride=2, ceil_mode=True)
@@ -93,29 +119,29 @@ class UNet(nn.Module):
             if taps is not None:
                 taps[f"dec{lvl}"] = h
         c = self.center
-        h = F.relu(c.at(0)(h))
-        h = F.relu(c.at(2)(h))
+        h = self._conv_act(c, I["center"], 0, h)
+        h = self._conv_act(c, I["center"], 1, h)
         h = self._drop(h, 1, dropout_masks)
-        h = F.relu(c.at(5)(h))
+        h = F.relu(c.at(I["center"][4])(h))
         if taps is not None:
             taps["center"] = h
         for lvl in (4, 3, 2):
             u = getattr(self, f"enc{lvl}").up
             h = torch.cat([h, _resize_bilinear(skips[lvl - 1], h.shape[2:])], 1)
-            h = F.relu(u.at(0)(h))
+            h = self._conv_act(u, I["enc"], 0, h)
             if taps is not None:
                 taps[f"e{lvl}a"] = h
-            h = F.relu(u.at(2)(h))
+            h = self._conv_act(u, I["enc"], 1, h)
             if taps is not None:
                 taps[f"e{lvl}b"] = h
-            h = F.relu(u.at(4)(h))
+            h = F.relu(u.at(I["enc"][4])(h))
             if taps is not None:
                 taps[f"enc{lvl}"] = h
         h = torch.cat([h, _resize_bilinear(skips[0], h.shape[2:])], 1)
-        h = F.relu(self.enc1.at(0)(h))
+        h = self._conv_act(self.enc1, I["enc1"], 0, h)
         if taps is not None:
             taps["e1a"] = h
-        h = F.relu(self.enc1.at(2)(h))
+        h = self._conv_act(self.enc1, I["enc1"], 1, h)
         if taps is not None:
             taps["enc1"] = h
         return _resize_bilinear(self.final(h), x.shape[2:])
@@ -265,6 +291,8 @@ def init_weights(net: nn.Module) -> nn.Module:
 def build_net(name: str, num_classes: int, **kw) -> nn.Module:
     if name == "unet":
         return init_weights(UNet(num_classes=num_classes, **kw))
+    if name == "unet_bn":
+        return init_weights(UNet(num_classes=num_classes, batchnorm=True, **kw))
     if name == "enet":
         return init_weights(Enet(num_classes=num_classes))
     raise ValueError(f"oracle has no arch {name!r}")

@@ -9,8 +9,24 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def host_cores() -> int:
+    """Cores this process may use: affinity capped by the cgroup CPU quota.  os.cpu_count() reports the whole host on the GPU
+    boxes (hundreds of cores) while the container owns 16: ATen's default pool then oversubscribes them and every CPU-oracle
+    step in a test runs an order of magnitude slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    torch.set_num_threads(host_cores())
 
 
 @pytest.fixture(scope="session")

@@ -98,6 +98,8 @@ def test_unet_bf16_trains_like_the_fp32_oracle():
 
 
 if __name__ == "__main__":
+    from conftest import host_cores
+    torch.set_num_threads(host_cores())
     res = {}
     for name, args in (("enet_bf16", ("enet", 96, 4, 3, 200, 10, torch.bfloat16)),
                        ("enet_f32", ("enet", 96, 4, 3, 200, 10, torch.float32)),

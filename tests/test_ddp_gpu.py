@@ -78,3 +78,101 @@ def test_two_ranks_one_gpu_fused_step_stays_in_sync(tmp_path):
     for a, b in zip(r0["w"], r1["w"]):
         assert torch.isfinite(a).all()
         assert torch.equal(a, b)                                  # same start (broadcast) + same averaged gradients
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Enet under data parallelism: the step replays two captured graphs around one eager all-reduce per model
+# (trainer/step_graph.py); optional bf16 gradient exchange (ddp.FlatGradSync(compress="bf16")).
+def _enet_trainer(tmp, rank, compress, graph):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import FakeLoader, blob_batches
+    from dct_amd.ddp import FlatGradSync
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    C, H, B, n = 3, 64, 2, 6
+    segs = []
+    for seed in (5 + 10 * rank, 6 + 10 * rank):
+        torch.manual_seed(seed)
+        segs.append(Segmentator({"name": "enet", "num_classes": C, "compute_dtype": torch.bfloat16},
+                                {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4}, {"name": "StepLR", "step_size": 90, "gamma": 0.1}))
+    lab = [FakeLoader(blob_batches(100 * rank + 31 + i, n, B, H, C), B) for i in range(2)]
+    unl = FakeLoader(blob_batches(100 * rank + 41, n, B, H, C), B)
+    crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tr = CoTrainer(segs, lab, unl, unl, crit, max_epoch=1, save_dir=tmp, device="cuda:0", axises=[1, 2],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False, steps_per_epoch=n)
+    for s in segs:
+        s.train()
+    tr.grad_sync = FlatGradSync(segs, compress=compress, measure=True)
+    tr.ddp_segmented_graph = graph
+    return tr, lab, unl, n
+
+
+def _enet_worker(rank, world, port, out, compress, graph):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    tr, lab, unl, n = _enet_trainer(os.path.join(out, f"r{rank}"), rank, compress, graph)
+    sups = []
+    for k in range(n):
+        lb = [(lab[i][k][0][0], lab[i][k][0][1]) for i in range(2)]
+        o = tr._run_step(lb, (unl[k][0][0], unl[k][0][1]), True, True, (0, 1))
+        sups.append([float(v) for v in o["sup"]])
+    torch.cuda.synchronize()
+    g = tr._step_graphs
+    w = [torch.cat([p.detach().flatten() for p in s.torchnet.parameters()]).cpu() for s in tr.segmentators]
+    torch.save(dict(w=w, sups=sups, captures=0 if g is None else g.captures, replays=0 if g is None else g.replays,
+                    two_graphs=g is not None and all(c.graph_opt is not None for c in g._graphs.values()),
+                    exposed=tr.grad_sync.exposed_ms(), bytes=tr.grad_sync.exchanged_bytes,
+                    steps=[s.optimizer._steps for s in tr.segmentators]), os.path.join(out, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_enet_two_ranks_segmented_graph_equals_eager_exchange(tmp_path):
+    """Six data-parallel Enet steps (JSD + FGSM) on two ranks: (a) eager launches with the per-model exchange, (b) two eager
+    steps, then the [forward + backward] / [optimizers] graphs replayed around the exchange.  Both ranks must end identical,
+    and (b) must equal (a) bit for bit."""
+    res = {}
+    for graph in (False, True):
+        out = str(tmp_path / f"g{int(graph)}")
+        os.makedirs(out)
+        mp.spawn(_enet_worker, args=(2, _free_port(), out, None, graph), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(out, "w0.pt"), weights_only=False)
+        r1 = torch.load(os.path.join(out, "w1.pt"), weights_only=False)
+        for a, b in zip(r0["w"], r1["w"]):
+            assert torch.isfinite(a).all() and torch.equal(a, b)
+        assert r0["steps"] == [6, 6]
+        if graph:
+            assert r0["captures"] == 1 and r0["replays"] == 4 and r0["two_graphs"]
+        else:
+            assert r0["captures"] == 0
+        res[graph] = r0
+    assert res[False]["sups"] == res[True]["sups"]
+    for a, b in zip(res[False]["w"], res[True]["w"]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.timeout(900)
+def test_enet_two_ranks_bf16_gradient_exchange(tmp_path):
+    """compress="bf16": half the bytes on the wire, ranks still bit-identical to each other, weights within bf16 rounding of the
+    fp32 exchange after six steps."""
+    res = {}
+    for compress in (None, "bf16"):
+        out = str(tmp_path / f"c{compress}")
+        os.makedirs(out)
+        mp.spawn(_enet_worker, args=(2, _free_port(), out, compress, True), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(out, "w0.pt"), weights_only=False)
+        r1 = torch.load(os.path.join(out, "w1.pt"), weights_only=False)
+        for a, b in zip(r0["w"], r1["w"]):
+            assert torch.equal(a, b)
+        res[compress] = r0
+    assert res["bf16"]["bytes"] * 2 == res[None]["bytes"]
+    for a, b in zip(res[None]["w"], res["bf16"]["w"]):
+        assert ((a - b).norm() / a.norm()).item() < 5e-3          # six Adam steps of lr 1e-3 on sign-like updates
+    assert res[None]["exposed"] >= 0.0

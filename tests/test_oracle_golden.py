@@ -177,3 +177,60 @@ def test_g6_dice(golden):
     np.testing.assert_allclose(log3.numpy(), g["log3d"], rtol=1e-6)
     np.testing.assert_allclose(log2.mean(0).numpy(), g["means2d"], rtol=1e-6)
     np.testing.assert_allclose(log2.std(0).numpy(), g["stds2d"], rtol=1e-5)
+
+
+def test_g3_unet_bn(golden):
+    """oracle UNet(batchnorm=True) == the reference's UNet_bn (network.py:243-290): train-mode logits / CE / gradients on a
+    batch of two, the running statistics it leaves, an eval-mode forward, and the state_dict keys."""
+    g = golden("g3_unet_bn")
+    C, H = int(g["C"]), int(g["H"])
+    torch.manual_seed(int(g["seed"]))
+    net = oracle.build_net("unet_bn", C, dropout_p=0.0)
+    assert list(net.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    net.train()
+    torch.manual_seed(100 + H)
+    x = torch.rand(2, 1, H, H)
+    t = torch.randint(0, C, (2, H, H))
+    x.requires_grad_(True)
+    y = net(x)
+    loss = oracle.cross_entropy_2d(y, t)
+    loss.backward()
+    np.testing.assert_allclose(y.detach().numpy(), g["train_logits"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss.item(), g["train_ce"], **TIGHT)
+    np.testing.assert_allclose(x.grad.numpy(), g["train_grad_x"], rtol=1e-4, atol=1e-9)
+    norms = {k: p.grad.double().norm().item() for k, p in net.named_parameters()}
+    np.testing.assert_allclose([norms[str(k)] for k in g["train_grad_names"]], g["train_grad_norms"], rtol=1e-4, atol=1e-9)
+    sd = net.state_dict()
+    np.testing.assert_allclose(np.stack([_digest(sd[str(k)]) for k in g["bn_keys"]]), g["bn_digest"], rtol=1e-5, atol=1e-7)
+    net.eval()
+    with torch.no_grad():
+        ye = net(x.detach()[:1])
+    np.testing.assert_allclose(ye.numpy(), g["eval_logits"], rtol=1e-5, atol=1e-6)
+
+
+def test_g7_ensembles(golden):
+    """oracle soft / hard voting + Dice == Summary.py's Ensembleway + the reference DiceMeter on the same predictions."""
+    g = golden("g7_eval")
+    C, H = int(g["C"]), int(g["H"])
+    nets = []
+    for s in g["net_seeds"]:
+        net = _seeded_net("enet", C, int(s)).eval()
+        nets.append(net)
+
+    def batches(seed, n, B):
+        gen = torch.Generator().manual_seed(seed)
+        return [(torch.rand(B, 1, H, H, generator=gen), torch.randint(0, C, (B, 1, H, H), generator=gen)) for _ in range(n)]
+
+    val = [b for s, B in zip(g["val_seeds"], g["val_sizes"]) for b in batches(int(s), 1, int(B))]
+    val1 = batches(int(g["hard_val_seed"]), int(g["hard_val_batches"]), 1)
+    for way, loader in (("soft", val), ("hard", val1)):
+        rows2, rows3 = [], []
+        with torch.no_grad():
+            for img, gt in loader:
+                probs = [oracle.softmax_channels(n(img)) for n in nets]
+                v = oracle.soft_vote(probs) if way == "soft" else oracle.hard_vote(probs, C)
+                rows2.append(oracle.dice_2d(v, gt))
+                rows3.append(oracle.dice_3d(v, gt).unsqueeze(0))
+        for rows, key in ((rows2, f"{way}_dice2d"), (rows3, f"{way}_dice3d")):
+            log = torch.cat(rows)
+            np.testing.assert_allclose(torch.stack((log.mean(0), log.std(0)), dim=1).numpy(), g[key], rtol=1e-5, atol=1e-6)

@@ -1,0 +1,189 @@
+"""SURVEY.md 8f rows 3 and 4 on the GPU: the BatchNorm'd UNet (``unet_bn``, network.py:243-290) against a golden captured
+from the reference module and against the oracle in a co-training step; ``CoTrainer._eval_loop`` / ``checkpoint`` and the
+voting-ensemble summary (Summary.py:70-172) through the HIP networks against goldens captured from the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+from helpers import FakeLoader, batches, digest  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _hip_unet_bn(C, seed, dtype):
+    from dct_amd.arch import get_arch
+    torch.manual_seed(seed)
+    onet = oracle.build_net("unet_bn", C, dropout_p=0.0)
+    net = get_arch("unet_bn", {"num_classes": C, "compute_dtype": dtype, "dropout_p": 0.0})
+    net.load_state_dict(onet.state_dict())
+    return net.to(DEV), onet
+
+
+def test_unet_bn_fp32_matches_reference_golden(golden):
+    from dct_amd.loss.loss import CrossEntropyLoss2d
+    g = golden("g3_unet_bn")
+    C, H = int(g["C"]), int(g["H"])
+    net, _ = _hip_unet_bn(C, int(g["seed"]), torch.float32)
+    assert list(net.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    net.train()
+    torch.manual_seed(100 + H)
+    x = torch.rand(2, 1, H, H)
+    t = torch.randint(0, C, (2, H, H))
+    xd = x.to(DEV).requires_grad_(True)
+    y = net(xd)
+    loss = CrossEntropyLoss2d()(y, t.to(DEV))
+    loss.backward()
+    ref = g["train_logits"]
+    assert np.abs(y.detach().cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    np.testing.assert_allclose(loss.item(), g["train_ce"], rtol=1e-5)
+    gx, rgx = xd.grad.cpu().numpy(), g["train_grad_x"]
+    assert np.linalg.norm(gx - rgx) <= 5e-3 * np.linalg.norm(rgx)
+    norms = {k: p.grad.double().norm().item() for k, p in net.named_parameters()}
+    got = np.array([norms[str(k)] for k in g["train_grad_names"]])
+    np.testing.assert_allclose(got, g["train_grad_norms"], rtol=5e-3, atol=1e-7)
+    sd = net.state_dict()
+    bn = np.stack([digest(sd[str(k)]) for k in g["bn_keys"]])
+    np.testing.assert_allclose(bn[:, 1:], g["bn_digest"][:, 1:], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["dec1.down.1.running_mean"].cpu().numpy(), g["bn_first_mean"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["dec1.down.1.running_var"].cpu().numpy(), g["bn_first_var"], rtol=1e-4, atol=1e-6)
+    net.eval()
+    with torch.no_grad():
+        ye = net(x[:1].to(DEV))
+    ref = g["eval_logits"]
+    assert np.abs(ye.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_unet_bn_bf16_tracks_oracle():
+    C, H = 3, 184
+    net, onet = _hip_unet_bn(C, 5, torch.bfloat16)
+    net.train()
+    onet.train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 1, H, H + 16, generator=g)
+    y = net.plan_forward(x.to(DEV), False)[0].permute(0, 3, 1, 2).float().cpu()
+    with torch.no_grad():
+        yo = onet(x)
+    assert ((y - yo).norm() / yo.norm()).item() < 5e-2
+
+
+@pytest.mark.parametrize("adv", [False, True])
+def test_unet_bn_cotraining_step_vs_oracle(tmp_path, adv):
+    """Two unet_bn models, one fused fp32 step (separate labeled / unlabeled / adversarial statistics batches) and a second
+    step through the captured graph path's eager warm-up, against the oracle."""
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    C, B, H, n = 3, 2, 176, 2
+    segs, oms = [], []
+    for seed in (5, 6):
+        torch.manual_seed(seed)
+        onet = oracle.build_net("unet_bn", C, dropout_p=0.0).train()
+        seg = Segmentator({"name": "unet_bn", "num_classes": C, "compute_dtype": torch.float32, "dropout_p": 0.0},
+                          {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4}, {"name": "StepLR", "step_size": 90, "gamma": 0.1})
+        seg.torchnet.load_state_dict(onet.state_dict())
+        segs.append(seg)
+        oms.append(oracle.OracleModel.make(onet))
+    lab = [FakeLoader(batches(61 + i, n, B, H, C), B) for i in range(2)]
+    unl = FakeLoader(batches(71, n, B, H, C), B)
+    crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tr = CoTrainer(segs, lab, unl, unl, crit, max_epoch=1, save_dir=str(tmp_path), device=DEV, axises=[1, 2],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False, steps_per_epoch=n)
+    assert tr._fused_ok()
+    for s in segs:
+        s.train()
+    for k in range(n):
+        lb = [(lab[i][k][0][0], lab[i][k][0][1]) for i in range(2)]
+        ub = (unl[k][0][0], unl[k][0][1])
+        out = tr._run_step(lb, ub, True, adv, (0, 1) if adv else None)
+        ref = oracle.cotrain_step(oms, lb, ub[0], True, adv, lam_cot=0.5, lam_adv=0.05, eps=0.03)
+        tol = 2e-5 if k == 0 else 5e-3
+        np.testing.assert_allclose([s.item() for s in out["sup"]], [s.item() for s in ref["sup"]], rtol=tol)
+        np.testing.assert_allclose(out["jsd"].item(), ref["jsd"].item(), rtol=max(tol, 1e-4))
+        if adv:
+            np.testing.assert_allclose(out["adv"].item(), ref["adv"].item(), rtol=5e-2)
+    for seg, om in zip(segs, oms):
+        a = torch.cat([p.detach().flatten().cpu() for p in seg.torchnet.parameters()]).double()
+        b = torch.cat([p.detach().flatten() for p in om.net.parameters()]).double()
+        assert ((a - b).norm() / b.norm()).item() < 2e-3
+        for (ka, va), (kb, vb) in zip(seg.torchnet.named_buffers(), om.net.named_buffers()):
+            if va.dtype.is_floating_point:
+                np.testing.assert_allclose(va.cpu().numpy(), vb.numpy(), rtol=2e-3, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------- eval loop / checkpoint / ensemble
+def _eval_setup(g, tmp_path, dtype=torch.float32):
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    C, H = int(g["C"]), int(g["H"])
+    segs = []
+    for s in g["net_seeds"]:
+        torch.manual_seed(int(s))
+        sd = oracle.build_net("enet", C).state_dict()
+        seg = Segmentator({"name": "enet", "num_classes": C, "compute_dtype": dtype}, {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                          {"name": "StepLR", "step_size": 90, "gamma": 0.1})
+        seg.torchnet.load_state_dict(sd)
+        segs.append(seg)
+    val = FakeLoader([b for s, B in zip(g["val_seeds"], g["val_sizes"]) for b in batches(int(s), 1, int(B), H, C)], 1)
+    lab = [FakeLoader(batches(31 + i, 1, 2, H, C), 2) for i in range(2)]
+    crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tr = CoTrainer(segs, lab, val, val, crit, max_epoch=1, save_dir=str(tmp_path), device=DEV, axises=[1, 2, 3],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False)
+    return tr, segs, val
+
+
+def test_eval_loop_and_checkpoint_on_hip_nets_match_reference_golden(golden, tmp_path):
+    """cotraining_totalloss.py:273-318 (eval mode, per-patient batches, 2-D and 3-D Dice) and :474-482 through the HIP Enets."""
+    from dct_amd import ModelMode
+    g = golden("g7_eval")
+    tr, segs, val = _eval_setup(g, tmp_path)
+    with torch.no_grad():
+        d2, d3 = tr._eval_loop(val, epoch=0, mode=ModelMode.EVAL, save=False)
+    assert not segs[0].training
+    np.testing.assert_allclose(d2.numpy(), g["dice2d"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(d3.numpy(), g["dice3d"], rtol=1e-4, atol=1e-5)
+    metric = d3[:, [1, 2, 3], 0].mean(1)
+    np.testing.assert_allclose(metric.numpy(), g["metric"], rtol=1e-4)
+    tr.checkpoint(metric, 0)
+    ck = torch.load(os.path.join(str(tmp_path), "best_0.pth"), map_location="cpu", weights_only=False)
+    assert sorted(ck.keys()) == [str(k) for k in g["ckpt_keys"]]
+    assert sorted(ck["segmentator"].keys()) == [str(k) for k in g["ckpt_seg_keys"]]
+    np.testing.assert_allclose(float(ck["best_score"]), float(g["ckpt_best_score"]), rtol=1e-4)
+    assert int(ck["best_epoch"]) == int(g["ckpt_best_epoch"])
+
+
+def test_ensemble_summary_from_checkpoints_matches_reference_golden(golden, tmp_path):
+    """Summary.py:70-172: reload the checkpoints into fresh Segmentators, soft voting over patient batches and hard voting
+    over single slices, 2-D / 3-D Dice of the ensemble."""
+    from dct_amd import ModelMode
+    from dct_amd import summary
+    g = golden("g7_eval")
+    C, H = int(g["C"]), int(g["H"])
+    tr, segs, val = _eval_setup(g, tmp_path)
+    with torch.no_grad():
+        _, d3 = tr._eval_loop(val, epoch=0, mode=ModelMode.EVAL, save=False)
+    tr.checkpoint(d3[:, [1, 2, 3], 0].mean(1), 0)
+    models = summary.load_models([os.path.join(str(tmp_path), f"best_{i}.pth") for i in range(2)])
+    for m, s in zip(models, segs):
+        for (ka, va), (kb, vb) in zip(m.torchnet.state_dict().items(), s.torchnet.state_dict().items()):
+            assert ka == kb and torch.equal(va.cpu(), vb.cpu())
+    res = summary.summarize(models, val, DEV, "soft", report_axises=[1, 2, 3])
+    for name, key in (("2d", "soft_dice2d"), ("3d", "soft_dice3d")):
+        got = [res[name]["ensemble"][f"DSC{j}"] for j in range(C)]
+        np.testing.assert_allclose(got, g[key][:, 0], rtol=1e-4, atol=1e-5)
+        got_std = [res[name]["ensemble_std"][f"DSC{j}"] for j in range(C)]
+        np.testing.assert_allclose(got_std, g[key][:, 1], rtol=1e-3, atol=1e-5)
+    val1 = FakeLoader(batches(int(g["hard_val_seed"]), int(g["hard_val_batches"]), 1, H, C), 1)
+    res = summary.summarize(models, val1, DEV, "hard", report_axises=[1, 2, 3])
+    for name, key in (("2d", "hard_dice2d"), ("3d", "hard_dice3d")):
+        got = [res[name]["ensemble"][f"DSC{j}"] for j in range(C)]
+        np.testing.assert_allclose(got, g[key][:, 0], rtol=1e-4, atol=1e-5)

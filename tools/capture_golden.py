@@ -110,7 +110,7 @@ def save(name, **arrs):
 def seeded_state(arch, C, seed):
     """Build-owned initializer: weights from the oracle net under torch.manual_seed(seed)."""
     torch.manual_seed(seed)
-    kw = {"dropout_p": 0.0} if arch == "unet" else {}
+    kw = {"dropout_p": 0.0} if arch in ("unet", "unet_bn") else {}
     return oracle.build_net(arch, C, **kw).state_dict()
 
 
@@ -210,6 +210,229 @@ def g3_g4_nets():
                 out[f"{tag}_bn_last_mean"] = sd["decoder.layers.4.block1x1_2.1.running_mean"]
                 out[f"{tag}_bn_last_var"] = sd["decoder.layers.4.block1x1_2.1.running_var"]
         save(f"g3_{arch}", **out)
+
+
+def g3_unet_bn():
+    """UNet_bn (arch/network.py:243-290): train-mode forward/backward on a batch of 2 (batch statistics), the running
+    statistics it leaves, and an eval-mode forward with those statistics."""
+    arch, C, seed, H = "unet_bn", 4, 13, 176
+    net = ref_net(arch, C, seed)
+    out = dict(arch=arch, C=C, seed=seed, H=H)
+    net.train()
+    torch.manual_seed(100 + H)
+    x = torch.rand(2, 1, H, H)
+    t = torch.randint(0, C, (2, H, H))
+    x.requires_grad_(True)
+    y = net(x)
+    loss = CrossEntropyLoss2d()(y, t)
+    loss.backward()
+    out["train_logits"], out["train_ce"], out["train_grad_x"] = y, loss, x.grad
+    names, norms = [], []
+    for k, p in net.named_parameters():
+        names.append(k)
+        norms.append(p.grad.double().norm().item())
+    out["train_grad_names"], out["train_grad_norms"] = np.array(names), np.array(norms)
+    sd = net.state_dict()
+    bn_keys = [k for k in sd if k.endswith("running_mean") or k.endswith("running_var")]
+    out["bn_keys"] = np.array(bn_keys)
+    out["bn_digest"] = np.stack([_tensor_digest(sd[k]) for k in bn_keys])
+    out["bn_first_mean"], out["bn_first_var"] = sd["dec1.down.1.running_mean"], sd["dec1.down.1.running_var"]
+    out["state_keys"] = np.array(list(sd.keys()))
+    net.eval()
+    with torch.no_grad():
+        ye = net(x.detach()[:1])
+    out["eval_logits"] = ye
+    save("g3_unet_bn", **out)
+
+
+# ----------------------------------------------------------------------------- G7 eval loop, checkpoint, ensemble
+def _reference_ensembleway():
+    """The Ensembleway class of /root/reference/Summary.py:92-126, taken out of the script by its AST (Summary.py parses
+    sys.argv and loads checkpoints at import) and executed here against the reference's own helpers."""
+    import ast
+    from typing import List
+    from generalframework.utils import class2one_hot
+    src = open(os.path.join(REF, "Summary.py")).read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "Ensembleway")
+    ns = dict(torch=torch, np=np, List=List, Tensor=torch.Tensor, class2one_hot=class2one_hot,
+              config={"Arch": {"num_classes": 4}})
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "Summary.py", "exec"), ns)
+    return ns["Ensembleway"]
+
+
+def g7_eval():
+    """CoTrainer._eval_loop (cotraining_totalloss.py:273-318) of two eval-mode Enets over three "patients" (batches of 3, 2
+    and 4 slices), the checkpoint it leads to (:474-482 -> trainer.py:208-220) and the soft / hard voting ensemble of
+    Summary.py:92-126,163-172 on the same batches."""
+    arch, C, H, seeds = "enet", 4, 64, (21, 22)
+    segs = []
+    for s in seeds:
+        seg = Segmentator({"name": arch, "num_classes": C}, {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                          {"name": "StepLR", "step_size": 90, "gamma": 0.1})
+        seg.torchnet.load_state_dict(seeded_state(arch, C, s))
+        segs.append(seg)
+    sizes = (3, 2, 4)
+    val = _FakeLoader([b for i, B in enumerate(sizes) for b in _batches(51 + i, 1, B, H, C)], 1)
+    lab = [_FakeLoader(_batches(31 + i, 1, 2, H, C), 2) for i in range(2)]
+    crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    tr = CoTrainer(segmentators=segs, labeled_dataloaders=lab, unlabeled_dataloader=val, val_dataloader=val,
+                   criterions=crit, max_epoch=1, save_dir=tmp, device="cpu", axises=[1, 2, 3],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False)
+    with torch.no_grad():
+        d2, d3 = tr._eval_loop(val, epoch=0, mode=ModelMode.EVAL, save=False)
+    metric = d3[:, [1, 2, 3], 0].mean(1)
+    tr.checkpoint(metric, 0)
+    ck = torch.load(os.path.join(tmp, "best_0.pth"), map_location="cpu", weights_only=False)
+    out = dict(arch=arch, C=C, H=H, net_seeds=np.array(seeds), val_seeds=np.array([51, 52, 53]), val_sizes=np.array(sizes),
+               dice2d=d2, dice3d=d3, metric=metric, ckpt_keys=np.array(sorted(ck.keys())),
+               ckpt_seg_keys=np.array(sorted(ck["segmentator"].keys())), ckpt_best_score=float(ck["best_score"]),
+               ckpt_best_epoch=int(ck["best_epoch"]))
+    Ens = _reference_ensembleway()
+    # hard voting concatenates the S argmax maps along the batch axis and votes over that axis (Summary.py:113-125): it is
+    # only meaningful -- and only passes DiceMeter's shape assert -- for single-slice batches, so it is captured on those
+    val1 = _FakeLoader(_batches(61, 4, 1, H, C), 1)
+    out["hard_val_seed"], out["hard_val_batches"] = 61, 4
+    for way, loader in (("soft", val), ("hard", val1)):
+        ens = Ens(way)
+        m2, m3 = DiceMeter(method="2d", report_axises=[1, 2, 3], C=C), DiceMeter(method="3d", report_axises=[1, 2, 3], C=C)
+        for s in segs:
+            s.eval()
+        with torch.no_grad():
+            for (img, gt), _, _ in loader:
+                preds = [s.predict(img, logit=False) for s in segs]
+                v = ens(preds)
+                m2.add(v, gt)
+                m3.add(v, gt)
+        out[f"{way}_dice2d"] = torch.stack(m2.value()[1], dim=1)
+        out[f"{way}_dice3d"] = torch.stack(m3.value()[1], dim=1)
+    save("g7_eval", **out)
+
+
+# ----------------------------------------------------------------------------- G8 data path
+def g8_data():
+    """The reference's MedicalImageDataset / PatientSampler / get_ACDC_split_dataloders / extract_patients
+    (dataset/medicalDataLoader.py:22-162, dataset/ACDC_helper.py:27-141) on (a) the file NAMES of the whole ACDC-all tree
+    (partition logic) and (b) the vendored subset tests/golden/acdc_subset (decoded batches).  torchvision is absent from this
+    image (stubbed), so the reference's `segment_transform` cannot run here; the dataset classes take a transform object and are
+    driven with the build's restatement of it (dct_amd.dataset.augment) -- what is pinned is everything around the transform."""
+    import generalframework.dataset.ACDC_helper as ref_helper
+    from generalframework.dataset import MedicalImageDataset as RefDataset
+    sys.path.insert(0, REPO)
+    import dct_amd  # noqa: F401
+    from dct_amd.dataset.augment import segment_transform
+    out = {}
+    # (a) partitions on the full tree: numpy RNG seeded as train_ACDC_cotraining.py does through fix_all_seed(1234)
+    full = os.path.join(REF, "dataset", "ACDC-all")
+    out["full_train_names"] = np.array(sorted(os.listdir(os.path.join(full, "train", "img"))))
+    out["full_val_names"] = np.array(sorted(os.listdir(os.path.join(full, "val", "img"))))
+    for tag, ratio, overlap, nm in (("a", 0.2, 1, 2), ("b", 0.5, 0.25, 3)):
+        config = {"Dataset": {"root_dir": full, "subfolders": ["img", "gt"], "transform": segment_transform((256, 256)),
+                              "augment": "PILaugment", "pin_memory": False},
+                  "Lab_Dataloader": {"pin_memory": False, "batch_size": 4, "num_workers": 0, "shuffle": True, "drop_last": True,
+                                     "batch_sampler": ["PatientSampler", {"grp_regex": r"(patient\d+_\d+)_\d+", "shuffle": False}]},
+                  "Unlab_Dataloader": {"pin_memory": False, "batch_size": 4, "num_workers": 0, "shuffle": True, "drop_last": True},
+                  "Lab_Partitions": {"num_models": nm, "partition_sets": ratio, "partition_overlap": overlap}}
+        np.random.seed(1234)
+        labs, unl, val = ref_helper.get_ACDC_split_dataloders(config)
+        out[f"{tag}_cfg"] = np.array([ratio, overlap, nm])
+        for i, l in enumerate(labs):
+            out[f"{tag}_lab{i}_names"] = np.array([os.path.basename(f) for f in l.dataset.filenames["img"]])
+        out[f"{tag}_unl_names"] = np.array([os.path.basename(f) for f in unl.dataset.filenames["img"]])
+        out[f"{tag}_val_batches"] = np.array(sorted(len(b) for b in val.batch_sampler))
+        out[f"{tag}_rng_after"] = np.random.randint(1 << 30)
+    # (b) decoded batches from the subset
+    sub = os.path.join(OUT, "acdc_subset")
+    ds = RefDataset(root_dir=sub, mode="train", subfolders=["img", "gt"], transform=segment_transform((256, 256)), augment="PILaugment",
+                    pin_memory=False, quite=True)
+    dv = RefDataset(root_dir=sub, mode="val", subfolders=["img", "gt"], transform=segment_transform((256, 256)), augment="PILaugment",
+                    pin_memory=False, quite=True)
+    from torch.utils.data import DataLoader
+    torch.manual_seed(77)
+    dl = DataLoader(ds, batch_size=4, shuffle=True, drop_last=True, num_workers=0)
+    names, dig = [], []
+    for k, ((img, gt), meta, fn) in enumerate(dl):
+        names.append(list(fn))
+        dig.append(np.concatenate([_tensor_digest(img), _tensor_digest(gt.float())]))
+        if k == 0:
+            out["sub_first_img"], out["sub_first_gt"] = img, gt.to(torch.uint8)
+            assert img.shape == (4, 1, 256, 256) and img.dtype == torch.float32 and gt.dtype == torch.int64
+    out["sub_epoch_names"], out["sub_epoch_digest"] = np.array(names), np.stack(dig)
+    sampler = ref_helper.PatientSampler(dv, r"(patient\d+_\d+)_\d+", shuffle=False, quite=True)
+    groups = sorted(sorted(dv.filenames["img"][i].split("/")[-1] for i in b) for b in sampler)
+    out["sub_val_groups"] = np.array([",".join(g) for g in groups])
+    ext = ref_helper.extract_patients(DataLoader(ds, batch_size=2), ["2", "4"])
+    out["sub_extract_names"] = np.array([os.path.basename(f) for f in ext.dataset.filenames["img"]])
+    save("g8_data", **out)
+
+
+# ----------------------------------------------------------------------------- G9 reference co-training on real ACDC slices
+def g9_acdc(n_steps=600):
+    """The reference's CoTrainer (2 x Enet, CE + JSD, bs 4 + 4, Adam 1e-3) for `n_steps` steps of `_train_loop` on the vendored
+    ACDC subset -- labeled: patients 1-2 for both models (Lab_Partitions overlap 1), unlabeled: patients 3-5 -- followed by
+    `_eval_loop` on the two validation patients.  Recorded: the slice names of every batch (data order), the supervised losses,
+    the validation 2-D / 3-D Dice.  This is the reference side of BASELINE.json's "DSC within 0.2 of the reference on ACDC at
+    equal steps"; tests/test_acdc_dsc_gpu.py runs the HIP bf16 trainer over the same batches."""
+    import generalframework.dataset.ACDC_helper as ref_helper
+    from generalframework.dataset import MedicalImageDataset as RefDataset
+    from torch.utils.data import DataLoader
+    sys.path.insert(0, REPO)
+    import dct_amd  # noqa: F401
+    from dct_amd.dataset.augment import segment_transform
+    sub = os.path.join(OUT, "acdc_subset")
+    C, seeds = 4, (31, 32)
+    kw = dict(root_dir=sub, subfolders=["img", "gt"], transform=segment_transform((256, 256)), augment="PILaugment",
+              pin_memory=False, quite=True)
+    train_set, val_set = RefDataset(mode="train", **kw), RefDataset(mode="val", **kw)
+    base = DataLoader(train_set, batch_size=4, shuffle=True, drop_last=True, num_workers=0)
+    labs = [ref_helper.extract_patients(base, ["1", "2"]) for _ in range(2)]
+    unl = ref_helper.extract_patients(DataLoader(RefDataset(mode="train", **kw), batch_size=4, shuffle=True, drop_last=True, num_workers=0),
+                                      ["3", "4", "5"])
+    val = DataLoader(val_set, batch_sampler=ref_helper.PatientSampler(val_set, r"(patient\d+_\d+)_\d+", shuffle=False, quite=True))
+    segs = []
+    for s in seeds:
+        seg = Segmentator({"name": "enet", "num_classes": C}, {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                          {"name": "StepLR", "step_size": 90, "gamma": 0.1})
+        seg.torchnet.load_state_dict(seeded_state("enet", C, s))
+        segs.append(seg)
+    sup_log, names_log = [], []
+    crit = {"sup": _Recorder(get_loss_fn("cross_entropy"), sup_log), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    tr = CoTrainer(segmentators=segs, labeled_dataloaders=labs, unlabeled_dataloader=unl, val_dataloader=val,
+                   criterions=crit, max_epoch=1, save_dir=tmp, device="cpu", axises=[1, 2, 3],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False)
+
+    def short_range(*a):
+        return range(n_steps) if a == (300,) else range(*a)
+    ref_trainer_mod.range = short_range
+    orig_iter = ref_trainer_mod.iterator_
+
+    class rec_iter(orig_iter):
+        def __next__(self):
+            b = super().__next__()
+            if isinstance(b, (list, tuple)) and len(b) == 3:     # (the progress-report toggle is an iterator_ over two strings)
+                names_log.append(list(b[2]))
+            return b
+    ref_trainer_mod.iterator_ = rec_iter
+    np.random.seed(1234)
+    try:
+        dice_lab, dice_unl = tr._train_loop(labs, unl, epoch=0, mode=ModelMode.TRAIN, save=False, train_jsd=True, train_adv=False)
+    finally:
+        del ref_trainer_mod.range
+        ref_trainer_mod.iterator_ = orig_iter
+    sup = torch.stack(sup_log).reshape(n_steps, 2)
+    with torch.no_grad():
+        v2, v3 = tr._eval_loop(val, epoch=0, mode=ModelMode.EVAL, save=False)
+    # the eval loop also calls the recorded criterion: keep the training part only
+    names = np.array([",".join(x) for x in names_log]).reshape(n_steps, 3)
+    save("g9_acdc", n_steps=n_steps, C=C, net_seeds=np.array(seeds), sup=sup[:n_steps], batch_names=names,
+         train_dice_lab=dice_lab, train_dice_unl=dice_unl, val_dice2d=v2, val_dice3d=v3)
+    print("reference sup first10", sup[:10].mean(0), "last20", sup[-20:].mean(0))
+    print("reference val 3-D DSC", v3[..., 0])
 
 
 # ----------------------------------------------------------------------------- G5 full steps
@@ -372,7 +595,7 @@ def g6_dice():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3bn", "g5", "g6", "g7", "g8"]
     if "g1" in which:
         g1_losses()
     if "g2" in which:
@@ -387,3 +610,11 @@ if __name__ == "__main__":
         g5_step("g5_step_unet_adv", "unet", 4, 176, 1, 2, train_adv=True)
     if "g6" in which:
         g6_dice()
+    if "g3bn" in which:
+        g3_unet_bn()
+    if "g7" in which:
+        g7_eval()
+    if "g8" in which:
+        g8_data()
+    if "g9" in which:
+        g9_acdc()
