@@ -117,6 +117,7 @@ SIGNATURES = {
     "dct_bn_fwd": (_i, [_VP, _P, _P, _f, _f, _P, _P, _i, _P, _P, _P, _P, _VP, _i, _i, _P, _sz, _P]),
     "dct_bn_bwd": (_i, [_VP, _VP, _P, _P, _P, _P, _P, _P, _i, _P, _i, _i, _VP, _i, _P, _sz, _P]),
     "dct_dice_counts": (_i, [_P, _P, _i, _i64, _i, _P, _P, _P, _P]),
+    "dct_dice_update": (_i, [_P, _P, _P, _i, _i, _i, C.c_uint32, _f, _P, _P, _P]),
     "dct_tune_set": (_i, [_i, _i]),
     "dct_prof_enable": (_i, [_i]),
     "dct_prof_read": (_i, [_P, _P, _i]),

@@ -584,6 +584,50 @@ extern "C" int dct_dice_counts(const float* logits, const int64_t* gt, int B, in
   return dct_check_launch();
 }
 
+// Dice of one DiceMeter.add from the counts, plus the meter's running moments, in ONE launch (one block): rows = B (2-D, per
+// slice) or 1 (3-D, counts summed over the batch); dice[row][c] = (2 inter + smooth) / (psum + gsum + smooth) in fp32 as
+// the reference's einsum formula gives it; acc[0][j] += value, acc[1][j] += value^2 (double) for the C classes and, at
+// j = C, for the row's mean over the report axes (bit c of axes_mask).  Rows are folded in order by one thread per column.
+__global__ __launch_bounds__(256) void dice_update_kernel(const int* inter, const int* psum, const int* gsum, int B, int C_, int rows,
+                                                          unsigned axes_mask, float smooth, float* dice, double* acc) {
+  __shared__ float sd[64 * 8];
+  for (int i = threadIdx.x; i < rows * C_; i += 256) {
+    const int r = i / C_, c = i - r * C_;
+    long long a = 0, b = 0, g = 0;
+    if (rows == B) { a = inter[i]; b = psum[i]; g = gsum[i]; }
+    else for (int k = 0; k < B; ++k) { a += inter[k * C_ + c]; b += psum[k * C_ + c]; g += gsum[k * C_ + c]; }
+    const float d = (2.f * (float)a + smooth) / ((float)(b + g) + smooth);
+    dice[i] = d;
+    if (r < 64) sd[r * 8 + c] = d;
+  }
+  __syncthreads();
+  const int j = threadIdx.x;
+  if (j <= C_) {
+    double s0 = 0.0, s1 = 0.0;
+    int naxes = 0;
+    for (int c = 0; c < C_; ++c) naxes += (axes_mask >> c) & 1;
+    for (int r = 0; r < rows; ++r) {
+      float v;
+      if (j < C_) v = sd[r * 8 + j];
+      else {
+        float t = 0.f;
+        for (int c = 0; c < C_; ++c) if ((axes_mask >> c) & 1) t += sd[r * 8 + c];
+        v = t / (float)naxes;
+      }
+      s0 += (double)v; s1 += (double)v * (double)v;
+    }
+    acc[j] += s0; acc[(C_ + 1) + j] += s1;
+  }
+}
+
+extern "C" int dct_dice_update(const int32_t* inter, const int32_t* psum, const int32_t* gsum, int B, int C_, int method3d,
+                               uint32_t axes_mask, float smooth, float* dice, double* acc, dct_stream stream) {
+  if (!inter || !psum || !gsum || !dice || !acc || B < 1 || B > 64 || C_ < 1 || C_ > 8 || !(axes_mask & ((1u << C_) - 1))) return DCT_ERR_BAD_ARG;
+  DCT_LAUNCH(DCT_PROF_LOSS, dice_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, inter, psum, gsum, B, C_, method3d ? 1 : B,
+             axes_mask, smooth, dice, acc);
+  return dct_check_launch();
+}
+
 extern "C" int dct_fgsm_step(const float* x, const float* g, float eps, float* x_adv, float* noise, int64_t n,
                              dct_stream stream) {
   if (!x || !g || !x_adv || n < 1) return DCT_ERR_BAD_ARG;

@@ -776,6 +776,9 @@ extern "C" int dct_cast(const dct_view* x, const dct_view* y, int dtype_in, int 
   else if (dtype_in == DCT_BF16 && dtype_out == DCT_F32) DCT_LAUNCH(DCT_PROF_POINTWISE, (cast_kernel<bf16_t, float>), grid, blk, 0, st, to_view(x), to_view(y));
   else if (dtype_in == DCT_F32 && dtype_out == DCT_F32) DCT_LAUNCH(DCT_PROF_POINTWISE, (cast_kernel<float, float>), grid, blk, 0, st, to_view(x), to_view(y));
   else if (dtype_in == DCT_BF16 && dtype_out == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, (cast_kernel<bf16_t, bf16_t>), grid, blk, 0, st, to_view(x), to_view(y));
+  else if (dtype_in == DCT_F32 && dtype_out == DCT_F16) DCT_LAUNCH(DCT_PROF_POINTWISE, (cast_kernel<float, f16_t>), grid, blk, 0, st, to_view(x), to_view(y));
+  else if (dtype_in == DCT_F16 && dtype_out == DCT_F32) DCT_LAUNCH(DCT_PROF_POINTWISE, (cast_kernel<f16_t, float>), grid, blk, 0, st, to_view(x), to_view(y));
+  else if (dtype_in == DCT_F16 && dtype_out == DCT_F16) DCT_LAUNCH(DCT_PROF_POINTWISE, (cast_kernel<f16_t, f16_t>), grid, blk, 0, st, to_view(x), to_view(y));
   else return DCT_ERR_BAD_ARG;
   return dct_check_launch();
 }

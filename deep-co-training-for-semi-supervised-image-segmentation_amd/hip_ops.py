@@ -318,6 +318,16 @@ def dice_counts(logits_bpc, gt_bp, B, C_):
     return cnt[0], cnt[1], cnt[2]
 
 
+def dice_update(inter, psum, gsum, method3d, axes_mask, smooth, acc):
+    """Dice rows of one DiceMeter.add + the meter's running moments (acc: float64 [2, C+1]) in one launch."""
+    B, C_ = inter.shape
+    rows = 1 if method3d else B
+    dice = torch.empty(rows, C_, dtype=torch.float32, device=inter.device)
+    call("dct_dice_update", ptr(inter), ptr(psum), ptr(gsum), B, C_, int(method3d), int(axes_mask), float(smooth), ptr(dice), ptr(acc),
+         stream())
+    return dice
+
+
 # ------------------------------------------------------------------------------ Enet family
 class Tf(object):
     """Producer transform act(scale*x + shift) applied by consumers on load (include/dct.h dct_enet_tf)."""

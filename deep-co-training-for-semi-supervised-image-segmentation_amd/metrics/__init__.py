@@ -41,16 +41,22 @@ class DiceMeter(object):
         if g.dtype != torch.int64 or not g.is_contiguous():
             g = g.to(torch.int64).contiguous()
         inter, ps, gs = K.dice_counts(lp, g, B, C)
-        if self.method == '3d':
-            inter, ps, gs = inter.sum(0, keepdim=True), ps.sum(0, keepdim=True), gs.sum(0, keepdim=True)
-        dice = (2 * inter.float() + smooth) / ((ps + gs).float() + smooth)
+        # the Dice rows and the running moments behind value() in one more launch: three launches per add, nothing that scales
+        # with the history (the reference re-concatenates the whole log 4 S times per reported step, :251-264)
+        if self._acc is None or self._acc.device != inter.device:
+            self._acc = torch.zeros(2, C + 1, dtype=torch.float64, device=inter.device)
+        axes = range(C) if self.report_axis == 'all' else self.report_axis
+        mask = sum(1 << int(a) for a in axes)
+        if B <= 64:
+            dice = K.dice_update(inter, ps, gs, self.method == '3d', mask, smooth, self._acc)
+        else:       # patient batches of more than 64 slices: the same arithmetic in torch ops
+            if self.method == '3d':
+                inter, ps, gs = inter.sum(0, keepdim=True), ps.sum(0, keepdim=True), gs.sum(0, keepdim=True)
+            dice = (2 * inter.float() + smooth) / ((ps + gs).float() + smooth)
+            rep = dice[:, list(axes)].mean(1, keepdim=True)
+            row = torch.cat((dice, rep), dim=1).double()
+            self._acc += torch.stack((row.sum(0), (row * row).sum(0)))
         self.diceLog.append(dice)
-        # running moments, so that value() (called 4 S times per reported step, cotraining_totalloss.py:251-264) costs O(1)
-        # instead of a torch.cat over the whole history
-        rep = dice.mean(1, keepdim=True) if self.report_axis == 'all' else dice[:, self.report_axis].mean(1, keepdim=True)
-        row = torch.cat((dice, rep), dim=1).double()
-        upd = torch.stack((row.sum(0), (row * row).sum(0)))
-        self._acc = upd if self._acc is None else self._acc + upd
         self._n += dice.shape[0]
 
     @property

@@ -122,6 +122,9 @@ class CoTrainer(Trainer):
         self.batch_lab_unlab = True         # one B_l+B_u pass per batch-independent net (see _run_step_fused)
         self.model_streams = True           # one HIP stream per model in the fused step (see _streams)
         self._stream_pool = None
+        self.pass_streams = True            # nets that support it (Enet): the backward passes of one model run on separate streams
+        self._pass_pool = None
+        self._pass_bufs = {}
         self.grad_overwrite = True          # nets that support it: first backward pass of a step writes the gradients (no zero fill)
         self._overwrite_models = set()
         self.use_hip_graph = True           # replay the fused step from a captured HIP graph (trainer/step_graph.py)
@@ -248,6 +251,14 @@ class CoTrainer(Trainer):
         if self._stream_pool is None or len(self._stream_pool) != len(self.segmentators):
             self._stream_pool = [torch.cuda.Stream(device=self.device) for _ in self.segmentators]
         return self._stream_pool
+
+    def _pass_streams_for(self, i, n):
+        if self._pass_pool is None:
+            self._pass_pool = {}
+        pool = self._pass_pool.setdefault(i, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=self.device))
+        return pool[:n]
 
     def _finish_step(self, backward_calls, streams=None):
         """zero_grad (after the forwards, :245) -> backward (:246-247) -> [gradient all-reduce] -> step (:248).
@@ -423,8 +434,38 @@ class CoTrainer(Trainer):
                     da = K.kl_logits_bwd(lp_adv, lp_real, C, torch.empty_like(lp_adv), **g_adv)
                     passes[a].append((tape, da))
 
+        def pass_parallel(i):
+            """Backward passes 1.. of model i on their own streams, each into its own flat gradient buffer (Enet: 1.45 MB),
+            concurrently with pass 0 on the model's stream; the buffers are then added in pass order (deterministic)."""
+            net, fp = nets[i], nets[i].flat_params
+            fp.ensure_grads()
+            cur = torch.cuda.current_stream(self.device)
+            extra = self._pass_streams_for(i, len(passes[i]) - 1)
+            bufs = []
+            for k, (tape, dl) in enumerate(passes[i][1:]):
+                key = (i, k, fp.total, str(self.device))
+                buf = self._pass_bufs.get(key)
+                if buf is None or torch.cuda.is_current_stream_capturing():
+                    buf = torch.empty(fp.total, dtype=torch.float32, device=self.device)
+                    if not torch.cuda.is_current_stream_capturing():
+                        self._pass_bufs[key] = buf
+                extra[k].wait_stream(cur)
+                with torch.cuda.stream(extra[k]):
+                    buf.zero_()
+                    net.plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=buf)
+                bufs.append(buf)
+            tape, dl = passes[i][0]
+            net.plan_backward(tape, dl, need_dx=False, need_dw=True)
+            for k, buf in enumerate(bufs):
+                cur.wait_stream(extra[k])
+                fp.gflat.add_(buf)
+            passes[i].clear()
+
         def backward_of(i):
             def run():
+                if self.pass_streams and self.device.type == 'cuda' and len(passes[i]) > 1 and \
+                        getattr(nets[i], "supports_pass_streams", False):
+                    return pass_parallel(i)
                 # data parallelism: during the LAST backward pass of a model its gradient buckets go out as they
                 # complete (earlier passes only accumulate)
                 ranges = nets[i].grad_bucket_ranges() if (self.grad_sync is not None and hasattr(nets[i], "grad_bucket_ranges")) else None

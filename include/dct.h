@@ -336,6 +336,12 @@ int dct_bn_bwd(const dct_view* raw, const dct_view* g, const float* scale, const
 int dct_dice_counts(const float* logits, const int64_t* gt, int B, int64_t pixels_per_image, int C,
                     int32_t* inter, int32_t* psum, int32_t* gsum, dct_stream stream);
 
+/* Dice rows of one DiceMeter.add from those counts (2-D: one row per slice; 3-D: one row for the batch) and the meter's
+ * running sums in the same launch: dice[rows][C] fp32; acc (double [2][C+1], caller-zeroed once) += value, value^2 per class and,
+ * in column C, for the row mean over the report axes (bit c of axes_mask).  B <= 64, C <= 8. */
+int dct_dice_update(const int32_t* inter, const int32_t* psum, const int32_t* gsum, int B, int C, int method3d,
+                    uint32_t axes_mask, float smooth, float* dice, double* acc, dct_stream stream);
+
 /* ---- per-kernel-class timing (bench.py roofline leg) --------------------------------------
  * When enabled every launch made through this library is bracketed by hipEvents on its stream;
  * dct_prof_read synchronises and returns accumulated milliseconds and launch counts per class. */

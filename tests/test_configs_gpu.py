@@ -4,7 +4,7 @@
         64 x 64 (valid convolutions: H >= 176), so cfg1's "4x1x64x64, 2-class" plumbing case runs ``enet``
         at 64 x 64 and ``unet`` at its 176 x 176 minimum -- never a padded UNet.
 * cfg2 / cfg3  exactly what ``bench.py`` times: ``bench.make_trainer`` (2 x UNet, 8 + 8 images of 256 x 256, C = 4, dropout
-        on, one HIP stream per model, labeled + unlabeled batch in one pass, HIP-graph replay after two eager steps), four
+        on, one HIP stream per model, labeled + unlabeled batch in one pass, HIP-graph replay after three eager steps), five
         steps against ``oracle.cotrain_step`` on the same weights, batches and (replayed) dropout masks: losses of every
         step, logits of step 0, per-tensor weight displacement after the last step; bf16 (the benchmarked mode) and fp32.
 """
@@ -104,7 +104,7 @@ def test_bench_path_full_size_vs_oracle(config, dtype):
     import bench
     cfg = bench.CONFIGS[config]
     tdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
-    n = 4
+    n = 5
     tr, lab, unl = bench.make_trainer(cfg, tdtype, torch.device(DEV), 0, 1, None, n_batches=n)
     assert tr._fused_ok() and tr.use_hip_graph and tr.model_streams and tr.batch_lab_unlab
     S, B_l, adv = cfg["S"], cfg["B_l"], cfg["train_adv"]
@@ -154,8 +154,9 @@ def test_bench_path_full_size_vs_oracle(config, dtype):
                 err = ((a - b).abs().max() / b.abs().max()).item()
                 _say("  logits model", m, "max-rel err", err)
                 assert err < (4e-2 if bf else 1e-5)
-    if tr._step_graphs is not None:
-        assert tr._step_graphs.captures == 1 and tr._step_graphs.replays == n - 2
+    # (the first step allocates gradient buffers and Adam moments, which changes the step signature: two eager steps of the
+    # steady signature follow, then the capture -- bench.py's set-up phase covers the same steps)
+    assert tr._step_graphs is not None and tr._step_graphs.captures == 1 and tr._step_graphs.replays == n - 3
     # weights after n steps: displacement from the initial weights, per tensor, HIP vs oracle
     for m, net in enumerate(nets):
         sd = net.state_dict()
