@@ -232,10 +232,12 @@ __global__ __launch_bounds__(256) void enet_reduce_kernel(RedP p, double* partia
 // Fixed-order fold of the per-block partials: thread (c, part) sums blocks part, part+NP, ... and the NP
 // partial sums of a channel are then added in ascending `part` -- deterministic, and 256/CP-way parallel
 // instead of one thread walking all blocks.  Result valid for threads with part == 0.
+constexpr int FT = 1024;      // threads of the one-block finalize kernels: with 256 a 128-channel fold walked 128 partial rows per
+                              // thread (11 us of dependent loads, 16 % of a cfg4 step's kernel time); 1024 threads walk 32
 __device__ __forceinline__ void fold_partials(const double* partial, int blocks, int C, double* red, double s[3]) {
   int CP = 1;
   while (CP < C) CP <<= 1;
-  const int NP = 256 / CP;
+  const int NP = FT / CP;
   const int c = threadIdx.x % CP, part = threadIdx.x / CP;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   if (c < C)
@@ -251,11 +253,11 @@ __device__ __forceinline__ void fold_partials(const double* partial, int blocks,
 }
 
 // BatchNorm forward finalize (one block of 256): statistics -> scale/shift (+ running statistics)
-__global__ __launch_bounds__(256) void enet_bn_finalize_kernel(const double* partial, int blocks, int C, double count,
+__global__ __launch_bounds__(FT) void enet_bn_finalize_kernel(const double* partial, int blocks, int C, double count,
                                         const float* gamma, const float* beta, float eps, float momentum,
                                         float* running_mean, float* running_var, int training,
                                         float* scale, float* shift, float* save_mean, float* save_invstd) {
-  __shared__ double red[256 * 3];
+  __shared__ double red[FT * 3];
   double s[3];
   fold_partials(partial, training ? blocks : 0, C, red, s);
   const int c = threadIdx.x;
@@ -284,9 +286,9 @@ __global__ __launch_bounds__(256) void enet_bn_finalize_kernel(const double* par
 }
 
 // BatchNorm backward finalize: dgamma/dbeta/dslope (+=) and the two per-channel means the apply pass needs
-__global__ __launch_bounds__(256) void enet_bn_bwd_finalize_kernel(const double* partial, int blocks, int C, double count, int training,
+__global__ __launch_bounds__(FT) void enet_bn_bwd_finalize_kernel(const double* partial, int blocks, int C, double count, int training,
                                             float* dgamma, float* dbeta, float* dslope, float* c1, float* c2) {
-  __shared__ double red[256 * 3];
+  __shared__ double red[FT * 3];
   double s[3];
   fold_partials(partial, blocks, C, red, s);
   const int c = threadIdx.x;
@@ -302,8 +304,8 @@ __global__ __launch_bounds__(256) void enet_bn_bwd_finalize_kernel(const double*
 }
 
 // plain per-channel sum finalize (bias gradient): out[c] += sum_b partial[b][c][0]
-__global__ __launch_bounds__(256) void enet_sum_finalize_kernel(const double* partial, int blocks, int C, float* out) {
-  __shared__ double red[256 * 3];
+__global__ __launch_bounds__(FT) void enet_sum_finalize_kernel(const double* partial, int blocks, int C, float* out) {
+  __shared__ double red[FT * 3];
   double s[3];
   fold_partials(partial, blocks, C, red, s);
   const int c = threadIdx.x;
@@ -669,7 +671,7 @@ extern "C" int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, co
     if (rc != DCT_OK) return rc;
   }
   const double count = (double)raw->n * raw->h * raw->w;
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, blocks, raw->c, count,
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_finalize_kernel, dim3(1), dim3(FT), 0, st, (const double*)workspace, blocks, raw->c, count,
              gamma, beta, eps, momentum, running_mean, running_var, training ? 1 : 0, scale, shift, save_mean, save_invstd);
   return dct_check_launch();
 }
@@ -693,7 +695,7 @@ extern "C" int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct
   const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
   if (rc != DCT_OK) return rc;
   const double count = (double)raw->n * raw->h * raw->w;
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, blocks, raw->c, count,
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_finalize_kernel, dim3(1), dim3(FT), 0, st, (const double*)workspace, blocks, raw->c, count,
              training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, c1c2 + raw->c);
   const long long total = (long long)raw->n * raw->h * raw->w * raw->c;
   const View vo = to_view(draw);
@@ -712,7 +714,7 @@ extern "C" int dct_enet_channel_sum(const dct_view* x, float* out, int f32_mask,
   int blocks = 0;
   const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
   if (rc != DCT_OK) return rc;
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, blocks, x->c, out);
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_sum_finalize_kernel, dim3(1), dim3(FT), 0, st, (const double*)workspace, blocks, x->c, out);
   return dct_check_launch();
 }
 

@@ -360,14 +360,23 @@ class CoTrainer(Trainer):
         def on(i):
             return torch.cuda.stream(streams[i]) if streams is not None else contextlib.nullcontext()
 
+        # backward-pass streams (two per model that supports them): like the model streams they enter a capture only through a
+        # wait on the origin stream -- a fork nested inside a forked stream crashes hipStreamEndCapture on ROCm 7.2 -- so they
+        # are forked and joined together with the model streams and idle until the backward passes are queued
+        side = []
+        if streams is not None and self.pass_streams:
+            for i in range(S):
+                if getattr(nets[i], "supports_pass_streams", False):
+                    side += self._pass_streams_for(i, 2)
+
         def fork():
             if streams is not None:
-                for st in streams:
+                for st in list(streams) + side:
                     st.wait_stream(main)
 
         def join():
             if streams is not None:
-                for st in streams:
+                for st in list(streams) + side:
                     main.wait_stream(st)
         fork()
         full = []                                                              # fuse: (tape, logits, dlogits) of the joint pass
@@ -463,7 +472,7 @@ class CoTrainer(Trainer):
 
         def backward_of(i):
             def run():
-                if self.pass_streams and self.device.type == 'cuda' and len(passes[i]) > 1 and \
+                if self.pass_streams and streams is not None and 1 < len(passes[i]) <= 3 and \
                         getattr(nets[i], "supports_pass_streams", False):
                     return pass_parallel(i)
                 # data parallelism: during the LAST backward pass of a model its gradient buckets go out as they
