@@ -272,11 +272,24 @@ class CoTrainer(Trainer):
                 continue
             with on(i):
                 seg.optimizer.zero_grad()
+        self._pass_pending = {}
         for idx, call in backward_calls:
             with on(idx):
                 call()
-                if self.grad_sync is not None and idx is not None:
+                if self.grad_sync is not None and idx is not None and idx not in self._pass_pending:
                     self.grad_sync.begin(idx)
+        if self._pass_pending:
+            # some backward passes ran on their own streams into their own gradient buffers: every stream joins the origin
+            # stream (never a forked one: see _run_step_fused), the buffers are added there in pass order, and what follows
+            # (gradient exchange, optimizers) is queued on the origin stream
+            self._pass_join()
+            for idx, (flat, bufs) in sorted(self._pass_pending.items()):
+                for buf in bufs:
+                    flat.gflat.add_(buf)
+                if self.grad_sync is not None:
+                    self.grad_sync.begin(idx)
+            streams = None
+            self._pass_pending = {}
         if self._defer_optimizer:
             return
         if self.grad_sync is not None and any(idx is None for idx, _ in backward_calls):
@@ -379,6 +392,8 @@ class CoTrainer(Trainer):
                 for st in list(streams) + side:
                     main.wait_stream(st)
         fork()
+        joined_after_forwards = False       # becomes True at the JSD join: labeled / unlabeled pass inputs are then final on main
+        self._pass_join = join
         full = []                                                              # fuse: (tape, logits, dlogits) of the joint pass
         for i in range(S):                                                     # :208-218
             with on(i):
@@ -412,6 +427,7 @@ class CoTrainer(Trainer):
                         lps.append(lp_u)
                         utapes.append(tape)
                         dl_outs.append(torch.empty_like(lp_u))
+            joined_after_forwards = True
             join()                                  # the JSD couples all S models: main stream, then fork again
             jsd = K.jsd_logits_fwd(lps, C)[0]
             unlab_probs = [_nchw(K.softmax_fwd(lp, C)) for lp in lps]
@@ -444,30 +460,32 @@ class CoTrainer(Trainer):
                     passes[a].append((tape, da))
 
         def pass_parallel(i):
-            """Backward passes 1.. of model i on their own streams, each into its own flat gradient buffer (Enet: 1.45 MB),
-            concurrently with pass 0 on the model's stream; the buffers are then added in pass order (deterministic)."""
+            """All but the last backward pass of model i on side streams, each into its own flat gradient buffer (Enet:
+            1.45 MB), concurrently with the last pass on the model's stream (the adversarial pass, when there is one: it is the
+            only one that depends on work queued on the model streams after the last fork).  The buffers are added to the
+            gradient buffer on the origin stream after the join (_finish_step), in pass order: deterministic."""
             net, fp = nets[i], nets[i].flat_params
             fp.ensure_grads()
             cur = torch.cuda.current_stream(self.device)
-            extra = self._pass_streams_for(i, len(passes[i]) - 1)
+            extra = self._pass_streams_for(i, 2)
             bufs = []
-            for k, (tape, dl) in enumerate(passes[i][1:]):
+            for k, (tape, dl) in enumerate(passes[i][:-1]):
                 key = (i, k, fp.total, str(self.device))
-                buf = self._pass_bufs.get(key)
-                if buf is None or torch.cuda.is_current_stream_capturing():
+                capturing = torch.cuda.is_current_stream_capturing()
+                buf = None if capturing else self._pass_bufs.get(key)
+                if buf is None:
                     buf = torch.empty(fp.total, dtype=torch.float32, device=self.device)
-                    if not torch.cuda.is_current_stream_capturing():
+                    if not capturing:
                         self._pass_bufs[key] = buf
-                extra[k].wait_stream(cur)
+                if not joined_after_forwards:      # the pass's inputs were produced on the model stream after the last fork
+                    extra[k].wait_stream(cur)
                 with torch.cuda.stream(extra[k]):
                     buf.zero_()
                     net.plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=buf)
                 bufs.append(buf)
-            tape, dl = passes[i][0]
+            tape, dl = passes[i][-1]
             net.plan_backward(tape, dl, need_dx=False, need_dw=True)
-            for k, buf in enumerate(bufs):
-                cur.wait_stream(extra[k])
-                fp.gflat.add_(buf)
+            self._pass_pending[i] = (fp, bufs)
             passes[i].clear()
 
         def backward_of(i):
