@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
     ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"],
                     help="N > 1: gradients travel as bf16 on the xGMI ring (half the bytes); default fp32, as the reference's sums are")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="dct_tune_set(KNOB, VALUE) before the run (A/B)")
+    ap.add_argument("--attr", action="append", default=[], metavar="NAME=0|1", help="boolean CoTrainer switch (pass_streams, ...) (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight gradients on a second stream per model (eager only)")
@@ -214,7 +216,14 @@ def main():
         from dct_amd.ddp import FlatGradSync
         return FlatGradSync(segs, compress=None if args.grad_compress == "none" else args.grad_compress, measure=True)
 
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.check(_lib.load().dct_tune_set(int(k), int(v)), f"dct_tune_set({kv})")
     tr, lab, unl = make_trainer(cfg, dtype, device, rank, world, sync_factory)
+    for kv in args.attr:
+        k, v = kv.split("=")
+        assert hasattr(tr, k), k
+        setattr(tr, k, bool(int(v)))
     S = cfg["S"]
     nb = len(unl)
     tr.model_streams = not args.single_stream

@@ -17,6 +17,8 @@
 #include "dct_common.h"
 
 int g_enet_reduce_ppt = 8;           // pixels per thread of a per-channel reduction (sets the number of partial rows)
+int g_enet_fold_threads = 1024;      // threads of the one-block finalize kernels (DCT_TUNE_ENET_FOLD_THREADS: 256 | 512 | 1024)
+int g_enet_reduce_vec = 1;           // 8-channel vector loads in the per-channel reductions (0: scalar kernel everywhere)
 int g_enet_wgrad_slices = 1;          // 0: one pixel slice per round whatever the tile count
 int g_enet_wgrad_max_blocks = 1024;   // dct_tune_set(DCT_TUNE_ENET_WGRAD_BLOCKS, n); <= WG_MAX_BLOCKS
 
@@ -229,6 +231,92 @@ __global__ __launch_bounds__(256) void enet_reduce_kernel(RedP p, double* partia
   }
 }
 
+// Same partial sums for channel counts that are multiples of 8 (Enet's 16 / 32 / 64 / 128-wide tensors: most of them): a thread
+// owns 8 consecutive channels and loads them as one or two 16-byte vectors per pixel (the scalar kernel above issues one 2- or
+// 4-byte load per element and a 64-bit-capable index decode per pixel); fp32 running sums over runs of 32 pixels are flushed
+// into doubles, rows of threads are folded through LDS in a fixed order.  Same partial layout, same finalize kernels.
+template <typename T> __device__ __forceinline__ void ld8(const View& v, long long off, int f32, float o[8]) {
+  if (f32 || sizeof(T) == 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(v.ptr) + off);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(v.ptr) + off + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+  } else {
+    typedef typename vec8_of<T>::type V8;
+    const V8 a = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(v.ptr) + off);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)a[i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void enet_reduce_vec_kernel(RedP p, double* partial) {
+  extern __shared__ double redv[];                // [rows][C][3]
+  const int C = p.x.c, CV = C / 8;                // CV in {2, 4, 8, 16}
+  const int rows = 256 / CV;
+  const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
+  const long long P = (long long)p.x.n * p.x.h * p.x.w;
+  const long long pbeg = (long long)blockIdx.x * p.ppb, pend = min(P, pbeg + p.ppb);
+  float sc[8], sh[8], sl[8], mu[8], is[8];
+  if (p.kind == 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = cv * 8 + i;
+      sc[i] = p.scale[c]; sh[i] = p.shift[c]; mu[i] = p.mean[c]; is[i] = p.invstd[c]; sl[i] = p.act == 2 ? p.slope[c] : 0.f;
+    }
+  }
+  float a0[8], a1[8], a2[8];
+  double d0[8], d1[8], d2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a0[i] = a1[i] = a2[i] = 0.f; d0[i] = d1[i] = d2[i] = 0.0; }
+  int run = 0;
+  for (long long pix = pbeg + row; pix < pend; pix += rows) {
+    int n, y, x;
+    pix3(pix, p.x.h, p.x.w, n, y, x);
+    float v[8];
+    ld8<T>(p.x, voff(p.x, n, y, x) + cv * 8, p.fm & 1, v);
+    if (p.kind == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { a0[i] += v[i]; a1[i] = fmaf(v[i], v[i], a1[i]); }
+    } else {
+      float g[8];
+      ld8<T>(p.g, voff(p.g, n, y, x) + cv * 8, p.fm & 2, g);
+      if (p.has_mask) {
+        float m[8];
+        ld8<T>(p.m, voff(p.m, n, y, x) + cv * 8, p.fm & 4, m);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (!(m[i] > 0.f)) g[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float z = fmaf(sc[i], v[i], sh[i]);
+        float dz = g[i];
+        if (p.act == 2) { if (!(z > 0.f)) { dz = g[i] * sl[i]; a2[i] = fmaf(g[i], z, a2[i]); } }
+        else if (p.act == 3) { if (!(z > 0.f)) dz = 0.f; }
+        const float xh = (v[i] - mu[i]) * is[i];
+        a0[i] += dz; a1[i] = fmaf(dz, xh, a1[i]);
+      }
+    }
+    if (++run == 32) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { d0[i] += (double)a0[i]; d1[i] += (double)a1[i]; d2[i] += (double)a2[i]; a0[i] = a1[i] = a2[i] = 0.f; }
+      run = 0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    double* o = redv + ((long long)row * C + cv * 8 + i) * 3;
+    o[0] = d0[i] + (double)a0[i]; o[1] = d1[i] + (double)a1[i]; o[2] = d2[i] + (double)a2[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) { const double* q = redv + ((long long)r * C + c) * 3; s0 += q[0]; s1 += q[1]; s2 += q[2]; }
+    double* o = partial + ((long long)blockIdx.x * C + c) * 3;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+  }
+}
+
 // Fixed-order fold of the per-block partials: thread (c, part) sums blocks part, part+NP, ... and the NP
 // partial sums of a channel are then added in ascending `part` -- deterministic, and 256/CP-way parallel
 // instead of one thread walking all blocks.  Result valid for threads with part == 0.
@@ -237,7 +325,7 @@ constexpr int FT = 1024;      // threads of the one-block finalize kernels: with
 __device__ __forceinline__ void fold_partials(const double* partial, int blocks, int C, double* red, double s[3]) {
   int CP = 1;
   while (CP < C) CP <<= 1;
-  const int NP = FT / CP;
+  const int NP = (int)blockDim.x / CP;        // blockDim.x = g_enet_fold_threads (256 ... FT)
   const int c = threadIdx.x % CP, part = threadIdx.x / CP;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   if (c < C)
@@ -650,7 +738,20 @@ static int enet_reduce_launch(const RedP& p0, int dtype, void* workspace, size_t
   const int blocks = red_plan(P, p.x.c, ppb);
   if (!workspace || workspace_bytes < (size_t)blocks * p.x.c * 3 * sizeof(double)) return DCT_ERR_WORKSPACE;
   p.ppb = ppb;
-  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_reduce_kernel<T>, dim3(blocks), dim3(256), 0, st, p, (double*)workspace));
+  // 8-channel vector path: every view it reads has 8-aligned strides and a 16-byte (T) / 32-byte (fp32) aligned base
+  auto v8 = [&](const View& v, int f32) {
+    const int esz = (f32 || dtype == DCT_F32) ? 4 : 2;
+    return v.c % 8 == 0 && v.sw % 8 == 0 && v.sh % 8 == 0 && v.sn % 8 == 0 && ((uintptr_t)v.ptr % (8 * esz)) == 0;
+  };
+  const int C = p.x.c;
+  bool vec = g_enet_reduce_vec && C >= 16 && C <= 128 && (C & (C - 1)) == 0 && v8(p.x, p.fm & 1);
+  if (vec && p.kind == 1) vec = v8(p.g, p.fm & 2) && (!p.has_mask || v8(p.m, p.fm & 4));
+  if (vec) {
+    const size_t lds = (size_t)(256 / (C / 8)) * C * 3 * sizeof(double);      // 48 KiB
+    ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_reduce_vec_kernel<T>, dim3(blocks), dim3(256), lds, st, p, (double*)workspace));
+  } else {
+    ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_reduce_kernel<T>, dim3(blocks), dim3(256), 0, st, p, (double*)workspace));
+  }
   blocks_out = blocks;
   return DCT_OK;
 }
@@ -671,7 +772,7 @@ extern "C" int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, co
     if (rc != DCT_OK) return rc;
   }
   const double count = (double)raw->n * raw->h * raw->w;
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_finalize_kernel, dim3(1), dim3(FT), 0, st, (const double*)workspace, blocks, raw->c, count,
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_finalize_kernel, dim3(1), dim3(g_enet_fold_threads), 0, st, (const double*)workspace, blocks, raw->c, count,
              gamma, beta, eps, momentum, running_mean, running_var, training ? 1 : 0, scale, shift, save_mean, save_invstd);
   return dct_check_launch();
 }
@@ -695,7 +796,7 @@ extern "C" int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct
   const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
   if (rc != DCT_OK) return rc;
   const double count = (double)raw->n * raw->h * raw->w;
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_finalize_kernel, dim3(1), dim3(FT), 0, st, (const double*)workspace, blocks, raw->c, count,
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_finalize_kernel, dim3(1), dim3(g_enet_fold_threads), 0, st, (const double*)workspace, blocks, raw->c, count,
              training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, c1c2 + raw->c);
   const long long total = (long long)raw->n * raw->h * raw->w * raw->c;
   const View vo = to_view(draw);
@@ -714,7 +815,7 @@ extern "C" int dct_enet_channel_sum(const dct_view* x, float* out, int f32_mask,
   int blocks = 0;
   const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
   if (rc != DCT_OK) return rc;
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_sum_finalize_kernel, dim3(1), dim3(FT), 0, st, (const double*)workspace, blocks, x->c, out);
+  DCT_LAUNCH(DCT_PROF_OTHER, enet_sum_finalize_kernel, dim3(1), dim3(g_enet_fold_threads), 0, st, (const double*)workspace, blocks, x->c, out);
   return dct_check_launch();
 }
 

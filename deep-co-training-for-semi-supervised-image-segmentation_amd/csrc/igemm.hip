@@ -1564,6 +1564,8 @@ extern "C" int dct_debug_stamps(unsigned long long* out16, int reset) {
 int dct_tune_set_wgrad(int knob, int value);  // wgrad.hip
 extern int g_enet_wgrad_max_blocks;           // enet.hip
 extern int g_enet_reduce_ppt;                 // enet.hip
+extern int g_enet_reduce_vec;                 // enet.hip
+extern int g_enet_fold_threads;               // enet.hip
 
 extern "C" int dct_tune_set(int knob, int value) {
   switch (knob) {
@@ -1579,6 +1581,8 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_HALO_COVER: g_tune_igemm_halo_cover = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT_TARGET: if (value < 64) return DCT_ERR_BAD_ARG; g_tune_igemm_split_target = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_PPT: if (value < 1 || value > 4096) return DCT_ERR_BAD_ARG; g_enet_reduce_ppt = value; return DCT_OK;
+    case DCT_TUNE_ENET_REDUCE_VEC: g_enet_reduce_vec = value ? 1 : 0; return DCT_OK;
+    case DCT_TUNE_ENET_FOLD_THREADS: if (value != 256 && value != 512 && value != 1024) return DCT_ERR_BAD_ARG; g_enet_fold_threads = value; return DCT_OK;
     case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }

@@ -252,6 +252,10 @@ class CoTrainer(Trainer):
             self._stream_pool = [torch.cuda.Stream(device=self.device) for _ in self.segmentators]
         return self._stream_pool
 
+    def _pass_parallel_ok(self, net, model_passes, streams) -> bool:
+        return bool(self.pass_streams and streams is not None and 1 < len(model_passes) <= 3 and
+                    getattr(net, "supports_pass_streams", False))
+
     def _pass_streams_for(self, i, n):
         if self._pass_pool is None:
             self._pass_pool = {}
@@ -284,7 +288,8 @@ class CoTrainer(Trainer):
             # (gradient exchange, optimizers) is queued on the origin stream
             self._pass_join()
             for idx, (flat, bufs) in sorted(self._pass_pending.items()):
-                for buf in bufs:
+                torch.add(bufs[0], bufs[1], out=flat.gflat)
+                for buf in bufs[2:]:
                     flat.gflat.add_(buf)
                 if self.grad_sync is not None:
                     self.grad_sync.begin(idx)
@@ -460,38 +465,40 @@ class CoTrainer(Trainer):
                     passes[a].append((tape, da))
 
         def pass_parallel(i):
-            """All but the last backward pass of model i on side streams, each into its own flat gradient buffer (Enet:
-            1.45 MB), concurrently with the last pass on the model's stream (the adversarial pass, when there is one: it is the
-            only one that depends on work queued on the model streams after the last fork).  The buffers are added to the
-            gradient buffer on the origin stream after the join (_finish_step), in pass order: deterministic."""
+            """The backward passes of model i on separate streams, each into its own flat gradient buffer (Enet: 1.45 MB): all
+            but the last on side streams, the last (the adversarial pass when there is one -- the only pass whose inputs are
+            queued on the model streams after the last fork) on the model's stream.  After the join the buffers are summed into
+            the gradient buffer on the origin stream in pass order (_finish_step): ((lab + unl) + adv), bit for bit what the
+            in-place accumulation of sequential passes produces."""
             net, fp = nets[i], nets[i].flat_params
-            fp.ensure_grads()
             cur = torch.cuda.current_stream(self.device)
             extra = self._pass_streams_for(i, 2)
+            capturing = torch.cuda.is_current_stream_capturing()
             bufs = []
-            for k, (tape, dl) in enumerate(passes[i][:-1]):
+            last = len(passes[i]) - 1
+            for k, (tape, dl) in enumerate(passes[i]):
                 key = (i, k, fp.total, str(self.device))
-                capturing = torch.cuda.is_current_stream_capturing()
                 buf = None if capturing else self._pass_bufs.get(key)
                 if buf is None:
                     buf = torch.empty(fp.total, dtype=torch.float32, device=self.device)
                     if not capturing:
                         self._pass_bufs[key] = buf
+                bufs.append(buf)
+                if k == last:
+                    buf.zero_()
+                    net.plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=buf)
+                    break
                 if not joined_after_forwards:      # the pass's inputs were produced on the model stream after the last fork
                     extra[k].wait_stream(cur)
                 with torch.cuda.stream(extra[k]):
                     buf.zero_()
                     net.plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=buf)
-                bufs.append(buf)
-            tape, dl = passes[i][-1]
-            net.plan_backward(tape, dl, need_dx=False, need_dw=True)
             self._pass_pending[i] = (fp, bufs)
             passes[i].clear()
 
         def backward_of(i):
             def run():
-                if self.pass_streams and streams is not None and 1 < len(passes[i]) <= 3 and \
-                        getattr(nets[i], "supports_pass_streams", False):
+                if self._pass_parallel_ok(nets[i], passes[i], streams) and nets[i].flat_params.grads_attached():
                     return pass_parallel(i)
                 # data parallelism: during the LAST backward pass of a model its gradient buckets go out as they
                 # complete (earlier passes only accumulate)
@@ -513,6 +520,9 @@ class CoTrainer(Trainer):
         # the first pass overwrites instead of zero_grad + accumulate (the reference's zero_grad at :245 has the same effect)
         self._overwrite_models = {i for i in range(S) if self.grad_overwrite and passes[i] and
                                   getattr(nets[i], "supports_grad_overwrite", False) and nets[i].flat_params.grads_attached()}
+        # (pass-parallel models write the whole gradient buffer as the sum of their pass buffers: no zero fill either)
+        self._overwrite_models |= {i for i in range(S) if self._pass_parallel_ok(nets[i], passes[i], streams) and
+                                   nets[i].flat_params.grads_attached()}
         try:
             self._finish_step([(i, backward_of(i)) for i in range(S)], streams)
         finally:

@@ -179,8 +179,9 @@ def test_bench_path_full_size_vs_oracle(config, dtype):
         # fp32 (measured): cos >= 0.9995 on every tensor; relative weight error <= 6e-3 on the weight tensors and 2.2e-2 on the
         # centre biases, whose gradients (behind dropout and mostly-dead ReLUs) are tiny: Adam turns their last bits into
         # +-lr steps (chaotic parity points)
-        assert worst_cos > (0.5 if bf else 0.995)
-        assert worst_rel < (0.2 if bf else 5e-2)
+        # bf16 (measured): cos >= 0.989 on every tensor of >= 4096 elements, relative weight error <= 0.17 (small bias tensors)
+        assert worst_cos > (0.95 if bf else 0.995)
+        assert worst_rel < (0.3 if bf else 5e-2)
 
 
 # ------------------------------------------------------------------------------------------------ ADVICE r1
