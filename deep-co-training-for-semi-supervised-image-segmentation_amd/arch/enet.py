@@ -24,6 +24,7 @@ No CPU path.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -188,7 +189,7 @@ class Enet(nn.Module):
         self.flat_params = FlatParams(list(self.parameters()))
         self._pidx = {id(p): i for i, p in enumerate(self.flat_params.params)}
         self._grad_target = None
-        self.skip_zero_bias_grads = True    # see _conv_wgrad
+        self.skip_zero_bias_grads = os.environ.get("DCT_ENET_BIAS_GRADS", "0") != "1"    # see _conv_wgrad
 
     supports_pass_streams = True            # plan_backward(grad_buffer=...): concurrent backward passes of one model (trainer)
 
