@@ -185,6 +185,8 @@ def main():
                     help="N > 1: gradients travel as bf16 on the xGMI ring (half the bytes); default fp32, as the reference's sums are")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="dct_tune_set(KNOB, VALUE) before the run (A/B)")
     ap.add_argument("--attr", action="append", default=[], metavar="NAME=0|1", help="boolean CoTrainer switch (pass_streams, ...) (A/B)")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="run the N > 1 code path (RCCL process group, gradient exchange, its report) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight gradients on a second stream per model (eager only)")
@@ -204,9 +206,14 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
+    ddp_on = world > 1 or args.force_ddp
     if world > 1:
         from dct_amd import ddp
         ddp.init_from_env("nccl")
+    elif args.force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
 
     from dct_amd import _lib
     cfg = CONFIGS[args.config]
@@ -219,7 +226,7 @@ def main():
     for kv in args.tune:
         k, v = kv.split("=")
         _lib.check(_lib.load().dct_tune_set(int(k), int(v)), f"dct_tune_set({kv})")
-    tr, lab, unl = make_trainer(cfg, dtype, device, rank, world, sync_factory)
+    tr, lab, unl = make_trainer(cfg, dtype, device, rank, 2 if (args.force_ddp and world == 1) else world, sync_factory)
     for kv in args.attr:
         k, v = kv.split("=")
         assert hasattr(tr, k), k
@@ -249,7 +256,7 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp_on:
         tr.grad_sync.exposed_ms(reset=True)
         tr.grad_sync.exchanged_bytes = 0
         dist.barrier()
@@ -258,12 +265,12 @@ def main():
     for i in range(args.steps):
         out = one_step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     exchange = None
-    if world > 1:
+    if ddp_on:
         ex = torch.tensor([tr.grad_sync.exposed_ms(reset=True) / args.steps], dtype=torch.float64, device=device)
         dist.all_reduce(ex, op=dist.ReduceOp.MAX)
         exchange = {"exposed_allreduce_ms_per_step_max_over_ranks": float(ex.item()),
@@ -321,9 +328,9 @@ def main():
         torch.cuda.synchronize()
         _lib.prof_enable(False)
         prof = _lib.prof_read(reset=True)
-    if world > 1:
+    if ddp_on:
         dist.barrier()
-    if world > 1:
+    if ddp_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -400,7 +407,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if ddp_on:
         dist.barrier()
         dist.destroy_process_group()
 
