@@ -397,7 +397,7 @@ def main():
             launches = prof["other"]["launches"] / args.steps
             ach = alg_bytes / (ms * 1e-3) / 1e9
             result["roofline"] = {
-                "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": pmc_traffic(args.config),
                 "kernel": "enet_* kernel family (fused conv / BN / tail / wgrad; aggregate, the net is launch bound)",
                 "algorithmic_bytes_per_step": alg_bytes, "kernel_ms_per_step": ms,
                 "avg_launch_us": 1e3 * ms / max(launches, 1), "launches_per_step": launches,
@@ -406,10 +406,20 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(result), flush=True)
     if ddp_on:
+        # RCCL writes a version banner to stdout when a rank tears down: tear down first, then rank 0 prints the JSON line,
+        # so that it stays the LAST line of the job's output; the ranks leave through os._exit (no further teardown output)
         dist.barrier()
         dist.destroy_process_group()
+        sys.stdout.flush()
+        if rank == 0:
+            time.sleep(1.0 if world > 1 else 0.0)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if ddp_on:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

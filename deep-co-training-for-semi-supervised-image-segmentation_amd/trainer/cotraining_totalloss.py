@@ -38,6 +38,21 @@ from ..utils.AEGenerator import FSGMGenerator
 from .trainer import Trainer
 
 
+# HIP streams are shared by every trainer of the process (model stream i, pass stream (i, k)): a test suite or a sweep builds
+# dozens of trainers, and stream objects that die with an old trainer would be destroyed whenever the cyclic GC runs --
+# including in the middle of a later trainer's graph capture, where hipStreamDestroy is not permitted.
+_STREAM_POOL = {}
+
+
+def _pooled_stream(device, *key):
+    k = (str(device),) + key
+    st = _STREAM_POOL.get(k)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _STREAM_POOL[k] = st
+    return st
+
+
 def fix_seed(seed):
     torch.manual_seed(seed)
     if torch.cuda.is_available():
@@ -249,7 +264,7 @@ class CoTrainer(Trainer):
         if not self.model_streams or self.device.type != 'cuda' or len(self.segmentators) < 2:
             return None
         if self._stream_pool is None or len(self._stream_pool) != len(self.segmentators):
-            self._stream_pool = [torch.cuda.Stream(device=self.device) for _ in self.segmentators]
+            self._stream_pool = [_pooled_stream(self.device, "model", i) for i in range(len(self.segmentators))]
         return self._stream_pool
 
     def _pass_parallel_ok(self, net, model_passes, streams) -> bool:
@@ -261,7 +276,7 @@ class CoTrainer(Trainer):
             self._pass_pool = {}
         pool = self._pass_pool.setdefault(i, [])
         while len(pool) < n:
-            pool.append(torch.cuda.Stream(device=self.device))
+            pool.append(_pooled_stream(self.device, "pass", i, len(pool)))
         return pool[:n]
 
     def _finish_step(self, backward_calls, streams=None):
@@ -527,6 +542,7 @@ class CoTrainer(Trainer):
             self._finish_step([(i, backward_of(i)) for i in range(S)], streams)
         finally:
             self._overwrite_models = set()
+            self._pass_join = None          # (a closure over this step's tapes and streams: not kept past the step)
         join()
         return dict(sup=sup, jsd=jsd, adv=adv, preds=preds, unlab_probs=unlab_probs)
 

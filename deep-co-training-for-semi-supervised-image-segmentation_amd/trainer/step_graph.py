@@ -145,6 +145,12 @@ class StepGraphCache(object):
         graph = torch.cuda.CUDAGraph()
         sync = tr.grad_sync
         cap.graph_opt = None
+        # no garbage collection while a capture is open: a collected object of an earlier trainer (streams, events, graphs)
+        # would be destroyed with HIP calls that are not permitted during capture
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
         try:
             if sync is None:
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
@@ -162,6 +168,8 @@ class StepGraphCache(object):
                 finally:
                     tr.grad_sync, tr._defer_optimizer = sync, False
         finally:
+            if gc_was_on:
+                gc.enable()
             for seg, s in zip(tr.segmentators, side):
                 if s is not None:
                     seg.torchnet.wgrad_side_stream = s

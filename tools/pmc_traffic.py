@@ -19,7 +19,11 @@ def per_kernel(path, counter):
                 continue
             name = r["Kernel_Name"]
             key = ("igemm3" if "igemm3" in name else "igemm2" if "igemm2_kernel" in name
-                   else "wgrad3" if "wgrad3_kernel" in name else "wgrad2" if "wgrad2_kernel" in name else None)
+                   else "wgrad3" if "wgrad3_kernel" in name else "wgrad2" if "wgrad2_kernel" in name
+                   else "enet_conv" if "enet_conv_kernel" in name else "enet_reduce" if "enet_reduce" in name
+                   else "enet_wgrad" if "enet_wgrad_kernel" in name else "enet_finalize" if "finalize_kernel" in name and "enet" in name
+                   else "enet_bn_bwd_apply" if "enet_bn_bwd_apply" in name else "enet_tail" if "enet_tail" in name
+                   else "enet_wgrad_reduce" if "enet_wgrad_reduce" in name else None)
             if key is None:
                 continue
             a = agg.setdefault(key, [0, 0.0])
@@ -30,6 +34,7 @@ def per_kernel(path, counter):
 
 def main():
     fetch, write, config = sys.argv[1], sys.argv[2], sys.argv[3]
+    launches_total = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # profiled steps incl. set-up / warm-up (per-step totals)
     fa, wa = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     out = {"unit": "bytes per launch (HBM-side, L2 fabric counters)", "config": config,
            "correction": "FETCH_SIZE x 1024 (KiB) x 2 (gfx950 wide-read undercount); WRITE_SIZE x 1024"}
@@ -39,6 +44,9 @@ def main():
         out[k] = {"launches": n, "fetch_bytes_per_launch": v * 1024 * 2 / max(n, 1),
                   "write_bytes_per_launch": vw * 1024 / max(nw, 1)}
         out[k]["bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
+    if launches_total:
+        tot = sum(v["bytes_per_launch"] * v["launches"] for k, v in out.items() if isinstance(v, dict))
+        out["all_listed_kernels"] = {"bytes_per_step": tot / launches_total, "steps_profiled": launches_total}
     print(json.dumps(out, indent=1))
 
 
