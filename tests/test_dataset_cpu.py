@@ -126,3 +126,31 @@ def test_segment_transform_resizes_like_pil():
     assert torch.equal(a[0], ref)
     same = segment_transform((256, 256))
     assert torch.equal(same["img"](img)[0], torch.from_numpy(np.array(img)).float() / 255)
+
+
+def test_gm_challenge_split_matches_reference(golden, tmp_path):
+    """get_GMC_split_dataloders (dataset/GM_helper.py:34-101; BASELINE configs[3]'s data set) on a tree of empty files named like
+    the whole GM_Challenge set: site-1 training acquisitions partitioned over the models with an overlap, sites 3 + 4 as
+    validation, the unlabeled folder, numpy RNG consumption."""
+    from dct_amd.dataset import get_GMC_split_dataloders, segment_transform
+    g = golden("g8_data")
+    for mode, names in (("train", g["gm_train_names"]), ("unlabeled", g["gm_unl_names"])):
+        for sub in ("img", "gt"):
+            d = tmp_path / mode / sub
+            d.mkdir(parents=True)
+            for n in names:
+                (d / str(n)).touch()
+    for tag in ("gma", "gmb"):
+        overlap, nm = g[f"{tag}_cfg"]
+        config = {"Dataset": {"root_dir": str(tmp_path), "subfolders": ["img", "gt"], "transform": segment_transform((200, 200)),
+                              "augment": "PILaugment", "pin_memory": False},
+                  "Unlab_Dataloader": {"pin_memory": False, "batch_size": 4, "num_workers": 0, "shuffle": True, "drop_last": True},
+                  "Lab_Partitions": {"num_models": int(nm), "partition_overlap": float(overlap)}}
+        np.random.seed(1234)
+        labs, unl, val = get_GMC_split_dataloders(config)
+        assert len(labs) == int(nm)
+        for i, l in enumerate(labs):
+            assert [os.path.basename(f) for f in l.dataset.filenames["img"]] == [str(x) for x in g[f"{tag}_lab{i}_names"]]
+        assert len(unl.dataset) == int(g[f"{tag}_unl_n"])
+        assert [os.path.basename(f) for f in val.dataset.filenames["img"]] == [str(x) for x in g[f"{tag}_val_names"]]
+        assert np.random.randint(1 << 30) == int(g[f"{tag}_rng_after"])

@@ -343,6 +343,23 @@ def g8_data():
         out[f"{tag}_unl_names"] = np.array([os.path.basename(f) for f in unl.dataset.filenames["img"]])
         out[f"{tag}_val_batches"] = np.array(sorted(len(b) for b in val.batch_sampler))
         out[f"{tag}_rng_after"] = np.random.randint(1 << 30)
+    # (a') the GM-challenge split (dataset/GM_helper.py:34-101) on the whole GM_Challenge tree: names only
+    import generalframework.dataset.GM_helper as ref_gm
+    gm_root = os.path.join(REF, "dataset", "GM_Challenge")
+    out["gm_train_names"] = np.array(sorted(os.listdir(os.path.join(gm_root, "train", "img"))))
+    out["gm_unl_names"] = np.array(sorted(os.listdir(os.path.join(gm_root, "unlabeled", "img"))))
+    for tag, overlap, nm in (("gma", 1, 2), ("gmb", 0.4, 3)):
+        config = {"Dataset": {"root_dir": gm_root, "subfolders": ["img", "gt"], "transform": segment_transform((200, 200)),
+                              "augment": "PILaugment", "pin_memory": False},
+                  "Unlab_Dataloader": {"pin_memory": False, "batch_size": 4, "num_workers": 0, "shuffle": True, "drop_last": True},
+                  "Lab_Partitions": {"num_models": nm, "partition_overlap": overlap}}
+        np.random.seed(1234)
+        labs, unl, val = ref_gm.get_GMC_split_dataloders(config)
+        for i, l in enumerate(labs):
+            out[f"{tag}_lab{i}_names"] = np.array([os.path.basename(f) for f in l.dataset.filenames["img"]])
+        out[f"{tag}_unl_n"], out[f"{tag}_val_names"] = len(unl.dataset), np.array([os.path.basename(f) for f in val.dataset.filenames["img"]])
+        out[f"{tag}_rng_after"] = np.random.randint(1 << 30)
+        out[f"{tag}_cfg"] = np.array([overlap, nm])
     # (b) decoded batches from the subset
     sub = os.path.join(OUT, "acdc_subset")
     ds = RefDataset(root_dir=sub, mode="train", subfolders=["img", "gt"], transform=segment_transform((256, 256)), augment="PILaugment",
