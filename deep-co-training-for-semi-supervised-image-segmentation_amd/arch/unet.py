@@ -411,6 +411,8 @@ class UNet(nn.Module):
         f = K.head_fwd(e1b, self._w(self.final), self.final.bias, new(h - 4, w - 4, self.num_classes, torch.float32))
         logits = K.bilinear_fwd(f, new(H, W, self.num_classes, torch.float32))
         A["bn"], A["bn_training"] = bn_recs, bool(self.training)
+        if bn_recs and self.training:      # nn.BatchNorm2d bookkeeping: one multi-tensor launch for all thirteen layers
+            torch._foreach_add_([rec[2].num_batches_tracked for rec in bn_recs.values()], 1)
         A["e1a"], A["e1b"] = e1a, e1b
         A["fshape"] = (h - 4, w - 4)
         if masks_out is not None:

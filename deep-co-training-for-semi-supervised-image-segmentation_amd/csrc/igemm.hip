@@ -1348,6 +1348,8 @@ static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images
 // Packed-rows shared-halo kernel (igemm3p_kernel) for small images: geometry and split over channel slices.
 struct PlanP { int use, PR, tiles_per_img, splits, cps; };
 int g_tune_igemm_packed = 0;     // 0: deep levels stay on the per-tap kernel
+int g_tune_igemm_packed_split = 400;   // packed kernel: layers with fewer blocks than this are split over channel slices (fp32 slabs)
+int g_tune_igemm_packed_fill = 76;     // percent: least fill of the packed 128-pixel tiles
 static PlanP make_plan_p(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int N) {
   PlanP pp = {0, 0, 0, 1, 0};
   if (!g_tune_igemm_halo || !g_tune_igemm_packed || dtype != DCT_BF16 || d->R != 3 || d->S != 3 || d->stride != 1 || d->dil != 1 ||
@@ -1362,16 +1364,16 @@ static PlanP make_plan_p(const dct_view* x, const dct_view* y, const dct_conv_de
   const int tiles = (Ho + PR - 1) / PR;
   // measured on the UNet deep levels (tools/bench_conv.py --ab-packed): +8-12 % where the tiles are >= 76 % full and every
   // block keeps >= 4 channel slices (36 K-steps); shorter blocks or emptier tiles are level with or behind the per-tap kernel
-  if ((double)Ho * Wo / (tiles * 128.0) < 0.76) return pp;
+  if ((double)Ho * Wo / (tiles * 128.0) < g_tune_igemm_packed_fill * 0.01) return pp;
   const int nch = x->c / 64;
   const long long blocks0 = (long long)y->n * tiles * (N / 128);
   int splits = 1;
-  if (blocks0 < 400) {
-    splits = (int)((448 + blocks0 - 1) / blocks0);
+  if (blocks0 < g_tune_igemm_packed_split) {
+    splits = (int)((g_tune_igemm_packed_split + 48 + blocks0 - 1) / blocks0);
     if (splits > nch) splits = nch;
     while (splits > 1 && nch / splits < 4) --splits;
   }
-  if (nch / splits < 4 || blocks0 * splits < 256) return pp;
+  if (nch / splits < 4 || blocks0 * splits < (g_tune_igemm_packed_split < 256 ? g_tune_igemm_packed_split : 256)) return pp;
   pp.cps = (nch + splits - 1) / splits;
   pp.splits = (nch + pp.cps - 1) / pp.cps;
   pp.use = 1; pp.PR = PR; pp.tiles_per_img = tiles;
@@ -1581,6 +1583,8 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_HALO_COVER: g_tune_igemm_halo_cover = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT_TARGET: if (value < 64) return DCT_ERR_BAD_ARG; g_tune_igemm_split_target = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_PPT: if (value < 1 || value > 4096) return DCT_ERR_BAD_ARG; g_enet_reduce_ppt = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_PACKED_SPLIT: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_split = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_VEC: g_enet_reduce_vec = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_FOLD_THREADS: if (value != 256 && value != 512 && value != 1024) return DCT_ERR_BAD_ARG; g_enet_fold_threads = value; return DCT_OK;
     case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;

@@ -42,14 +42,16 @@ from .trainer import Trainer
 # dozens of trainers, and stream objects that die with an old trainer would be destroyed whenever the cyclic GC runs --
 # including in the middle of a later trainer's graph capture, where hipStreamDestroy is not permitted.
 _STREAM_POOL = {}
+POOL_STREAMS = os.environ.get("DCT_POOL_STREAMS", "0") == "1"
 
 
 def _pooled_stream(device, *key):
     k = (str(device),) + key
-    st = _STREAM_POOL.get(k)
+    st = _STREAM_POOL.get(k) if POOL_STREAMS else None
     if st is None:
         st = torch.cuda.Stream(device=device)
-        _STREAM_POOL[k] = st
+        if POOL_STREAMS:
+            _STREAM_POOL[k] = st
     return st
 
 

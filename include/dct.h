@@ -372,7 +372,9 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
        DCT_TUNE_IGEMM_HALO_MIN_BLOCKS = 19,  /* default 400: fewest blocks for which the shared-halo patch kernel is taken */
        DCT_TUNE_IGEMM_HALO_COVER = 20,       /* percent (default 75): least image cover of its 8 x 16 patches */
        DCT_TUNE_ENET_REDUCE_VEC = 21,        /* 1 (default): 8-channel vector loads in the Enet per-channel reductions; 0: scalar kernel */
-       DCT_TUNE_ENET_FOLD_THREADS = 22 };    /* 256 | 512 | 1024 (default): threads of the one-block fold kernels behind those reductions */
+       DCT_TUNE_ENET_FOLD_THREADS = 22,      /* 256 | 512 | 1024 (default): threads of the one-block fold kernels behind those reductions */
+       DCT_TUNE_IGEMM_PACKED_SPLIT = 23,     /* default 400: packed-rows kernel splits layers with fewer blocks over channel slices */
+       DCT_TUNE_IGEMM_PACKED_FILL = 24 };    /* percent (default 76): least fill of the packed-rows kernel's 128-pixel tiles */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 

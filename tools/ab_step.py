@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=15)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--single-stream", action="store_true")
+    ap.add_argument("--pre", action="append", default=[], metavar="KNOB=VALUE", help="knobs set once before both arms")
     args = ap.parse_args()
     cfg = bench.CONFIGS[args.config]
     dev = torch.device("cuda", 0)
@@ -37,6 +38,9 @@ def main():
     tr.model_streams = not args.single_stream
     S, nb = cfg["S"], len(unl)
     lib = _lib.load()
+    for kv in args.pre:
+        k, v = kv.split("=")
+        assert lib.dct_tune_set(int(k), int(v)) == 0, kv
 
     def one_step(i):
         lb = [(lab[m][i % nb][0][0], lab[m][i % nb][0][1]) for m in range(S)]
