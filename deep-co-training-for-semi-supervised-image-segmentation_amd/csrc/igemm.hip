@@ -1347,8 +1347,11 @@ static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images
 
 // Packed-rows shared-halo kernel (igemm3p_kernel) for small images: geometry and split over channel slices.
 struct PlanP { int use, PR, tiles_per_img, splits, cps; };
-int g_tune_igemm_packed = 0;     // 0: deep levels stay on the per-tap kernel
-int g_tune_igemm_packed_split = 400;   // packed kernel: layers with fewer blocks than this are split over channel slices (fp32 slabs)
+int g_tune_igemm_packed = 1;     // packed-rows shared-halo kernel for the deep levels (0: they stay on the per-tap kernel).  Round 1 had it
+                                 // level on the step because every layer under 400 blocks was split over channel slices (fp32 slabs);
+                                 // with the split only under 100 blocks -- the two model streams supply the parallelism -- it is
+                                 // +0.9 / +2.1 / +1.3 % on the cfg2 step (three in-process A/B rounds, tools/ab_step.py --pre 23=100 --knob 10)
+int g_tune_igemm_packed_split = 100;   // packed kernel: layers with fewer blocks than this are split over channel slices (fp32 slabs)
 int g_tune_igemm_packed_fill = 76;     // percent: least fill of the packed 128-pixel tiles
 static PlanP make_plan_p(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int N) {
   PlanP pp = {0, 0, 0, 1, 0};

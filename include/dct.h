@@ -360,7 +360,7 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
        DCT_TUNE_IGEMM_HALO = 7,    /* 1 (default): shared-halo kernel for 3x3 stride-1 layers on large images; 0: v2 everywhere */
        DCT_TUNE_WGRAD_ROWS = 8,    /* 1 (default): filter-row weight-gradient kernel (three taps share the x strip); 0: v2 */
        DCT_TUNE_WGRAD_ROWS_FILL = 9,   /* percent (default 70): minimum fill of the filter-row kernel's 64-pixel K-steps */
-       DCT_TUNE_IGEMM_PACKED = 10,     /* 1: packed-rows shared-halo kernel for 3x3 stride-1 layers on small images (default 0: per-tap) */
+       DCT_TUNE_IGEMM_PACKED = 10,     /* 1 (default): packed-rows shared-halo kernel for 3x3 stride-1 layers on small images; 0: per-tap kernel */
        DCT_TUNE_IGEMM_MFMA16 = 11,     /* 1 (default): shared-halo kernel on v_mfma_f32_16x16x32_bf16; 0: 32x32x16 */
        DCT_TUNE_ENET_WGRAD_BLOCKS = 12,/* 1..1024 (default 1024): cap on the pixel chunks (blocks) of dct_enet_wgrad */
        DCT_TUNE_WGRAD_GROUPS = 13,     /* 1 | 2 (default 2): wave groups per block of the filter-row weight-gradient kernel */
@@ -373,7 +373,7 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
        DCT_TUNE_IGEMM_HALO_COVER = 20,       /* percent (default 75): least image cover of its 8 x 16 patches */
        DCT_TUNE_ENET_REDUCE_VEC = 21,        /* 1 (default): 8-channel vector loads in the Enet per-channel reductions; 0: scalar kernel */
        DCT_TUNE_ENET_FOLD_THREADS = 22,      /* 256 | 512 | 1024 (default): threads of the one-block fold kernels behind those reductions */
-       DCT_TUNE_IGEMM_PACKED_SPLIT = 23,     /* default 400: packed-rows kernel splits layers with fewer blocks over channel slices */
+       DCT_TUNE_IGEMM_PACKED_SPLIT = 23,     /* default 100: packed-rows kernel splits layers with fewer blocks over channel slices */
        DCT_TUNE_IGEMM_PACKED_FILL = 24 };    /* percent (default 76): least fill of the packed-rows kernel's 128-pixel tiles */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);

@@ -119,15 +119,16 @@ def test_conv2d_3x3_shared_halo(ops, B, Cin, H, W, Cout, pad, mfma16):
     if mfma16 and H < 90:
         pytest.skip("the 16x16x32 variant exists for the patch kernel only")
     _lib.load().dct_tune_set(11, mfma16)
-    _lib.load().dct_tune_set(10, 1)          # small images: the packed-rows kernel (off by default) is what these cases test
+    _lib.load().dct_tune_set(10, 1)          # small images: the packed-rows kernel is what these cases test
     try:
         _shared_halo_case(ops, B, Cin, H, W, Cout, pad)
     finally:
         _lib.load().dct_tune_set(11, _MFMA16_DEFAULT)
-        _lib.load().dct_tune_set(10, 0)
+        _lib.load().dct_tune_set(10, _PACKED_DEFAULT)
 
 
 _MFMA16_DEFAULT = 1
+_PACKED_DEFAULT = 1
 
 
 def _shared_halo_case(ops, B, Cin, H, W, Cout, pad):
