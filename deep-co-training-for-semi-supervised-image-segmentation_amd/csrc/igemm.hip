@@ -35,7 +35,8 @@ struct IgemmParams {
   int kiters, kiters_per_split, cin_iters;
   int cout;  // real Cout (N/4 in scatter mode)
   int staged;  // v2: LDS-staged epilogue with 16-byte row stores (host-checked alignment / 32-bit offsets)
-  int xcd_tiles, xcd_total;  // v3m: XCD-aware 1-D tile order (0: plain 2-D grid)
+  int xcd_tiles, xcd_total;  // v3m / v2: XCD-aware 1-D tile order (0: plain grid)
+  int xcd_gm, xcd_gn;        // v2: tiles along M and N of the plain grid (decode of the 1-D order)
 };
 
 template <typename T> struct Mfma;
@@ -272,7 +273,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WAVES_M, wm = wave % WAVES_M;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order (knob DCT_TUNE_IGEMM_XCD2): workgroups go round-robin over the 8 XCDs, each with its own 4 MiB L2.
+  // The plain (M tile fastest) grid hands every XCD every eighth pixel tile of EVERY channel tile, so each XCD streams the
+  // whole weight matrix (cen_b: 18.9 MB, deep levels: the dominant operand) through its L2.  Here XCD x gets a contiguous
+  // range of the (split, channel tile, pixel tile) order: few channel tiles per XCD, whose weight slices stay L2-resident.
+  int bxi, byi, bzi;
+  if (p.xcd_tiles > 0) {
+    const int slot = blockIdx.x >> 3;
+    int t = (blockIdx.x & 7) * p.xcd_tiles + slot;
+    if (slot >= p.xcd_tiles || t >= p.xcd_total) return;
+    bxi = t % p.xcd_gm; t /= p.xcd_gm;
+    byi = t % p.xcd_gn; bzi = t / p.xcd_gn;
+  } else { bxi = blockIdx.x; byi = blockIdx.y; bzi = blockIdx.z; }
+  const int m0 = bxi * BM, n0 = byi * BN;
   const int srow = wave * 8 + (lane >> 3);                 // staging row within a pass
   const int schunk = (lane & 7) ^ ((srow >> 1) & 7);       // source chunk for this lane's LDS slot
   const long long Ktot = (long long)p.R * p.S * p.Cin;
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
   const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
   const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
 
-  const int kbeg = blockIdx.z * p.kiters_per_split;
+  const int kbeg = bzi * p.kiters_per_split;
   const int kend = min(p.kiters, kbeg + p.kiters_per_split);
   int tap = kbeg / p.cin_iters;
   int cit = kbeg - tap * p.cin_iters;
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
     }
     __syncthreads();
     constexpr int NCH4 = BM * CPR4 / (NW * 64);
-    float* slab = p.partial + ((long long)blockIdx.z * p.M + m0) * p.N + n0;
+    float* slab = p.partial + ((long long)bzi * p.M + m0) * p.N + n0;
 #pragma unroll
     for (int t = 0; t < NCH4; ++t) {
       const int id = t * (NW * 64) + tid;
@@ -1255,6 +1268,7 @@ int g_tune_igemm_waves8 = 1;    // 8 waves per tile (32 pixels x 64 channels eac
                                 // cycles, so halving the pieces per wave shortens every K-step (+4..15 % in-process A/B)
 int g_tune_igemm_staged = 1;    // 0: scattered 8-byte epilogue stores instead of the LDS-staged epilogue
 int g_tune_igemm_xcd = 0;       // XCD-aware tile order of the shared-halo kernel
+int g_tune_igemm_xcd2 = 0;      // XCD-aware tile order of the per-tap kernel (weight slices stay in one XCD's L2)
 int g_tune_igemm_mfma16 = 1;    // shared-halo kernel on 16x16x32 MFMAs (igemm3m_kernel)
 int g_tune_igemm_halo_cover = 75;      // percent of the image the 8 x 16 patches must cover
 int g_tune_igemm_halo_min_blocks = 400;
@@ -1311,6 +1325,14 @@ static void launch_v2(const IgemmParams& p, dim3 grid, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, BOUNDS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
+  }
+  if (g_tune_igemm_xcd2 && (long long)grid.x * grid.y * grid.z >= 16) {
+    IgemmParams q = p;
+    q.xcd_gm = (int)grid.x; q.xcd_gn = (int)grid.y;
+    q.xcd_total = (int)(grid.x * grid.y * grid.z);
+    q.xcd_tiles = (q.xcd_total + 7) / 8;
+    DCT_LAUNCH(DCT_PROF_IGEMM, (igemm2_kernel<BM, BN, WM, WN, BOUNDS>), dim3((unsigned)(q.xcd_tiles * 8)), dim3(WM * WN * 64), lds, st, q);
+    return;
   }
   DCT_LAUNCH(DCT_PROF_IGEMM, (igemm2_kernel<BM, BN, WM, WN, BOUNDS>), grid, dim3(WM * WN * 64), lds, st, p);
 }
@@ -1489,7 +1511,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   p.cin_iters = x->c / pl.bk;
   p.partial = nullptr;
   p.staged = 0;
-  p.xcd_tiles = 0; p.xcd_total = 0;
+  p.xcd_tiles = 0; p.xcd_total = 0; p.xcd_gm = 0; p.xcd_gn = 0;
   if (pl.v2 && pl.splits == 1 && !d->accumulate && g_tune_igemm_staged) {
     const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
                      (long long)y->n * y->sn < (1ll << 31);
@@ -1586,6 +1608,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_HALO_COVER: g_tune_igemm_halo_cover = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT_TARGET: if (value < 64) return DCT_ERR_BAD_ARG; g_tune_igemm_split_target = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_PPT: if (value < 1 || value > 4096) return DCT_ERR_BAD_ARG; g_enet_reduce_ppt = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_XCD2: g_tune_igemm_xcd2 = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_SPLIT: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_VEC: g_enet_reduce_vec = value ? 1 : 0; return DCT_OK;
