@@ -22,11 +22,13 @@ class DiceMeter(object):
         self.C = C
         self._acc = None        # float64 [2, C + 1] on the device: running sum / sum of squares per class and of the report mean
         self._n = 0
+        self._cache = None
 
     def reset(self):
         self.diceLog = []
         self._acc = None
         self._n = 0
+        self._cache = None
 
     def add(self, pred_logit: torch.Tensor, gt: torch.Tensor, smooth: float = 1e-8):
         """pred_logit [B,C,H,W] (logits or probabilities: only the argmax matters, dice_meter.py:28-32),
@@ -72,11 +74,17 @@ class DiceMeter(object):
             log = self.log
             report_means = log.mean(1) if self.report_axis == 'all' else log[:, self.report_axis].mean(1)
             return (report_means.mean(), report_means.std()), (log.mean(0), log.std(0))
-        n = self._n
-        mean = self._acc[0] / n
-        var = (self._acc[1] - n * mean * mean).clamp_min(0.0) / (n - 1) if n > 1 else torch.full_like(mean, float('nan'))
-        mean, std = mean.float(), var.sqrt().float()
-        return (mean[-1], std[-1]), (mean[:-1], std[:-1])
+        # ONE device->host copy of the 2 x (C + 1) running sums per reading (cached until the next add): the per-class floats
+        # the progress bar then takes (4 S readings of C values each, cotraining_totalloss.py:251-264) cost no further
+        # synchronisation -- a blocking read of a device scalar is ~ms on this stack, the arithmetic below is nothing
+        if self._cache is None or self._cache[0] != self._n:
+            acc = self._acc.cpu()
+            n = self._n
+            mean = acc[0] / n
+            var = (acc[1] - n * mean * mean).clamp_min(0.0) / (n - 1) if n > 1 else torch.full_like(mean, float('nan'))
+            mean, std = mean.float(), var.sqrt().float()
+            self._cache = (n, ((mean[-1], std[-1]), (mean[:-1], std[:-1])))
+        return self._cache[1]
 
     def detailed_summary(self) -> dict:
         _, (means, _) = self.value()

@@ -23,3 +23,13 @@ for n, what in ((200, "add"), (50, "add+value")):
     torch.cuda.synchronize()
     td = time.perf_counter() - t0
     print(f"{what}: host {1e6 * th / n:.1f} us/call, host+device {1e6 * td / n:.1f} us/call")
+
+x = torch.zeros(4, device=dev)
+torch.cuda.synchronize()
+for what, fn in (("synchronize()", lambda: torch.cuda.synchronize()), (".item()", lambda: x[0].item()), (".cpu()", lambda: x.cpu()),
+                 ("double ops + item", lambda: ((x.double() / 3).sqrt().float())[0].item())):
+    t0 = time.perf_counter()
+    for _ in range(50):
+        x.add_(1.0)
+        fn()
+    print(f"{what}: {1e6 * (time.perf_counter() - t0) / 50:.1f} us per (tiny kernel + call)")
