@@ -115,6 +115,13 @@ def test_unet_bn_cotraining_step_vs_oracle(tmp_path, adv):
         if adv:
             np.testing.assert_allclose(out["adv"].item(), ref["adv"].item(), rtol=5e-2 if k == 0 else 0.3)
         if k == 0:
+            # running statistics after the first step's forward passes (labeled, unlabeled[, adversarial]: identical weights)
+            for seg, om in zip(segs, oms):
+                for (ka, va), (kb, vb) in zip(seg.torchnet.named_buffers(), om.net.named_buffers()):
+                    if va.dtype.is_floating_point:
+                        np.testing.assert_allclose(va.cpu().numpy(), vb.numpy(), rtol=1e-2 if adv else 2e-3, atol=2e-4 if adv else 2e-5, err_msg=ka)   # (adv: FGSM sign flips move isolated pixels of the third batch)
+                    else:
+                        assert int(va) == int(vb), ka           # num_batches_tracked
             # gradients of step 0 (identical weights): Adam's first moment after one step is (1 - beta1) * g
             for seg, om in zip(segs, oms):
                 for (name, p), po in zip(seg.torchnet.named_parameters(), om.net.parameters()):
@@ -129,9 +136,8 @@ def test_unet_bn_cotraining_step_vs_oracle(tmp_path, adv):
         # two sign-like Adam steps of lr 1e-3 on weights of magnitude ~3e-2: elements whose tiny gradient flips sign between the
         # two arithmetics differ by up to 4e-3 (measured 2e-2 overall; the BatchNorm'd convolutions have large near-null spaces)
         assert ((a - b).norm() / b.norm()).item() < 5e-2
-        for (ka, va), (kb, vb) in zip(seg.torchnet.named_buffers(), om.net.named_buffers()):
-            if va.dtype.is_floating_point:      # running statistics after the second (post-Adam, sign-chaotic) step: 1.7 % measured
-                np.testing.assert_allclose(va.cpu().numpy(), vb.numpy(), rtol=0.1, atol=1e-2)
+        for (ka, va) in seg.torchnet.named_buffers():
+            assert torch.isfinite(va.float()).all(), ka
 
 
 # ---------------------------------------------------------------------------------------- eval loop / checkpoint / ensemble

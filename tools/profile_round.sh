@@ -21,7 +21,7 @@ find $OUT -name "*.csv" | head -40
 for c in cfg2 cfg4; do
   python3 tools/rocprof_summary.py $(find $OUT/k_$c -name "*kernel_trace.csv" | head -1) > $OUT/${c}_single_stream_kernel_stats.txt
   python3 tools/rocprof_summary.py $(find $OUT/kd_$c -name "*kernel_trace.csv" | head -1) > $OUT/${c}_default_command_kernel_stats.txt
-  python3 tools/pmc_traffic.py "$(find $OUT/f_$c -name "*counter_collection.csv" | head -1)" "$(find $OUT/w_$c -name "*counter_collection.csv" | head -1)" $c 12 > $OUT/${c}_pmc_traffic.json
+  python3 tools/pmc_traffic.py "$(find $OUT/f_$c -name "*counter_collection.csv" | head -1)" "$(find $OUT/w_$c -name "*counter_collection.csv" | head -1)" $c 16 > $OUT/${c}_pmc_traffic.json
 done
 # raw csvs are large: keep only the summaries
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
