@@ -274,10 +274,10 @@ class Enet(nn.Module):
         t = conv.taps
         if conv.transposed:
             K.enet_conv(src, w, b, src_tf, dst, R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1],
-                        transposed=True, ws=(1, conv.cout, t * conv.cout))
+                        transposed=True, ws=(1, conv.cout, t * conv.cout), compute=self.compute_dtype)
         else:
             K.enet_conv(src, w, b, src_tf, dst, R=conv.kh, S=conv.kw, stride=conv.stride, dil=conv.dil, pad_h=conv.pad[0],
-                        pad_w=conv.pad[1], ws=(t * conv.cin, conv.cin, 1))
+                        pad_w=conv.pad[1], ws=(t * conv.cin, conv.cin, 1), compute=self.compute_dtype)
 
     def _conv_dgrad(self, g, conv, dst, accumulate=False, resid=None):
         """dst (+)= d(loss)/d(conv input) given g = d/d(conv output)."""
@@ -286,11 +286,11 @@ class Enet(nn.Module):
         rg, rm = resid if resid is not None else (None, None)
         if conv.transposed:
             K.enet_conv(g, w, None, None, dst, R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1],
-                        ws=(t * conv.cout, conv.cout, 1), accumulate=accumulate, resid_grad=rg, resid_mask=rm)
+                        ws=(t * conv.cout, conv.cout, 1), accumulate=accumulate, resid_grad=rg, resid_mask=rm, compute=self.compute_dtype)
         else:
             K.enet_conv(g, w, None, None, dst, R=conv.kh, S=conv.kw, stride=conv.stride, dil=conv.dil, pad_h=conv.pad[0],
                         pad_w=conv.pad[1], transposed=True, ws=(1, conv.cin, t * conv.cin), accumulate=accumulate,
-                        resid_grad=rg, resid_mask=rm)
+                        resid_grad=rg, resid_mask=rm, compute=self.compute_dtype)
         return dst
 
     def _conv_wgrad(self, g, conv, src, src_tf, before_bn=False):

@@ -18,6 +18,8 @@
 
 int g_enet_reduce_ppt = 8;           // pixels per thread of a per-channel reduction (sets the number of partial rows)
 int g_enet_fold_threads = 1024;      // threads of the one-block finalize kernels (DCT_TUNE_ENET_FOLD_THREADS: 256 | 512 | 1024)
+int g_enet_mfma = 3;                 // bf16 / f16 mode: bit 0 = MFMA form of the convolutions with >= 16 input channels, bit 1 = of the
+                                     // weight gradients (0: the fp32 VALU kernels)
 int g_enet_reduce_vec = 1;           // 8-channel vector loads in the per-channel reductions (0: scalar kernel everywhere)
 int g_enet_wgrad_slices = 1;          // 0: one pixel slice per round whatever the tile count
 int g_enet_wgrad_max_blocks = 1024;   // dct_tune_set(DCT_TUNE_ENET_WGRAD_BLOCKS, n); <= WG_MAX_BLOCKS
@@ -81,6 +83,7 @@ struct ConvP {
   int G;                          // output-channel groups of 8
   int fm;                         // f32 mask: bit0 x, bit1 y, bit2 resid grad, bit3 resid mask
   int vec;                        // input rows can be read 8 channels at a time
+  int wvec;          // MFMA form: weight rows are K-major and 16-byte aligned (one 32-byte load per B fragment)
 };
 
 // One thread = one output pixel x 8 output channels.  Weights live in LDS as [tap][i][G*8].
@@ -170,6 +173,170 @@ __global__ __launch_bounds__(256) void enet_conv_kernel(ConvP p) {
   }
 }
 
+// 8 consecutive channels of one pixel as one (T) or two (fp32) 16-byte loads
+template <typename T> __device__ __forceinline__ void ld8(const View& v, long long off, int f32, float o[8]) {
+  if (f32 || sizeof(T) == 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(v.ptr) + off);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(v.ptr) + off + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+  } else {
+    typedef typename vec8_of<T>::type V8;
+    const V8 a = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(v.ptr) + off);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)a[i];
+  }
+}
+
+// ---- MFMA form of the small-channel convolution (bf16 / f16 compute modes) -----------------------
+// The VALU kernel above gives one thread a whole reduction (taps x Cin multiply-adds in sequence: 288 for a 3x3 on 32 channels)
+// and a stage-3 tensor (8 x 25 x 25 pixels) only ~80 blocks: 50 us per launch at 1.7 TFLOP/s, latency-bound (tools/
+// bench_enet_layers.py).  Where the contraction is MFMA-shaped -- Cin a multiple of 8 and taps x Cin a multiple of 16, i.e.
+// every convolution of stages 1-3 -- a wave instead owns 32 output pixels x all output channels and walks K = taps x Cin in
+// steps of 16 on v_mfma_f32_32x32x16_{bf16,f16}: lane (r, h) loads the 8 consecutive input channels [c0 + 8h, +8) of ITS pixel
+// at the tap's offset straight from HBM/L2 (NHWC: one 16- or 32-byte load; the producer's BatchNorm + activation is applied on
+// load as before, out-of-image taps are zeros), which IS its A fragment; the B fragment is 8 consecutive K of weight row
+// o = 32 j + r (one 32-byte load where the weights are K-major for this role, eight coalesced scalar loads otherwise).  No
+// LDS, no barrier.  The operands are rounded to the compute dtype (mixed precision, fp32 accumulate); fp32 mode keeps the
+// VALU kernel.  D[pixel][channel]: a lane holds one output channel of 16 pixels, so 32 lanes store 128 contiguous bytes.
+template <typename T> struct LowMfma;
+template <> struct LowMfma<bf16_t> {
+  typedef bf16x8 frag;
+  __device__ static __forceinline__ f32x16 run(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct LowMfma<f16_t> {
+  typedef f16x8 frag;
+  __device__ static __forceinline__ f32x16 run(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct LowMfma<float> {      // never launched (fp32 mode stays on the VALU kernel); keeps ENET_T instantiable
+  typedef f16x8 frag;
+  __device__ static __forceinline__ f32x16 run(frag, frag, f32x16 c) { return c; }
+};
+
+template <typename T, int NT>
+__global__ __launch_bounds__(64) void enet_mconv_kernel(ConvP p, int ngroups) {
+  typedef typename LowMfma<T>::frag frag;
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int Cin = p.x.c, Cout = p.y.c;
+  const long long P = (long long)p.y.n * p.y.h * p.y.w;
+  const int cbase = (int)(blockIdx.x % ngroups) * (32 * NT);             // first output channel of this wave
+  const long long wbase = (long long)(blockIdx.x / ngroups) * 32;        // first output pixel of this wave
+  const long long pix = wbase + r;
+  const bool pvalid = pix < P;
+  int n = 0, oy = 0, ox = 0;
+  if (pvalid) pix3(pix, p.y.h, p.y.w, n, oy, ox);
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const int xf = p.fm & 1;
+  const bool wvec = p.wvec != 0;
+  const int mode = p.tf.mode;
+  for (int c0 = 0; c0 < Cin; c0 += 16) {
+    const int ci = c0 + 8 * h;
+    float sc[8], sh[8], sl[8];
+    if (mode != 0) {
+      *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(p.tf.scale + ci);
+      *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(p.tf.scale + ci + 4);
+      *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(p.tf.shift + ci);
+      *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(p.tf.shift + ci + 4);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sl[k] = mode == 2 ? p.tf.slope[ci + k] : 0.f;      // ReLU = PReLU with slope 0
+    }
+    for (int rr = 0; rr < p.R; ++rr) {
+      int iy;
+      bool vy = pvalid;
+      if (p.transposed) {
+        const int ty = oy + p.pad_h - rr * p.dil;
+        vy = vy && ty >= 0 && (ty % p.stride) == 0;
+        iy = ty / p.stride;
+      } else {
+        iy = oy * p.stride - p.pad_h + rr * p.dil;
+      }
+      vy = vy && (unsigned)iy < (unsigned)p.x.h;
+      for (int ss = 0; ss < p.S; ++ss) {
+        int ix;
+        bool v = vy;
+        if (p.transposed) {
+          const int tx = ox + p.pad_w - ss * p.dil;
+          v = v && tx >= 0 && (tx % p.stride) == 0;
+          ix = tx / p.stride;
+        } else {
+          ix = ox * p.stride - p.pad_w + ss * p.dil;
+        }
+        v = v && (unsigned)ix < (unsigned)p.x.w;
+        float a8[8];
+        if (v) {
+          ld8<T>(p.x, voff(p.x, n, iy, ix) + ci, xf, a8);
+          if (mode != 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float z = fmaf(sc[k], a8[k], sh[k]);
+              a8[k] = (mode == 1 || z > 0.f) ? z : z * sl[k];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a8[k] = 0.f;
+        }
+        frag A;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) A[k] = from_f32<T>(a8[k]);
+        const long long wtap = (long long)(rr * p.S + ss) * p.ws_tap + (long long)ci * p.ws_in;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int o = cbase + 32 * j + r;
+          float w8[8];
+          if (o < Cout) {
+            const float* wp = p.w + (long long)o * p.ws_out + wtap;
+            if (wvec) {
+              *reinterpret_cast<f32x4*>(w8) = *reinterpret_cast<const f32x4*>(wp);
+              *reinterpret_cast<f32x4*>(w8 + 4) = *reinterpret_cast<const f32x4*>(wp + 4);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) w8[k] = wp[(long long)k * p.ws_in];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w8[k] = 0.f;
+          }
+          frag B;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) B[k] = from_f32<T>(w8[k]);
+          acc[j] = LowMfma<T>::run(A, B, acc[j]);
+        }
+      }
+    }
+  }
+  // epilogue: accumulator e of lane (r, h) is output pixel wbase + (e & 3) + 8 (e >> 2) + 4 h, channel 32 j + r.  The lane that
+  // owns a pixel as its A row has its offsets; they travel by shuffle.
+  const long long yo_mine = pvalid ? voff(p.y, n, oy, ox) : -1;
+  const long long rg_mine = (pvalid && p.has_resid) ? voff(p.rg, n, oy, ox) : 0;
+  const long long rm_mine = (pvalid && p.has_resid) ? voff(p.rm, n, oy, ox) : 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int prow = (e & 3) + 8 * (e >> 2) + 4 * h;
+    const long long yo = __shfl(yo_mine, prow, 64);
+    const long long rgo = p.has_resid ? __shfl(rg_mine, prow, 64) : 0;
+    const long long rmo = p.has_resid ? __shfl(rm_mine, prow, 64) : 0;
+    if (yo < 0) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int c = cbase + 32 * j + r;
+      if (c >= Cout) continue;
+      float val = acc[j][e];
+      if (p.bias) val += p.bias[c];
+      if (p.has_resid) {
+        if (ldv<T>(p.rm, rmo + c, p.fm & 8) > 0.f) val += ldv<T>(p.rg, rgo + c, p.fm & 4);
+      }
+      if (p.accumulate) val += ldv<T>(p.y, yo + c, p.fm & 2);
+      stv<T>(p.y, yo + c, p.fm & 2, val);
+    }
+  }
+}
+
 // ---- per-channel sums over pixels: partial[blk][c][k], k < NS, double accumulators -------------
 // kind 0: {sum x, sum x^2}                                  (BatchNorm statistics; bias grad uses k = 0)
 // kind 1: {sum dz, sum dz*xhat, sum g*z*[z<0]}              (BatchNorm / PReLU backward)
@@ -235,20 +402,6 @@ __global__ __launch_bounds__(256) void enet_reduce_kernel(RedP p, double* partia
 // owns 8 consecutive channels and loads them as one or two 16-byte vectors per pixel (the scalar kernel above issues one 2- or
 // 4-byte load per element and a 64-bit-capable index decode per pixel); fp32 running sums over runs of 32 pixels are flushed
 // into doubles, rows of threads are folded through LDS in a fixed order.  Same partial layout, same finalize kernels.
-template <typename T> __device__ __forceinline__ void ld8(const View& v, long long off, int f32, float o[8]) {
-  if (f32 || sizeof(T) == 4) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(v.ptr) + off);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(v.ptr) + off + 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
-  } else {
-    typedef typename vec8_of<T>::type V8;
-    const V8 a = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(v.ptr) + off);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (float)a[i];
-  }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void enet_reduce_vec_kernel(RedP p, double* partial) {
   extern __shared__ double redv[];                // [rows][C][3]
@@ -653,6 +806,74 @@ __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, 
   }
 }
 
+// MFMA form of the weight gradient (bf16 / f16 compute modes).  dW[o][k] = sum over pixels of A[pixel][o] * B[pixel + tap(k)][c(k)]
+// is a GEMM whose reduction runs over PIXELS, the strided dimension of both NHWC operands, so a v_mfma_f32_32x32x16 fragment
+// (8 consecutive K of one row) is 8 pixels of one channel: eight 2- or 4-byte loads per lane, which the 32 lanes of a half-wave
+// issue for 32 adjacent channels (64 - 128 contiguous bytes per load instruction).  One wave = one 32 x 32 tile of dW over one
+// slice of the pixels; a stage-3 gradient (5000 pixels, 32 x 288) becomes ~180 independent waves of 16 MFMA steps instead of 78
+// blocks of two barrier-separated rounds.  Lane r of the B fragment owns column k = 32 nt + r, i.e. its own (tap, channel): ragged
+// channel counts and taps need no special case.  The slices are folded in fixed order by enet_wgrad_reduce_kernel as before.
+// The layer input is rounded to the compute dtype exactly as the forward's MFMA form rounds it; the gradient operand is stored
+// in that dtype already.
+template <typename T>
+__global__ __launch_bounds__(64) void enet_mwgrad_kernel(WgP p, float* partial, int E, int pps, int mtiles, int ntiles) {
+  typedef typename LowMfma<T>::frag frag;
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int Ca = p.a.c, Cb = p.b.c, kb = p.R * p.S * Cb;
+  int u = blockIdx.x;
+  const int nt = u % ntiles; u /= ntiles;
+  const int mt = u % mtiles;
+  const int split = u / mtiles;
+  const long long P = (long long)p.a.n * p.a.h * p.a.w;
+  const long long pbeg = (long long)split * pps, pend = min(P, pbeg + pps);
+  const int o = mt * 32 + r;
+  const bool ov = o < Ca;
+  const int k = nt * 32 + r;
+  const bool kv = k < kb;
+  const int tap = kv ? k / Cb : 0, c = kv ? k % Cb : 0;
+  const int dy = (tap / p.S) * p.dil - p.pad_h, dx = (tap % p.S) * p.dil - p.pad_w;
+  const int amode = ov ? p.tfa.mode : 0, bmode = kv ? p.tfb.mode : 0;
+  float asc = 1.f, ash = 0.f, asl = 0.f, bsc = 1.f, bsh = 0.f, bsl = 0.f;
+  if (amode) { asc = p.tfa.scale[o]; ash = p.tfa.shift[o]; asl = amode == 2 ? p.tfa.slope[o] : 0.f; }
+  if (bmode) { bsc = p.tfb.scale[c]; bsh = p.tfb.shift[c]; bsl = bmode == 2 ? p.tfb.slope[c] : 0.f; }
+  const int af = p.fm & 1, bf = p.fm & 2;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (long long p0 = pbeg; p0 < pend; p0 += 16) {
+    const long long q = p0 + 8 * h;
+    int n = 0, y = 0, x = 0;
+    if (q < pend) pix3(q, p.a.h, p.a.w, n, y, x);
+    frag A, B;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float av = 0.f, bv = 0.f;
+      if (q + j < pend) {
+        if (ov) {
+          av = ldv<T>(p.a, voff(p.a, n, y, x) + o, af);
+          if (amode) { const float z = fmaf(asc, av, ash); av = (amode == 1 || z > 0.f) ? z : z * asl; }
+        }
+        const int by = y * p.stride + dy, bx = x * p.stride + dx;
+        if (kv && (unsigned)by < (unsigned)p.b.h && (unsigned)bx < (unsigned)p.b.w) {
+          bv = ldv<T>(p.b, voff(p.b, n, by, bx) + c, bf);
+          if (bmode) { const float z = fmaf(bsc, bv, bsh); bv = (bmode == 1 || z > 0.f) ? z : z * bsl; }
+        }
+      }
+      A[j] = from_f32<T>(av);
+      B[j] = from_f32<T>(bv);
+      if (++x == p.a.w) { x = 0; if (++y == p.a.h) { y = 0; ++n; } }
+    }
+    acc = LowMfma<T>::run(A, B, acc);
+  }
+  if (kv) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int oo = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (oo < Ca) partial[(long long)split * E + (long long)oo * kb + k] = acc[e];
+    }
+  }
+}
+
 // dw[e] += sum_b partial[b][e]: 16 entries per block, 16 strided partial sums each, folded in fixed order
 __global__ __launch_bounds__(256) void enet_wgrad_reduce_kernel(const float* partial, float* dw, int E, int blocks) {
   __shared__ float red[256];
@@ -703,7 +924,7 @@ extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bia
   p.R = d->R; p.S = d->S; p.stride = d->stride; p.dil = d->dil; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
   p.transposed = transposed ? 1 : 0; p.accumulate = d->accumulate ? 1 : 0;
   p.ws_out = ws_out; p.ws_tap = ws_tap; p.ws_in = ws_in;
-  p.has_resid = 0;
+  p.has_resid = 0; p.wvec = 0;
   p.rg = p.y; p.rm = p.y;
   if (resid_grad) {
     if (!view_ok(resid_grad) || !view_ok(resid_mask)) return DCT_ERR_BAD_ARG;
@@ -717,6 +938,25 @@ extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bia
   {
     const int xbytes = ((f32_mask & 1) || dtype == DCT_F32) ? 4 : 2;   // bf16 and f16 are both 2 bytes
     p.vec = (x->c % 8 == 0 && x->sw % 8 == 0 && x->sh % 8 == 0 && x->sn % 8 == 0 && ((uintptr_t)x->ptr % (8 * xbytes)) == 0) ? 1 : 0;
+  }
+  hipStream_t st0 = (hipStream_t)stream;
+  if ((g_enet_mfma & 1) && dtype != DCT_F32 && p.vec && x->c >= 16 && x->c % 8 == 0 && (d->R * d->S * x->c) % 16 == 0 && y->c <= 128 &&
+      (!tf || !tf->mode || (((uintptr_t)tf->scale | (uintptr_t)tf->shift) % 16 == 0))) {
+    p.wvec = (ws_in == 1 && (uintptr_t)w % 16 == 0 && ws_out % 4 == 0 && ws_tap % 4 == 0) ? 1 : 0;
+    // one wave (= one 64-thread block) per 32 pixels x 32 NT channels; NT > 1 only where the pixel tiles alone fill the chip
+    const long long Pm = (long long)y->n * y->h * y->w;
+    const long long ptiles = (Pm + 31) / 32;
+    const int ntiles = (y->c + 31) / 32;
+    int nt = 1;
+    if (ntiles >= 4 && ptiles >= 2048) nt = 4;
+    else if (ntiles >= 2 && ptiles * ((ntiles + 1) / 2) >= 2048) nt = 2;
+    const int ngroups = (ntiles + nt - 1) / nt;
+    if (ptiles * ngroups > 0x7fffffffLL) return DCT_ERR_UNSUPPORTED;
+    const unsigned gridm = (unsigned)(ptiles * ngroups);
+    if (nt == 1) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 1>), dim3(gridm), dim3(64), 0, st0, p, ngroups));
+    else if (nt == 2) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 2>), dim3(gridm), dim3(64), 0, st0, p, ngroups));
+    else ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 4>), dim3(gridm), dim3(64), 0, st0, p, ngroups));
+    return dct_check_launch();
   }
   const size_t lds = (size_t)d->R * d->S * x->c * Gp * 8 * sizeof(float);
   if (lds > 64 * 1024) return DCT_ERR_UNSUPPORTED;
@@ -862,6 +1102,31 @@ extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const d
                               void* workspace, size_t workspace_bytes, dct_stream stream) {
   if (!view_ok(a) || !view_ok(b) || !dw || !d || !ok_dtype(dtype) || a->n != b->n) return DCT_ERR_BAD_ARG;
   const int E = a->c * d->R * d->S * b->c;
+  if ((g_enet_mfma & 2) && dtype != DCT_F32) {
+    WgP p;
+    p.a = to_view(a); p.b = to_view(b); p.tfa = to_tf(tfa); p.tfb = to_tf(tfb);
+    p.R = d->R; p.S = d->S; p.stride = d->stride; p.dil = d->dil; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+    p.fm = f32_mask; p.ppb = 0;
+    const long long P = (long long)a->n * a->h * a->w;
+    const int kb = d->R * d->S * b->c;
+    const int mtiles = (a->c + 31) / 32, ntiles = (kb + 31) / 32;
+    // pixel slices: enough waves to fill the chip (~2048), >= 4 MFMA steps (64 pixels) each, <= WG_MAX_BLOCKS slices of workspace
+    const long long steps = (P + 15) / 16;
+    long long ks = 2048 / ((long long)mtiles * ntiles);
+    if (ks < 1) ks = 1;
+    long long sps = (steps + ks - 1) / ks;
+    if (sps < 4) sps = 4;
+    if ((steps + sps - 1) / sps > WG_MAX_BLOCKS) sps = (steps + WG_MAX_BLOCKS - 1) / WG_MAX_BLOCKS;
+    const long long pps = sps * 16;
+    const long long nsl = (P + pps - 1) / pps;
+    if (pps > 0x7fffffffLL || nsl * mtiles * ntiles > 0x7fffffffLL) return DCT_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < (size_t)nsl * E * sizeof(float)) return DCT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_mwgrad_kernel<T>, dim3((unsigned)(nsl * mtiles * ntiles)), dim3(64), 0, st, p,
+                             (float*)workspace, E, (int)pps, mtiles, ntiles));
+    DCT_LAUNCH(DCT_PROF_OTHER, enet_wgrad_reduce_kernel, dim3(div_up(E, 16)), dim3(256), 0, st, (const float*)workspace, dw, E, (int)nsl);
+    return dct_check_launch();
+  }
   const int CaP = (a->c + 3) & ~3, kbP = (d->R * d->S * b->c + 7) & ~7;
   if ((CaP / 4) * (kbP / 8) > 256 * WG_TPT) return DCT_ERR_UNSUPPORTED;
   const int ntiles = (CaP / 4) * (kbP / 8);

@@ -379,13 +379,17 @@ def _mixed(*ts):
 
 
 def enet_conv(x, w, bias, tf, y, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, transposed=False, ws=(0, 0, 0),
-              resid_grad=None, resid_mask=None, accumulate=False):
+              resid_grad=None, resid_mask=None, accumulate=False, compute=None):
+    """``compute``: the net's compute dtype.  A forward conv reads a raw fp32 tensor and writes one, so no view says which mode
+    the call belongs to; in bf16 / f16 mode the contraction's operands are rounded to that type (MFMA form, csrc/enet.hip)."""
     d = conv_desc(R, S, stride, dil, pad_h, pad_w, accumulate=accumulate)
     vx, vy = view(x), view(y)
     keep, tfp = _tfp(tf)
     vrg = view(resid_grad) if resid_grad is not None else None
     vrm = view(resid_mask) if resid_mask is not None else None
     dt, fm = _mixed(x, y, resid_grad, resid_mask)
+    if dt == F32 and compute in (torch.bfloat16, torch.float16):
+        dt = DTYPE_OF[compute]
     call("dct_enet_conv", C.byref(vx), ptr(w), ptr(bias), tfp, C.byref(vy), C.byref(d), int(transposed),
          int(ws[0]), int(ws[1]), int(ws[2]), C.byref(vrg) if vrg is not None else None,
          C.byref(vrm) if vrm is not None else None, fm, dt, stream())

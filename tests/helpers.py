@@ -74,3 +74,37 @@ class MaskReplayNet(torch.nn.Module):
     def forward(self, x):
         masks = self.queue.pop(0) if self.queue else None
         return self.net(x, dropout_masks=masks) if masks is not None else self.net(x)
+
+
+def round_conv_operands(onet, dtype):
+    """Make the oracle's convolutions round BOTH operands to ``dtype`` wherever the HIP plan's MFMA form does (csrc/enet.hip::
+    enet_mconv_kernel: low-precision mode, >= 16 input channels in whole groups of 8, taps x Cin in whole steps of 16, <= 128
+    output channels); accumulation stays fp32 on both sides.  The weight gradient still lands on the fp32 parameter.  (The
+    MFMA weight gradient rounds the layer input of EVERY convolution; for the ineligible ones -- the 1-channel image, the 3-/13-/14-
+    channel ends -- the oracle keeps fp32 there, inside the tests' bands.)"""
+    import torch
+
+    def eligible(m):
+        if isinstance(m, torch.nn.ConvTranspose2d):
+            cin, cout = m.in_channels, m.out_channels
+        elif isinstance(m, torch.nn.Conv2d):
+            cin, cout = m.in_channels, m.out_channels
+        else:
+            return False
+        taps = m.kernel_size[0] * m.kernel_size[1]
+        return cin >= 16 and cin % 8 == 0 and (taps * cin) % 16 == 0 and cout <= 128
+
+    def pre(m, inp):
+        m._w_full = m.weight.data
+        m.weight.data = m.weight.data.to(dtype).float()
+        return (inp[0].to(dtype).float(),) + tuple(inp[1:])
+
+    def post(m, _i, _o):
+        m.weight.data = m._w_full
+        del m._w_full
+
+    for m in onet.modules():
+        if eligible(m):
+            m.register_forward_pre_hook(pre)
+            m.register_forward_hook(post)
+    return onet

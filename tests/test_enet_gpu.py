@@ -9,6 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import oracle  # noqa: E402
+from helpers import round_conv_operands  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -98,7 +99,7 @@ def _bf16_points(onet):
     for m in onet.modules():
         if m.__class__.__name__ in ("_Bottleneck", "_Initial"):
             m.register_forward_hook(rnd)
-    return onet
+    return round_conv_operands(onet, torch.bfloat16)   # ... and the MFMA convolutions' operands
 
 
 # Tolerances (L2-relative per tensor).

@@ -58,17 +58,34 @@ def make_tf(K, C, mode, g):
     return tf, apply, (scale, shift, slope)
 
 
-@pytest.mark.parametrize("dt", DTYPES)
+def mfma_form(dt, cin, cout, taps):
+    """dct_enet_conv's MFMA form (csrc/enet.hip::enet_mconv_kernel): low-precision modes, >= 16 input channels in whole 8-channel
+    groups, K = taps * cin in whole steps of 16.  It rounds BOTH operands of the contraction to the compute dtype (fp32 accumulate);
+    the VALU form multiplies the stored values in fp32.  dct_enet_wgrad's MFMA form (enet_mwgrad_kernel) takes every shape."""
+    return dt != torch.float32 and cin >= 16 and cin % 8 == 0 and (taps * cin) % 16 == 0 and cout <= 128
+
+
+def set_mfma(on):
+    from dct_amd import _lib
+    _lib.check(_lib.load().dct_tune_set(26, int(on)), "dct_tune_set(ENET_MFMA)")
+
+
+@pytest.mark.parametrize("dt,mfma", [(torch.float32, 3), (torch.bfloat16, 3), (torch.float16, 3), (torch.bfloat16, 0)])
 @pytest.mark.parametrize("cin,cout,kh,kw,stride,pad,dil,in_f32,mode", [
     (64, 16, 1, 1, 1, (0, 0), 1, False, 0),      # block1x1_1 on a block output
     (16, 16, 3, 3, 1, (1, 1), 1, True, 2),       # middle 3x3 on a raw input through BN+PReLU
     (32, 32, 3, 3, 1, (4, 4), 4, True, 2),       # dilated
     (32, 32, 5, 1, 1, (2, 0), 1, True, 3),       # asymmetric 5x1
+    (16, 64, 1, 1, 1, (0, 0), 1, True, 2),       # block1x1_2: two 32-channel MFMA column tiles
+    (32, 128, 1, 1, 1, (0, 0), 1, True, 3),      # ... four
+    (24, 40, 3, 3, 1, (1, 1), 1, False, 0),      # ragged: K = 216 is not a multiple of 16 (VALU form), 40 channels out
+    (32, 24, 3, 3, 2, (1, 1), 1, False, 0),      # strided 3x3, a partly filled column tile
+    (32, 40, 1, 1, 2, (0, 0), 1, False, 0),      # strided 1x1, a partly filled second column tile
     (14, 16, 2, 2, 2, (0, 0), 1, False, 0),      # down-sampling 2x2 s2
     (1, 13, 3, 3, 2, (1, 1), 1, True, 0),        # initial conv on the fp32 image
     (3, 14, 1, 1, 1, (0, 0), 1, True, 3),        # tiny widths of the last up-sampling bottleneck
 ])
-def test_enet_conv_direct_dgrad_wgrad(K, dt, cin, cout, kh, kw, stride, pad, dil, in_f32, mode):
+def test_enet_conv_direct_dgrad_wgrad(K, dt, mfma, cin, cout, kh, kw, stride, pad, dil, in_f32, mode):
     g = torch.Generator().manual_seed(1)
     B, H, W = 2, 12, 10
     xs = torch.float32 if in_f32 else dt
@@ -76,33 +93,47 @@ def test_enet_conv_direct_dgrad_wgrad(K, dt, cin, cout, kh, kw, stride, pad, dil
     w = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
     bias = torch.randn(cout, generator=g)
     tf, apply, _ = make_tf(K, cin, mode, g) if mode else (None, (lambda t: t), None)
-    xin = apply(x).requires_grad_(True)
-    wr = w.clone().requires_grad_(True)
-    ref = F.conv2d(xin, wr, bias, stride=stride, padding=pad, dilation=dil)
+    xin = apply(x)
+    fq = dt if (mfma & 1 and mfma_form(dt, cin, cout, kh * kw)) else torch.float32  # operand rounding of the forward contraction
+    bq = dt if (mfma & 1 and mfma_form(dt, cout, cin, kh * kw)) else torch.float32  # ... of the data gradient (reduces over cout)
+    wq = dt if mfma & 2 else torch.float32                                          # ... of the weight gradient (any shape)
+    conv = lambda a, b, bb=None: F.conv2d(a, b, bb, stride=stride, padding=pad, dilation=dil)
+    ref = conv(q(xin, fq), q(w, fq), bias)
     wk = w.permute(0, 2, 3, 1).contiguous().to(DEV)          # [co][kh][kw][ci]
     y = torch.empty(B, ref.shape[2], ref.shape[3], cout, dtype=torch.float32, device=DEV)   # raw outputs: fp32
     xd = nhwc(x, xs)
-    K.enet_conv(xd, wk, bias.to(DEV), tf, y, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1],
-                ws=(kh * kw * cin, cin, 1))
-    close(nchw(y), ref.detach(), torch.float32, "conv fwd", r32=2e-4)
-    gy = q(torch.randn(ref.shape, generator=g), dt)
-    ref.backward(gy)
-    gyd = nhwc(gy, dt)
-    dx = torch.empty(B, H, W, cin, dtype=dt, device=DEV)
-    K.enet_conv(gyd, wk, None, None, dx, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1], transposed=True,
-                ws=(1, cin, kh * kw * cin))
-    close(nchw(dx), xin.grad, dt, "conv dgrad")
-    dw = torch.zeros(cout * kh * kw * cin, device=DEV)
-    K.enet_wgrad(gyd, None, xd, tf, dw, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1])
-    K.enet_wgrad(gyd, None, xd, tf, dw, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1])   # "+=" twice
-    close(dw.view(cout, kh, kw, cin).permute(0, 3, 1, 2).cpu(), 2 * wr.grad, torch.float32, "conv wgrad", r32=5e-4)
-    db = torch.zeros(cout, device=DEV)
-    K.enet_channel_sum(gyd, db)
-    close(db.cpu(), gy.sum((0, 2, 3)), torch.float32, "bias grad", r32=1e-4)
+    set_mfma(mfma)
+    try:
+        K.enet_conv(xd, wk, bias.to(DEV), tf, y, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1],
+                    ws=(kh * kw * cin, cin, 1), compute=dt)
+        close(nchw(y), ref, torch.float32, "conv fwd", r32=2e-4)
+        gy = q(torch.randn(ref.shape, generator=g), dt)
+        xr = xin.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        gx_ref, = torch.autograd.grad(conv(xr, q(w, bq)), xr, gy)
+        gw_ref, = torch.autograd.grad(conv(q(xin, wq), wr), wr, gy)
+        gyd = nhwc(gy, dt)
+        dx = torch.empty(B, H, W, cin, dtype=dt, device=DEV)
+        K.enet_conv(gyd, wk, None, None, dx, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1], transposed=True,
+                    ws=(1, cin, kh * kw * cin))
+        close(nchw(dx), gx_ref, dt, "conv dgrad")
+        dx32 = torch.empty(B, H, W, cin, dtype=torch.float32, device=DEV)       # fp32 destination: the rounding is the operands' only
+        K.enet_conv(gyd, wk, None, None, dx32, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1], transposed=True,
+                    ws=(1, cin, kh * kw * cin))
+        close(nchw(dx32), gx_ref, torch.float32, "conv dgrad (fp32 out)", r32=2e-4)
+        dw = torch.zeros(cout * kh * kw * cin, device=DEV)
+        K.enet_wgrad(gyd, None, xd, tf, dw, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1])
+        K.enet_wgrad(gyd, None, xd, tf, dw, R=kh, S=kw, stride=stride, dil=dil, pad_h=pad[0], pad_w=pad[1])   # "+=" twice
+        close(dw.view(cout, kh, kw, cin).permute(0, 3, 1, 2).cpu(), 2 * gw_ref, torch.float32, "conv wgrad", r32=5e-4)
+        db = torch.zeros(cout, device=DEV)
+        K.enet_channel_sum(gyd, db)
+        close(db.cpu(), gy.sum((0, 2, 3)), torch.float32, "bias grad", r32=1e-4)
+    finally:
+        set_mfma(3)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cin,cout,k,pad,opad,in_f32", [(16, 16, 3, 1, 1, True), (3, 3, 3, 1, 1, True), (14, 4, 2, 0, 0, False)])
+@pytest.mark.parametrize("cin,cout,k,pad,opad,in_f32", [(16, 16, 3, 1, 1, True), (32, 16, 3, 1, 1, False), (3, 3, 3, 1, 1, True), (14, 4, 2, 0, 0, False)])
 def test_enet_convT(K, dt, cin, cout, k, pad, opad, in_f32):
     g = torch.Generator().manual_seed(2)
     B, H, W = 2, 9, 7
@@ -110,21 +141,25 @@ def test_enet_convT(K, dt, cin, cout, k, pad, opad, in_f32):
     x = q(torch.randn(B, cin, H, W, generator=g), xs).requires_grad_(True)
     w = (torch.randn(cin, cout, k, k, generator=g) / math.sqrt(cin * k * k)).requires_grad_(True)
     bias = torch.randn(cout, generator=g)
-    ref = F.conv_transpose2d(x, w, bias, stride=2, padding=pad, output_padding=opad)
+    fq = dt if mfma_form(dt, cin, cout, k * k) else torch.float32
+    bq = dt if mfma_form(dt, cout, cin, k * k) else torch.float32
+    ref = F.conv_transpose2d(q(x.detach(), fq), q(w.detach(), fq), bias, stride=2, padding=pad, output_padding=opad)
     wk = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV)     # [ci][kh][kw][co]
     y = torch.empty(B, ref.shape[2], ref.shape[3], cout, dtype=torch.float32, device=DEV)
     xd = nhwc(x.detach(), xs)
-    K.enet_conv(xd, wk, bias.to(DEV), None, y, R=k, S=k, stride=2, pad_h=pad, pad_w=pad, transposed=True, ws=(1, cout, k * k * cout))
+    K.enet_conv(xd, wk, bias.to(DEV), None, y, R=k, S=k, stride=2, pad_h=pad, pad_w=pad, transposed=True, ws=(1, cout, k * k * cout), compute=dt)
     close(nchw(y), ref.detach(), torch.float32, "convT fwd", r32=2e-4)
     gy = q(torch.randn(ref.shape, generator=g), dt)
-    ref.backward(gy)
+    convT = lambda a, b: F.conv_transpose2d(a, b, None, stride=2, padding=pad, output_padding=opad)
+    gx_ref, = torch.autograd.grad(convT(x, q(w.detach(), bq)), x, gy)
+    gw_ref, = torch.autograd.grad(convT(q(x.detach(), dt), w), w, gy)       # the MFMA weight gradient rounds the layer input too
     gyd = nhwc(gy, dt)
     dx = torch.empty(B, H, W, cin, dtype=dt, device=DEV)
     K.enet_conv(gyd, wk, None, None, dx, R=k, S=k, stride=2, pad_h=pad, pad_w=pad, ws=(k * k * cout, cout, 1))
-    close(nchw(dx), x.grad, dt, "convT dgrad")
+    close(nchw(dx), gx_ref, dt, "convT dgrad")
     dw = torch.zeros(cin * k * k * cout, device=DEV)
     K.enet_wgrad(xd, None, gyd, None, dw, R=k, S=k, stride=2, pad_h=pad, pad_w=pad)
-    close(dw.view(cin, k, k, cout).permute(0, 3, 1, 2).cpu(), w.grad, torch.float32, "convT wgrad", r32=5e-4)
+    close(dw.view(cin, k, k, cout).permute(0, 3, 1, 2).cpu(), gw_ref, torch.float32, "convT wgrad", r32=5e-4)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
