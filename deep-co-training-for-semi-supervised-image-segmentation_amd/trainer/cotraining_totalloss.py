@@ -35,6 +35,7 @@ from ..metrics import AverageValueMeter, DiceMeter
 from ..models import Segmentator
 from ..utils import iterator_, map_, dict_merge, tqdm_
 from ..utils.AEGenerator import FSGMGenerator
+from .stream_sched import EagerSchedule, StreamDealer
 from .trainer import Trainer
 
 
@@ -45,11 +46,11 @@ _STREAM_POOL = {}
 POOL_STREAMS = os.environ.get("DCT_POOL_STREAMS", "0") == "1"
 
 
-def _pooled_stream(device, *key):
+def _pooled_stream(device, *key, dealer=None):
     k = (str(device),) + key
     st = _STREAM_POOL.get(k) if POOL_STREAMS else None
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        st = dealer.take() if dealer is not None else torch.cuda.Stream(device=device)
         if POOL_STREAMS:
             _STREAM_POOL[k] = st
     return st
@@ -139,11 +140,19 @@ class CoTrainer(Trainer):
         self.batch_lab_unlab = True         # one B_l+B_u pass per batch-independent net (see _run_step_fused)
         self.model_streams = True           # one HIP stream per model in the fused step (see _streams)
         self._stream_pool = None
+        self._sched = EagerSchedule()       # stream operations of the fused step: eager, or recorded (trainer/stream_sched.py)
+        self.spread_streams = True          # deal the model / pass streams over different hardware queues (stream_sched.queue_groups)
+        self._dealer = None
         self.pass_streams = True            # nets that support it (Enet): the backward passes of one model run on separate streams
         self._pass_pool = None
         self._pass_bufs = {}
+        self.early_backward = True          # start the labeled / unlabeled backward passes right after the JSD, beside the
+                                            # adversarial block (pass-stream nets; see _run_step_fused)
         self.grad_overwrite = True          # nets that support it: first backward pass of a step writes the gradients (no zero fill)
         self._overwrite_models = set()
+        self._pass_early = {}
+        self.segmented_graphs = True        # capture the step as one graph per stream segment (they then run on different hardware
+                                            # queues) instead of one graph with forked streams inside (one queue): stream_sched.py
         self.use_hip_graph = True           # replay the fused step from a captured HIP graph (trainer/step_graph.py)
         self._step_graphs = None
         self.last_step = None
@@ -242,8 +251,10 @@ class CoTrainer(Trainer):
             # the exchange must overlap the backward) stay eager -- their eager step is within 3 % of the replayed one; networks
             # without (Enet: 1.45 MB per model, ~2500 launches per model-step, host-bound when eager) replay two graphs around
             # one eager all-reduce per model
+            # (with segmented graphs -- trainer/stream_sched.py -- every gradient exchange is a host callback between two graph
+            # segments, so both kinds replay)
             segmented = (self.grad_sync is not None and self.ddp_segmented_graph and
-                         not any(hasattr(s.torchnet, "grad_bucket_ranges") for s in self.segmentators))
+                         (self.segmented_graphs or not any(hasattr(s.torchnet, "grad_bucket_ranges") for s in self.segmentators)))
             if self.use_hip_graph and graphable and (self.grad_sync is None or segmented) and \
                     all(s.torchnet.training for s in self.segmentators):
                 if self._step_graphs is None:
@@ -266,8 +277,15 @@ class CoTrainer(Trainer):
         if not self.model_streams or self.device.type != 'cuda' or len(self.segmentators) < 2:
             return None
         if self._stream_pool is None or len(self._stream_pool) != len(self.segmentators):
-            self._stream_pool = [_pooled_stream(self.device, "model", i) for i in range(len(self.segmentators))]
+            self._stream_pool = [_pooled_stream(self.device, "model", i, dealer=self._stream_dealer()) for i in range(len(self.segmentators))]
         return self._stream_pool
+
+    def _stream_dealer(self):
+        if not self.spread_streams or self.device.type != 'cuda':
+            return None
+        if self._dealer is None:
+            self._dealer = StreamDealer(self.device)
+        return self._dealer
 
     def _pass_parallel_ok(self, net, model_passes, streams) -> bool:
         return bool(self.pass_streams and streams is not None and 1 < len(model_passes) <= 3 and
@@ -278,8 +296,31 @@ class CoTrainer(Trainer):
             self._pass_pool = {}
         pool = self._pass_pool.setdefault(i, [])
         while len(pool) < n:
-            pool.append(_pooled_stream(self.device, "pass", i, len(pool)))
+            pool.append(_pooled_stream(self.device, "pass", i, len(pool), dealer=self._stream_dealer()))
         return pool[:n]
+
+    def _pass_buffer(self, i, k, fp):
+        """Flat gradient buffer of backward pass k of model i (eager steps reuse it; a capture takes it from the graph's pool)."""
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (i, k, fp.total, str(self.device))
+        buf = None if capturing else self._pass_bufs.get(key)
+        if buf is None:
+            buf = torch.empty(fp.total, dtype=torch.float32, device=self.device)
+            if not capturing:
+                self._pass_bufs[key] = buf
+        return buf
+
+    def _start_passes(self, i, net, model_passes, side_streams, bufs):
+        """Queue backward passes of model i on ``side_streams`` (which already wait for the passes' inputs), each into its own
+        gradient buffer appended to ``bufs``.  -> (flat parameters, bufs)."""
+        fp = net.flat_params
+        for (tape, dl), st in zip(model_passes, side_streams):
+            buf = self._pass_buffer(i, len(bufs), fp)
+            bufs.append(buf)
+            with self._sched.on(st):
+                buf.zero_()
+                net.plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=buf)
+        return fp, bufs
 
     def _finish_step(self, backward_calls, streams=None):
         """zero_grad (after the forwards, :245) -> backward (:246-247) -> [gradient all-reduce] -> step (:248).
@@ -287,46 +328,49 @@ class CoTrainer(Trainer):
         model's all-reduce starts as soon as its backward is enqueued and overlaps the next one.
         With ``streams`` model i's zero_grad / backward / all-reduce / Adam are all queued on streams[i]."""
         def on(i):
-            return torch.cuda.stream(streams[i]) if streams is not None and i is not None else contextlib.nullcontext()
+            return self._sched.on(streams[i]) if streams is not None and i is not None else contextlib.nullcontext()
         for i, seg in enumerate(self.segmentators):
             if i in self._overwrite_models:      # the first backward pass of this model writes every gradient element
                 continue
             with on(i):
                 seg.optimizer.zero_grad()
-        self._pass_pending = {}
+        self._pass_pending = dict(getattr(self, "_pass_early", None) or {})      # passes already queued beside the adversarial block
         for idx, call in backward_calls:
             with on(idx):
                 call()
                 if self.grad_sync is not None and idx is not None and idx not in self._pass_pending:
-                    self.grad_sync.begin(idx)
+                    self._sched.call(lambda idx=idx: self.grad_sync.begin(idx))
         if self._pass_pending:
             # some backward passes ran on their own streams into their own gradient buffers: every stream joins the origin
             # stream (never a forked one: see _run_step_fused), the buffers are added there in pass order, and what follows
             # (gradient exchange, optimizers) is queued on the origin stream
             self._pass_join()
             for idx, (flat, bufs) in sorted(self._pass_pending.items()):
-                torch.add(bufs[0], bufs[1], out=flat.gflat)
+                if len(bufs) == 1:
+                    flat.gflat.copy_(bufs[0])
+                else:
+                    torch.add(bufs[0], bufs[1], out=flat.gflat)
                 for buf in bufs[2:]:
                     flat.gflat.add_(buf)
                 if self.grad_sync is not None:
-                    self.grad_sync.begin(idx)
+                    self._sched.call(lambda idx=idx: self.grad_sync.begin(idx))
             streams = None
             self._pass_pending = {}
         if self._defer_optimizer:
             return
         if self.grad_sync is not None and any(idx is None for idx, _ in backward_calls):
-            self.grad_sync.all_reduce()
+            self._sched.call(lambda: self.grad_sync.all_reduce())
         self._optimizer_phase(streams)
 
     def _optimizer_phase(self, streams=None):
         """[wait for model i's gradient exchange] -> optimizer step (:248), per model on its stream."""
         def on(i):
-            return torch.cuda.stream(streams[i]) if streams is not None else contextlib.nullcontext()
+            return self._sched.on(streams[i]) if streams is not None else contextlib.nullcontext()
         unscale = getattr(self, "_grad_unscale", 1.0)
         for i, seg in enumerate(self.segmentators):
             with on(i):
                 if self.grad_sync is not None:
-                    self.grad_sync.finish(i)     # model i's all-reduce only: later ones overlap this Adam launch
+                    self._sched.call(lambda i=i: self.grad_sync.finish(i))     # model i's all-reduce only: later ones overlap this Adam launch
                 if hasattr(seg.optimizer, "grad_scale"):
                     seg.optimizer.grad_scale = unscale          # fused Adam: folded into the update
                 elif unscale != 1.0:
@@ -393,7 +437,7 @@ class CoTrainer(Trainer):
         main = torch.cuda.current_stream(self.device)
 
         def on(i):
-            return torch.cuda.stream(streams[i]) if streams is not None else contextlib.nullcontext()
+            return self._sched.on(streams[i]) if streams is not None else contextlib.nullcontext()
 
         # backward-pass streams (two per model that supports them): like the model streams they enter a capture only through a
         # wait on the origin stream -- a fork nested inside a forked stream crashes hipStreamEndCapture on ROCm 7.2 -- so they
@@ -406,13 +450,11 @@ class CoTrainer(Trainer):
 
         def fork():
             if streams is not None:
-                for st in list(streams) + side:
-                    st.wait_stream(main)
+                self._sched.wait([(st, main) for st in list(streams) + side])
 
         def join():
             if streams is not None:
-                for st in list(streams) + side:
-                    main.wait_stream(st)
+                self._sched.wait([(main, st) for st in list(streams) + side])
         fork()
         joined_after_forwards = False       # becomes True at the JSD join: labeled / unlabeled pass inputs are then final on main
         self._pass_join = join
@@ -464,6 +506,16 @@ class CoTrainer(Trainer):
             fork()
         for i, f in enumerate(full):
             passes[i].append((f[0], f[2]))
+        # Early backward.  After the JSD the labeled and unlabeled logit gradients are final, and the adversarial block that
+        # follows is one dependent chain (FGSM forward + input gradient on model b, then model a's forward on the perturbed
+        # batch) that leaves every other hardware queue idle.  Nets whose passes write their own gradient buffers (pass
+        # streams) start those two backward passes now, on their pass streams; the adversarial pass joins them later on the
+        # model's stream.  Nothing the adversarial block writes is read by them (weights are constant until the optimizers,
+        # saved tensors and BatchNorm batch statistics are per pass, running statistics are only touched by forwards).  The
+        # sum order of the pass buffers, ((lab + unl) + adv), is unchanged.  The tapes stay referenced until the step ends:
+        # they were allocated on the model's stream, which keeps allocating while the pass streams still read them.
+        self._pass_early = {}
+        keep_alive = []
         adv = 0
         if train_adv:                                                          # :233-244 -> :371-392
             a, b = adv_choice
@@ -472,8 +524,19 @@ class CoTrainer(Trainer):
             with on(b):
                 x = torch.cat((img_b, unl[0]), dim=0)
                 x_adv, noise, lp_real = self._fgsm_fused(nets[b], x, gt_b, eps, ignore)
-            if streams is not None and a != b:
-                streams[a].wait_stream(streams[b])  # the adversarial images and the detached target come from model b
+            # (queued after the FGSM chain and its completion mark, and before model a's wait for that mark: streams that share
+            # a hardware queue run in issue order -- the critical chain goes first, its mark must not land behind another
+            # stream's segment, and nothing may be parked behind model a's blocked wait)
+            fgsm_done = self._sched.record(streams[b]) if streams is not None and a != b else None
+            if train_adv and self.early_backward and joined_after_forwards and streams is not None and self.pass_streams:
+                for i in range(S):
+                    if (1 <= len(passes[i]) <= 2 and getattr(nets[i], "supports_pass_streams", False) and
+                            nets[i].flat_params.grads_attached() and (self.grad_sync is None or not hasattr(nets[i], "grad_bucket_ranges"))):
+                        self._pass_early[i] = self._start_passes(i, nets[i], passes[i], self._pass_streams_for(i, 2), [])
+                        keep_alive.append(list(passes[i]))
+                        passes[i].clear()
+            if fgsm_done is not None:
+                self._sched.wait_event(streams[a], fgsm_done)  # the adversarial images and the detached target come from model b
             with on(a):
                 lp_adv, tape = nets[a].plan_forward(x_adv, True)
                 adv = K.kl_logits_fwd(lp_adv, lp_real, C)[0]
@@ -489,40 +552,34 @@ class CoTrainer(Trainer):
             in-place accumulation of sequential passes produces."""
             net, fp = nets[i], nets[i].flat_params
             cur = torch.cuda.current_stream(self.device)
-            extra = self._pass_streams_for(i, 2)
-            capturing = torch.cuda.is_current_stream_capturing()
-            bufs = []
-            last = len(passes[i]) - 1
-            for k, (tape, dl) in enumerate(passes[i]):
-                key = (i, k, fp.total, str(self.device))
-                buf = None if capturing else self._pass_bufs.get(key)
-                if buf is None:
-                    buf = torch.empty(fp.total, dtype=torch.float32, device=self.device)
-                    if not capturing:
-                        self._pass_bufs[key] = buf
+            started = self._pass_early.get(i)
+            bufs = list(started[1]) if started is not None else []
+            extra = self._pass_streams_for(i, 2)[len(bufs):]
+            side_passes, last = (passes[i][:-1], passes[i][-1]) if passes[i] else ([], None)
+            if side_passes:
+                if not joined_after_forwards:      # the passes' inputs were produced on the model stream after the last fork
+                    self._sched.wait([(extra[k], cur) for k in range(len(side_passes))])
+                _, bufs = self._start_passes(i, net, side_passes, extra, bufs)
+            if last is not None:
+                buf = self._pass_buffer(i, len(bufs), fp)
                 bufs.append(buf)
-                if k == last:
-                    buf.zero_()
-                    net.plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=buf)
-                    break
-                if not joined_after_forwards:      # the pass's inputs were produced on the model stream after the last fork
-                    extra[k].wait_stream(cur)
-                with torch.cuda.stream(extra[k]):
-                    buf.zero_()
-                    net.plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=buf)
+                buf.zero_()
+                net.plan_backward(last[0], last[1], need_dx=False, need_dw=True, grad_buffer=buf)
             self._pass_pending[i] = (fp, bufs)
             passes[i].clear()
 
         def backward_of(i):
             def run():
-                if self._pass_parallel_ok(nets[i], passes[i], streams) and nets[i].flat_params.grads_attached():
+                if i in self._pass_early or (self._pass_parallel_ok(nets[i], passes[i], streams) and
+                                             nets[i].flat_params.grads_attached()):
                     return pass_parallel(i)
                 # data parallelism: during the LAST backward pass of a model its gradient buckets go out as they
                 # complete (earlier passes only accumulate)
                 ranges = nets[i].grad_bucket_ranges() if (self.grad_sync is not None and hasattr(nets[i], "grad_bucket_ranges")) else None
                 for k, (tape, dl) in enumerate(passes[i]):
                     if ranges is not None and k == len(passes[i]) - 1:
-                        nets[i]._grad_hook = lambda b, i=i, r=ranges: self.grad_sync.begin_bucket(i, r[b][0], r[b][1])
+                        nets[i]._grad_hook = lambda b, i=i, r=ranges: self._sched.call(
+                            lambda: self.grad_sync.begin_bucket(i, r[b][0], r[b][1]))
                     try:
                         if i in self._overwrite_models:
                             nets[i].plan_backward(tape, dl, need_dx=False, need_dw=True, overwrite=(k == 0))
@@ -540,12 +597,15 @@ class CoTrainer(Trainer):
         # (pass-parallel models write the whole gradient buffer as the sum of their pass buffers: no zero fill either)
         self._overwrite_models |= {i for i in range(S) if self._pass_parallel_ok(nets[i], passes[i], streams) and
                                    nets[i].flat_params.grads_attached()}
+        self._overwrite_models |= set(self._pass_early)
         try:
             self._finish_step([(i, backward_of(i)) for i in range(S)], streams)
         finally:
             self._overwrite_models = set()
+            self._pass_early = {}
             self._pass_join = None          # (a closure over this step's tapes and streams: not kept past the step)
         join()
+        del keep_alive
         return dict(sup=sup, jsd=jsd, adv=adv, preds=preds, unlab_probs=unlab_probs)
 
     def _fgsm_fused(self, net, x, gt, eps, ignore):

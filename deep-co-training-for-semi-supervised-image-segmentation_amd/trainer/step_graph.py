@@ -32,7 +32,7 @@ import torch
 
 
 class _Captured(object):
-    __slots__ = ("graph", "graph_opt", "lab", "unl", "out", "counters")
+    __slots__ = ("graph", "graph_opt", "program", "lab", "unl", "out", "counters")
 
 
 class StepGraphCache(object):
@@ -52,7 +52,8 @@ class StepGraphCache(object):
     def _signature(self, lab, unl, train_jsd, train_adv, adv_choice, lam) -> tuple:
         tr = self.tr
         sig: List = [bool(train_jsd), bool(train_adv), tuple(adv_choice) if adv_choice is not None else None,
-                     lam[0] != 0.0, lam[1] != 0.0, bool(tr.model_streams), bool(tr.batch_lab_unlab), tr.grad_sync is not None]
+                     lam[0] != 0.0, lam[1] != 0.0, bool(tr.model_streams), bool(tr.batch_lab_unlab), tr.grad_sync is not None,
+                     bool(tr.segmented_graphs), bool(tr.pass_streams)]
         for img, gt in lab:
             sig.append((tuple(img.shape), img.dtype, tuple(gt.shape), gt.dtype))
         if unl is not None:
@@ -113,7 +114,10 @@ class StepGraphCache(object):
             s_gt.copy_(gt, non_blocking=True)
         if cap.unl is not None:
             cap.unl[0].copy_(unl[0], non_blocking=True)
-        cap.graph.replay()
+        if cap.program is not None:            # one graph per stream segment, launched on the segments' own streams
+            cap.program.replay()
+        else:
+            cap.graph.replay()
         if cap.graph_opt is not None:          # data parallelism: exchange the gradients between the two graphs
             for i in range(len(tr.segmentators)):
                 tr.grad_sync.begin(i)
@@ -145,6 +149,7 @@ class StepGraphCache(object):
         graph = torch.cuda.CUDAGraph()
         sync = tr.grad_sync
         cap.graph_opt = None
+        cap.program = None
         # no garbage collection while a capture is open: a collected object of an earlier trainer (streams, events, graphs)
         # would be destroyed with HIP calls that are not permitted during capture
         import gc
@@ -152,7 +157,21 @@ class StepGraphCache(object):
         gc.collect()
         gc.disable()
         try:
-            if sync is None:
+            if tr.segmented_graphs:
+                from .stream_sched import EagerSchedule, SegmentRecorder
+                rec = SegmentRecorder(tr.device)
+                tr._sched = rec
+                try:
+                    rec.start()
+                    cap.out = tr._run_step_fused(cap.lab, cap.unl, train_jsd, train_adv, adv_choice, lam_dev=lam_dev)
+                    cap.program = rec.finish()
+                except BaseException:
+                    rec.abort()
+                    raise
+                finally:
+                    tr._sched = EagerSchedule()
+                graph = None
+            elif sync is None:
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     cap.out = tr._run_step_fused(cap.lab, cap.unl, train_jsd, train_adv, adv_choice, lam_dev=lam_dev)
             else:

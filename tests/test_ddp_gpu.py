@@ -126,7 +126,8 @@ def _enet_worker(rank, world, port, out, compress, graph):
     g = tr._step_graphs
     w = [torch.cat([p.detach().flatten() for p in s.torchnet.parameters()]).cpu() for s in tr.segmentators]
     torch.save(dict(w=w, sups=sups, captures=0 if g is None else g.captures, replays=0 if g is None else g.replays,
-                    two_graphs=g is not None and all(c.graph_opt is not None for c in g._graphs.values()),
+                    two_graphs=g is not None and all((c.graph_opt is not None) or (c.program is not None and any(o[0] == 'call' for o in c.program.ops))
+                                                      for c in g._graphs.values()),   # the exchange sits BETWEEN captured graphs
                     exposed=tr.grad_sync.exposed_ms(), bytes=tr.grad_sync.exchanged_bytes,
                     steps=[s.optimizer._steps for s in tr.segmentators]), os.path.join(out, f"w{rank}.pt"))
     dist.barrier()
