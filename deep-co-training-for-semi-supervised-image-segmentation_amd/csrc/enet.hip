@@ -20,6 +20,9 @@ int g_enet_reduce_ppt = 8;           // pixels per thread of a per-channel reduc
 int g_enet_fold_threads = 1024;      // threads of the one-block finalize kernels (DCT_TUNE_ENET_FOLD_THREADS: 256 | 512 | 1024)
 int g_enet_mfma = 3;                 // bf16 / f16 mode: bit 0 = MFMA form of the convolutions with >= 16 input channels, bit 1 = of the
                                      // weight gradients (0: the fp32 VALU kernels)
+int g_enet_bn_owner = 0;             // small tensors: one-launch channel-owner BatchNorm statistics / backward (0: split reduction).
+                                     // Measured SLOWER (8 x 25 x 25 x 32 backward: 60 us against 14 us for the three split launches --
+                                     // C / 8 blocks cannot pull the tensor through 4-16 CUs fast enough): kept for A/B only
 int g_enet_reduce_vec = 1;           // 8-channel vector loads in the per-channel reductions (0: scalar kernel everywhere)
 int g_enet_wgrad_slices = 1;          // 0: one pixel slice per round whatever the tile count
 int g_enet_wgrad_max_blocks = 1024;   // dct_tune_set(DCT_TUNE_ENET_WGRAD_BLOCKS, n); <= WG_MAX_BLOCKS
@@ -213,128 +216,210 @@ template <> struct LowMfma<float> {      // never launched (fp32 mode stays on t
   __device__ static __forceinline__ f32x16 run(frag, frag, f32x16 c) { return c; }
 };
 
-template <typename T, int NT>
-__global__ __launch_bounds__(64) void enet_mconv_kernel(ConvP p, int ngroups) {
+// Straight-line loads.  These kernels are a chain of dependent memory round trips (~1 us each on this chip), so what matters is
+// how many loads are in flight per trip: the storage type of every view is a template flag (a run-time `f32 ? a : b` per
+// load is a branch per load), out-of-range taps load element 0 and are zeroed afterwards, and the K loop is unrolled by U
+// steps whose loads are all issued before the first MFMA.
+template <typename T, bool F32> __device__ __forceinline__ float ld1(const void* ptr, long long off) {
+  if constexpr (F32 || sizeof(T) == 4) return reinterpret_cast<const float*>(ptr)[off];
+  else return to_f32(reinterpret_cast<const T*>(ptr)[off]);
+}
+template <typename T, bool F32> __device__ __forceinline__ void ld8t(const void* ptr, long long off, float o[8]) {
+  if constexpr (F32 || sizeof(T) == 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(ptr) + off);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(ptr) + off + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+  } else {
+    typedef typename vec8_of<T>::type V8;
+    const V8 a = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(ptr) + off);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)a[i];
+  }
+}
+__device__ __forceinline__ void pix3u(unsigned pix, int h, int w, int& n, int& y, int& x) {
+  const unsigned row = pix / (unsigned)w;
+  x = (int)(pix - row * (unsigned)w);
+  const unsigned img = row / (unsigned)h;
+  y = (int)(row - img * (unsigned)h);
+  n = (int)img;
+}
+
+// One block = 4 waves on the SAME 32 pixels x 32 NT channels, each wave taking every fourth K-step (a 3x3 on 32 channels is 18
+// steps: <= 5 per wave, all in flight after one or two round trips instead of 18 in sequence); the four partial tiles meet in
+// LDS, are added in wave order, and each wave stores 8 of the 32 pixel rows.  The producer's BatchNorm + activation sits in LDS
+// as (scale, shift, negative-side slope) per input channel -- identity (1, 0, 1) without a transform, slope 0 for ReLU, 1 for the
+// affine form -- so applying it is branch-free.
+constexpr int MC_W = 4;            // waves per block = K-split factor
+constexpr int MC_U = 3;            // K-steps of one wave whose loads are issued together
+
+template <typename T, int NT, bool XF, bool WV>
+__device__ __forceinline__ void mconv_main(const ConvP& p, const float* tfs, int cbase, bool pvalid, int n, int oy, int ox, int r, int h,
+                                           int wave, f32x16 (&acc)[NT]) {
   typedef typename LowMfma<T>::frag frag;
-  const int lane = threadIdx.x;
-  const int r = lane & 31, h = lane >> 5;
   const int Cin = p.x.c, Cout = p.y.c;
-  const long long P = (long long)p.y.n * p.y.h * p.y.w;
-  const int cbase = (int)(blockIdx.x % ngroups) * (32 * NT);             // first output channel of this wave
-  const long long wbase = (long long)(blockIdx.x / ngroups) * 32;        // first output pixel of this wave
-  const long long pix = wbase + r;
+  const int taps = p.R * p.S, nsteps = taps * (Cin >> 4);
+  for (int s0 = wave; s0 < nsteps; s0 += MC_W * MC_U) {
+    float a8[MC_U][8], w8[MC_U][NT][8];
+    bool v[MC_U];
+    int cis[MC_U];
+#pragma unroll
+    for (int u = 0; u < MC_U; ++u) {
+      const int sreal = s0 + MC_W * u;
+      const int sidx = min(sreal, nsteps - 1);
+      const int cblk = sidx / taps, tap = sidx - cblk * taps;
+      const int rr = tap / p.S, ss = tap - rr * p.S;
+      const int ci = cblk * 16 + 8 * h;
+      cis[u] = ci;
+      int iy, ix;
+      bool ok = pvalid && sreal < nsteps;
+      if (p.transposed) {
+        const int ty = oy + p.pad_h - rr * p.dil, tx = ox + p.pad_w - ss * p.dil;
+        ok = ok && ty >= 0 && tx >= 0 && (ty % p.stride) == 0 && (tx % p.stride) == 0;
+        iy = ty / p.stride; ix = tx / p.stride;
+      } else {
+        iy = oy * p.stride - p.pad_h + rr * p.dil; ix = ox * p.stride - p.pad_w + ss * p.dil;
+      }
+      ok = ok && (unsigned)iy < (unsigned)p.x.h && (unsigned)ix < (unsigned)p.x.w;
+      v[u] = ok;
+      ld8t<T, XF>(p.x.ptr, ok ? voff(p.x, n, iy, ix) + ci : 0, a8[u]);
+      const long long wtap = (long long)tap * p.ws_tap + (long long)ci * p.ws_in;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int o = cbase + 32 * j + r;
+        const float* wp = p.w + (o < Cout ? (long long)o * p.ws_out + wtap : (long long)ci * p.ws_in);   // (a column past Cout is never stored)
+        if constexpr (WV) {
+          *reinterpret_cast<f32x4*>(w8[u][j]) = *reinterpret_cast<const f32x4*>(wp);
+          *reinterpret_cast<f32x4*>(w8[u][j] + 4) = *reinterpret_cast<const f32x4*>(wp + 4);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) w8[u][j][k] = wp[(long long)k * p.ws_in];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < MC_U; ++u) {
+      float sc[8], sh[8], sl[8];
+      *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(tfs + cis[u]);
+      *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(tfs + cis[u] + 4);
+      *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(tfs + 128 + cis[u]);
+      *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(tfs + 128 + cis[u] + 4);
+      *reinterpret_cast<f32x4*>(sl) = *reinterpret_cast<const f32x4*>(tfs + 256 + cis[u]);
+      *reinterpret_cast<f32x4*>(sl + 4) = *reinterpret_cast<const f32x4*>(tfs + 256 + cis[u] + 4);
+      frag A;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = fmaf(sc[k], a8[u][k], sh[k]);
+        const float t = z > 0.f ? z : z * sl[k];
+        A[k] = from_f32<T>(v[u] ? t : 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        frag B;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) B[k] = from_f32<T>(w8[u][j][k]);
+        acc[j] = LowMfma<T>::run(A, B, acc[j]);
+      }
+    }
+  }
+}
+
+template <typename T, int NT, bool YF>
+__device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, int cbase, long long wbase, long long P, int r, int h, int wave) {
+  // after the K-split fold this wave owns accumulators e = 4 wave + i, i < 4: pixel rows 8 wave + 4 h + i, channel cbase + 32 j + r
+  const int Cout = p.y.c;
+  float val[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < MC_W; ++w) t += red[((w * NT + j) * 16 + 4 * wave + i) * 64 + 32 * h + r];   // fixed order
+      val[i][j] = t;
+    }
+  long long yo[4], rgo[4], rmo[4];
+  bool pv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long pix = wbase + 8 * wave + 4 * h + i;
+    pv[i] = pix < P;
+    int n, oy, ox;
+    pix3u((unsigned)(pv[i] ? pix : 0), p.y.h, p.y.w, n, oy, ox);
+    yo[i] = voff(p.y, n, oy, ox);
+    rgo[i] = p.has_resid ? voff(p.rg, n, oy, ox) : 0;
+    rmo[i] = p.has_resid ? voff(p.rm, n, oy, ox) : 0;
+  }
+  float add[4][NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int c = cbase + 32 * j + r;
+    const bool cv = c < Cout;
+    const float b = (p.bias && cv) ? p.bias[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = pv[i] && cv;
+      float t = b;
+      if (p.has_resid) {       // (MFMA form: residual gradient and mask are stored as T -- host check)
+        const float m = ld1<T, false>(p.rm.ptr, ok ? rmo[i] + c : 0), g = ld1<T, false>(p.rg.ptr, ok ? rgo[i] + c : 0);
+        t += m > 0.f ? g : 0.f;
+      }
+      if (p.accumulate) t += ld1<T, YF>(p.y.ptr, ok ? yo[i] + c : 0);
+      add[i][j] = t;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int c = cbase + 32 * j + r;
+      if (pv[i] && c < Cout) {
+        const float out = val[i][j] + add[i][j];
+        if constexpr (YF || sizeof(T) == 4) reinterpret_cast<float*>(p.y.ptr)[yo[i] + c] = out;
+        else reinterpret_cast<T*>(p.y.ptr)[yo[i] + c] = from_f32<T>(out);
+      }
+    }
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(64 * MC_W) void enet_mconv_kernel(ConvP p, int ngroups) {
+  __shared__ __attribute__((aligned(16))) float tfs[3 * 128];
+  __shared__ float red[MC_W * NT * 16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  for (int c = threadIdx.x; c < 128; c += 64 * MC_W) {
+    const bool on = p.tf.mode != 0 && c < p.x.c;
+    tfs[c] = on ? p.tf.scale[c] : 1.f;
+    tfs[128 + c] = on ? p.tf.shift[c] : 0.f;
+    tfs[256 + c] = (on && p.tf.mode == 2) ? p.tf.slope[c] : ((on && p.tf.mode == 3) ? 0.f : 1.f);
+  }
+  const long long P = (long long)p.y.n * p.y.h * p.y.w;                  // < 2^31 (host check)
+  const int cbase = (int)(blockIdx.x % ngroups) * (32 * NT);             // first output channel of this block
+  const long long wbase = (long long)(blockIdx.x / ngroups) * 32;        // first output pixel of this block
+  const long long pix = wbase + r;                                       // this lane's A row
   const bool pvalid = pix < P;
   int n = 0, oy = 0, ox = 0;
-  if (pvalid) pix3(pix, p.y.h, p.y.w, n, oy, ox);
+  if (pvalid) pix3u((unsigned)pix, p.y.h, p.y.w, n, oy, ox);
   f32x16 acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-  const int xf = p.fm & 1;
-  const bool wvec = p.wvec != 0;
-  const int mode = p.tf.mode;
-  for (int c0 = 0; c0 < Cin; c0 += 16) {
-    const int ci = c0 + 8 * h;
-    float sc[8], sh[8], sl[8];
-    if (mode != 0) {
-      *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(p.tf.scale + ci);
-      *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(p.tf.scale + ci + 4);
-      *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(p.tf.shift + ci);
-      *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(p.tf.shift + ci + 4);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) sl[k] = mode == 2 ? p.tf.slope[ci + k] : 0.f;      // ReLU = PReLU with slope 0
-    }
-    for (int rr = 0; rr < p.R; ++rr) {
-      int iy;
-      bool vy = pvalid;
-      if (p.transposed) {
-        const int ty = oy + p.pad_h - rr * p.dil;
-        vy = vy && ty >= 0 && (ty % p.stride) == 0;
-        iy = ty / p.stride;
-      } else {
-        iy = oy * p.stride - p.pad_h + rr * p.dil;
-      }
-      vy = vy && (unsigned)iy < (unsigned)p.x.h;
-      for (int ss = 0; ss < p.S; ++ss) {
-        int ix;
-        bool v = vy;
-        if (p.transposed) {
-          const int tx = ox + p.pad_w - ss * p.dil;
-          v = v && tx >= 0 && (tx % p.stride) == 0;
-          ix = tx / p.stride;
-        } else {
-          ix = ox * p.stride - p.pad_w + ss * p.dil;
-        }
-        v = v && (unsigned)ix < (unsigned)p.x.w;
-        float a8[8];
-        if (v) {
-          ld8<T>(p.x, voff(p.x, n, iy, ix) + ci, xf, a8);
-          if (mode != 0) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float z = fmaf(sc[k], a8[k], sh[k]);
-              a8[k] = (mode == 1 || z > 0.f) ? z : z * sl[k];
-            }
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) a8[k] = 0.f;
-        }
-        frag A;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) A[k] = from_f32<T>(a8[k]);
-        const long long wtap = (long long)(rr * p.S + ss) * p.ws_tap + (long long)ci * p.ws_in;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int o = cbase + 32 * j + r;
-          float w8[8];
-          if (o < Cout) {
-            const float* wp = p.w + (long long)o * p.ws_out + wtap;
-            if (wvec) {
-              *reinterpret_cast<f32x4*>(w8) = *reinterpret_cast<const f32x4*>(wp);
-              *reinterpret_cast<f32x4*>(w8 + 4) = *reinterpret_cast<const f32x4*>(wp + 4);
-            } else {
-#pragma unroll
-              for (int k = 0; k < 8; ++k) w8[k] = wp[(long long)k * p.ws_in];
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) w8[k] = 0.f;
-          }
-          frag B;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) B[k] = from_f32<T>(w8[k]);
-          acc[j] = LowMfma<T>::run(A, B, acc[j]);
-        }
-      }
-    }
+  __syncthreads();
+  if (p.fm & 1) {
+    if (p.wvec) mconv_main<T, NT, true, true>(p, tfs, cbase, pvalid, n, oy, ox, r, h, wave, acc);
+    else mconv_main<T, NT, true, false>(p, tfs, cbase, pvalid, n, oy, ox, r, h, wave, acc);
+  } else {
+    if (p.wvec) mconv_main<T, NT, false, true>(p, tfs, cbase, pvalid, n, oy, ox, r, h, wave, acc);
+    else mconv_main<T, NT, false, false>(p, tfs, cbase, pvalid, n, oy, ox, r, h, wave, acc);
   }
-  // epilogue: accumulator e of lane (r, h) is output pixel wbase + (e & 3) + 8 (e >> 2) + 4 h, channel 32 j + r.  The lane that
-  // owns a pixel as its A row has its offsets; they travel by shuffle.
-  const long long yo_mine = pvalid ? voff(p.y, n, oy, ox) : -1;
-  const long long rg_mine = (pvalid && p.has_resid) ? voff(p.rg, n, oy, ox) : 0;
-  const long long rm_mine = (pvalid && p.has_resid) ? voff(p.rm, n, oy, ox) : 0;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int prow = (e & 3) + 8 * (e >> 2) + 4 * h;
-    const long long yo = __shfl(yo_mine, prow, 64);
-    const long long rgo = p.has_resid ? __shfl(rg_mine, prow, 64) : 0;
-    const long long rmo = p.has_resid ? __shfl(rm_mine, prow, 64) : 0;
-    if (yo < 0) continue;
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int c = cbase + 32 * j + r;
-      if (c >= Cout) continue;
-      float val = acc[j][e];
-      if (p.bias) val += p.bias[c];
-      if (p.has_resid) {
-        if (ldv<T>(p.rm, rmo + c, p.fm & 8) > 0.f) val += ldv<T>(p.rg, rgo + c, p.fm & 4);
-      }
-      if (p.accumulate) val += ldv<T>(p.y, yo + c, p.fm & 2);
-      stv<T>(p.y, yo + c, p.fm & 2, val);
-    }
-  }
+    for (int e = 0; e < 16; ++e) red[((wave * NT + j) * 16 + e) * 64 + lane] = acc[j][e];
+  __syncthreads();
+  if (p.fm & 2) mconv_store<T, NT, true>(p, red, cbase, wbase, P, r, h, wave);
+  else mconv_store<T, NT, false>(p, red, cbase, wbase, P, r, h, wave);
 }
 
 // ---- per-channel sums over pixels: partial[blk][c][k], k < NS, double accumulators -------------
@@ -554,6 +639,169 @@ __global__ __launch_bounds__(FT) void enet_sum_finalize_kernel(const double* par
   while (CP < C) CP <<= 1;
   if (c >= C || threadIdx.x >= CP) return;
   out[c] += (float)s[0];
+}
+
+// ---- channel-owner BatchNorm kernels for small tensors -----------------------------------------------
+// Stage-2/3 tensors (8 x 25 x 25 x 32...128, 8 x 50 x 50 x 16...64) hold 0.3 - 2.5 MB: the split reduction above is three
+// dependent launches of ~6-9 us each for a few microseconds of memory traffic, and those launches sit on the step's critical
+// chain (tools/probe_step_program.py).  Here one block OWNS 8 channels for all pixels, so nothing crosses blocks: sums, the
+// per-channel finalize and (backward) the apply pass over the same pixels -- L2-resident by then -- are ONE launch of C / 8
+// blocks x 1024 threads.  Per thread <= 32 pixels in fp32, then doubles through a fixed shuffle tree and a fixed-order fold
+// of the 16 waves.
+constexpr int OWN_T = 1024;
+constexpr long long OWN_MAX_PIXELS = 32768;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// s[k][i]: sum k of owned channel i, valid in every thread after the call
+template <int NS>
+__device__ __forceinline__ void own_fold(const float (&a)[3][8], double (&s)[3][8], double* red /* [16][NS][8] */) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const double w = wave_sum((double)a[k][i]);
+      if (lane == 0) red[(wave * NS + k) * 8 + i] = w;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      double t = 0.0;
+      for (int w = 0; w < OWN_T / 64; ++w) t += red[(w * NS + k) * 8 + i];
+      s[k][i] = t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(OWN_T) void enet_bn_fwd_owner_kernel(RedP p, double count, const float* gamma, const float* beta, float eps,
+                                                                  float momentum, float* running_mean, float* running_var,
+                                                                  float* scale, float* shift, float* save_mean, float* save_invstd) {
+  __shared__ double red[(OWN_T / 64) * 2 * 8];
+  const int c0 = blockIdx.x * 8;
+  const long long P = (long long)p.x.n * p.x.h * p.x.w;
+  float a[3][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[0][i] = a[1][i] = a[2][i] = 0.f;
+  for (long long pix = threadIdx.x; pix < P; pix += OWN_T) {
+    int n, y, x;
+    pix3(pix, p.x.h, p.x.w, n, y, x);
+    float v[8];
+    ld8<T>(p.x, voff(p.x, n, y, x) + c0, p.fm & 1, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[0][i] += v[i]; a[1][i] = fmaf(v[i], v[i], a[1][i]); }
+  }
+  double s[3][8];
+  own_fold<2>(a, s, red);
+  if (threadIdx.x < 8) {
+    const int i = threadIdx.x, c = c0 + i;
+    // (select by constant index: s[][] lives in registers)
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j == i) { s0 = s[0][j]; s1 = s[1][j]; }
+    const double m = s0 / count;
+    double v = s1 / count - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mean = (float)m, var = (float)v;
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(OWN_T) void enet_bn_bwd_owner_kernel(RedP p, double count, int training, float* dgamma, float* dbeta,
+                                                                  float* dslope, float* c1c2, View out) {
+  __shared__ double red[(OWN_T / 64) * 3 * 8];
+  __shared__ float cc[2][8];
+  const int c0 = blockIdx.x * 8, C = p.x.c;
+  const long long P = (long long)p.x.n * p.x.h * p.x.w;
+  float sc[8], sh[8], sl[8], mu[8], is[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = c0 + i;
+    sc[i] = p.scale[c]; sh[i] = p.shift[c]; mu[i] = p.mean[c]; is[i] = p.invstd[c]; sl[i] = p.act == 2 ? p.slope[c] : 0.f;
+  }
+  float a[3][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[0][i] = a[1][i] = a[2][i] = 0.f;
+  for (long long pix = threadIdx.x; pix < P; pix += OWN_T) {
+    int n, y, x;
+    pix3(pix, p.x.h, p.x.w, n, y, x);
+    float v[8], g[8];
+    ld8<T>(p.x, voff(p.x, n, y, x) + c0, p.fm & 1, v);
+    ld8<T>(p.g, voff(p.g, n, y, x) + c0, p.fm & 2, g);
+    if (p.has_mask) {
+      float m[8];
+      ld8<T>(p.m, voff(p.m, n, y, x) + c0, p.fm & 4, m);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (!(m[i] > 0.f)) g[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float z = fmaf(sc[i], v[i], sh[i]);
+      float dz = g[i];
+      if (p.act == 2) { if (!(z > 0.f)) { dz = g[i] * sl[i]; a[2][i] = fmaf(g[i], z, a[2][i]); } }
+      else if (p.act == 3) { if (!(z > 0.f)) dz = 0.f; }
+      const float xh = (v[i] - mu[i]) * is[i];
+      a[0][i] += dz; a[1][i] = fmaf(dz, xh, a[1][i]);
+    }
+  }
+  double s[3][8];
+  own_fold<3>(a, s, red);
+  if (threadIdx.x < 8) {
+    const int i = threadIdx.x, c = c0 + i;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j == i) { s0 = s[0][j]; s1 = s[1][j]; s2 = s[2][j]; }
+    if (dbeta) dbeta[c] += (float)s0;
+    if (dgamma) dgamma[c] += (float)s1;
+    if (dslope) dslope[c] += (float)s2;
+    const float k1 = training ? (float)(s0 / count) : 0.f, k2 = training ? (float)(s1 / count) : 0.f;
+    cc[0][i] = k1; cc[1][i] = k2;
+    c1c2[c] = k1; c1c2[C + c] = k2;
+  }
+  __syncthreads();
+  float k1[8], k2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { k1[i] = cc[0][i]; k2[i] = cc[1][i]; }
+  // apply: draw = scale * (dz - c1 - xhat * c2), same arithmetic as enet_bn_bwd_apply_kernel
+  for (long long pix = threadIdx.x; pix < P; pix += OWN_T) {
+    int n, y, x;
+    pix3(pix, p.x.h, p.x.w, n, y, x);
+    float v[8], g[8];
+    ld8<T>(p.x, voff(p.x, n, y, x) + c0, p.fm & 1, v);
+    ld8<T>(p.g, voff(p.g, n, y, x) + c0, p.fm & 2, g);
+    if (p.has_mask) {
+      float m[8];
+      ld8<T>(p.m, voff(p.m, n, y, x) + c0, p.fm & 4, m);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (!(m[i] > 0.f)) g[i] = 0.f;
+    }
+    const long long oo = voff(out, n, y, x) + c0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float z = fmaf(sc[i], v[i], sh[i]);
+      float dz = g[i];
+      if (p.act == 2) { if (!(z > 0.f)) dz = g[i] * sl[i]; }
+      else if (p.act == 3) { if (!(z > 0.f)) dz = 0.f; }
+      const float xh = (v[i] - mu[i]) * is[i];
+      stv<T>(out, oo + i, p.fm & 8, sc[i] * (dz - k1[i] - xh * k2[i]));
+    }
+  }
 }
 
 // draw = scale * (dz - c1 - xhat * c2)
@@ -815,16 +1063,17 @@ __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, 
 // channel counts and taps need no special case.  The slices are folded in fixed order by enet_wgrad_reduce_kernel as before.
 // The layer input is rounded to the compute dtype exactly as the forward's MFMA form rounds it; the gradient operand is stored
 // in that dtype already.
-template <typename T>
-__global__ __launch_bounds__(64) void enet_mwgrad_kernel(WgP p, float* partial, int E, int pps, int mtiles, int ntiles) {
+template <typename T, bool AF, bool BF>
+__device__ __forceinline__ void mwgrad_body(const WgP& p, float* partial, int E, int pps, int mtiles, int ntiles) {
   typedef typename LowMfma<T>::frag frag;
+  constexpr int U = 4;                                   // MFMA steps (16 pixels each) whose 16 U loads are in flight together
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int Ca = p.a.c, Cb = p.b.c, kb = p.R * p.S * Cb;
-  int u = blockIdx.x;
-  const int nt = u % ntiles; u /= ntiles;
-  const int mt = u % mtiles;
-  const int split = u / mtiles;
-  const long long P = (long long)p.a.n * p.a.h * p.a.w;
+  int u0 = blockIdx.x;
+  const int nt = u0 % ntiles; u0 /= ntiles;
+  const int mt = u0 % mtiles;
+  const int split = u0 / mtiles;
+  const long long P = (long long)p.a.n * p.a.h * p.a.w;  // < 2^31 (host check)
   const long long pbeg = (long long)split * pps, pend = min(P, pbeg + pps);
   const int o = mt * 32 + r;
   const bool ov = o < Ca;
@@ -833,37 +1082,52 @@ __global__ __launch_bounds__(64) void enet_mwgrad_kernel(WgP p, float* partial, 
   const int tap = kv ? k / Cb : 0, c = kv ? k % Cb : 0;
   const int dy = (tap / p.S) * p.dil - p.pad_h, dx = (tap % p.S) * p.dil - p.pad_w;
   const int amode = ov ? p.tfa.mode : 0, bmode = kv ? p.tfb.mode : 0;
-  float asc = 1.f, ash = 0.f, asl = 0.f, bsc = 1.f, bsh = 0.f, bsl = 0.f;
-  if (amode) { asc = p.tfa.scale[o]; ash = p.tfa.shift[o]; asl = amode == 2 ? p.tfa.slope[o] : 0.f; }
-  if (bmode) { bsc = p.tfb.scale[c]; bsh = p.tfb.shift[c]; bsl = bmode == 2 ? p.tfb.slope[c] : 0.f; }
-  const int af = p.fm & 1, bf = p.fm & 2;
+  float asc = 1.f, ash = 0.f, asl = 1.f, bsc = 1.f, bsh = 0.f, bsl = 1.f;      // negative-side slope: PReLU's, 0 for ReLU, 1 = none
+  if (amode) { asc = p.tfa.scale[o]; ash = p.tfa.shift[o]; asl = amode == 2 ? p.tfa.slope[o] : (amode == 3 ? 0.f : 1.f); }
+  if (bmode) { bsc = p.tfb.scale[c]; bsh = p.tfb.shift[c]; bsl = bmode == 2 ? p.tfb.slope[c] : (bmode == 3 ? 0.f : 1.f); }
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  for (long long p0 = pbeg; p0 < pend; p0 += 16) {
-    const long long q = p0 + 8 * h;
-    int n = 0, y = 0, x = 0;
-    if (q < pend) pix3(q, p.a.h, p.a.w, n, y, x);
-    frag A, B;
+  for (long long p0 = pbeg; p0 < pend; p0 += 16 * U) {
+    float av[U][8], bv[U][8];
+    unsigned am = 0, bm = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float av = 0.f, bv = 0.f;
-      if (q + j < pend) {
-        if (ov) {
-          av = ldv<T>(p.a, voff(p.a, n, y, x) + o, af);
-          if (amode) { const float z = fmaf(asc, av, ash); av = (amode == 1 || z > 0.f) ? z : z * asl; }
-        }
+    for (int u = 0; u < U; ++u) {
+      const long long q = p0 + 16 * u + 8 * h;
+      int n, y, x;
+      pix3u((unsigned)min(q, P - 1), p.a.h, p.a.w, n, y, x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool pv = q + j < pend;
+        const bool va = pv && ov;
+        av[u][j] = ld1<T, AF>(p.a.ptr, va ? voff(p.a, n, y, x) + o : 0);
         const int by = y * p.stride + dy, bx = x * p.stride + dx;
-        if (kv && (unsigned)by < (unsigned)p.b.h && (unsigned)bx < (unsigned)p.b.w) {
-          bv = ldv<T>(p.b, voff(p.b, n, by, bx) + c, bf);
-          if (bmode) { const float z = fmaf(bsc, bv, bsh); bv = (bmode == 1 || z > 0.f) ? z : z * bsl; }
-        }
+        const bool vb = pv && kv && (unsigned)by < (unsigned)p.b.h && (unsigned)bx < (unsigned)p.b.w;
+        bv[u][j] = ld1<T, BF>(p.b.ptr, vb ? voff(p.b, n, by, bx) + c : 0);
+        am |= (unsigned)va << (u * 8 + j);
+        bm |= (unsigned)vb << (u * 8 + j);
+        ++x;
+        const bool wx = x == p.a.w;
+        x = wx ? 0 : x;
+        y += wx ? 1 : 0;
+        const bool wy = y == p.a.h;
+        y = wy ? 0 : y;
+        n += wy ? 1 : 0;
       }
-      A[j] = from_f32<T>(av);
-      B[j] = from_f32<T>(bv);
-      if (++x == p.a.w) { x = 0; if (++y == p.a.h) { y = 0; ++n; } }
     }
-    acc = LowMfma<T>::run(A, B, acc);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      frag A, B;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = av[u][j], b = bv[u][j];
+        { const float z = fmaf(asc, a, ash); a = z > 0.f ? z : z * asl; }      // identity (1, 0, 1) without a transform
+        { const float z = fmaf(bsc, b, bsh); b = z > 0.f ? z : z * bsl; }
+        A[j] = from_f32<T>(((am >> (u * 8 + j)) & 1u) ? a : 0.f);
+        B[j] = from_f32<T>(((bm >> (u * 8 + j)) & 1u) ? b : 0.f);
+      }
+      acc = LowMfma<T>::run(A, B, acc);
+    }
   }
   if (kv) {
 #pragma unroll
@@ -871,6 +1135,17 @@ __global__ __launch_bounds__(64) void enet_mwgrad_kernel(WgP p, float* partial, 
       const int oo = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
       if (oo < Ca) partial[(long long)split * E + (long long)oo * kb + k] = acc[e];
     }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void enet_mwgrad_kernel(WgP p, float* partial, int E, int pps, int mtiles, int ntiles) {
+  if (p.fm & 1) {
+    if (p.fm & 2) mwgrad_body<T, true, true>(p, partial, E, pps, mtiles, ntiles);
+    else mwgrad_body<T, true, false>(p, partial, E, pps, mtiles, ntiles);
+  } else {
+    if (p.fm & 2) mwgrad_body<T, false, true>(p, partial, E, pps, mtiles, ntiles);
+    else mwgrad_body<T, false, false>(p, partial, E, pps, mtiles, ntiles);
   }
 }
 
@@ -940,7 +1215,8 @@ extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bia
     p.vec = (x->c % 8 == 0 && x->sw % 8 == 0 && x->sh % 8 == 0 && x->sn % 8 == 0 && ((uintptr_t)x->ptr % (8 * xbytes)) == 0) ? 1 : 0;
   }
   hipStream_t st0 = (hipStream_t)stream;
-  if ((g_enet_mfma & 1) && dtype != DCT_F32 && p.vec && x->c >= 16 && x->c % 8 == 0 && (d->R * d->S * x->c) % 16 == 0 && y->c <= 128 &&
+  if ((g_enet_mfma & 1) && dtype != DCT_F32 && p.vec && x->c >= 16 && x->c % 16 == 0 && y->c <= 128 && (long long)y->n * y->h * y->w < 0x7fffffffLL &&
+      (!tf || tf->mode != 2 || tf->slope) && (!resid_grad || (f32_mask & 12) == 0) &&
       (!tf || !tf->mode || (((uintptr_t)tf->scale | (uintptr_t)tf->shift) % 16 == 0))) {
     p.wvec = (ws_in == 1 && (uintptr_t)w % 16 == 0 && ws_out % 4 == 0 && ws_tap % 4 == 0) ? 1 : 0;
     // one wave (= one 64-thread block) per 32 pixels x 32 NT channels; NT > 1 only where the pixel tiles alone fill the chip
@@ -953,9 +1229,9 @@ extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bia
     const int ngroups = (ntiles + nt - 1) / nt;
     if (ptiles * ngroups > 0x7fffffffLL) return DCT_ERR_UNSUPPORTED;
     const unsigned gridm = (unsigned)(ptiles * ngroups);
-    if (nt == 1) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 1>), dim3(gridm), dim3(64), 0, st0, p, ngroups));
-    else if (nt == 2) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 2>), dim3(gridm), dim3(64), 0, st0, p, ngroups));
-    else ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 4>), dim3(gridm), dim3(64), 0, st0, p, ngroups));
+    if (nt == 1) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 1>), dim3(gridm), dim3(64 * MC_W), 0, st0, p, ngroups));
+    else if (nt == 2) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 2>), dim3(gridm), dim3(64 * MC_W), 0, st0, p, ngroups));
+    else ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 4>), dim3(gridm), dim3(64 * MC_W), 0, st0, p, ngroups));
     return dct_check_launch();
   }
   const size_t lds = (size_t)d->R * d->S * x->c * Gp * 8 * sizeof(float);
@@ -969,6 +1245,21 @@ extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bia
 
 extern "C" size_t dct_enet_reduce_workspace_bytes(int channels) {
   return (size_t)256 * (channels > 0 ? channels : 1) * 3 * sizeof(double);
+}
+
+// channel-owner form: whole 8-channel groups, vector-loadable views, few enough pixels for one block per group
+static bool enet_owner_ok(const RedP& p, int dtype, const View* out) {
+  if (!g_enet_bn_owner) return false;
+  const long long P = (long long)p.x.n * p.x.h * p.x.w;
+  if (P > OWN_MAX_PIXELS || p.x.c % 8 != 0 || p.x.c < 8) return false;
+  auto v8 = [&](const View& v, int f32) {
+    const int esz = (f32 || dtype == DCT_F32) ? 4 : 2;
+    return v.c % 8 == 0 && v.sw % 8 == 0 && v.sh % 8 == 0 && v.sn % 8 == 0 && ((uintptr_t)v.ptr % (8 * esz)) == 0;
+  };
+  if (!v8(p.x, p.fm & 1)) return false;
+  if (p.kind == 1 && (!v8(p.g, p.fm & 2) || (p.has_mask && !v8(p.m, p.fm & 4)))) return false;
+  (void)out;
+  return true;
 }
 
 static int enet_reduce_launch(const RedP& p0, int dtype, void* workspace, size_t workspace_bytes, hipStream_t st, int& blocks_out) {
@@ -1008,6 +1299,12 @@ extern "C" int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, co
     RedP p; p.x = to_view(raw); p.g = p.x; p.m = p.x;
     p.scale = p.shift = p.slope = p.mean = p.invstd = nullptr;
     p.act = 0; p.has_mask = 0; p.kind = 0; p.ppb = 0; p.fm = f32_mask & 1;
+    if (enet_owner_ok(p, dtype, nullptr)) {
+      const double cnt = (double)raw->n * raw->h * raw->w;
+      ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_fwd_owner_kernel<T>, dim3(raw->c / 8), dim3(OWN_T), 0, st, p, cnt, gamma, beta, eps,
+                               momentum, running_mean, running_var, scale, shift, save_mean, save_invstd));
+      return dct_check_launch();
+    }
     const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
     if (rc != DCT_OK) return rc;
   }
@@ -1033,6 +1330,17 @@ extern "C" int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct
   p.act = act; p.kind = 1; p.ppb = 0; p.fm = f32_mask;
   hipStream_t st = (hipStream_t)stream;
   int blocks = 0;
+  {
+    const View vo0 = to_view(draw);
+    const int oesz = ((f32_mask & 8) || dtype == DCT_F32) ? 4 : 2;
+    if (enet_owner_ok(p, dtype, &vo0) && vo0.c == p.x.c && vo0.n == p.x.n && vo0.h == p.x.h && vo0.w == p.x.w &&
+        ((uintptr_t)vo0.ptr % oesz) == 0) {
+      const double cnt = (double)raw->n * raw->h * raw->w;
+      ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_owner_kernel<T>, dim3(raw->c / 8), dim3(OWN_T), 0, st, p, cnt, training ? 1 : 0,
+                               dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, vo0));
+      return dct_check_launch();
+    }
+  }
   const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
   if (rc != DCT_OK) return rc;
   const double count = (double)raw->n * raw->h * raw->w;
@@ -1117,6 +1425,8 @@ extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const d
     long long sps = (steps + ks - 1) / ks;
     if (sps < 4) sps = 4;
     if ((steps + sps - 1) / sps > WG_MAX_BLOCKS) sps = (steps + WG_MAX_BLOCKS - 1) / WG_MAX_BLOCKS;
+    sps = (sps + 3) / 4 * 4;                               // the kernel walks its slice four steps at a time
+    if (P >= 0x7fffffffLL) return DCT_ERR_UNSUPPORTED;
     const long long pps = sps * 16;
     const long long nsl = (P + pps - 1) / pps;
     if (pps > 0x7fffffffLL || nsl * mtiles * ntiles > 0x7fffffffLL) return DCT_ERR_UNSUPPORTED;

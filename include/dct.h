@@ -374,10 +374,12 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
        DCT_TUNE_ENET_REDUCE_VEC = 21,        /* 1 (default): 8-channel vector loads in the Enet per-channel reductions; 0: scalar kernel */
        DCT_TUNE_ENET_FOLD_THREADS = 22,      /* 256 | 512 | 1024 (default): threads of the one-block fold kernels behind those reductions */
        DCT_TUNE_IGEMM_PACKED_SPLIT = 23,     /* default 100: packed-rows kernel splits layers with fewer blocks over channel slices */
-       DCT_TUNE_IGEMM_PACKED_FILL = 24,
-       DCT_TUNE_IGEMM_XCD2 = 25,
-       DCT_TUNE_ENET_MFMA = 26 };            /* bf16 / f16 Enet: bit 0 = MFMA form of the convolutions with >= 16 input channels, bit 1 = of the weight
-                                                gradients; 3 (default), 0 = the fp32 VALU kernels */           /* 1: XCD-aware tile order in the per-tap kernel (each XCD keeps few channel tiles' weight slices in its L2) */    /* percent (default 76): least fill of the packed-rows kernel's 128-pixel tiles */
+       DCT_TUNE_IGEMM_PACKED_FILL = 24,      /* percent (default 76): least fill of the packed-rows kernel's 128-pixel tiles */
+       DCT_TUNE_IGEMM_XCD2 = 25,             /* 1: XCD-aware tile order in the per-tap kernel (default 0: level on the step) */
+       DCT_TUNE_ENET_MFMA = 26,              /* bf16 / f16 Enet: bit 0 = MFMA form of the convolutions with >= 16 input channels,
+                                                bit 1 = of the weight gradients; 3 (default), 0 = the fp32 VALU kernels */
+       DCT_TUNE_ENET_BN_OWNER = 27 };        /* 1: one-launch channel-owner BatchNorm statistics / backward for tensors of <= 32768 pixels
+                                                with whole 8-channel groups (measured slower); 0 (default): split reduction + fold [+ apply] */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 

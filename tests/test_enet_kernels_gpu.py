@@ -165,9 +165,21 @@ def test_enet_convT(K, dt, cin, cout, k, pad, opad, in_f32):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("C,act", [(16, 2), (64, 3), (13, 2), (3, 3), (64, 0)])
 @pytest.mark.parametrize("training", [True, False])
-def test_enet_bn_fwd_bwd(K, dt, C, act, training):
+@pytest.mark.parametrize("owner,shape", [(1, (2, 9, 11)), (1, (3, 41, 37)), (0, (3, 41, 37))])
+def test_enet_bn_fwd_bwd(K, dt, C, act, training, owner, shape):
+    """owner = 1: the one-launch channel-owner kernels where they apply (whole 8-channel groups; the 13- and 3-channel cases
+    take the split reduction either way); owner = 0: split reduction + fold + apply everywhere."""
+    from dct_amd import _lib
+    _lib.check(_lib.load().dct_tune_set(27, owner), "dct_tune_set(ENET_BN_OWNER)")
+    try:
+        _bn_fwd_bwd(K, dt, C, act, training, shape)
+    finally:
+        _lib.check(_lib.load().dct_tune_set(27, 0), "dct_tune_set(ENET_BN_OWNER)")
+
+
+def _bn_fwd_bwd(K, dt, C, act, training, shape):
     g = torch.Generator().manual_seed(3)
-    B, H, W = 2, 9, 11
+    B, H, W = shape
     raw = (torch.randn(B, C, H, W, generator=g) * 2 + 3).requires_grad_(True)       # raw conv outputs: fp32, mean >> 0
     gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
     beta = torch.randn(C, generator=g).requires_grad_(True)
