@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdct_hip.so")
+LIB_PATH = os.environ.get("DCT_LIB_PATH") or os.path.join(_HERE, "libdct_hip.so")      # (override: A/B of two builds in one run)
 
 F32, BF16, F16 = 0, 1, 2
 DTYPE_OF = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
