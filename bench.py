@@ -276,7 +276,7 @@ def main():
         exchange = {"exposed_allreduce_ms_per_step_max_over_ranks": float(ex.item()),
                     "bytes_per_step_per_rank": tr.grad_sync.exchanged_bytes / args.steps,
                     "wire_dtype": "bf16" if args.grad_compress == "bf16" else "f32",
-                    "mode": "two captured graphs around one eager all-reduce per model" if tr._step_graphs is not None and tr._step_graphs.captures
+                    "mode": "captured graph segments around the eager all-reduces" if tr._step_graphs is not None and tr._step_graphs.captures
                     else "eager launches, bucketed all-reduce from inside the backward pass"}
     # The step with the in-step meters on (SURVEY.md 8d asks for it separately): what _train_loop adds around _run_step --
     # DiceMeter.add on the labeled and unlabeled predictions, the loss meters, and the progress read-out every 10 steps.
@@ -353,6 +353,15 @@ def main():
                               "blob-structured synthetic slices (tests/helpers.py::blob_batches)"},
         "losses_last_step": losses,
     }
+    caps = list(tr._step_graphs._graphs.values()) if getattr(tr, "_step_graphs", None) is not None else []
+    if caps and getattr(caps[0], "program", None) is not None:
+        prog = caps[0].program
+        result["config"]["step_execution"] = {"mode": "program of per-stream HIP graphs (trainer/stream_sched.py)", "graphs": prog.n_graphs,
+                                              "kernel_nodes": prog.n_nodes, "ops": len(prog.ops)}
+    elif caps:
+        result["config"]["step_execution"] = {"mode": "one HIP graph"}
+    else:
+        result["config"]["step_execution"] = {"mode": "eager launches"}
     if exchange is not None:
         result["gradient_exchange"] = exchange
     if meters_ms is not None:

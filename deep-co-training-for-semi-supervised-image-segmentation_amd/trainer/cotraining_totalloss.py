@@ -151,8 +151,11 @@ class CoTrainer(Trainer):
         self.grad_overwrite = True          # nets that support it: first backward pass of a step writes the gradients (no zero fill)
         self._overwrite_models = set()
         self._pass_early = {}
-        self.segmented_graphs = True        # capture the step as one graph per stream segment (they then run on different hardware
-                                            # queues) instead of one graph with forked streams inside (one queue): stream_sched.py
+        self.segmented_graphs = None        # capture the step as one graph per stream segment (they then run on different hardware
+                                            # queues) instead of one graph with forked streams inside (one queue): stream_sched.py.
+                                            # None = by network: those made of many short launches ask for it (Enet: ~780 launches of
+                                            # ~8 us per pass; 39 -> 22 ms per cfg4 step), those whose kernels fill the chip do not
+                                            # (UNet: 6.24 against 6.06 ms per cfg2 step)
         self.use_hip_graph = True           # replay the fused step from a captured HIP graph (trainer/step_graph.py)
         self._step_graphs = None
         self.last_step = None
@@ -254,7 +257,7 @@ class CoTrainer(Trainer):
             # (with segmented graphs -- trainer/stream_sched.py -- every gradient exchange is a host callback between two graph
             # segments, so both kinds replay)
             segmented = (self.grad_sync is not None and self.ddp_segmented_graph and
-                         (self.segmented_graphs or not any(hasattr(s.torchnet, "grad_bucket_ranges") for s in self.segmentators)))
+                         (self._use_segments() or not any(hasattr(s.torchnet, "grad_bucket_ranges") for s in self.segmentators)))
             if self.use_hip_graph and graphable and (self.grad_sync is None or segmented) and \
                     all(s.torchnet.training for s in self.segmentators):
                 if self._step_graphs is None:
@@ -279,6 +282,11 @@ class CoTrainer(Trainer):
         if self._stream_pool is None or len(self._stream_pool) != len(self.segmentators):
             self._stream_pool = [_pooled_stream(self.device, "model", i, dealer=self._stream_dealer()) for i in range(len(self.segmentators))]
         return self._stream_pool
+
+    def _use_segments(self) -> bool:
+        if self.segmented_graphs is not None:
+            return bool(self.segmented_graphs)
+        return any(getattr(seg.torchnet, "prefers_segmented_graphs", False) for seg in self.segmentators)
 
     def _stream_dealer(self):
         if not self.spread_streams or self.device.type != 'cuda':
