@@ -21,6 +21,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import time
+import warnings
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -136,7 +137,9 @@ class SegmentRecorder(object):
         stream, g = self._open
         self._open = None
         torch.cuda.set_stream(stream)
-        g.capture_end()
+        with warnings.catch_warnings():         # ("The CUDA Graph is empty": expected for a stream switch with nothing in between)
+            warnings.simplefilter("ignore")
+            g.capture_end()
         n = _graph_node_count(g)
         if n == 0:                              # a stream switch with nothing launched in between: not replayed, but kept alive
             self._empty.append(g)               # (the stream's private pool dies with the last graph that used it)

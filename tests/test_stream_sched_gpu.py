@@ -1,0 +1,163 @@
+"""trainer/stream_sched.py: the fused step captured as a PROGRAM of per-stream HIP graphs, the early backward passes beside the
+adversarial block, and the hardware-queue probe.
+
+The bar is bit-equality: whatever way the launches are scheduled -- eagerly, as one captured graph with forked streams, as one
+graph per stream segment, with the labeled / unlabeled backward passes queued before or after the adversarial block -- the same
+kernels run on the same operands in the same per-stream order, and gradient buffers are summed in pass order, so seven steps
+must leave identical weights, Adam moments, BatchNorm running statistics and losses (cotraining_totalloss.py:203-248)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import FakeLoader, batches  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _run(tmp_path, arch, adv, n=7, S=2, **attrs):
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    C, B, H = 3, 2, (176 if arch == "unet" else 64)
+    segs = []
+    for seed in range(11, 11 + S):
+        torch.manual_seed(seed)
+        segs.append(Segmentator({"name": arch, "num_classes": C, "compute_dtype": torch.bfloat16},
+                                {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4}, {"name": "StepLR", "step_size": 90, "gamma": 0.1}))
+    lab = [FakeLoader(batches(81 + i, n, B, H, C), B) for i in range(S)]
+    unl = FakeLoader(batches(91, n, 2 * B, H, C), 2 * B)
+    crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tr = CoTrainer(segs, lab, unl, unl, crit, max_epoch=1, save_dir=str(tmp_path), device=DEV, axises=[1, 2],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False, steps_per_epoch=n)
+    for k, v in attrs.items():
+        assert hasattr(tr, k), k
+        setattr(tr, k, v)
+    for s in segs:
+        s.train()
+    sups = []
+    for k in range(n):
+        lb = [(lab[i][k][0][0], lab[i][k][0][1]) for i in range(S)]
+        out = tr._run_step(lb, (unl[k][0][0], unl[k][0][1]), True, adv, (0, S - 1) if adv else None)
+        sups.append([float(v) for v in out["sup"]] + [float(out["jsd"]), float(out["adv"]) if adv else 0.0])
+    torch.cuda.synchronize()
+    state = []
+    for s in segs:
+        state.append(torch.cat([p.detach().flatten() for p in s.torchnet.parameters()]).cpu())
+        state.append(s.optimizer._m.cpu())
+        state += [b.detach().clone().cpu() for b in s.torchnet.buffers()]
+    return tr, sups, state
+
+
+def _same(a, b):
+    assert a[1] == b[1]
+    assert len(a[2]) == len(b[2])
+    for x, y in zip(a[2], b[2]):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("arch,adv,S", [("enet", True, 2), ("enet", False, 2), ("enet", True, 3), ("unet", True, 2)])
+def test_program_of_graphs_equals_one_graph_equals_eager(tmp_path, arch, adv, S):
+    eager = _run(tmp_path, arch, adv, S=S, use_hip_graph=False)
+    one = _run(tmp_path, arch, adv, S=S, segmented_graphs=False)
+    prog = _run(tmp_path, arch, adv, S=S, segmented_graphs=True)
+    assert eager[0]._step_graphs is None
+    cap1 = list(one[0]._step_graphs._graphs.values())
+    capp = list(prog[0]._step_graphs._graphs.values())
+    assert cap1 and all(c.program is None and c.graph is not None for c in cap1)
+    assert capp and all(c.program is not None for c in capp)
+    p = capp[0].program
+    assert p.n_graphs >= 2 * S + 1 and p.n_nodes > 100
+    # every hand-over between streams is an explicit op of the program, and a mark is recorded before it is waited for
+    seen = set()
+    for op in p.ops:
+        if op[0] == 'record':
+            seen.add(id(op[2]))
+        elif op[0] == 'wait_event':
+            assert id(op[2]) in seen
+    assert one[0]._step_graphs.replays == prog[0]._step_graphs.replays >= 4
+    _same(eager, one)
+    _same(eager, prog)
+
+
+def test_default_mode_follows_the_network(tmp_path):
+    """Enet (hundreds of short launches per pass) asks for the program of graphs, UNet (kernels that fill the chip) for one graph."""
+    e = _run(tmp_path, "enet", False, n=4)
+    u = _run(tmp_path, "unet", False, n=4)
+    assert e[0]._use_segments() and all(c.program is not None for c in e[0]._step_graphs._graphs.values())
+    assert not u[0]._use_segments() and all(c.program is None for c in u[0]._step_graphs._graphs.values())
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_early_backward_changes_nothing(tmp_path, graph):
+    """The labeled / unlabeled backward passes queued right after the FGSM chain (beside the adversarial forward) or after it:
+    same pass buffers, same ((lab + unl) + adv) sum."""
+    a = _run(tmp_path, "enet", True, use_hip_graph=graph, early_backward=True)
+    b = _run(tmp_path, "enet", True, use_hip_graph=graph, early_backward=False)
+    c = _run(tmp_path, "enet", True, use_hip_graph=graph, pass_streams=False)          # sequential in-place accumulation
+    _same(a, b)
+    _same(a, c)
+
+
+def test_queue_groups_partition_the_candidates():
+    from dct_amd.trainer.stream_sched import StreamDealer, queue_groups
+    groups = queue_groups(DEV)
+    flat = [s for g in groups for s in g]
+    assert 1 <= len(groups) <= len(flat) and len({s.cuda_stream for s in flat}) == len(flat) == 8
+    assert queue_groups(DEV) is groups                  # probed once per device
+    d = StreamDealer(DEV)
+    first = [d.take() for _ in range(len(groups))]
+    # the first len(groups) streams dealt come from different groups
+    where = [next(i for i, g in enumerate(groups) if any(s.cuda_stream == t.cuda_stream for s in g)) for t in first]
+    assert sorted(where) == list(range(len(groups)))
+    more = [d.take() for _ in range(12)]                # more than the candidates: still streams
+    assert all(isinstance(s, torch.cuda.Stream) for s in more)
+
+
+def test_recorder_drops_empty_segments_and_replays_in_order():
+    """A hand-made schedule: two streams, a hand-over by record / wait_event, a host callback, stream switches with nothing in
+    between.  Replaying twice applies the captured work twice, in order."""
+    from dct_amd.trainer.stream_sched import EagerSchedule, SegmentRecorder
+    s1, s2 = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+    x = torch.zeros(1 << 16, device=DEV)
+    y = torch.zeros(1 << 16, device=DEV)
+    calls = []
+
+    def body(sched, main):
+        sched.wait([(s1, main), (s2, main)])
+        with sched.on(s1):
+            x.add_(1.0)
+            x.mul_(2.0)
+        mark = sched.record(s1)
+        with sched.on(s2):
+            pass                                    # nothing launched: no graph for it
+        sched.wait_event(s2, mark)
+        with sched.on(s2):
+            y.copy_(x)
+            y.add_(0.5)
+        sched.call(lambda: calls.append(len(calls)))
+        sched.wait([(main, s1), (main, s2)])
+        y.mul_(1.0)
+
+    body(EagerSchedule(), torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert float(x[0]) == 2.0 and float(y[0]) == 2.5 and calls == [0]
+    rec = SegmentRecorder(torch.device(DEV))
+    rec.start()
+    try:
+        body(rec, rec.main)
+        prog = rec.finish()
+    except BaseException:
+        rec.abort()
+        raise
+    torch.cuda.synchronize()
+    assert float(x[0]) == 2.0 and calls == [0]      # recording launches nothing and calls nothing
+    kinds = [op[0] for op in prog.ops]
+    assert kinds.count('graph') == 3 and kinds.count('call') == 1 and kinds.index('record') < kinds.index('wait_event')
+    assert [op[3] for op in prog.ops if op[0] == 'graph'] == [2, 2, 1]
+    prog.replay()
+    prog.replay()
+    torch.cuda.synchronize()
+    assert float(x[0]) == 14.0 and float(y[0]) == 14.5 and calls == [0, 1, 2]       # ((2 + 1) * 2 + 1) * 2
