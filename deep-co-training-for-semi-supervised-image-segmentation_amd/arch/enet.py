@@ -189,6 +189,8 @@ class Enet(nn.Module):
         self.flat_params = FlatParams(list(self.parameters()))
         self._pidx = {id(p): i for i, p in enumerate(self.flat_params.params)}
         self._grad_target = None
+        self._bn_stats = []                  # (bn, batch mean, unbiased batch variance) of the forward pass being planned
+        self._defer_running = False
         self.skip_zero_bias_grads = os.environ.get("DCT_ENET_BIAS_GRADS", "0") != "1"    # see _conv_wgrad
 
     supports_pass_streams = True         # plan_backward(grad_buffer=...): concurrent backward passes of one model (trainer)
@@ -222,10 +224,40 @@ class Enet(nn.Module):
             raise RuntimeError("Enet needs H and W divisible by 8 (three stride-2 stages, enet.py:26,132)")
 
     # Autograd-free entry points of the execution plan (see arch/unet.py::plan_forward)
-    def plan_forward(self, x: torch.Tensor, save: bool = True):
+    def plan_forward(self, x: torch.Tensor, save: bool = True, defer_running: bool = False):
+        """``defer_running`` (training mode, ``save``): the running statistics are NOT updated; the batch statistics of the 84
+        BatchNorms travel in the tape and ``apply_running_updates`` folds them in later.  The forward passes a model sees per
+        step (labeled, unlabeled, FGSM, adversarial) then have no order among themselves and can run on different streams; the
+        caller applies their updates in the reference's order."""
         self._check_input(x)
         self.flat_params.ensure()
-        return self._run_forward(x, save)
+        self._defer_running = bool(defer_running and save and self.training)
+        try:
+            return self._run_forward(x, save)
+        finally:
+            self._defer_running = False
+
+    supports_deferred_running_stats = True
+
+    def _apply_running(self, stats):
+        """r <- (1 - momentum) r + momentum b for every BatchNorm of one forward pass: four multi-tensor launches.  Every
+        training-mode forward goes through here (immediately, or deferred), so the arithmetic does not depend on the schedule."""
+        if not stats:
+            return
+        mom = stats[0][0].momentum
+        assert all(bn.momentum == mom for bn, _, _ in stats)
+        rms, rvs = [bn.running_mean for bn, _, _ in stats], [bn.running_var for bn, _, _ in stats]
+        torch._foreach_mul_(rms, 1.0 - mom)
+        torch._foreach_add_(rms, [m for _, m, _ in stats], alpha=mom)
+        torch._foreach_mul_(rvs, 1.0 - mom)
+        torch._foreach_add_(rvs, [v for _, _, v in stats], alpha=mom)
+
+    def apply_running_updates(self, tapes):
+        """The deferred running-statistics updates of ``tapes`` (plan_forward(defer_running=True)), in the order given."""
+        for tape in tapes:
+            stats = tape[-1].pop("bn_stats", None)
+            if stats is not None:
+                self._apply_running(stats)
 
     def plan_backward(self, tape, dlogits: torch.Tensor, need_dx: bool = False, need_dw: bool = True, grad_buffer=None):
         """``grad_buffer``: flat fp32 tensor (flat_params.total elements, zeroed by the caller) that receives this pass's
@@ -258,9 +290,16 @@ class Enet(nn.Module):
         rec = _Rec()
         rec.raw, rec.conv, rec.bn, rec.act, rec.src, rec.src_tf = raw, conv, bn, act, src, src_tf
         c = conv.cout
-        vec = torch.empty(4, c, dtype=torch.float32, device=dev)
-        K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                            self.training, vec[0], vec[1], vec[2], vec[3])
+        if self.training:
+            # batch statistics only: the running statistics are updated by _apply_running from (mean, unbiased variance)
+            vec = torch.empty(5, c, dtype=torch.float32, device=dev)
+            K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, None, None,
+                                True, vec[0], vec[1], vec[2], vec[3], save_var=vec[4])
+            self._bn_stats.append((bn, vec[2], vec[4]))
+        else:
+            vec = torch.empty(4, c, dtype=torch.float32, device=dev)
+            K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                False, vec[0], vec[1], vec[2], vec[3])
         if isinstance(act, _PReLU):
             rec.tf = Tf(vec[0], vec[1], self._w(act.weight), Tf.PRELU)
         elif isinstance(act, _ReLU):
@@ -382,8 +421,14 @@ class Enet(nn.Module):
         self._conv_fwd(h, None, fin, logits)
         if self.training:      # nn.BatchNorm2d bookkeeping, one multi-tensor launch for all 84 layers
             torch._foreach_add_(self._nbt, 1)
+        stats, self._bn_stats = self._bn_stats, []
         if save:
             tape.append({"kind": "final", "x": h, "training": self.training})
+        if self.training:
+            if getattr(self, "_defer_running", False):
+                tape[-1]["bn_stats"] = stats
+            else:
+                self._apply_running(stats)
         return logits, tape
 
     # ------------------------------------------------------------------------------ backward plan

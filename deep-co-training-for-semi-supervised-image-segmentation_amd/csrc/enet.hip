@@ -583,7 +583,7 @@ __device__ __forceinline__ void fold_partials(const double* partial, int blocks,
 __global__ __launch_bounds__(FT) void enet_bn_finalize_kernel(const double* partial, int blocks, int C, double count,
                                         const float* gamma, const float* beta, float eps, float momentum,
                                         float* running_mean, float* running_var, int training,
-                                        float* scale, float* shift, float* save_mean, float* save_invstd) {
+                                        float* scale, float* shift, float* save_mean, float* save_invstd, float* save_var) {
   __shared__ double red[FT * 3];
   double s[3];
   fold_partials(partial, training ? blocks : 0, C, red, s);
@@ -597,11 +597,12 @@ __global__ __launch_bounds__(FT) void enet_bn_finalize_kernel(const double* part
     double v = s[1] / count - m * m;
     if (v < 0.0) v = 0.0;
     mean = (float)m; var = (float)v;
+    const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
     if (running_mean) {
-      const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
+    if (save_var) save_var[c] = (float)unbiased;       // what a deferred running-statistics update needs
   } else {
     mean = running_mean[c]; var = running_var[c];
   }
@@ -726,7 +727,8 @@ __device__ __forceinline__ void own_fold(const float (&a)[3][8], double (&s)[3][
 template <typename T>
 __global__ __launch_bounds__(OWN_T) void enet_bn_fwd_owner_kernel(RedP p, double count, const float* gamma, const float* beta, float eps,
                                                                   float momentum, float* running_mean, float* running_var,
-                                                                  float* scale, float* shift, float* save_mean, float* save_invstd) {
+                                                                  float* scale, float* shift, float* save_mean, float* save_invstd,
+                                                                  float* save_var) {
   __shared__ double red[(OWN_T / 64) * 2 * 8];
   const int c0 = blockIdx.x * 8;
   const long long P = (long long)p.x.n * p.x.h * p.x.w;
@@ -753,11 +755,12 @@ __global__ __launch_bounds__(OWN_T) void enet_bn_fwd_owner_kernel(RedP p, double
     double v = s1 / count - m * m;
     if (v < 0.0) v = 0.0;
     const float mean = (float)m, var = (float)v;
+    const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
     if (running_mean) {
-      const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
+    if (save_var) save_var[c] = (float)unbiased;
     const float invstd = 1.0f / sqrtf(var + eps);
     const float sc = gamma[c] * invstd;
     scale[c] = sc;
@@ -1333,7 +1336,7 @@ static int enet_reduce_launch(const RedP& p0, int dtype, void* workspace, size_t
 
 extern "C" int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, const float* beta, float eps, float momentum,
                                      float* running_mean, float* running_var, int training,
-                                     float* scale, float* shift, float* save_mean, float* save_invstd,
+                                     float* scale, float* shift, float* save_mean, float* save_invstd, float* save_var,
                                      int f32_mask, int dtype, void* workspace, size_t workspace_bytes, dct_stream stream) {
   if (!view_ok(raw) || !gamma || !beta || !scale || !shift || !ok_dtype(dtype) || raw->c > 128) return DCT_ERR_BAD_ARG;
   if (!training && (!running_mean || !running_var)) return DCT_ERR_BAD_ARG;
@@ -1346,7 +1349,7 @@ extern "C" int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, co
     if (enet_owner_ok(p, dtype, nullptr)) {
       const double cnt = (double)raw->n * raw->h * raw->w;
       ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_fwd_owner_kernel<T>, dim3(raw->c / 8), dim3(OWN_T), 0, st, p, cnt, gamma, beta, eps,
-                               momentum, running_mean, running_var, scale, shift, save_mean, save_invstd));
+                               momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, save_var));
       return dct_check_launch();
     }
     const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
@@ -1354,7 +1357,7 @@ extern "C" int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, co
   }
   const double count = (double)raw->n * raw->h * raw->w;
   DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_finalize_kernel, dim3(1), dim3(g_enet_fold_threads), 0, st, (const double*)workspace, blocks, raw->c, count,
-             gamma, beta, eps, momentum, running_mean, running_var, training ? 1 : 0, scale, shift, save_mean, save_invstd);
+             gamma, beta, eps, momentum, running_mean, running_var, training ? 1 : 0, scale, shift, save_mean, save_invstd, save_var);
   return dct_check_launch();
 }
 

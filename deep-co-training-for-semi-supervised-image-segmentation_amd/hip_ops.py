@@ -397,12 +397,13 @@ def enet_conv(x, w, bias, tf, y, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, tra
 
 
 def enet_bn_fwd_stats(raw, gamma, beta, eps, momentum, running_mean, running_var, training, scale, shift, mean, invstd,
-                      dtype_hint=None):
+                      dtype_hint=None, save_var=None):
     vr = view(raw)
     ws = _enet_ws(raw.device, _lib.load().dct_enet_reduce_workspace_bytes(raw.shape[3]))
     dt, fm = _mixed(raw)
     call("dct_enet_bn_fwd_stats", C.byref(vr), ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(running_mean),
-         ptr(running_var), int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), fm, dt, ptr(ws), ws.numel(), stream())
+         ptr(running_var), int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(save_var), fm, dt, ptr(ws), ws.numel(),
+         stream())
 
 
 def enet_bn_bwd(raw, g, g_mask, tf, mean, invstd, dgamma, dbeta, dslope, c1c2, draw, training=True):

@@ -146,6 +146,9 @@ class CoTrainer(Trainer):
         self.pass_streams = True            # nets that support it (Enet): the backward passes of one model run on separate streams
         self._pass_pool = None
         self._pass_bufs = {}
+        self.wide_forward = True            # networks with deferred running statistics: lay the step out on four hardware queues
+                                            # (see _run_step_wide)
+        self._qstreams = None
         self.early_backward = True          # start the labeled / unlabeled backward passes right after the JSD, beside the
                                             # adversarial block (pass-stream nets; see _run_step_fused)
         self.grad_overwrite = True          # nets that support it: first backward pass of a step writes the gradients (no zero fill)
@@ -443,6 +446,8 @@ class CoTrainer(Trainer):
                         getattr(n, "external_dropout_masks", None) is None for n in nets))
         streams = self._streams()
         main = torch.cuda.current_stream(self.device)
+        if self._wide_ok(nets, streams, train_jsd, unl, fuse):
+            return self._run_step_wide(lab, unl, train_adv, adv_choice, nets, gs, g_cot, g_adv, lam_cot, lam_adv, ignore)
 
         def on(i):
             return self._sched.on(streams[i]) if streams is not None else contextlib.nullcontext()
@@ -531,7 +536,7 @@ class CoTrainer(Trainer):
             img_b, gt_b = lab[b]
             with on(b):
                 x = torch.cat((img_b, unl[0]), dim=0)
-                x_adv, noise, lp_real = self._fgsm_fused(nets[b], x, gt_b, eps, ignore)
+                x_adv, noise, lp_real, _ = self._fgsm_fused(nets[b], x, gt_b, eps, ignore)
             # (queued after the FGSM chain and its completion mark, and before model a's wait for that mark: streams that share
             # a hardware queue run in issue order -- the critical chain goes first, its mark must not land behind another
             # stream's segment, and nothing may be parked behind model a's blocked wait)
@@ -616,13 +621,133 @@ class CoTrainer(Trainer):
         del keep_alive
         return dict(sup=sup, jsd=jsd, adv=adv, preds=preds, unlab_probs=unlab_probs)
 
-    def _fgsm_fused(self, net, x, gt, eps, ignore):
+    # ------------------------------------------------------------------------------ the step on four hardware queues
+    def _wide_ok(self, nets, streams, train_jsd, unl, fuse) -> bool:
+        """Every network defers its running statistics and writes per-pass gradient buffers, the gradient buffers exist, and the
+        device has four distinguishable hardware queues."""
+        if not (self.wide_forward and streams is not None and self.pass_streams and train_jsd and unl is not None and not fuse):
+            return False
+        if not all(getattr(n, "supports_deferred_running_stats", False) and getattr(n, "supports_pass_streams", False) and
+                   n.training and n.flat_params.grads_attached() for n in nets):
+            return False
+        return self._queue_streams() is not None
+
+    def _queue_streams(self):
+        """One stream per hardware queue (stream_sched.queue_groups), or None when the probe found fewer than four."""
+        if self._qstreams is None:
+            from .stream_sched import queue_groups
+            groups = queue_groups(self.device)
+            self._qstreams = [g[0] for g in groups][:4] if len(groups) >= 4 else False
+        return self._qstreams or None
+
+    def _run_step_wide(self, lab, unl, train_adv, adv_choice, nets, gs, g_cot, g_adv, lam_cot, lam_adv, ignore) -> dict:
+        """The step laid out on the device's four hardware queues (JSD on, networks with deferred running statistics).
+
+        With the running-statistics updates taken out of the forward passes (arch/enet.py::plan_forward(defer_running=True); they
+        are applied at the end in the reference's order: labeled, unlabeled, FGSM, adversarial) the 2S + 2 forward passes of a step
+        have no order among themselves, and with per-pass gradient buffers neither have the backward passes.  What remains are
+        the data dependencies, i.e. two chains:
+          adversarial: FGSM forward + input gradient on model b -> forward of model a on the perturbed batch -> its backward;
+          co-training: 2S labeled / unlabeled forwards -> JSD -> their 2S backward passes.
+        The adversarial chain gets a queue of its own and is issued first (it is the longer one: 13 ms of launches against
+        2 + 4 per co-training pass for 2 x Enet, tools/probe_step_program.py); the 2S passes share the other three, each pass
+        staying on one queue from its forward to its backward.  Streams that share a hardware queue run in issue order, so a
+        'stream' here IS a queue: one per group of stream_sched.queue_groups.  Results are bit for bit those of the sequential
+        step: same kernels on the same operands, gradient buffers summed in pass order ((lab + unl) + adv)."""
+        from .. import hip_ops as K
+        from ..loss.loss import _nchw
+        S, C = len(nets), self.C
+        sched = self._sched
+        main = torch.cuda.current_stream(self.device)
+        Q = self._queue_streams()
+        adv_q = Q[3] if train_adv else None
+        free = Q[:3] if train_adv else Q
+        lab_q = [free[i % len(free)] for i in range(S)]
+        unl_q = [free[(S + i) % len(free)] for i in range(S)]
+        sched.wait([(st, main) for st in Q])
+        self._pass_join = lambda: sched.wait([(main, st) for st in Q])
+        bufs = [[None, None, None] for _ in range(S)]          # per model: gradient buffers of the (lab, unl, adv) passes
+        tapes = [[] for _ in range(S)]                         # per model: tapes in the reference's forward order
+        fp = [n.flat_params for n in nets]
+
+        def backward(i, k, tape, dl):
+            buf = bufs[i][k] = self._pass_buffer(i, k, fp[i])
+            buf.zero_()
+            nets[i].plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=buf)
+
+        adv, adv_tapes = 0, {}
+        if train_adv:                                                          # :233-244 -> :371-392
+            a, b = adv_choice
+            eps = float(self.adv_training_dict.get('eplision', 0.05))
+            with sched.on(adv_q):
+                x = torch.cat((lab[b][0], unl[0]), dim=0)
+                x_adv, noise, lp_real, ftape = self._fgsm_fused(nets[b], x, lab[b][1], eps, ignore, defer_running=True)
+                lp_adv, atape = nets[a].plan_forward(x_adv, True, defer_running=True)
+                adv = K.kl_logits_fwd(lp_adv, lp_real, C)[0]
+                if lam_adv != 0.0:
+                    da = K.kl_logits_bwd(lp_adv, lp_real, C, torch.empty_like(lp_adv), **g_adv)
+                    backward(a, 2, atape, da)
+            adv_tapes = {"fgsm": (b, ftape), "adv": (a, atape)}
+        sup, preds, lab_pass = [], [], []
+        for i in range(S):                                                     # :208-218
+            with sched.on(lab_q[i]):
+                img, gt = lab[i]
+                lp, tape = nets[i].plan_forward(img, True, defer_running=True)
+                dl = torch.empty_like(lp)
+                t = gt.reshape(-1)
+                out = K.ce_fwd(lp, t, C, ignore)
+                K.ce_bwd(lp, t, C, out[1:2], dl, gmul=gs, ignore_index=ignore)
+                sup.append(out[0])
+                preds.append(_nchw(lp))
+                lab_pass.append((tape, dl))
+                tapes[i].append(tape)
+        lps, dl_outs, utapes = [], [], []
+        for i in range(S):                                                     # :219-227
+            with sched.on(unl_q[i]):
+                lp_u, tape = nets[i].plan_forward(unl[0], True, defer_running=True)
+                lps.append(lp_u)
+                utapes.append(tape)
+                dl_outs.append(torch.empty_like(lp_u))
+                tapes[i].append(tape)
+        # the JSD couples all S models.  It runs on the first co-training queue, NOT on the origin stream: the origin stream
+        # sits on one of the four hardware queues too -- here the adversarial chain's, behind which the JSD would wait 10 ms
+        jq = free[0]
+        sched.wait([(jq, st) for st in free[1:]])
+        with sched.on(jq):
+            jsd = K.jsd_logits_fwd(lps, C)[0]
+            unlab_probs = [_nchw(K.softmax_fwd(lp, C)) for lp in lps]
+            if lam_cot != 0.0:
+                K.jsd_logits_bwd(lps, C, dl_outs, **g_cot)
+        sched.wait([(st, jq) for st in free[1:]])
+        for i in range(S):
+            with sched.on(lab_q[i]):
+                backward(i, 0, *lab_pass[i])
+        if lam_cot != 0.0:
+            for i in range(S):
+                with sched.on(unl_q[i]):
+                    backward(i, 1, utapes[i], dl_outs[i])
+        if train_adv:
+            tapes[adv_tapes["fgsm"][0]].append(adv_tapes["fgsm"][1])
+            tapes[adv_tapes["adv"][0]].append(adv_tapes["adv"][1])
+        self._pass_early = {i: (fp[i], [bf for bf in bufs[i] if bf is not None]) for i in range(S)}
+        self._overwrite_models = set(range(S))
+        try:
+            self._finish_step([], None)             # join, sum the pass buffers in order, [gradient exchange], optimizers
+        finally:
+            self._overwrite_models = set()
+            self._pass_early = {}
+            self._pass_join = None
+        for i in range(S):                          # running statistics: labeled, unlabeled, FGSM, adversarial (reference order)
+            nets[i].apply_running_updates(tapes[i])
+        return dict(sup=sup, jsd=jsd, adv=adv, preds=preds, unlab_probs=unlab_probs)
+
+    def _fgsm_fused(self, net, x, gt, eps, ignore, defer_running=False):
         """FSGMGenerator (AEGenerator.py:16-51) on the fused kernels: forward, pseudo-label the
         unlabeled tail, CE, backward to the input only, x + eps*sign(g).  Returns the physical
-        NHWC logits of the clean pass (their softmax is the detached KL target)."""
+        NHWC logits of the clean pass (their softmax is the detached KL target) and the tape."""
         from .. import hip_ops as K
         C = self.C
-        lp, tape = net.plan_forward(x, True)
+        lp, tape = net.plan_forward(x, True, defer_running=True) if defer_running else net.plan_forward(x, True)
         t = gt.reshape(-1)
         if x.shape[0] > gt.shape[0]:
             pseudo = K.argmax(lp, C)
@@ -632,7 +757,7 @@ class CoTrainer(Trainer):
         dl = K.ce_bwd(lp, t, C, out[1:2], torch.empty_like(lp), gmul=getattr(self, "_loss_scale", 1.0), ignore_index=ignore)
         gx = net.plan_backward(tape, dl, need_dx=True, need_dw=False)
         x_adv, noise = K.fgsm_step(x.detach().contiguous(), gx.contiguous(), eps)
-        return x_adv, noise, lp
+        return x_adv, noise, lp, tape
 
     # ------------------------------------------------------------------------------ loops
     def _train_loop(self, labeled_dataloaders: List, unlabeled_dataloader, epoch: int, mode: ModelMode, save: bool,

@@ -276,10 +276,13 @@ size_t dct_enet_reduce_workspace_bytes(int channels);
 /* nn.BatchNorm2d(eps 1e-3, momentum 0.1) forward statistics of a raw conv output (enet.py:22,55-122):
  * training: batch mean / biased var (double accumulation, fixed-order fold), running stats updated
  * with the unbiased var; eval: running stats.  Writes scale = gamma*invstd, shift = beta - mean*scale
- * (what consumers apply on load) and save_mean / save_invstd for the backward.  f32_mask bit 0: raw. */
+ * (what consumers apply on load) and save_mean / save_invstd for the backward.  f32_mask bit 0: raw.
+ * Deferred running statistics: with running_mean = running_var = NULL in training mode nothing is updated and save_var
+ * (nullable) receives the batch's UNBIASED variance, so that the caller can apply r = (1 - momentum) r + momentum b for
+ * several forward passes later, in the reference's order (the passes themselves may then run concurrently). */
 int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, int training,
-                          float* scale, float* shift, float* save_mean, float* save_invstd,
+                          float* scale, float* shift, float* save_mean, float* save_invstd, float* save_var,
                           int f32_mask, int dtype, void* workspace, size_t workspace_bytes, dct_stream stream);
 /* Backward of act(BN(raw)) given g = grad wrt the activation output (optionally gated by
  * g_mask > 0, the ReLU of the bottleneck sum): dgamma/dbeta/dslope += ..., and

@@ -101,6 +101,18 @@ def test_early_backward_changes_nothing(tmp_path, graph):
     _same(a, c)
 
 
+@pytest.mark.parametrize("adv,S", [(True, 2), (False, 2), (True, 3)])
+def test_four_queue_layout_changes_nothing(tmp_path, adv, S):
+    """CoTrainer._run_step_wide (forward passes with deferred running statistics, every pass on one of four hardware queues, the
+    adversarial chain issued first) against the sequential layout: same weights, moments, running statistics, losses."""
+    wide = _run(tmp_path, "enet", adv, S=S, wide_forward=True)
+    seq = _run(tmp_path, "enet", adv, S=S, wide_forward=False)
+    eager_wide = _run(tmp_path, "enet", adv, S=S, wide_forward=True, use_hip_graph=False)
+    assert wide[0]._queue_streams() is not None, "fewer than four hardware queues found: the layout was not exercised"
+    _same(wide, seq)
+    _same(wide, eager_wide)
+
+
 def test_queue_groups_partition_the_candidates():
     from dct_amd.trainer.stream_sched import StreamDealer, queue_groups
     groups = queue_groups(DEV)
