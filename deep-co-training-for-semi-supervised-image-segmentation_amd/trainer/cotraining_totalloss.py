@@ -627,6 +627,8 @@ class CoTrainer(Trainer):
         device has four distinguishable hardware queues."""
         if not (self.wide_forward and streams is not None and self.pass_streams and train_jsd and unl is not None and not fuse):
             return False
+        if torch.cuda.is_current_stream_capturing() and not self._sched.capturing:
+            return False        # ONE graph being captured: the JSD's join into a forked stream crashes hipStreamEndCapture (ROCm 7.2)
         if not all(getattr(n, "supports_deferred_running_stats", False) and getattr(n, "supports_pass_streams", False) and
                    n.training and n.flat_params.grads_attached() for n in nets):
             return False
