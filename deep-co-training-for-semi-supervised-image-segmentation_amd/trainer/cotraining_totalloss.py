@@ -164,8 +164,8 @@ class CoTrainer(Trainer):
         self.last_step = None
         self.force_loss_scale = None        # tests: a power of two applied to every loss gradient and divided out by the optimizers
         self._defer_optimizer = False       # segmented capture: _finish_step stops after the backward passes (see _optimizer_phase)
-        self.ddp_segmented_graph = True     # data parallelism, nets without gradient buckets (Enet): replay [forward + backward] and
-                                            # [optimizers] as two captured graphs around one eager all-reduce per model
+        self.ddp_segmented_graph = True     # data parallelism: replay the step as graph segments around the eager all-reduces (UNet:
+                                            # one per gradient bucket, issued from inside the backward pass; Enet: one per model)
 
     def to(self, device: torch.device):
         [segmentator.to(device) for segmentator in self.segmentators]
@@ -253,14 +253,10 @@ class CoTrainer(Trainer):
         if self._fused_ok():
             # replay needs every per-step scalar on the device: only the fused Adam keeps its step count / lr there
             graphable = all(hasattr(s.optimizer, "refresh_lr") and hasattr(s.optimizer, "_steps") for s in self.segmentators)
-            # data parallelism: networks that hand out gradient buckets from inside their backward pass (UNet: 124 MB per model,
-            # the exchange must overlap the backward) stay eager -- their eager step is within 3 % of the replayed one; networks
-            # without (Enet: 1.45 MB per model, ~2500 launches per model-step, host-bound when eager) replay two graphs around
-            # one eager all-reduce per model
-            # (with segmented graphs -- trainer/stream_sched.py -- every gradient exchange is a host callback between two graph
-            # segments, so both kinds replay)
-            segmented = (self.grad_sync is not None and self.ddp_segmented_graph and
-                         (self._use_segments() or not any(hasattr(s.torchnet, "grad_bucket_ranges") for s in self.segmentators)))
+            # data parallelism: the RCCL all-reduces are not captured.  The step is recorded as a program of graph segments
+            # (trainer/stream_sched.py) in which every gradient exchange -- UNet's buckets handed out from inside the backward
+            # pass, Enet's one buffer per model -- is a host callback between two segments
+            segmented = self.grad_sync is not None and self.ddp_segmented_graph
             if self.use_hip_graph and graphable and (self.grad_sync is None or segmented) and \
                     all(s.torchnet.training for s in self.segmentators):
                 if self._step_graphs is None:
@@ -289,6 +285,8 @@ class CoTrainer(Trainer):
     def _use_segments(self) -> bool:
         if self.segmented_graphs is not None:
             return bool(self.segmented_graphs)
+        if self.grad_sync is not None and self.ddp_segmented_graph:
+            return True         # data parallelism: the gradient exchanges are host callbacks BETWEEN graph segments
         return any(getattr(seg.torchnet, "prefers_segmented_graphs", False) for seg in self.segmentators)
 
     def _stream_dealer(self):

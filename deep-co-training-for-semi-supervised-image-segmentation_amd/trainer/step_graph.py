@@ -143,7 +143,7 @@ class StepGraphCache(object):
         before = [getattr(o, n) for o, n in self._counters()]
         side = [getattr(seg.torchnet, "wgrad_side_stream", None) for seg in tr.segmentators]
         for seg in tr.segmentators:          # a fork nested inside a forked stream crashes hipStreamEndCapture (ROCm 7.2)
-            if tr.model_streams and hasattr(seg.torchnet, "wgrad_side_stream"):
+            if (tr.model_streams or tr._use_segments()) and hasattr(seg.torchnet, "wgrad_side_stream"):   # (nor may a segment end with unjoined work)
                 seg.torchnet.wgrad_side_stream = False
         torch.cuda.synchronize(tr.device)
         graph = torch.cuda.CUDAGraph()
