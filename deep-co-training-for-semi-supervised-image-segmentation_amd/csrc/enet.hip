@@ -20,7 +20,6 @@ int g_enet_reduce_ppt = 8;           // pixels per thread of a per-channel reduc
 int g_enet_fold_threads = 1024;      // threads of the one-block finalize kernels (DCT_TUNE_ENET_FOLD_THREADS: 256 | 512 | 1024)
 int g_enet_mfma = 3;                 // bf16 / f16 mode: bit 0 = MFMA form of the convolutions with >= 16 input channels, bit 1 = of the
                                      // weight gradients (0: the fp32 VALU kernels)
-int g_enet_bn_fold_apply = 1;        // BatchNorm backward: the apply kernel folds the partial rows itself (no finalize launch)
 int g_enet_bn_owner = 0;             // small tensors: one-launch channel-owner BatchNorm statistics / backward (0: split reduction).
                                      // Measured SLOWER (8 x 25 x 25 x 32 backward: 60 us against 14 us for the three split launches --
                                      // C / 8 blocks cannot pull the tensor through 4-16 CUs fast enough): kept for A/B only
@@ -641,49 +640,6 @@ __global__ __launch_bounds__(FT) void enet_sum_finalize_kernel(const double* par
   while (CP < C) CP <<= 1;
   if (c >= C || threadIdx.x >= CP) return;
   out[c] += (float)s[0];
-}
-
-// draw = scale * (dz - c1 - xhat * c2) with the fold of the reduction's partial rows done by EVERY block in its prologue (C threads
-// x `rows` rows, one batch of loads) instead of by a one-block kernel in between: one launch and one dependent round trip less
-// per BatchNorm on the backward chain (~7 us of ~20).  Block 0 also performs the finalize kernel's writes (dgamma, dbeta,
-// dslope +=; c1, c2).  Rows are added in ascending order in double precision (the finalize kernel associates them in <= 32
-// strided parts: the two forms can differ in the last bit of a double, i.e. almost never after the rounding to float).
-template <typename T>
-__global__ __launch_bounds__(256) void enet_bn_bwd_apply_fold_kernel(RedP p, const double* partial, int rows, double count, int training,
-                                                                     float* dgamma, float* dbeta, float* dslope, float* c1c2, View out) {
-  __shared__ float k1s[128], k2s[128];
-  const int C = p.x.c;
-  if ((int)threadIdx.x < C) {
-    const int c = threadIdx.x;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < rows; ++b) {
-      const double* q = partial + ((long long)b * C + c) * 3;
-      s0 += q[0]; s1 += q[1]; s2 += q[2];
-    }
-    const float k1 = training ? (float)(s0 / count) : 0.f, k2 = training ? (float)(s1 / count) : 0.f;
-    k1s[c] = k1; k2s[c] = k2;
-    if (blockIdx.x == 0) {
-      if (dbeta) dbeta[c] += (float)s0;
-      if (dgamma) dgamma[c] += (float)s1;
-      if (dslope) dslope[c] += (float)s2;
-      c1c2[c] = k1; c1c2[C + c] = k2;
-    }
-  }
-  __syncthreads();
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = (long long)p.x.n * p.x.h * p.x.w * C;
-  if (idx >= total) return;
-  int c, n, y, x;
-  pix3(split_c(idx, C, c), p.x.h, p.x.w, n, y, x);
-  const float v = ldv<T>(p.x, voff(p.x, n, y, x) + c, p.fm & 1);
-  const float g = grad_in<T>(p, n, y, x, c);
-  const float z = fmaf(p.scale[c], v, p.shift[c]);
-  float dz = g;
-  if (p.act == 2) { if (!(z > 0.f)) dz = g * p.slope[c]; }
-  else if (p.act == 3) { if (!(z > 0.f)) dz = 0.f; }
-  const float xh = (v - p.mean[c]) * p.invstd[c];
-  const float r = p.scale[c] * (dz - k1s[c] - xh * k2s[c]);
-  stv<T>(out, voff(out, n, y, x) + c, p.fm & 8, r);
 }
 
 // ---- channel-owner BatchNorm kernels for small tensors -----------------------------------------------
@@ -1393,14 +1349,6 @@ extern "C" int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct
   const double count = (double)raw->n * raw->h * raw->w;
   const long long total = (long long)raw->n * raw->h * raw->w * raw->c;
   const View vo = to_view(draw);
-  {
-    // few partial rows (the planner makes <= ~20 for Enet's stage-1..3 tensors): every apply block folds them itself
-    if (g_enet_bn_fold_apply && blocks <= 32) {
-      ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_apply_fold_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, p,
-                               (const double*)workspace, blocks, count, training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, vo));
-      return dct_check_launch();
-    }
-  }
   DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_finalize_kernel, dim3(1), dim3(g_enet_fold_threads), 0, st, (const double*)workspace, blocks, raw->c, count,
              training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, c1c2 + raw->c);
   ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_apply_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, p,
