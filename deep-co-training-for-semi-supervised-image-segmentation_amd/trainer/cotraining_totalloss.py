@@ -290,8 +290,8 @@ class CoTrainer(Trainer):
         return any(getattr(seg.torchnet, "prefers_segmented_graphs", False) for seg in self.segmentators)
 
     def _stream_dealer(self):
-        if not self.spread_streams or self.device.type != 'cuda':
-            return None
+        if not self.spread_streams or self.device.type != 'cuda' or not self._use_segments():
+            return None         # (one captured graph runs on one hardware queue whatever streams were forked inside it)
         if self._dealer is None:
             self._dealer = StreamDealer(self.device)
         return self._dealer

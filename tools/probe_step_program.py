@@ -1,5 +1,5 @@
 """The captured step PROGRAM of a bench configuration (trainer/stream_sched.py): its segments, and host vs device time of a replay.
-    python tools/probe_step_program.py cfg4 [bf16]"""
+    python tools/probe_step_program.py cfg4 [switch=0|1 ...]"""
 import os
 import sys
 import time
@@ -15,6 +15,11 @@ name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 cfg = bench.CONFIGS[name]
 dev = torch.device("cuda:0")
 tr, lab, unl = bench.make_trainer(cfg, torch.bfloat16, dev, 0, 1, None)
+for kv in sys.argv[2:]:                      # CoTrainer switches: name=0|1
+    if "=" in kv:
+        k_, v_ = kv.split("=")
+        assert hasattr(tr, k_), k_
+        setattr(tr, k_, bool(int(v_)))
 S, nb = cfg["S"], len(unl)
 
 
