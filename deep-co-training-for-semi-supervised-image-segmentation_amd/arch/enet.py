@@ -191,6 +191,7 @@ class Enet(nn.Module):
         self._grad_target = None
         self._bn_stats = []                  # (bn, batch mean, unbiased batch variance) of the forward pass being planned
         self._defer_running = False
+        self.fuse_bn_stats = os.environ.get("DCT_ENET_FUSE_BN_STATS", "1") != "0"     # BatchNorm partial sums from the conv epilogue
         self.skip_zero_bias_grads = os.environ.get("DCT_ENET_BIAS_GRADS", "0") != "1"    # see _conv_wgrad
 
     supports_pass_streams = True         # plan_backward(grad_buffer=...): concurrent backward passes of one model (trainer)
@@ -286,7 +287,15 @@ class Enet(nn.Module):
         dt, dev = self.compute_dtype, src.device
         B = src.shape[0]
         raw = torch.empty(B, out_hw[0], out_hw[1], conv.cout, dtype=torch.float32, device=dev)   # raw: always fp32
-        self._conv_fwd(src, src_tf, conv, raw)
+        stats, rows = None, 0
+        tiles = (B * out_hw[0] * out_hw[1] + 31) // 32
+        if (self.training and self.fuse_bn_stats and dt != torch.float32 and conv.cin >= 16 and conv.cin % 16 == 0 and
+                conv.cout <= 128 and tiles <= 1024):
+            # MFMA convolution: its epilogue writes the BatchNorm partial sums (one launch and one read of `raw` less per seam)
+            stats = torch.empty(tiles * conv.cout * 3, dtype=torch.float64, device=dev)
+            rows = self._conv_fwd(src, src_tf, conv, raw, stats=stats)
+        else:
+            self._conv_fwd(src, src_tf, conv, raw)
         rec = _Rec()
         rec.raw, rec.conv, rec.bn, rec.act, rec.src, rec.src_tf = raw, conv, bn, act, src, src_tf
         c = conv.cout
@@ -294,7 +303,7 @@ class Enet(nn.Module):
             # batch statistics only: the running statistics are updated by _apply_running from (mean, unbiased variance)
             vec = torch.empty(5, c, dtype=torch.float32, device=dev)
             K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, None, None,
-                                True, vec[0], vec[1], vec[2], vec[3], save_var=vec[4])
+                                True, vec[0], vec[1], vec[2], vec[3], save_var=vec[4], partial=stats, partial_rows=rows)
             self._bn_stats.append((bn, vec[2], vec[4]))
         else:
             vec = torch.empty(4, c, dtype=torch.float32, device=dev)
@@ -309,10 +318,17 @@ class Enet(nn.Module):
         rec.mean, rec.invstd = vec[2], vec[3]
         return rec
 
-    def _conv_fwd(self, src, src_tf, conv, dst):
+    def _conv_fwd(self, src, src_tf, conv, dst, stats=None):
+        """``stats`` (float64 scratch): the convolution's epilogue also writes the BatchNorm partial sums of ``dst`` where it can;
+        -> number of partial rows (0: not written)."""
         w = self._w(conv.weight)
         b = self._w(conv.bias) if conv.bias is not None else None
         t = conv.taps
+        if stats is not None:
+            kw = dict(R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1], compute=self.compute_dtype)
+            if conv.transposed:
+                return K.enet_conv_stats(src, w, b, src_tf, dst, stats, transposed=True, ws=(1, conv.cout, t * conv.cout), **kw)
+            return K.enet_conv_stats(src, w, b, src_tf, dst, stats, dil=conv.dil, ws=(t * conv.cin, conv.cin, 1), **kw)
         if conv.transposed:
             K.enet_conv(src, w, b, src_tf, dst, R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1],
                         transposed=True, ws=(1, conv.cout, t * conv.cout), compute=self.compute_dtype)

@@ -87,6 +87,7 @@ struct ConvP {
   int fm;                         // f32 mask: bit0 x, bit1 y, bit2 resid grad, bit3 resid mask
   int vec;                        // input rows can be read 8 channels at a time
   int wvec;          // MFMA form: weight rows are K-major and 16-byte aligned (one 32-byte load per B fragment)
+  double* stats;     // MFMA form, optional: per-tile channel sums {sum, sum of squares, 0} of the stored outputs, [pixel tile][Cout][3]
 };
 
 // One thread = one output pixel x 8 output channels.  Weights live in LDS as [tap][i][G*8].
@@ -325,7 +326,8 @@ __device__ __forceinline__ void mconv_main(const ConvP& p, const float* tfs, int
 }
 
 template <typename T, int NT, bool YF>
-__device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, int cbase, long long wbase, long long P, int r, int h, int wave) {
+__device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, float* srd, int cbase, long long wbase, long long P, int r, int h,
+                                            int wave) {
   // after the K-split fold this wave owns accumulators e = 4 wave + i, i < 4: pixel rows 8 wave + 4 h + i, channel cbase + 32 j + r
   const int Cout = p.y.c;
   float val[4][NT];
@@ -368,6 +370,9 @@ __device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, in
       add[i][j] = t;
     }
   }
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -377,14 +382,42 @@ __device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, in
         const float out = val[i][j] + add[i][j];
         if constexpr (YF || sizeof(T) == 4) reinterpret_cast<float*>(p.y.ptr)[yo[i] + c] = out;
         else reinterpret_cast<T*>(p.y.ptr)[yo[i] + c] = from_f32<T>(out);
+        s1[j] += out; s2[j] = fmaf(out, out, s2[j]);
       }
     }
+  if (p.stats) {
+    // BatchNorm statistics of this tile ride along: the consumer's reduction launch (a full read of the tensor and one more
+    // seam on the forward chain) is replaced by 32 more partial rows... per-channel sums over the tile's 32 pixels -- 4 rows per
+    // lane, the two half-waves by shuffle, the four waves through LDS in wave order -- as doubles in the reduction's layout
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32, 64);
+      s2[j] += __shfl_xor(s2[j], 32, 64);
+      if (h == 0) { srd[((wave * NT + j) * 32 + r) * 2] = s1[j]; srd[((wave * NT + j) * 32 + r) * 2 + 1] = s2[j]; }
+    }
+    __syncthreads();
+    if (wave == 0 && h == 0) {
+      const long long row = wbase / 32;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int c = cbase + 32 * j + r;
+        if (c < Cout) {
+          double a = 0.0, b = 0.0;
+#pragma unroll
+          for (int w = 0; w < MC_W; ++w) { a += (double)srd[((w * NT + j) * 32 + r) * 2]; b += (double)srd[((w * NT + j) * 32 + r) * 2 + 1]; }
+          double* o = p.stats + (row * Cout + c) * 3;
+          o[0] = a; o[1] = b; o[2] = 0.0;
+        }
+      }
+    }
+  }
 }
 
 template <typename T, int NT>
 __global__ __launch_bounds__(64 * MC_W) void enet_mconv_kernel(ConvP p, int ngroups) {
   __shared__ __attribute__((aligned(16))) float tfs[3 * 128];
   __shared__ float red[MC_W * NT * 16 * 64];
+  __shared__ float srd[MC_W * NT * 32 * 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   for (int c = threadIdx.x; c < 128; c += 64 * MC_W) {
@@ -418,8 +451,8 @@ __global__ __launch_bounds__(64 * MC_W) void enet_mconv_kernel(ConvP p, int ngro
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[((wave * NT + j) * 16 + e) * 64 + lane] = acc[j][e];
   __syncthreads();
-  if (p.fm & 2) mconv_store<T, NT, true>(p, red, cbase, wbase, P, r, h, wave);
-  else mconv_store<T, NT, false>(p, red, cbase, wbase, P, r, h, wave);
+  if (p.fm & 2) mconv_store<T, NT, true>(p, red, srd, cbase, wbase, P, r, h, wave);
+  else mconv_store<T, NT, false>(p, red, srd, cbase, wbase, P, r, h, wave);
 }
 
 // ---- per-channel sums over pixels: partial[blk][c][k], k < NS, double accumulators -------------
@@ -1188,11 +1221,12 @@ static inline int red_plan(long long P, int C, int& ppb) {
 #define ENET_T(dtype, ...) do { if ((dtype) == DCT_BF16) { using T = bf16_t; __VA_ARGS__; } else if ((dtype) == DCT_F16) { using T = f16_t; __VA_ARGS__; } \
                                else { using T = float; __VA_ARGS__; } } while (0)
 
-extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
-                             const dct_view* y, const dct_conv_desc* d, int transposed,
-                             int ws_out, int ws_tap, int ws_in,
-                             const dct_view* resid_grad, const dct_view* resid_mask,
-                             int f32_mask, int dtype, dct_stream stream) {
+static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
+                          const dct_view* y, const dct_conv_desc* d, int transposed,
+                          int ws_out, int ws_tap, int ws_in,
+                          const dct_view* resid_grad, const dct_view* resid_mask,
+                          int f32_mask, int dtype, double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream) {
+  if (stats_rows) *stats_rows = 0;
   if (!view_ok(x) || !view_ok(y) || !w || !d || !ok_dtype(dtype) || x->n != y->n) return DCT_ERR_BAD_ARG;
   if (d->R < 1 || d->S < 1 || d->stride < 1 || d->dil < 1) return DCT_ERR_BAD_ARG;
   if (y->c > 128 || x->c > 128) return DCT_ERR_UNSUPPORTED;
@@ -1202,7 +1236,7 @@ extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bia
   p.R = d->R; p.S = d->S; p.stride = d->stride; p.dil = d->dil; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
   p.transposed = transposed ? 1 : 0; p.accumulate = d->accumulate ? 1 : 0;
   p.ws_out = ws_out; p.ws_tap = ws_tap; p.ws_in = ws_in;
-  p.has_resid = 0; p.wvec = 0;
+  p.has_resid = 0; p.wvec = 0; p.stats = nullptr;
   p.rg = p.y; p.rm = p.y;
   if (resid_grad) {
     if (!view_ok(resid_grad) || !view_ok(resid_mask)) return DCT_ERR_BAD_ARG;
@@ -1226,6 +1260,7 @@ extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bia
     const long long Pm = (long long)y->n * y->h * y->w;
     const long long ptiles = (Pm + 31) / 32;
     const int ntiles = (y->c + 31) / 32;
+    if (stats_partial && stats_rows && ptiles <= stats_capacity_rows && !d->accumulate) { p.stats = stats_partial; *stats_rows = (int)ptiles; }
     int nt = 1;
     if (ntiles >= 4 && ptiles >= 2048) nt = 4;
     else if (ntiles >= 2 && ptiles * ((ntiles + 1) / 2) >= 2048) nt = 2;
@@ -1244,6 +1279,24 @@ extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bia
   hipStream_t st = (hipStream_t)stream;
   ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_conv_kernel<T>, dim3(grid), dim3(256), lds, st, p));
   return dct_check_launch();
+}
+
+extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
+                             const dct_view* y, const dct_conv_desc* d, int transposed,
+                             int ws_out, int ws_tap, int ws_in,
+                             const dct_view* resid_grad, const dct_view* resid_mask,
+                             int f32_mask, int dtype, dct_stream stream) {
+  return enet_conv_impl(x, w, bias, tf, y, d, transposed, ws_out, ws_tap, ws_in, resid_grad, resid_mask, f32_mask, dtype, nullptr, 0, nullptr,
+                        stream);
+}
+
+extern "C" int dct_enet_conv_stats(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
+                                   const dct_view* y, const dct_conv_desc* d, int transposed,
+                                   int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
+                                   double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream) {
+  if (!stats_partial || !stats_rows || stats_capacity_rows < 1) return DCT_ERR_BAD_ARG;
+  return enet_conv_impl(x, w, bias, tf, y, d, transposed, ws_out, ws_tap, ws_in, nullptr, nullptr, f32_mask, dtype, stats_partial,
+                        stats_capacity_rows, stats_rows, stream);
 }
 
 extern "C" size_t dct_enet_reduce_workspace_bytes(int channels) {
@@ -1294,11 +1347,23 @@ extern "C" int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, co
                                      float* running_mean, float* running_var, int training,
                                      float* scale, float* shift, float* save_mean, float* save_invstd, float* save_var,
                                      int f32_mask, int dtype, void* workspace, size_t workspace_bytes, dct_stream stream) {
+  return dct_enet_bn_fwd_stats_rows(raw, gamma, beta, eps, momentum, running_mean, running_var, training, scale, shift, save_mean, save_invstd,
+                                    save_var, f32_mask, dtype, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int dct_enet_bn_fwd_stats_rows(const dct_view* raw, const float* gamma, const float* beta, float eps, float momentum,
+                                          float* running_mean, float* running_var, int training,
+                                          float* scale, float* shift, float* save_mean, float* save_invstd, float* save_var,
+                                          int f32_mask, int dtype, void* workspace, size_t workspace_bytes, int partial_rows,
+                                          dct_stream stream) {
   if (!view_ok(raw) || !gamma || !beta || !scale || !shift || !ok_dtype(dtype) || raw->c > 128) return DCT_ERR_BAD_ARG;
   if (!training && (!running_mean || !running_var)) return DCT_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   int blocks = 0;
-  if (training) {
+  if (training && partial_rows > 0) {       // the producing convolution wrote the partial rows (dct_enet_conv_stats)
+    if (!workspace || workspace_bytes < (size_t)partial_rows * raw->c * 3 * sizeof(double)) return DCT_ERR_WORKSPACE;
+    blocks = partial_rows;
+  } else if (training) {
     RedP p; p.x = to_view(raw); p.g = p.x; p.m = p.x;
     p.scale = p.shift = p.slope = p.mean = p.invstd = nullptr;
     p.act = 0; p.has_mask = 0; p.kind = 0; p.ppb = 0; p.fm = f32_mask & 1;

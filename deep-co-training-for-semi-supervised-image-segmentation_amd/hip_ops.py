@@ -396,11 +396,33 @@ def enet_conv(x, w, bias, tf, y, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, tra
     return y
 
 
+def enet_conv_stats(x, w, bias, tf, y, stats, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, transposed=False, ws=(0, 0, 0), compute=None):
+    """enet_conv with the consumer BatchNorm's partial sums written by the convolution's epilogue into ``stats`` (float64,
+    >= tiles * C * 3 elements, tiles = ceil(pixels / 32)).  -> number of partial rows written, 0 when the call did not take the
+    MFMA form (the statistics then need the usual reduction)."""
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w)
+    vx, vy = view(x), view(y)
+    keep, tfp = _tfp(tf)
+    dt, fm = _mixed(x, y)
+    if dt == F32 and compute in (torch.bfloat16, torch.float16):
+        dt = DTYPE_OF[compute]
+    rows = C.c_int(0)
+    cap = stats.numel() // (3 * y.shape[3])
+    call("dct_enet_conv_stats", C.byref(vx), ptr(w), ptr(bias), tfp, C.byref(vy), C.byref(d), int(transposed),
+         int(ws[0]), int(ws[1]), int(ws[2]), fm, dt, ptr(stats), int(cap), C.byref(rows), stream())
+    return int(rows.value)
+
+
 def enet_bn_fwd_stats(raw, gamma, beta, eps, momentum, running_mean, running_var, training, scale, shift, mean, invstd,
-                      dtype_hint=None, save_var=None):
+                      dtype_hint=None, save_var=None, partial=None, partial_rows=0):
     vr = view(raw)
-    ws = _enet_ws(raw.device, _lib.load().dct_enet_reduce_workspace_bytes(raw.shape[3]))
     dt, fm = _mixed(raw)
+    if partial is not None and partial_rows > 0:          # rows written by enet_conv_stats: fold only
+        call("dct_enet_bn_fwd_stats_rows", C.byref(vr), ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(running_mean),
+             ptr(running_var), int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(save_var), fm, dt, ptr(partial),
+             partial.numel() * partial.element_size(), int(partial_rows), stream())
+        return
+    ws = _enet_ws(raw.device, _lib.load().dct_enet_reduce_workspace_bytes(raw.shape[3]))
     call("dct_enet_bn_fwd_stats", C.byref(vr), ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(running_mean),
          ptr(running_var), int(training), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(save_var), fm, dt, ptr(ws), ws.numel(),
          stream())

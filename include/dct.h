@@ -271,6 +271,15 @@ int dct_enet_conv(const dct_view* x, const float* w, const float* bias, const dc
                   int ws_out, int ws_tap, int ws_in,
                   const dct_view* resid_grad, const dct_view* resid_mask,
                   int f32_mask, int dtype, dct_stream stream);
+/* The same convolution (no residual gate) with the consumer BatchNorm's batch statistics riding along: where the MFMA form is
+ * taken (bf16 / f16, >= 16 input channels) and the output has <= stats_capacity_rows tiles of 32 pixels, every tile writes
+ * its per-channel {sum, sum of squares, 0} as doubles to stats_partial[tile][y.c][3] and *stats_rows = the tile count;
+ * dct_enet_bn_fwd_stats_rows(..., workspace = stats_partial, partial_rows = *stats_rows) then only folds them.  Otherwise
+ * *stats_rows = 0 and the statistics need the usual reduction. */
+int dct_enet_conv_stats(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
+                        const dct_view* y, const dct_conv_desc* d, int transposed,
+                        int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
+                        double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream);
 
 size_t dct_enet_reduce_workspace_bytes(int channels);
 /* nn.BatchNorm2d(eps 1e-3, momentum 0.1) forward statistics of a raw conv output (enet.py:22,55-122):
@@ -284,6 +293,10 @@ int dct_enet_bn_fwd_stats(const dct_view* raw, const float* gamma, const float* 
                           float* running_mean, float* running_var, int training,
                           float* scale, float* shift, float* save_mean, float* save_invstd, float* save_var,
                           int f32_mask, int dtype, void* workspace, size_t workspace_bytes, dct_stream stream);
+int dct_enet_bn_fwd_stats_rows(const dct_view* raw, const float* gamma, const float* beta, float eps, float momentum,
+                               float* running_mean, float* running_var, int training,
+                               float* scale, float* shift, float* save_mean, float* save_invstd, float* save_var,
+                               int f32_mask, int dtype, void* workspace, size_t workspace_bytes, int partial_rows, dct_stream stream);
 /* Backward of act(BN(raw)) given g = grad wrt the activation output (optionally gated by
  * g_mask > 0, the ReLU of the bottleneck sum): dgamma/dbeta/dslope += ..., and
  * draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) (training; eval mode: gamma*invstd*dz with the

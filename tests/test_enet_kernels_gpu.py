@@ -276,3 +276,44 @@ def test_enet_tails(K, dt):
     dimg = torch.ones(B, 2 * h, 2 * w, 1, device=DEV)
     K.enet_tail_bwd(nhwc(d14, dt), imgd, None, 13, 3, dimg, accumulate=True)
     close(nchw(dimg), dimg_ref, torch.float32, "initial tail bwd")
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout,k", [(32, 32, 3), (16, 64, 1), (32, 128, 1), (16, 24, 3)])
+def test_enet_conv_epilogue_bn_statistics(K, dt, cin, cout, k):
+    """dct_enet_conv_stats: the MFMA convolution's epilogue writes the consumer BatchNorm's partial sums (one row per tile of 32
+    pixels, the reduction's [row][C][3] double layout) and dct_enet_bn_fwd_stats_rows folds them -- against the separate
+    reduction over the stored tensor.  429 pixels: 14 tiles, the last one ragged."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 3, 13, 11
+    x = torch.randn(B, cin, H, W, generator=g) * 2 + 1
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    bias = torch.randn(cout, generator=g)
+    tf, _, _ = make_tf(K, cin, 2, g)
+    gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(DEV), torch.randn(cout, generator=g).to(DEV)
+    wk = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    xd = nhwc(x, torch.float32)
+    kw = dict(R=k, S=k, pad_h=k // 2, pad_w=k // 2, ws=(k * k * cin, cin, 1), compute=dt)
+    y1 = torch.empty(B, H, W, cout, dtype=torch.float32, device=DEV)
+    K.enet_conv(xd, wk, bias.to(DEV), tf, y1, **kw)
+    v1 = torch.empty(5, cout, device=DEV)
+    K.enet_bn_fwd_stats(y1, gamma, beta, 1e-3, 0.1, None, None, True, v1[0], v1[1], v1[2], v1[3], save_var=v1[4])
+    tiles = (B * H * W + 31) // 32
+    stats = torch.full((tiles * cout * 3,), float("nan"), dtype=torch.float64, device=DEV)
+    y2 = torch.empty_like(y1)
+    rows = K.enet_conv_stats(xd, wk, bias.to(DEV), tf, y2, stats, **kw)
+    assert rows == tiles == 14
+    assert torch.equal(y1, y2)
+    st = stats.view(tiles, cout, 3)
+    assert torch.isfinite(st).all() and (st[:, :, 2] == 0).all()
+    yp = y1.reshape(-1, cout).double()
+    np.testing.assert_allclose(st[:, :, 0].sum(0).cpu().numpy(), yp.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(st[:, :, 1].sum(0).cpu().numpy(), (yp * yp).sum(0).cpu().numpy(), rtol=1e-5)
+    v2 = torch.empty(5, cout, device=DEV)
+    K.enet_bn_fwd_stats(y2, gamma, beta, 1e-3, 0.1, None, None, True, v2[0], v2[1], v2[2], v2[3], save_var=v2[4], partial=stats, partial_rows=rows)
+    np.testing.assert_allclose(v2.cpu().numpy(), v1.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    # a tensor with more tiles than the scratch holds: nothing written, the caller reduces as usual
+    small = torch.empty(5 * cout * 3, dtype=torch.float64, device=DEV)
+    assert K.enet_conv_stats(xd, wk, bias.to(DEV), tf, y2, small, **kw) == 0 and torch.equal(y1, y2)
+    # fp32 mode keeps the VALU kernel: no rows either
+    assert K.enet_conv_stats(xd, wk, bias.to(DEV), tf, y2, stats, **dict(kw, compute=torch.float32)) == 0
