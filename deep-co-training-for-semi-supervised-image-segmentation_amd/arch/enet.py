@@ -245,6 +245,7 @@ class Enet(nn.Module):
         training-mode forward goes through here (immediately, or deferred), so the arithmetic does not depend on the schedule."""
         if not stats:
             return
+        torch._foreach_add_(self._nbt, 1)       # nn.BatchNorm2d bookkeeping (num_batches_tracked), one launch for all 84 layers
         mom = stats[0][0].momentum
         assert all(bn.momentum == mom for bn, _, _ in stats)
         rms, rvs = [bn.running_mean for bn, _, _ in stats], [bn.running_var for bn, _, _ in stats]
@@ -435,8 +436,6 @@ class Enet(nn.Module):
         fin = self.decoder.layers[5]
         logits = torch.empty(B, H, W, self.num_classes, dtype=torch.float32, device=dev)
         self._conv_fwd(h, None, fin, logits)
-        if self.training:      # nn.BatchNorm2d bookkeeping, one multi-tensor launch for all 84 layers
-            torch._foreach_add_(self._nbt, 1)
         stats, self._bn_stats = self._bn_stats, []
         if save:
             tape.append({"kind": "final", "x": h, "training": self.training})

@@ -35,7 +35,7 @@ from ..metrics import AverageValueMeter, DiceMeter
 from ..models import Segmentator
 from ..utils import iterator_, map_, dict_merge, tqdm_
 from ..utils.AEGenerator import FSGMGenerator
-from .stream_sched import EagerSchedule, StreamDealer
+from .stream_sched import EagerSchedule, StreamDealer, own_stream
 from .trainer import Trainer
 
 
@@ -50,7 +50,7 @@ def _pooled_stream(device, *key, dealer=None):
     k = (str(device),) + key
     st = _STREAM_POOL.get(k) if POOL_STREAMS else None
     if st is None:
-        st = dealer.take() if dealer is not None else torch.cuda.Stream(device=device)
+        st = dealer.take() if dealer is not None else own_stream(device)
         if POOL_STREAMS:
             _STREAM_POOL[k] = st
     return st

@@ -54,18 +54,42 @@ class EagerSchedule(object):
 
 
 _hip = None
+_OWN_STREAMS = {}
+
+
+def _hiplib():
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+        _hip.hipGraphGetNodes.restype = ctypes.c_int
+        _hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        _hip.hipStreamCreateWithFlags.restype = ctypes.c_int
+    return _hip
+
+
+def own_stream(device) -> torch.cuda.Stream:
+    """A HIP stream of this package's own (hipStreamCreateWithFlags, non-blocking), never destroyed.  ``torch.cuda.Stream()``
+    hands out the 32 streams of torch's pool round-robin: in a long-lived process two 'different' Stream objects can be the same
+    stream -- e.g. a model stream and the stream a later graph capture runs on -- and an object that dies with its trainer
+    returns nothing.  Streams that take part in captured programs are therefore created outside that pool."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):
+        h = ctypes.c_void_p()
+        rc = _hiplib().hipStreamCreateWithFlags(ctypes.byref(h), 1)          # hipStreamNonBlocking
+    if rc != 0 or not h.value:
+        return torch.cuda.Stream(dev)
+    st = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
+    _OWN_STREAMS.setdefault(idx, []).append(st)
+    return st
 
 
 def _graph_node_count(graph: torch.cuda.CUDAGraph) -> int:
     """Number of nodes of a captured (keep_graph) graph, -1 when it cannot be asked."""
-    global _hip
     try:
-        if _hip is None:
-            _hip = ctypes.CDLL("libamdhip64.so")
-            _hip.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
-            _hip.hipGraphGetNodes.restype = ctypes.c_int
         n = ctypes.c_size_t(0)
-        if _hip.hipGraphGetNodes(ctypes.c_void_p(int(graph.raw_cuda_graph())), None, ctypes.byref(n)) != 0:
+        if _hiplib().hipGraphGetNodes(ctypes.c_void_p(int(graph.raw_cuda_graph())), None, ctypes.byref(n)) != 0:
             return -1
         return int(n.value)
     except Exception:
@@ -112,7 +136,7 @@ class SegmentRecorder(object):
 
     def __init__(self, device):
         self.device = device
-        self.main = torch.cuda.Stream(device)          # stands in for the caller's stream while recording
+        self.main = own_stream(device)                 # stands in for the caller's stream while recording
         self.ops: List[tuple] = []
         self._pools = {}
         self._empty: List[torch.cuda.CUDAGraph] = []
@@ -255,7 +279,7 @@ def queue_groups(device, candidates: int = 8, links: int = 150) -> List[List[tor
     if key in _QUEUE_GROUPS:
         return _QUEUE_GROUPS[key]
     dev = torch.device(device)
-    streams = [torch.cuda.Stream(dev) for _ in range(candidates)]
+    streams = [own_stream(dev) for _ in range(candidates)]
     xs = [torch.ones(65536, device=dev) for _ in streams]
     graphs = [_chain_graph(s, x, links) for s, x in zip(streams, xs)]
     torch.cuda.synchronize(dev)
@@ -308,7 +332,7 @@ class StreamDealer(object):
                         order.append(g.pop(0))
             self._order = order
         if self._next >= len(self._order):
-            return torch.cuda.Stream(self.device)           # more chains than candidates: whatever HIP picks
+            return own_stream(self.device)                  # more chains than candidates: whatever HIP picks
         s = self._order[self._next]
         self._next += 1
         return s
