@@ -149,6 +149,8 @@ class CoTrainer(Trainer):
         self.wide_forward = True            # networks with deferred running statistics: lay the step out on four hardware queues
                                             # (see _run_step_wide)
         self._qstreams = None
+        self.adv_chain_layout = True        # two batch-independent networks (UNet) with FGSM: see _run_step_adv_chain
+        self._step_hint_adv_chain = False
         self.early_backward = True          # start the labeled / unlabeled backward passes right after the JSD, beside the
                                             # adversarial block (pass-stream nets; see _run_step_fused)
         self.grad_overwrite = True          # nets that support it: first backward pass of a step writes the gradients (no zero fill)
@@ -250,6 +252,12 @@ class CoTrainer(Trainer):
         unl = None
         if unlab_batch is not None and (train_jsd or train_adv):
             unl = (_img(unlab_batch[0]), _gt(unlab_batch[1]) if unlab_batch[1] is not None else None)
+        self._step_hint_adv_chain = bool(
+            self.adv_chain_layout and train_jsd and train_adv and unl is not None and adv_choice is not None and
+            len(self.segmentators) == 2 and adv_choice[0] != adv_choice[1] and self.batch_lab_unlab and self.model_streams and
+            self.grad_sync is None and
+            all(getattr(s.torchnet, "batch_independent", False) and getattr(s.torchnet, "supports_grad_overwrite", False) and
+                getattr(s.torchnet, "external_dropout_masks", None) is None for s in self.segmentators))
         if self._fused_ok():
             # replay needs every per-step scalar on the device: only the fused Adam keeps its step count / lr there
             graphable = all(hasattr(s.optimizer, "refresh_lr") and hasattr(s.optimizer, "_steps") for s in self.segmentators)
@@ -285,6 +293,8 @@ class CoTrainer(Trainer):
     def _use_segments(self) -> bool:
         if self.segmented_graphs is not None:
             return bool(self.segmented_graphs)
+        if self._step_hint_adv_chain:
+            return True         # two batch-independent nets + FGSM: the adversarial chain gets a hardware queue (_run_step_adv_chain)
         if self.grad_sync is not None and self.ddp_segmented_graph:
             return True         # data parallelism: the gradient exchanges are host callbacks BETWEEN graph segments
         return any(getattr(seg.torchnet, "prefers_segmented_graphs", False) for seg in self.segmentators)
@@ -446,6 +456,8 @@ class CoTrainer(Trainer):
         main = torch.cuda.current_stream(self.device)
         if self._wide_ok(nets, streams, train_jsd, unl, fuse):
             return self._run_step_wide(lab, unl, train_adv, adv_choice, nets, gs, g_cot, g_adv, lam_cot, lam_adv, ignore)
+        if fuse and self._adv_chain_ok(nets, streams, train_jsd, train_adv, adv_choice, unl):
+            return self._run_step_adv_chain(lab, unl, adv_choice, nets, gs, g_cot, g_adv, lam_cot, lam_adv, ignore)
 
         def on(i):
             return self._sched.on(streams[i]) if streams is not None else contextlib.nullcontext()
@@ -739,6 +751,92 @@ class CoTrainer(Trainer):
             self._pass_join = None
         for i in range(S):                          # running statistics: labeled, unlabeled, FGSM, adversarial (reference order)
             nets[i].apply_running_updates(tapes[i])
+        return dict(sup=sup, jsd=jsd, adv=adv, preds=preds, unlab_probs=unlab_probs)
+
+    def _adv_chain_ok(self, nets, streams, train_jsd, train_adv, adv_choice, unl) -> bool:
+        if not (self._step_hint_adv_chain and streams is not None and self.grad_overwrite):
+            return False
+        if torch.cuda.is_current_stream_capturing() and not self._sched.capturing:
+            return False        # ONE graph being captured: joins into forked streams crash hipStreamEndCapture (ROCm 7.2)
+        if not all(n.training and n.flat_params.grads_attached() for n in nets):
+            return False
+        return self._queue_streams() is not None
+
+    def _run_step_adv_chain(self, lab, unl, adv_choice, nets, gs, g_cot, g_adv, lam_cot, lam_adv, ignore) -> dict:
+        """Two batch-independent networks (UNet), CE + JSD + FGSM, on three hardware queues.
+
+        In the sequential layout the adversarial block is a tail of its own: both joint forwards -> JSD -> FGSM forward + input
+        gradient on model b ALONE (2.6 of a 12.6 ms cfg3 step) -> model a's forward on the perturbed batch ALONE (1.2 ms) -> the
+        backward passes, model a's two one after the other while model b's queue idles (tools/probe_step_program.py cfg3).  But the
+        FGSM chain needs nothing from the JSD: it is queued on model b's queue right behind b's joint forward, followed there by
+        model a's adversarial forward; the JSD and model b's backward pass take a third queue; model a's queue runs its forward,
+        its backward, then -- once the adversarial forward has arrived -- the adversarial backward, accumulating as before.
+        Per network the order of forward passes (dropout counter) and of gradient accumulation is the sequential one, so the
+        results are bit for bit the same.  Optimizers: model b's waits for the adversarial chain (the last reader of b's weights)."""
+        from .. import hip_ops as K
+        from ..loss.loss import _nchw
+        C = self.C
+        a, b = adv_choice
+        sched = self._sched
+        main = torch.cuda.current_stream(self.device)
+        Q = self._queue_streams()
+        qa, qb, qj = Q[0], Q[1], Q[2]
+        used = (qa, qb, qj)
+        q_of = {a: qa, b: qb}
+        sched.wait([(st, main) for st in used])
+        full, sup, preds, fwd_done = {}, [None, None], [None, None], {}
+        B_l = lab[0][0].shape[0]
+        for i in (b, a):                                                       # :208-227 (joint labeled + unlabeled pass)
+            with sched.on(q_of[i]):
+                img, gt = lab[i]
+                lp_all, tape = nets[i].plan_forward(torch.cat((img, unl[0]), dim=0), True)
+                dl_all = torch.empty_like(lp_all)
+                full[i] = (tape, lp_all, dl_all)
+                lp, t = lp_all[:B_l], gt.reshape(-1)
+                out = K.ce_fwd(lp, t, C, ignore)
+                K.ce_bwd(lp, t, C, out[1:2], dl_all[:B_l], gmul=gs, ignore_index=ignore)
+                sup[i] = out[0]
+                preds[i] = _nchw(lp)
+            fwd_done[i] = sched.record(q_of[i])
+        eps = float(self.adv_training_dict.get('eplision', 0.05))              # :233-244 -> :371-392
+        with sched.on(qb):
+            x = torch.cat((lab[b][0], unl[0]), dim=0)
+            x_adv, noise, lp_real, _ = self._fgsm_fused(nets[b], x, lab[b][1], eps, ignore)
+        sched.wait_event(qb, fwd_done[a])           # model a's passes keep their order (dropout counter, weight packs)
+        da = None
+        with sched.on(qb):
+            lp_adv, atape = nets[a].plan_forward(x_adv, True)
+            adv = K.kl_logits_fwd(lp_adv, lp_real, C)[0]
+            if lam_adv != 0.0:
+                da = K.kl_logits_bwd(lp_adv, lp_real, C, torch.empty_like(lp_adv), **g_adv)
+        adv_done = sched.record(qb)
+        sched.wait_event(qj, fwd_done[a])
+        sched.wait_event(qj, fwd_done[b])
+        with sched.on(qj):
+            lps = [full[i][1][B_l:] for i in range(2)]
+            dl_outs = [full[i][2][B_l:] for i in range(2)]
+            jsd = K.jsd_logits_fwd(lps, C)[0]
+            unlab_probs = [_nchw(K.softmax_fwd(lp, C)) for lp in lps]
+            if lam_cot != 0.0:
+                K.jsd_logits_bwd(lps, C, dl_outs, **g_cot)
+            else:
+                for d in dl_outs:
+                    d.zero_()
+        jsd_done = sched.record(qj)
+        with sched.on(qj):                          # model b's backward: its own queue is busy with the adversarial chain
+            nets[b].plan_backward(full[b][0], full[b][2], need_dx=False, need_dw=True, overwrite=True)
+        sched.wait_event(qa, jsd_done)
+        with sched.on(qa):
+            nets[a].plan_backward(full[a][0], full[a][2], need_dx=False, need_dw=True, overwrite=True)
+        sched.wait_event(qa, adv_done)
+        if da is not None:
+            with sched.on(qa):
+                nets[a].plan_backward(atape, da, need_dx=False, need_dw=True)
+        sched.wait_event(qj, adv_done)              # the adversarial chain read model b's weights
+        opt_streams = [None, None]
+        opt_streams[a], opt_streams[b] = qa, qj
+        self._optimizer_phase(opt_streams)
+        sched.wait([(main, st) for st in used])
         return dict(sup=sup, jsd=jsd, adv=adv, preds=preds, unlab_probs=unlab_probs)
 
     def _fgsm_fused(self, net, x, gt, eps, ignore, defer_running=False):

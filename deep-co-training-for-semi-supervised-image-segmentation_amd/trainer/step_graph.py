@@ -53,7 +53,8 @@ class StepGraphCache(object):
         tr = self.tr
         sig: List = [bool(train_jsd), bool(train_adv), tuple(adv_choice) if adv_choice is not None else None,
                      lam[0] != 0.0, lam[1] != 0.0, bool(tr.model_streams), bool(tr.batch_lab_unlab), tr.grad_sync is not None,
-                     bool(tr._use_segments()), bool(tr.pass_streams), bool(tr.early_backward), bool(tr.wide_forward)]
+                     bool(tr._use_segments()), bool(tr.pass_streams), bool(tr.early_backward), bool(tr.wide_forward),
+                     bool(tr.adv_chain_layout)]
         for img, gt in lab:
             sig.append((tuple(img.shape), img.dtype, tuple(gt.shape), gt.dtype))
         if unl is not None:

@@ -113,6 +113,19 @@ def test_four_queue_layout_changes_nothing(tmp_path, adv, S):
     _same(wide, eager_wide)
 
 
+def test_unet_adversarial_chain_layout_changes_nothing(tmp_path):
+    """CoTrainer._run_step_adv_chain (2 x UNet + FGSM: the adversarial chain queued behind model b's forward, JSD and model b's
+    backward on a third queue) against the sequential layout, dropout on: same weights, moments, losses."""
+    new = _run(tmp_path, "unet", True, adv_chain_layout=True)
+    old = _run(tmp_path, "unet", True, adv_chain_layout=False)
+    new_eager = _run(tmp_path, "unet", True, adv_chain_layout=True, use_hip_graph=False)
+    assert new[0]._queue_streams() is not None, "fewer than four hardware queues found: the layout was not exercised"
+    assert all(c.program is not None for c in new[0]._step_graphs._graphs.values())      # adversarial steps replay as a program
+    assert all(c.program is None for c in old[0]._step_graphs._graphs.values())
+    _same(new, old)
+    _same(new, new_eager)
+
+
 def test_queue_groups_partition_the_candidates():
     from dct_amd.trainer.stream_sched import StreamDealer, queue_groups
     groups = queue_groups(DEV)
