@@ -110,6 +110,8 @@ SIGNATURES = {
     "dct_enet_bn_fwd_stats_rows": (_i, [_VP, _P, _P, _f, _f, _P, _P, _i, _P, _P, _P, _P, _P, _i, _i, _P, _sz, _i, _P]),
     "dct_enet_conv_stats": (_i, [_VP, _P, _P, _TP, _VP, _DP, _i, _i, _i, _i, _i, _i, _P, _i, _P, _P]),
     "dct_enet_bn_bwd": (_i, [_VP, _VP, _VP, _P, _P, _P, _i, _P, _P, _P, _P, _P, _P, _i, _VP, _i, _i, _P, _sz, _P]),
+    "dct_enet_bn_bwd_rows": (_i, [_VP, _VP, _VP, _P, _P, _P, _i, _P, _P, _P, _P, _P, _P, _i, _VP, _i, _i, _P, _sz, _i, _P]),
+    "dct_enet_conv_bnbwd_stats": (_i, [_VP, _P, _VP, _DP, _i, _i, _i, _i, _i, _i, _VP, _P, _P, _P, _i, _P, _P, _P, _i, _P, _P]),
     "dct_enet_channel_sum": (_i, [_VP, _P, _i, _i, _P, _sz, _P]),
     "dct_enet_tail_fwd": (_i, [_VP, _TP, _VP, _VP, _TP, _P, _i, _i, _VP, _i, _i, _P]),
     "dct_enet_tail_bwd": (_i, [_VP, _VP, _P, _i, _i, _i, _VP, _i, _i, _P]),

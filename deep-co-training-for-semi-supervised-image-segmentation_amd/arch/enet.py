@@ -192,6 +192,10 @@ class Enet(nn.Module):
         self._bn_stats = []                  # (bn, batch mean, unbiased batch variance) of the forward pass being planned
         self._defer_running = False
         self.fuse_bn_stats = os.environ.get("DCT_ENET_FUSE_BN_STATS", "1") != "0"     # BatchNorm partial sums from the conv epilogue
+        # ... and the backward sums from the data-gradient epilogue (dct_enet_conv_bnbwd_stats): -270 launches per cfg4 step but level
+        # on the step (17.05 vs 17.15 ms) -- off; tests/test_enet_kernels_gpu.py pins the kernel, tools/debug_fuse_bn.py compares a
+        # whole backward pass (3e-3 in fp16 / 3e-2 in bf16 on the smallest gradients: rounding ties of the 16-bit draw tensors)
+        self.fuse_bn_bwd_stats = os.environ.get("DCT_ENET_FUSE_BN_BWD", "0") == "1"
         self.skip_zero_bias_grads = os.environ.get("DCT_ENET_BIAS_GRADS", "0") != "1"    # see _conv_wgrad
 
     supports_pass_streams = True         # plan_backward(grad_buffer=...): concurrent backward passes of one model (trainer)
@@ -337,10 +341,30 @@ class Enet(nn.Module):
             K.enet_conv(src, w, b, src_tf, dst, R=conv.kh, S=conv.kw, stride=conv.stride, dil=conv.dil, pad_h=conv.pad[0],
                         pad_w=conv.pad[1], ws=(t * conv.cin, conv.cin, 1), compute=self.compute_dtype)
 
-    def _conv_dgrad(self, g, conv, dst, accumulate=False, resid=None):
-        """dst (+)= d(loss)/d(conv input) given g = d/d(conv output)."""
+    def _conv_dgrad(self, g, conv, dst, accumulate=False, resid=None, bn_of_dst=None):
+        """dst (+)= d(loss)/d(conv input) given g = d/d(conv output).
+
+        ``bn_of_dst`` (a _Rec): dst is the gradient wrt act(BN(rec.raw)); where the MFMA form runs, its epilogue also writes that
+        BatchNorm's backward partial sums -> (dst, stats, rows) for _bn_bwd (rows = 0: not written)."""
         w = self._w(conv.weight)
         t = conv.taps
+        if bn_of_dst is not None:
+            rec = bn_of_dst
+            tiles = (dst.shape[0] * dst.shape[1] * dst.shape[2] + 31) // 32
+            cin_g = g.shape[3]
+            if (self.fuse_bn_bwd_stats and self._tape_training and self.compute_dtype != torch.float32 and cin_g >= 16 and cin_g % 16 == 0 and
+                    dst.shape[3] <= 128 and tiles <= 1024 and not accumulate and resid is None):
+                stats = torch.empty(tiles * dst.shape[3] * 3, dtype=torch.float64, device=dst.device)
+                kw = dict(R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1], compute=self.compute_dtype)
+                if conv.transposed:
+                    rows = K.enet_conv_bnbwd_stats(g, w, dst, stats, rec.raw, rec.tf, rec.mean, rec.invstd,
+                                                   ws=(t * conv.cout, conv.cout, 1), **kw)
+                else:
+                    rows = K.enet_conv_bnbwd_stats(g, w, dst, stats, rec.raw, rec.tf, rec.mean, rec.invstd, dil=conv.dil,
+                                                   transposed=True, ws=(1, conv.cin, t * conv.cin), **kw)
+                return dst, stats, rows
+            self._conv_dgrad(g, conv, dst)
+            return dst, None, 0
         rg, rm = resid if resid is not None else (None, None)
         if conv.transposed:
             K.enet_conv(g, w, None, None, dst, R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1],
@@ -447,8 +471,9 @@ class Enet(nn.Module):
         return logits, tape
 
     # ------------------------------------------------------------------------------ backward plan
-    def _bn_bwd(self, rec: _Rec, g, g_mask, need_dw):
-        """grad wrt act(bn(raw)) -> grad wrt raw; accumulates dgamma / dbeta / dslope."""
+    def _bn_bwd(self, rec: _Rec, g, g_mask, need_dw, partial=None, rows=0):
+        """grad wrt act(bn(raw)) -> grad wrt raw; accumulates dgamma / dbeta / dslope.  ``partial`` / ``rows``: the reduction's
+        partial sums, already written by the data-gradient convolution that produced g (_conv_dgrad(bn_of_dst=rec))."""
         dev = rec.raw.device
         c = rec.raw.shape[3]
         draw = torch.empty(rec.raw.shape, dtype=self.compute_dtype, device=dev)
@@ -457,7 +482,8 @@ class Enet(nn.Module):
         db = self._g(rec.bn.bias) if need_dw else None
         ds = self._g(rec.act.weight) if (need_dw and isinstance(rec.act, _PReLU)) else None
         # FGSM pass (need_dw False): the finalize kernel skips null parameter gradients -- no throw-away zero buffers
-        K.enet_bn_bwd(rec.raw, g, g_mask, rec.tf, rec.mean, rec.invstd, dg, db, ds, scratch, draw, training=self._tape_training)
+        K.enet_bn_bwd(rec.raw, g, g_mask, rec.tf, rec.mean, rec.invstd, dg, db, ds, scratch, draw, training=self._tape_training,
+                      partial=partial, partial_rows=rows)
         return draw
 
     def _bottleneck_bwd(self, st, dout, need_dw, need_dx=True):
@@ -469,8 +495,8 @@ class Enet(nn.Module):
         d3 = self._bn_bwd(r3, dout, out, need_dw)
         if need_dw:
             self._conv_wgrad(d3, r3.conv, r2.raw, r2.tf, before_bn=True)
-        g2 = self._conv_dgrad(d3, r3.conv, torch.empty(r2.raw.shape, dtype=dt, device=r2.raw.device))
-        d2 = self._bn_bwd(r2, g2, None, need_dw)
+        g2, p2, n2 = self._conv_dgrad(d3, r3.conv, torch.empty(r2.raw.shape, dtype=dt, device=r2.raw.device), bn_of_dst=r2)
+        d2 = self._bn_bwd(r2, g2, None, need_dw, partial=p2, rows=n2)
         if blk.kind == "asym":
             c5, c15 = blk.middle_block.at(0).at(0), blk.middle_block.at(0).at(1)
             mid_raw = st["mid_raw"]
@@ -479,12 +505,12 @@ class Enet(nn.Module):
             gmid = self._conv_dgrad(d2, c15, torch.empty(mid_raw.shape, dtype=dt, device=mid_raw.device))
             if need_dw:
                 self._conv_wgrad(gmid, c5, r1.raw, r1.tf)
-            g1 = self._conv_dgrad(gmid, c5, torch.empty(r1.raw.shape, dtype=dt, device=r1.raw.device))
+            g1, p1, n1 = self._conv_dgrad(gmid, c5, torch.empty(r1.raw.shape, dtype=dt, device=r1.raw.device), bn_of_dst=r1)
         else:
             if need_dw:
                 self._conv_wgrad(d2, r2.conv, r1.raw, r1.tf, before_bn=True)
-            g1 = self._conv_dgrad(d2, r2.conv, torch.empty(r1.raw.shape, dtype=dt, device=r1.raw.device))
-        d1 = self._bn_bwd(r1, g1, None, need_dw)
+            g1, p1, n1 = self._conv_dgrad(d2, r2.conv, torch.empty(r1.raw.shape, dtype=dt, device=r1.raw.device), bn_of_dst=r1)
+        d1 = self._bn_bwd(r1, g1, None, need_dw, partial=p1, rows=n1)
         if need_dw:
             self._conv_wgrad(d1, r1.conv, x, None, before_bn=True)
         # ---- input gradient = extension branch + main branch

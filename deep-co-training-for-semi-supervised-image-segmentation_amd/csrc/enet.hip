@@ -88,6 +88,9 @@ struct ConvP {
   int vec;                        // input rows can be read 8 channels at a time
   int wvec;          // MFMA form: weight rows are K-major and 16-byte aligned (one 32-byte load per B fragment)
   double* stats;     // MFMA form, optional: per-tile channel sums {sum, sum of squares, 0} of the stored outputs, [pixel tile][Cout][3]
+  // MFMA form, optional (data gradients): the outputs are g = d/d act(BN(braw)) of the producing layer; per-tile BatchNorm-backward
+  // sums {sum dz, sum dz xhat, sum g z [z<0]} (enet_reduce kind 1) go to stats instead
+  View braw; const float* bscale; const float* bshift; const float* bslope; const float* bmean; const float* binvstd; int bact; int bn_bwd;
 };
 
 // One thread = one output pixel x 8 output channels.  Weights live in LDS as [tap][i][G*8].
@@ -370,21 +373,58 @@ __device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, fl
       add[i][j] = t;
     }
   }
-  float s1[NT], s2[NT];
+  float s1[NT], s2[NT], s3[NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = s3[j] = 0.f;
+  if (p.stats && p.bn_bwd) {
+    // the stored value g (rounded to its storage type, as the BatchNorm-backward reduction would read it back) against the
+    // producing layer's raw output: dz = g act'(z), xhat -- the reduction kernel's arithmetic, one tile of it
+    float braw[4][NT], bsc[NT], bsh[NT], bsl[NT], bmu[NT], bis[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int c = cbase + 32 * j + r;
-      if (pv[i] && c < Cout) {
-        const float out = val[i][j] + add[i][j];
-        if constexpr (YF || sizeof(T) == 4) reinterpret_cast<float*>(p.y.ptr)[yo[i] + c] = out;
-        else reinterpret_cast<T*>(p.y.ptr)[yo[i] + c] = from_f32<T>(out);
-        s1[j] += out; s2[j] = fmaf(out, out, s2[j]);
+      const int c = min(cbase + 32 * j + r, Cout - 1);
+      bsc[j] = p.bscale[c]; bsh[j] = p.bshift[c]; bmu[j] = p.bmean[c]; bis[j] = p.binvstd[c]; bsl[j] = p.bact == 2 ? p.bslope[c] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long pix = wbase + 8 * wave + 4 * h + i;
+        int n, oy, ox;
+        pix3u((unsigned)(pv[i] ? pix : 0), p.y.h, p.y.w, n, oy, ox);
+        braw[i][j] = reinterpret_cast<const float*>(p.braw.ptr)[(pv[i] && cbase + 32 * j + r < Cout) ? voff(p.braw, n, oy, ox) + c : 0];
       }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int c = cbase + 32 * j + r;
+        if (pv[i] && c < Cout) {
+          const float out = val[i][j] + add[i][j];
+          float g;
+          if constexpr (YF || sizeof(T) == 4) { reinterpret_cast<float*>(p.y.ptr)[yo[i] + c] = out; g = out; }
+          else { const T q = from_f32<T>(out); reinterpret_cast<T*>(p.y.ptr)[yo[i] + c] = q; g = to_f32(q); }
+          const float v = braw[i][j];
+          const float z = fmaf(bsc[j], v, bsh[j]);
+          float dz = g;
+          if (p.bact == 2) { if (!(z > 0.f)) { dz = g * bsl[j]; s3[j] = fmaf(g, z, s3[j]); } }
+          else if (p.bact == 3) { if (!(z > 0.f)) dz = 0.f; }
+          const float xh = (v - bmu[j]) * bis[j];
+          s1[j] += dz; s2[j] = fmaf(dz, xh, s2[j]);
+        }
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int c = cbase + 32 * j + r;
+        if (pv[i] && c < Cout) {
+          const float out = val[i][j] + add[i][j];
+          if constexpr (YF || sizeof(T) == 4) reinterpret_cast<float*>(p.y.ptr)[yo[i] + c] = out;
+          else reinterpret_cast<T*>(p.y.ptr)[yo[i] + c] = from_f32<T>(out);
+          s1[j] += out; s2[j] = fmaf(out, out, s2[j]);
+        }
+      }
+  }
   if (p.stats) {
     // BatchNorm statistics of this tile ride along: the consumer's reduction launch (a full read of the tensor and one more
     // seam on the forward chain) is replaced by 32 more partial rows... per-channel sums over the tile's 32 pixels -- 4 rows per
@@ -393,7 +433,10 @@ __device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, fl
     for (int j = 0; j < NT; ++j) {
       s1[j] += __shfl_xor(s1[j], 32, 64);
       s2[j] += __shfl_xor(s2[j], 32, 64);
-      if (h == 0) { srd[((wave * NT + j) * 32 + r) * 2] = s1[j]; srd[((wave * NT + j) * 32 + r) * 2 + 1] = s2[j]; }
+      s3[j] += __shfl_xor(s3[j], 32, 64);
+      if (h == 0) {
+        srd[((wave * NT + j) * 32 + r) * 3] = s1[j]; srd[((wave * NT + j) * 32 + r) * 3 + 1] = s2[j]; srd[((wave * NT + j) * 32 + r) * 3 + 2] = s3[j];
+      }
     }
     __syncthreads();
     if (wave == 0 && h == 0) {
@@ -402,11 +445,14 @@ __device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, fl
       for (int j = 0; j < NT; ++j) {
         const int c = cbase + 32 * j + r;
         if (c < Cout) {
-          double a = 0.0, b = 0.0;
+          double a = 0.0, b = 0.0, d2 = 0.0;
 #pragma unroll
-          for (int w = 0; w < MC_W; ++w) { a += (double)srd[((w * NT + j) * 32 + r) * 2]; b += (double)srd[((w * NT + j) * 32 + r) * 2 + 1]; }
+          for (int w = 0; w < MC_W; ++w) {
+            a += (double)srd[((w * NT + j) * 32 + r) * 3]; b += (double)srd[((w * NT + j) * 32 + r) * 3 + 1];
+            d2 += (double)srd[((w * NT + j) * 32 + r) * 3 + 2];
+          }
           double* o = p.stats + (row * Cout + c) * 3;
-          o[0] = a; o[1] = b; o[2] = 0.0;
+          o[0] = a; o[1] = b; o[2] = d2;
         }
       }
     }
@@ -417,7 +463,7 @@ template <typename T, int NT>
 __global__ __launch_bounds__(64 * MC_W) void enet_mconv_kernel(ConvP p, int ngroups) {
   __shared__ __attribute__((aligned(16))) float tfs[3 * 128];
   __shared__ float red[MC_W * NT * 16 * 64];
-  __shared__ float srd[MC_W * NT * 32 * 2];
+  __shared__ float srd[MC_W * NT * 32 * 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   for (int c = threadIdx.x; c < 128; c += 64 * MC_W) {
@@ -1225,7 +1271,9 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
                           const dct_view* y, const dct_conv_desc* d, int transposed,
                           int ws_out, int ws_tap, int ws_in,
                           const dct_view* resid_grad, const dct_view* resid_mask,
-                          int f32_mask, int dtype, double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream) {
+                          int f32_mask, int dtype, double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream,
+                          const dct_view* bn_raw = nullptr, const float* bn_scale = nullptr, const float* bn_shift = nullptr,
+                          const float* bn_slope = nullptr, int bn_act = 0, const float* bn_mean = nullptr, const float* bn_invstd = nullptr) {
   if (stats_rows) *stats_rows = 0;
   if (!view_ok(x) || !view_ok(y) || !w || !d || !ok_dtype(dtype) || x->n != y->n) return DCT_ERR_BAD_ARG;
   if (d->R < 1 || d->S < 1 || d->stride < 1 || d->dil < 1) return DCT_ERR_BAD_ARG;
@@ -1236,7 +1284,8 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
   p.R = d->R; p.S = d->S; p.stride = d->stride; p.dil = d->dil; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
   p.transposed = transposed ? 1 : 0; p.accumulate = d->accumulate ? 1 : 0;
   p.ws_out = ws_out; p.ws_tap = ws_tap; p.ws_in = ws_in;
-  p.has_resid = 0; p.wvec = 0; p.stats = nullptr;
+  p.has_resid = 0; p.wvec = 0; p.stats = nullptr; p.bn_bwd = 0; p.bact = 0; p.braw = p.y;
+  p.bscale = p.bshift = p.bslope = p.bmean = p.binvstd = nullptr;
   p.rg = p.y; p.rm = p.y;
   if (resid_grad) {
     if (!view_ok(resid_grad) || !view_ok(resid_mask)) return DCT_ERR_BAD_ARG;
@@ -1260,7 +1309,19 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
     const long long Pm = (long long)y->n * y->h * y->w;
     const long long ptiles = (Pm + 31) / 32;
     const int ntiles = (y->c + 31) / 32;
-    if (stats_partial && stats_rows && ptiles <= stats_capacity_rows && !d->accumulate) { p.stats = stats_partial; *stats_rows = (int)ptiles; }
+    if (stats_partial && stats_rows && ptiles <= stats_capacity_rows && !d->accumulate) {
+      bool ok = true;
+      if (bn_raw) {       // BatchNorm-backward sums: the producing layer's raw fp32 output, same pixels and channels as y
+        ok = view_ok(bn_raw) && bn_raw->n == y->n && bn_raw->h == y->h && bn_raw->w == y->w && bn_raw->c == y->c && bn_scale && bn_shift &&
+             bn_mean && bn_invstd && (bn_act != 2 || bn_slope) &&
+             (long long)bn_raw->n * bn_raw->sn + (long long)bn_raw->h * bn_raw->sh + (long long)bn_raw->w * bn_raw->sw < 0x7fffffffLL;
+        if (ok) {
+          p.bn_bwd = 1; p.braw = to_view(bn_raw); p.bscale = bn_scale; p.bshift = bn_shift; p.bslope = bn_slope; p.bmean = bn_mean;
+          p.binvstd = bn_invstd; p.bact = bn_act;
+        }
+      }
+      if (ok) { p.stats = stats_partial; *stats_rows = (int)ptiles; }
+    }
     int nt = 1;
     if (ntiles >= 4 && ptiles >= 2048) nt = 4;
     else if (ntiles >= 2 && ptiles * ((ntiles + 1) / 2) >= 2048) nt = 2;
@@ -1288,6 +1349,16 @@ extern "C" int dct_enet_conv(const dct_view* x, const float* w, const float* bia
                              int f32_mask, int dtype, dct_stream stream) {
   return enet_conv_impl(x, w, bias, tf, y, d, transposed, ws_out, ws_tap, ws_in, resid_grad, resid_mask, f32_mask, dtype, nullptr, 0, nullptr,
                         stream);
+}
+
+extern "C" int dct_enet_conv_bnbwd_stats(const dct_view* x, const float* w, const dct_view* y, const dct_conv_desc* d, int transposed,
+                                         int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
+                                         const dct_view* bn_raw, const float* bn_scale, const float* bn_shift, const float* bn_slope, int bn_act,
+                                         const float* bn_mean, const float* bn_invstd,
+                                         double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream) {
+  if (!stats_partial || !stats_rows || stats_capacity_rows < 1 || !bn_raw) return DCT_ERR_BAD_ARG;
+  return enet_conv_impl(x, w, nullptr, nullptr, y, d, transposed, ws_out, ws_tap, ws_in, nullptr, nullptr, f32_mask, dtype, stats_partial,
+                        stats_capacity_rows, stats_rows, stream, bn_raw, bn_scale, bn_shift, bn_slope, bn_act, bn_mean, bn_invstd);
 }
 
 extern "C" int dct_enet_conv_stats(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
@@ -1388,8 +1459,19 @@ extern "C" int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct
                                float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
                                const dct_view* draw, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
                                dct_stream stream) {
+  return dct_enet_bn_bwd_rows(raw, g, g_mask, scale, shift, slope, act, mean, invstd, dgamma, dbeta, dslope, c1c2, training, draw, f32_mask,
+                              dtype, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int dct_enet_bn_bwd_rows(const dct_view* raw, const dct_view* g, const dct_view* g_mask,
+                                    const float* scale, const float* shift, const float* slope, int act,
+                                    const float* mean, const float* invstd,
+                                    float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
+                                    const dct_view* draw, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
+                                    int partial_rows, dct_stream stream) {
   if (!view_ok(raw) || !view_ok(g) || !view_ok(draw) || !scale || !shift || !mean || !invstd || !c1c2 || !ok_dtype(dtype))
     return DCT_ERR_BAD_ARG;
+  if (partial_rows > 0 && g_mask) return DCT_ERR_BAD_ARG;
   if (raw->c > 128 || (act == 2 && !slope)) return DCT_ERR_BAD_ARG;
   RedP p; p.x = to_view(raw); p.g = to_view(g); p.m = p.g;
   p.has_mask = 0;
@@ -1401,7 +1483,7 @@ extern "C" int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct
   {
     const View vo0 = to_view(draw);
     const int oesz = ((f32_mask & 8) || dtype == DCT_F32) ? 4 : 2;
-    if (enet_owner_ok(p, dtype, &vo0) && vo0.c == p.x.c && vo0.n == p.x.n && vo0.h == p.x.h && vo0.w == p.x.w &&
+    if (partial_rows <= 0 && enet_owner_ok(p, dtype, &vo0) && vo0.c == p.x.c && vo0.n == p.x.n && vo0.h == p.x.h && vo0.w == p.x.w &&
         ((uintptr_t)vo0.ptr % oesz) == 0) {
       const double cnt = (double)raw->n * raw->h * raw->w;
       ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_owner_kernel<T>, dim3(raw->c / 8), dim3(OWN_T), 0, st, p, cnt, training ? 1 : 0,
@@ -1409,8 +1491,13 @@ extern "C" int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct
       return dct_check_launch();
     }
   }
-  const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
-  if (rc != DCT_OK) return rc;
+  if (partial_rows > 0) {         // the data-gradient convolution that produced g wrote the partial rows (dct_enet_conv_bnbwd_stats)
+    if (!workspace || workspace_bytes < (size_t)partial_rows * raw->c * 3 * sizeof(double)) return DCT_ERR_WORKSPACE;
+    blocks = partial_rows;
+  } else {
+    const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
+    if (rc != DCT_OK) return rc;
+  }
   const double count = (double)raw->n * raw->h * raw->w;
   const long long total = (long long)raw->n * raw->h * raw->w * raw->c;
   const View vo = to_view(draw);

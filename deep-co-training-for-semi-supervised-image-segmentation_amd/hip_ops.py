@@ -428,12 +428,37 @@ def enet_bn_fwd_stats(raw, gamma, beta, eps, momentum, running_mean, running_var
          stream())
 
 
-def enet_bn_bwd(raw, g, g_mask, tf, mean, invstd, dgamma, dbeta, dslope, c1c2, draw, training=True):
+def enet_conv_bnbwd_stats(x, w, y, stats, rec_raw, rec_tf, rec_mean, rec_invstd, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0,
+                          transposed=False, ws=(0, 0, 0), compute=None):
+    """Data-gradient convolution y = dgrad(x) (enet_conv without bias / transform / residual) whose epilogue also writes the
+    BatchNorm-backward partial sums of the layer that produced y's tensor (raw output ``rec_raw``, consumer transform ``rec_tf``,
+    saved statistics) into ``stats`` (float64, >= tiles * C * 3).  -> partial rows written (0: the usual reduction is needed)."""
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w)
+    vx, vy, vr = view(x), view(y), view(rec_raw)
+    dt, fm = _mixed(x, y)
+    if dt == F32 and compute in (torch.bfloat16, torch.float16):
+        dt = DTYPE_OF[compute]
+    act = rec_tf.mode if rec_tf.mode in (2, 3) else 0
+    rows = C.c_int(0)
+    cap = stats.numel() // (3 * y.shape[3])
+    call("dct_enet_conv_bnbwd_stats", C.byref(vx), ptr(w), C.byref(vy), C.byref(d), int(transposed), int(ws[0]), int(ws[1]), int(ws[2]),
+         fm, dt, C.byref(vr), ptr(rec_tf.scale), ptr(rec_tf.shift), ptr(rec_tf.slope), int(act), ptr(rec_mean), ptr(rec_invstd),
+         ptr(stats), int(cap), C.byref(rows), stream())
+    return int(rows.value)
+
+
+def enet_bn_bwd(raw, g, g_mask, tf, mean, invstd, dgamma, dbeta, dslope, c1c2, draw, training=True, partial=None, partial_rows=0):
     vr, vg, vd = view(raw), view(g), view(draw)
     vm = view(g_mask) if g_mask is not None else None
-    ws = _enet_ws(raw.device, _lib.load().dct_enet_reduce_workspace_bytes(raw.shape[3]))
     act = tf.mode if tf.mode in (2, 3) else 0
     dt, fm = _mixed(raw, g, g_mask, draw)
+    if partial is not None and partial_rows > 0:          # rows written by enet_conv_bnbwd_stats: fold + apply only
+        call("dct_enet_bn_bwd_rows", C.byref(vr), C.byref(vg), None,
+             ptr(tf.scale), ptr(tf.shift), ptr(tf.slope), int(act), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(dslope),
+             ptr(c1c2), int(training), C.byref(vd), fm, dt, ptr(partial), partial.numel() * partial.element_size(), int(partial_rows),
+             stream())
+        return draw
+    ws = _enet_ws(raw.device, _lib.load().dct_enet_reduce_workspace_bytes(raw.shape[3]))
     call("dct_enet_bn_bwd", C.byref(vr), C.byref(vg), C.byref(vm) if vm is not None else None,
          ptr(tf.scale), ptr(tf.shift), ptr(tf.slope), int(act), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(dslope),
          ptr(c1c2), int(training), C.byref(vd), fm, dt, ptr(ws), ws.numel(), stream())

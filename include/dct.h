@@ -307,6 +307,21 @@ int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct_view* g_ma
                     float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
                     const dct_view* draw, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
                     dct_stream stream);
+int dct_enet_bn_bwd_rows(const dct_view* raw, const dct_view* g, const dct_view* g_mask,
+                         const float* scale, const float* shift, const float* slope, int act,
+                         const float* mean, const float* invstd,
+                         float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
+                         const dct_view* draw, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
+                         int partial_rows, dct_stream stream);
+/* The data-gradient convolution y = dgrad(x) whose output is the gradient wrt act(BN(bn_raw)) of the producing layer, with that
+ * BatchNorm's backward sums riding along (MFMA form only, as dct_enet_conv_stats): every tile of 32 pixels writes
+ * {sum dz, sum dz xhat, sum g z [z<0]} per channel to stats_partial[tile][y.c][3]; dct_enet_bn_bwd_rows(..., workspace =
+ * stats_partial, partial_rows = *stats_rows) then skips its reduction launch.  *stats_rows = 0: nothing written. */
+int dct_enet_conv_bnbwd_stats(const dct_view* x, const float* w, const dct_view* y, const dct_conv_desc* d, int transposed,
+                              int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
+                              const dct_view* bn_raw, const float* bn_scale, const float* bn_shift, const float* bn_slope, int bn_act,
+                              const float* bn_mean, const float* bn_invstd,
+                              double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream);
 /* out[c] += sum over pixels of x[.., c]   (bias gradients).  f32_mask bit 0: x. */
 int dct_enet_channel_sum(const dct_view* x, float* out, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
                          dct_stream stream);

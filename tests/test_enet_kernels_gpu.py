@@ -317,3 +317,46 @@ def test_enet_conv_epilogue_bn_statistics(K, dt, cin, cout, k):
     assert K.enet_conv_stats(xd, wk, bias.to(DEV), tf, y2, small, **kw) == 0 and torch.equal(y1, y2)
     # fp32 mode keeps the VALU kernel: no rows either
     assert K.enet_conv_stats(xd, wk, bias.to(DEV), tf, y2, stats, **dict(kw, compute=torch.float32)) == 0
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cg,cx,k,act", [(64, 16, 1, 2), (32, 32, 3, 2), (128, 32, 1, 3), (16, 24, 3, 0)])
+def test_enet_dgrad_epilogue_bn_backward_sums(K, dt, cg, cx, k, act):
+    """dct_enet_conv_bnbwd_stats: the data-gradient convolution's epilogue writes the BatchNorm-backward partial sums of the layer
+    whose activation gradient it produces; dct_enet_bn_bwd_rows then folds and applies -- against the separate reduction."""
+    g0 = torch.Generator().manual_seed(6)
+    B, H, W = 3, 13, 11
+    gy = q(torch.randn(B, cg, H, W, generator=g0), dt)                         # gradient wrt the conv's output
+    w = torch.randn(cg, cx, k, k, generator=g0) / math.sqrt(cx * k * k)         # the forward conv cx -> cg
+    raw = torch.randn(B, cx, H, W, generator=g0) * 2 + 1                        # producing layer's raw (pre-BatchNorm) output
+    gamma, beta = torch.rand(cx, generator=g0) + 0.5, torch.randn(cx, generator=g0)
+    slope = torch.rand(cx, generator=g0) * 0.5
+    wk = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    gyd, rawd = nhwc(gy, dt), nhwc(raw, torch.float32)
+    vec = torch.empty(5, cx, device=DEV)
+    K.enet_bn_fwd_stats(rawd, gamma.to(DEV), beta.to(DEV), 1e-3, 0.1, None, None, True, vec[0], vec[1], vec[2], vec[3], save_var=vec[4])
+    tf = K.Tf(vec[0], vec[1], slope.to(DEV) if act == 2 else None, {2: 2, 3: 3, 0: 1}[act])
+    kw = dict(R=k, S=k, pad_h=k // 2, pad_w=k // 2, transposed=True, ws=(1, cx, k * k * cx), compute=dt)
+
+    def grads():
+        return torch.zeros(cx, device=DEV), torch.zeros(cx, device=DEV), torch.zeros(cx, device=DEV)
+    # separate: dgrad, then reduction + fold + apply
+    g1 = torch.empty(B, H, W, cx, dtype=dt, device=DEV)
+    K.enet_conv(gyd, wk, None, None, g1, **kw)
+    dg1, db1, ds1 = grads()
+    d1 = K.enet_bn_bwd(rawd, g1, None, tf, vec[2], vec[3], dg1, db1, ds1 if act == 2 else None, torch.empty(2 * cx, device=DEV),
+                       torch.empty(B, H, W, cx, dtype=dt, device=DEV))
+    # fused
+    tiles = (B * H * W + 31) // 32
+    stats = torch.full((tiles * cx * 3,), float("nan"), dtype=torch.float64, device=DEV)
+    g2 = torch.empty_like(g1)
+    rows = K.enet_conv_bnbwd_stats(gyd, wk, g2, stats, rawd, tf, vec[2], vec[3], **kw)
+    assert rows == tiles and torch.equal(g1, g2) and torch.isfinite(stats).all()
+    dg2, db2, ds2 = grads()
+    d2 = K.enet_bn_bwd(rawd, g2, None, tf, vec[2], vec[3], dg2, db2, ds2 if act == 2 else None, torch.empty(2 * cx, device=DEV),
+                       torch.empty(B, H, W, cx, dtype=dt, device=DEV), partial=stats, partial_rows=rows)
+    close(dg2, dg1, torch.float32, "dgamma", r32=2e-5)
+    close(db2, db1, torch.float32, "dbeta", r32=2e-5)
+    if act == 2:
+        close(ds2, ds1, torch.float32, "dslope", r32=2e-5)
+    close(d2, d1, dt, "draw", r32=1e-5, r16=1e-2)
