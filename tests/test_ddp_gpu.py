@@ -80,6 +80,82 @@ def test_two_ranks_one_gpu_fused_step_stays_in_sync(tmp_path):
         assert torch.equal(a, b)                                  # same start (broadcast) + same averaged gradients
 
 
+def _unet_prog_worker(rank, world, port, out, graph, backend):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    dev = rank if backend == "nccl" else 0          # RCCL: one GPU per rank; gloo: both ranks on cuda:0
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import FakeLoader, batches
+    from dct_amd.ddp import FlatGradSync
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    C, H, B, n = 3, 176, 1, 8
+    segs = []
+    for seed in (5 + 10 * rank, 6 + 10 * rank):
+        torch.manual_seed(seed)
+        segs.append(Segmentator({"name": "unet", "num_classes": C, "compute_dtype": torch.bfloat16, "dropout_p": 0.0},
+                                {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4}, {"name": "StepLR", "step_size": 90, "gamma": 0.1}))
+    lab = [FakeLoader(batches(100 * rank + 31 + i, n, B, H, C), B) for i in range(2)]
+    unl = FakeLoader(batches(100 * rank + 41, n, B, H, C), B)
+    crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tr = CoTrainer(segs, lab, unl, unl, crit, max_epoch=1, save_dir=os.path.join(out, f"r{rank}"), device=f"cuda:{dev}", axises=[1, 2],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False, steps_per_epoch=n)
+    for s_ in segs:
+        s_.train()
+    tr.grad_sync = FlatGradSync(segs)
+    tr.use_hip_graph = graph
+    for k in range(n):
+        lb = [(lab[i][k][0][0], lab[i][k][0][1]) for i in range(2)]
+        tr._run_step(lb, (unl[k][0][0], unl[k][0][1]), True, k % 2 == 0, (0, 1) if k % 2 == 0 else None)   # FGSM every other step
+    torch.cuda.synchronize()
+    g = tr._step_graphs
+    w = [torch.cat([p.detach().flatten() for p in s_.torchnet.parameters()]).cpu() for s_ in tr.segmentators]
+    torch.save(dict(w=w, buckets=tr.grad_sync.bucket_calls, replays=0 if g is None else g.replays,
+                    programs=0 if g is None else sum(1 for c in g._graphs.values() if c.program is not None and
+                                                     sum(1 for o in c.program.ops if o[0] == 'call') >= 6)),
+               os.path.join(out, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _unet_prog_case(tmp_path, backend):
+    res = {}
+    for graph in (False, True):
+        out = os.path.join(str(tmp_path), f"g{int(graph)}")
+        os.makedirs(out)
+        mp.spawn(_unet_prog_worker, args=(2, _free_port(), out, graph, backend), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(out, "w0.pt"), weights_only=False)
+        r1 = torch.load(os.path.join(out, "w1.pt"), weights_only=False)
+        for a, b in zip(r0["w"], r1["w"]):
+            assert torch.isfinite(a).all() and torch.equal(a, b)
+        assert r0["buckets"] == 3 * 2 * 8
+        if graph:     # both step signatures (with / without FGSM) were captured as programs with the bucket hand-overs between graphs
+            assert r0["replays"] >= 2 and r0["programs"] >= 1
+        res[graph] = r0
+    for a, b in zip(res[False]["w"], res[True]["w"]):
+        assert torch.equal(a, b)                    # replayed segments around the exchanges == eager launches around them
+
+
+@pytest.mark.timeout(900)
+def test_unet_two_ranks_program_around_bucketed_exchange_equals_eager(tmp_path):
+    """2 x UNet under data parallelism: the step replayed as graph segments with the three gradient buckets per model handed to
+    the exchange BETWEEN segments (host callbacks of the program) must leave exactly the weights of the eager step."""
+    _unet_prog_case(tmp_path, "gloo")
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
+def test_unet_two_ranks_rccl_program_equals_eager(tmp_path):
+    """The same over RCCL, one GPU per rank (runs only where two devices are visible)."""
+    _unet_prog_case(tmp_path, "nccl")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Enet under data parallelism: the step replays two captured graphs around one eager all-reduce per model
 # (trainer/step_graph.py); optional bf16 gradient exchange (ddp.FlatGradSync(compress="bf16")).
