@@ -20,6 +20,8 @@ int g_enet_reduce_ppt = 8;           // pixels per thread of a per-channel reduc
 int g_enet_fold_threads = 1024;      // threads of the one-block finalize kernels (DCT_TUNE_ENET_FOLD_THREADS: 256 | 512 | 1024)
 int g_enet_mfma = 3;                 // bf16 / f16 mode: bit 0 = MFMA form of the convolutions with >= 16 input channels, bit 1 = of the
                                      // weight gradients (0: the fp32 VALU kernels)
+int g_enet_mwgrad_waves = 2048;      // MFMA weight gradient: waves a launch aims for (pixel slices x tiles) ...
+int g_enet_mwgrad_min_steps = 4;     // ... with at least this many 16-pixel MFMA steps per slice (multiple of 4)
 int g_enet_bn_owner = 0;             // small tensors: one-launch channel-owner BatchNorm statistics / backward (0: split reduction).
                                      // Measured SLOWER (8 x 25 x 25 x 32 backward: 60 us against 14 us for the three split launches --
                                      // C / 8 blocks cannot pull the tensor through 4-16 CUs fast enough): kept for A/B only
@@ -1575,10 +1577,10 @@ extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const d
     const int mtiles = (a->c + 31) / 32, ntiles = (kb + 31) / 32;
     // pixel slices: enough waves to fill the chip (~2048), >= 4 MFMA steps (64 pixels) each, <= WG_MAX_BLOCKS slices of workspace
     const long long steps = (P + 15) / 16;
-    long long ks = 2048 / ((long long)mtiles * ntiles);
+    long long ks = g_enet_mwgrad_waves / ((long long)mtiles * ntiles);
     if (ks < 1) ks = 1;
     long long sps = (steps + ks - 1) / ks;
-    if (sps < 4) sps = 4;
+    if (sps < g_enet_mwgrad_min_steps) sps = g_enet_mwgrad_min_steps;
     if ((steps + sps - 1) / sps > WG_MAX_BLOCKS) sps = (steps + WG_MAX_BLOCKS - 1) / WG_MAX_BLOCKS;
     sps = (sps + 3) / 4 * 4;                               // the kernel walks its slice four steps at a time
     if (P >= 0x7fffffffLL) return DCT_ERR_UNSUPPORTED;

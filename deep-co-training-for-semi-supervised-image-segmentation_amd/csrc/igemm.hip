@@ -1595,6 +1595,7 @@ extern int g_enet_reduce_vec;                 // enet.hip
 extern int g_enet_fold_threads;               // enet.hip
 extern int g_enet_mfma;                       // enet.hip
 extern int g_enet_bn_owner;                   // enet.hip
+extern int g_enet_mwgrad_waves, g_enet_mwgrad_min_steps;
 
 extern "C" int dct_tune_set(int knob, int value) {
   switch (knob) {
@@ -1610,6 +1611,8 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_HALO_COVER: g_tune_igemm_halo_cover = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT_TARGET: if (value < 64) return DCT_ERR_BAD_ARG; g_tune_igemm_split_target = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_PPT: if (value < 1 || value > 4096) return DCT_ERR_BAD_ARG; g_enet_reduce_ppt = value; return DCT_OK;
+    case DCT_TUNE_ENET_MWGRAD_WAVES: if (value < 64) return DCT_ERR_BAD_ARG; g_enet_mwgrad_waves = value; return DCT_OK;
+    case DCT_TUNE_ENET_MWGRAD_MIN_STEPS: if (value < 4 || value % 4) return DCT_ERR_BAD_ARG; g_enet_mwgrad_min_steps = value; return DCT_OK;
     case DCT_TUNE_ENET_BN_OWNER: g_enet_bn_owner = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_MFMA: if (value < 0 || value > 3) return DCT_ERR_BAD_ARG; g_enet_mfma = value; return DCT_OK;
     case DCT_TUNE_IGEMM_XCD2: g_tune_igemm_xcd2 = value ? 1 : 0; return DCT_OK;

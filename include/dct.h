@@ -409,8 +409,10 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
        DCT_TUNE_IGEMM_XCD2 = 25,             /* 1: XCD-aware tile order in the per-tap kernel (default 0: level on the step) */
        DCT_TUNE_ENET_MFMA = 26,              /* bf16 / f16 Enet: bit 0 = MFMA form of the convolutions with >= 16 input channels,
                                                 bit 1 = of the weight gradients; 3 (default), 0 = the fp32 VALU kernels */
-       DCT_TUNE_ENET_BN_OWNER = 27 };        /* 1: one-launch channel-owner BatchNorm statistics / backward for tensors of <= 32768 pixels
+       DCT_TUNE_ENET_BN_OWNER = 27,          /* 1: one-launch channel-owner BatchNorm statistics / backward for tensors of <= 32768 pixels
                                                 with whole 8-channel groups (measured slower); 0 (default): split reduction + fold [+ apply] */
+       DCT_TUNE_ENET_MWGRAD_WAVES = 28,      /* >= 64 (default 2048): waves an MFMA weight-gradient launch aims for */
+       DCT_TUNE_ENET_MWGRAD_MIN_STEPS = 29 };/* multiple of 4 (default 4): least 16-pixel MFMA steps per pixel slice */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 
