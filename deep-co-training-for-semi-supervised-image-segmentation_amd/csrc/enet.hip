@@ -257,7 +257,10 @@ __device__ __forceinline__ void pix3u(unsigned pix, int h, int w, int& n, int& y
 // as (scale, shift, negative-side slope) per input channel -- identity (1, 0, 1) without a transform, slope 0 for ReLU, 1 for the
 // affine form -- so applying it is branch-free.
 constexpr int MC_W = 4;            // waves per block = K-split factor
-constexpr int MC_U = 3;            // K-steps of one wave whose loads are issued together
+constexpr int MC_U = 1;            // K-steps of one wave whose loads are issued together.  3 is the fastest ALONE (3x3 32->32: 6.6 us)
+                                   // and the slowest in the step: with four hardware queues busy, cfg4 / cfg5 ms per step for
+                                   // U = 4 / 3 / 2 / 1 read 18.1 / 17.4 / 16.9 / 16.4 and 44.6 / 41.8 / 39.9 / 38.2 -- registers and loads
+                                   // in flight per wave are what the concurrent kernels compete for
 
 template <typename T, int NT, bool XF, bool WV>
 __device__ __forceinline__ void mconv_main(const ConvP& p, const float* tfs, int cbase, bool pvalid, int n, int oy, int ox, int r, int h,
@@ -1150,7 +1153,8 @@ __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, 
 template <typename T, bool AF, bool BF>
 __device__ __forceinline__ void mwgrad_body(const WgP& p, float* partial, int E, int pps, int mtiles, int ntiles) {
   typedef typename LowMfma<T>::frag frag;
-  constexpr int U = 4;                                   // MFMA steps (16 pixels each) whose 16 U loads are in flight together
+  constexpr int U = 1;                                   // MFMA steps (16 pixels each) whose 16 U loads are in flight together (as MC_U:
+                                                         // 4 is fastest alone, 1 in the step -- cfg5 38.2 -> 36.8 ms)
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int Ca = p.a.c, Cb = p.b.c, kb = p.R * p.S * Cb;
   int u0 = blockIdx.x;

@@ -173,11 +173,19 @@ class StepGraphCache(object):
                     tr._sched = EagerSchedule()
                 graph = None
             elif sync is None:
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    cap.out = tr._run_step_fused(cap.lab, cap.unl, train_jsd, train_adv, adv_choice, lam_dev=lam_dev)
+                # ONE graph: only the model streams fork inside it (the layout captured since round 1).  Pass streams add forks whose
+                # marks are waited for by other forked streams; hipStreamEndCapture / hipGraphLaunch of such captures have crashed
+                # on ROCm 7.2, and the sequential accumulation they replace is bit-identical (tests/test_stream_sched_gpu.py)
+                keep_pass, tr.pass_streams = tr.pass_streams, False
+                try:
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        cap.out = tr._run_step_fused(cap.lab, cap.unl, train_jsd, train_adv, adv_choice, lam_dev=lam_dev)
+                finally:
+                    tr.pass_streams = keep_pass
             else:
                 # no collective inside a capture: graph 1 ends after the backward passes, graph 2 holds the optimizer steps
                 tr.grad_sync, tr._defer_optimizer = None, True
+                keep_pass, tr.pass_streams = tr.pass_streams, False
                 try:
                     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                         cap.out = tr._run_step_fused(cap.lab, cap.unl, train_jsd, train_adv, adv_choice, lam_dev=lam_dev)
@@ -187,6 +195,7 @@ class StepGraphCache(object):
                         tr._optimizer_phase(None)      # S small launches on the capture stream
                 finally:
                     tr.grad_sync, tr._defer_optimizer = sync, False
+                    tr.pass_streams = keep_pass
         finally:
             if gc_was_on:
                 gc.enable()
