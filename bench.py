@@ -356,8 +356,10 @@ def main():
     caps = list(tr._step_graphs._graphs.values()) if getattr(tr, "_step_graphs", None) is not None else []
     if caps and getattr(caps[0], "program", None) is not None:
         prog = caps[0].program
+        from dct_amd.trainer.stream_sched import _QUEUE_GROUPS
         result["config"]["step_execution"] = {"mode": "program of per-stream HIP graphs (trainer/stream_sched.py)", "graphs": prog.n_graphs,
-                                              "kernel_nodes": prog.n_nodes, "ops": len(prog.ops)}
+                                              "kernel_nodes": prog.n_nodes, "ops": len(prog.ops),
+                                              "hardware_queue_groups_found": [len(g) for g in next(iter(_QUEUE_GROUPS.values()), [])]}
     elif caps:
         result["config"]["step_execution"] = {"mode": "one HIP graph"}
     else:

@@ -257,6 +257,8 @@ __device__ __forceinline__ void pix3u(unsigned pix, int h, int w, int& n, int& y
 // as (scale, shift, negative-side slope) per input channel -- identity (1, 0, 1) without a transform, slope 0 for ReLU, 1 for the
 // affine form -- so applying it is branch-free.
 constexpr int MC_W = 4;            // waves per block = K-split factor
+constexpr int MC_E = 16 / MC_W;    // accumulators (pixel rows per half-wave) a wave stores after the fold
+__device__ __forceinline__ int mc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }      // MFMA 32x32 D layout: row of accumulator e
 constexpr int MC_U = 1;            // K-steps of one wave whose loads are issued together.  3 is the fastest ALONE (3x3 32->32: 6.6 us)
                                    // and the slowest in the step: with four hardware queues busy, cfg4 / cfg5 ms per step for
                                    // U = 4 / 3 / 2 / 1 read 18.1 / 17.4 / 16.9 / 16.4 and 44.6 / 41.8 / 39.9 / 38.2 -- registers and loads
@@ -336,23 +338,23 @@ __device__ __forceinline__ void mconv_main(const ConvP& p, const float* tfs, int
 template <typename T, int NT, bool YF>
 __device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, float* srd, int cbase, long long wbase, long long P, int r, int h,
                                             int wave) {
-  // after the K-split fold this wave owns accumulators e = 4 wave + i, i < 4: pixel rows 8 wave + 4 h + i, channel cbase + 32 j + r
+  // after the K-split fold this wave owns accumulators e = MC_E wave + i, i < MC_E = 16 / MC_W (pixel rows mc_row(e, h)), channel cbase + 32 j + r
   const int Cout = p.y.c;
-  float val[4][NT];
+  float val[MC_E][NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MC_E; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < MC_W; ++w) t += red[((w * NT + j) * 16 + 4 * wave + i) * 64 + 32 * h + r];   // fixed order
+      for (int w = 0; w < MC_W; ++w) t += red[((w * NT + j) * 16 + MC_E * wave + i) * 64 + 32 * h + r];   // fixed order
       val[i][j] = t;
     }
-  long long yo[4], rgo[4], rmo[4];
-  bool pv[4];
+  long long yo[MC_E], rgo[MC_E], rmo[MC_E];
+  bool pv[MC_E];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long long pix = wbase + 8 * wave + 4 * h + i;
+  for (int i = 0; i < MC_E; ++i) {
+    const long long pix = wbase + mc_row(MC_E * wave + i, h);
     pv[i] = pix < P;
     int n, oy, ox;
     pix3u((unsigned)(pv[i] ? pix : 0), p.y.h, p.y.w, n, oy, ox);
@@ -360,14 +362,14 @@ __device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, fl
     rgo[i] = p.has_resid ? voff(p.rg, n, oy, ox) : 0;
     rmo[i] = p.has_resid ? voff(p.rm, n, oy, ox) : 0;
   }
-  float add[4][NT];
+  float add[MC_E][NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int c = cbase + 32 * j + r;
     const bool cv = c < Cout;
     const float b = (p.bias && cv) ? p.bias[c] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MC_E; ++i) {
       const bool ok = pv[i] && cv;
       float t = b;
       if (p.has_resid) {       // (MFMA form: residual gradient and mask are stored as T -- host check)
@@ -384,21 +386,21 @@ __device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, fl
   if (p.stats && p.bn_bwd) {
     // the stored value g (rounded to its storage type, as the BatchNorm-backward reduction would read it back) against the
     // producing layer's raw output: dz = g act'(z), xhat -- the reduction kernel's arithmetic, one tile of it
-    float braw[4][NT], bsc[NT], bsh[NT], bsl[NT], bmu[NT], bis[NT];
+    float braw[MC_E][NT], bsc[NT], bsh[NT], bsl[NT], bmu[NT], bis[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int c = min(cbase + 32 * j + r, Cout - 1);
       bsc[j] = p.bscale[c]; bsh[j] = p.bshift[c]; bmu[j] = p.bmean[c]; bis[j] = p.binvstd[c]; bsl[j] = p.bact == 2 ? p.bslope[c] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const long long pix = wbase + 8 * wave + 4 * h + i;
+      for (int i = 0; i < MC_E; ++i) {
+        const long long pix = wbase + mc_row(MC_E * wave + i, h);
         int n, oy, ox;
         pix3u((unsigned)(pv[i] ? pix : 0), p.y.h, p.y.w, n, oy, ox);
         braw[i][j] = reinterpret_cast<const float*>(p.braw.ptr)[(pv[i] && cbase + 32 * j + r < Cout) ? voff(p.braw, n, oy, ox) + c : 0];
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MC_E; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int c = cbase + 32 * j + r;
@@ -418,7 +420,7 @@ __device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, fl
       }
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MC_E; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int c = cbase + 32 * j + r;

@@ -297,15 +297,18 @@ def queue_groups(device, candidates: int = 8, links: int = 150) -> List[List[tor
         return best
     cur = torch.cuda.current_stream(dev)
     try:
-        one = min(t([i]) for i in range(len(streams)))
-        groups: List[List[int]] = []
-        for i in range(len(streams)):
-            for g in groups:
-                if t([g[0], i]) > 1.6 * one:
-                    g.append(i)
-                    break
-            else:
-                groups.append([i])
+        for attempt in range(3):                # (a noisy first pass -- clocks ramping up -- is repeated: HIP has four queues by default)
+            one = min(t([i]) for i in range(len(streams)))
+            groups: List[List[int]] = []
+            for i in range(len(streams)):
+                for g in groups:
+                    if t([g[0], i]) > 1.6 * one:
+                        g.append(i)
+                        break
+                else:
+                    groups.append([i])
+            if len(groups) == 4 and max(len(g) for g in groups) <= 3:
+                break
     finally:
         torch.cuda.set_stream(cur)
     del graphs
