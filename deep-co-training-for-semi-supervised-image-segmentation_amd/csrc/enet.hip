@@ -20,6 +20,8 @@ int g_enet_reduce_ppt = 8;           // pixels per thread of a per-channel reduc
 int g_enet_fold_threads = 1024;      // threads of the one-block finalize kernels (DCT_TUNE_ENET_FOLD_THREADS: 256 | 512 | 1024)
 int g_enet_mfma = 3;                 // bf16 / f16 mode: bit 0 = MFMA form of the convolutions with >= 16 input channels, bit 1 = of the
                                      // weight gradients (0: the fp32 VALU kernels)
+int g_enet_apply_vec = 0;            // BatchNorm backward apply on 8 channels per thread (vector loads / stores, an eighth of the threads):
+                                     // SLOWER in the step (cfg4 16.6 vs 15.9 ms, cfg5 38.9 vs 36.8) -- off, kept for A/B
 int g_enet_mwgrad_waves = 2048;      // MFMA weight gradient: waves a launch aims for (pixel slices x tiles) ...
 int g_enet_mwgrad_min_steps = 4;     // ... with at least this many 16-pixel MFMA steps per slice (multiple of 4)
 int g_enet_bn_owner = 0;             // small tensors: one-launch channel-owner BatchNorm statistics / backward (0: split reduction).
@@ -726,6 +728,53 @@ __global__ __launch_bounds__(FT) void enet_sum_finalize_kernel(const double* par
   while (CP < C) CP <<= 1;
   if (c >= C || threadIdx.x >= CP) return;
   out[c] += (float)s[0];
+}
+
+// The same for whole 8-channel groups (every BatchNorm of stages 1-3): a thread owns 8 consecutive channels of one pixel -- one or
+// two 16-byte loads per operand and one 16-byte store instead of eight scalar round trips, an eighth of the threads.
+template <typename T>
+__global__ __launch_bounds__(256) void enet_bn_bwd_apply_vec_kernel(RedP p, const float* c1, const float* c2, View out) {
+  const int C = p.x.c, CV = C >> 3;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)p.x.n * p.x.h * p.x.w * CV;
+  if (idx >= total) return;
+  const int cv = (int)(idx % CV);
+  int n, y, x;
+  pix3(idx / CV, p.x.h, p.x.w, n, y, x);
+  const int c0 = cv * 8;
+  float v[8], g[8];
+  ld8<T>(p.x, voff(p.x, n, y, x) + c0, p.fm & 1, v);
+  ld8<T>(p.g, voff(p.g, n, y, x) + c0, p.fm & 2, g);
+  if (p.has_mask) {
+    float m[8];
+    ld8<T>(p.m, voff(p.m, n, y, x) + c0, p.fm & 4, m);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (!(m[i] > 0.f)) g[i] = 0.f;
+  }
+  float r[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = c0 + i;
+    const float sc = p.scale[c];
+    const float z = fmaf(sc, v[i], p.shift[c]);
+    float dz = g[i];
+    if (p.act == 2) { if (!(z > 0.f)) dz = g[i] * p.slope[c]; }
+    else if (p.act == 3) { if (!(z > 0.f)) dz = 0.f; }
+    const float xh = (v[i] - p.mean[c]) * p.invstd[c];
+    r[i] = sc * (dz - c1[c] - xh * c2[c]);
+  }
+  const long long oo = voff(out, n, y, x) + c0;
+  if ((p.fm & 8) || sizeof(T) == 4) {
+    float* o = reinterpret_cast<float*>(out.ptr) + oo;
+    *reinterpret_cast<f32x4*>(o) = f32x4{r[0], r[1], r[2], r[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{r[4], r[5], r[6], r[7]};
+  } else {
+    typedef typename vec8_of<T>::type V8;
+    V8 q;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = from_f32<T>(r[i]);
+    *reinterpret_cast<V8*>(reinterpret_cast<T*>(out.ptr) + oo) = q;
+  }
 }
 
 // ---- channel-owner BatchNorm kernels for small tensors -----------------------------------------------
@@ -1511,6 +1560,18 @@ extern "C" int dct_enet_bn_bwd_rows(const dct_view* raw, const dct_view* g, cons
   const View vo = to_view(draw);
   DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_finalize_kernel, dim3(1), dim3(g_enet_fold_threads), 0, st, (const double*)workspace, blocks, raw->c, count,
              training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, c1c2 + raw->c);
+  {
+    auto v8 = [&](const View& v, int f32) {
+      const int esz = (f32 || dtype == DCT_F32) ? 4 : 2;
+      return v.c % 8 == 0 && v.sw % 8 == 0 && v.sh % 8 == 0 && v.sn % 8 == 0 && ((uintptr_t)v.ptr % (8 * esz)) == 0;
+    };
+    if (g_enet_apply_vec && v8(p.x, p.fm & 1) && v8(p.g, p.fm & 2) && (!p.has_mask || v8(p.m, p.fm & 4)) && v8(vo, p.fm & 8) &&
+        vo.c == p.x.c) {
+      ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_apply_vec_kernel<T>, dim3(div_up(total / 8, 256)), dim3(256), 0, st, p,
+                               (const float*)c1c2, (const float*)(c1c2 + raw->c), vo));
+      return dct_check_launch();
+    }
+  }
   ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_apply_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, p,
                            (const float*)c1c2, (const float*)(c1c2 + raw->c), vo));
   return dct_check_launch();

@@ -1595,7 +1595,7 @@ extern int g_enet_reduce_vec;                 // enet.hip
 extern int g_enet_fold_threads;               // enet.hip
 extern int g_enet_mfma;                       // enet.hip
 extern int g_enet_bn_owner;                   // enet.hip
-extern int g_enet_mwgrad_waves, g_enet_mwgrad_min_steps;
+extern int g_enet_mwgrad_waves, g_enet_mwgrad_min_steps, g_enet_apply_vec;
 
 extern "C" int dct_tune_set(int knob, int value) {
   switch (knob) {
@@ -1613,6 +1613,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_ENET_REDUCE_PPT: if (value < 1 || value > 4096) return DCT_ERR_BAD_ARG; g_enet_reduce_ppt = value; return DCT_OK;
     case DCT_TUNE_ENET_MWGRAD_WAVES: if (value < 64) return DCT_ERR_BAD_ARG; g_enet_mwgrad_waves = value; return DCT_OK;
     case DCT_TUNE_ENET_MWGRAD_MIN_STEPS: if (value < 4 || value % 4) return DCT_ERR_BAD_ARG; g_enet_mwgrad_min_steps = value; return DCT_OK;
+    case DCT_TUNE_ENET_APPLY_VEC: g_enet_apply_vec = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_BN_OWNER: g_enet_bn_owner = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_MFMA: if (value < 0 || value > 3) return DCT_ERR_BAD_ARG; g_enet_mfma = value; return DCT_OK;
     case DCT_TUNE_IGEMM_XCD2: g_tune_igemm_xcd2 = value ? 1 : 0; return DCT_OK;
