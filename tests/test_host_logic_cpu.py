@@ -330,3 +330,29 @@ def test_run_step_normalises_loader_dtypes(tmp_path, monkeypatch):
     out = tr._run_step(lb, (unl[0][0][0].half(), unl[0][0][1].int()), True, False)
     assert seen["lab"] == [(torch.float32, torch.int64, True)] * 2 and seen["unl"] == torch.float32
     assert all(torch.isfinite(s) for s in out["sup"])
+
+
+def test_step_scheduling_switches_on_cpu_modules(tmp_path, monkeypatch):
+    """The scheduling switches are HIP-path decisions: with plain nn.Modules on the CPU the generic step runs, no layout is
+    chosen and no stream is created, whatever the switches say (trainer/stream_sched.py is imported but idle)."""
+    from dct_amd.trainer.stream_sched import EagerSchedule
+    tr, lab, unl = _make_trainer(tmp_path, monkeypatch, "enet", 2, 32, 2, 2)
+    for s in tr.segmentators:
+        s.train()
+    assert isinstance(tr._sched, EagerSchedule) and tr._sched.capturing is False
+    assert tr.segmented_graphs is None and tr._use_segments() is False             # oracle modules do not ask for segments
+    tr.segmented_graphs = True
+    assert tr._use_segments() is True
+    tr.segmented_graphs = None
+    lb = [(lab[i][0][0][0], lab[i][0][0][1]) for i in range(2)]
+    np.random.seed(3)
+    tr._run_step(lb, (unl[0][0][0], unl[0][0][1]), True, True, (0, 1))
+    assert tr._step_hint_adv_chain is False        # needs batch-independent HIP networks with gradient overwrite
+    assert tr._streams() is None and tr._stream_dealer() is None and tr._step_graphs is None
+    # the eager schedule's null stream is a no-op context
+    with tr._sched.on(None):
+        pass
+    tr._sched.wait([])
+    seen = []
+    tr._sched.call(lambda: seen.append(1))
+    assert seen == [1]
