@@ -20,9 +20,16 @@ A signature is captured after WARMUP eager steps (which are ordinary training st
 Anything that re-allocates the weights, gradients or moments (load_state_dict, .to()) changes the signature and
 leads to a new capture.
 
-Data parallelism: the RCCL all-reduce is not captured.  Networks with gradient buckets (UNet) run the step eagerly so that the
-exchange overlaps the backward pass; for the others (Enet) the step is captured as TWO graphs -- [forwards, losses, zero_grad,
-backward passes] and [optimizer steps] -- replayed around one eager all-reduce per model (1.45 MB each).
+Two capture forms (CoTrainer._use_segments):
+  * ONE graph (UNet): the per-model streams fork and join inside the capture; only the model streams -- pass streams are
+    switched off for such a capture (their cross-stream marks have crashed hipStreamEndCapture / hipGraphLaunch on ROCm 7.2);
+  * a PROGRAM of per-stream graphs (trainer/stream_sched.py; Enet, 2 x UNet + FGSM, every data-parallel step): one hipGraphLaunch
+    feeds one hardware queue, so chains that should overlap are captured as separate graphs and launched on their own streams,
+    with the cross-stream waits and the host callbacks (gradient exchange) replayed between them.
+
+Data parallelism: the RCCL all-reduces are never captured; they are host callbacks of the program (UNet: one per gradient bucket,
+issued from inside the backward pass; Enet: one per model).  ``segmented_graphs=False`` falls back to two graphs -- [forwards,
+losses, backward passes] and [optimizer steps] -- around one eager (un-bucketed) all-reduce per model.
 """
 from __future__ import annotations
 
