@@ -173,6 +173,17 @@ class StepGraphCache(object):
                     rec.start()
                     cap.out = tr._run_step_fused(cap.lab, cap.unl, train_jsd, train_adv, adv_choice, lam_dev=lam_dev)
                     cap.program = rec.finish()
+                except RuntimeError as e:
+                    # a capture the runtime refuses must not take the training down: nothing was launched while recording, the
+                    # host counters the recorded pass advanced are put back, and this signature stays on eager launches
+                    rec.abort()
+                    tr._sched = EagerSchedule()
+                    for (o, n), v in zip(self._counters(), before):
+                        setattr(o, n, v)
+                    self._seen[sig] = -(1 << 30)
+                    import warnings
+                    warnings.warn(f"dct_amd: capturing the step as a program of HIP graphs failed ({e}); this step shape runs eagerly")
+                    return None
                 except BaseException:
                     rec.abort()
                     raise

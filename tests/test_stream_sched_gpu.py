@@ -186,3 +186,20 @@ def test_recorder_drops_empty_segments_and_replays_in_order():
     prog.replay()
     torch.cuda.synchronize()
     assert float(x[0]) == 14.0 and float(y[0]) == 14.5 and calls == [0, 1, 2]       # ((2 + 1) * 2 + 1) * 2
+
+
+def test_refused_capture_falls_back_to_eager(tmp_path, monkeypatch):
+    """A program capture the runtime refuses (RuntimeError while recording) must leave the training on eager launches with the
+    host counters intact: same results as a run that never captured."""
+    from dct_amd.trainer import stream_sched
+    eager = _run(tmp_path, "enet", True, n=6, use_hip_graph=False)
+
+    def boom(self):
+        raise RuntimeError("capture refused (test)")
+    monkeypatch.setattr(stream_sched.SegmentRecorder, "finish", boom)
+    with pytest.warns(UserWarning, match="runs eagerly"):
+        fell = _run(tmp_path, "enet", True, n=6)
+    g = fell[0]._step_graphs
+    assert g is not None and g.captures == 0 and g.replays == 0
+    assert [s.optimizer._steps for s in fell[0].segmentators] == [6, 6]
+    _same(eager, fell)
