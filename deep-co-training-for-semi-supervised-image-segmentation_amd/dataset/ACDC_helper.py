@@ -7,10 +7,10 @@ from __future__ import annotations
 
 import random
 import re
+from collections import defaultdict
 from copy import deepcopy as dcopy
-from itertools import repeat
 from pathlib import Path
-from typing import Callable, Dict, List
+from typing import Dict, List
 
 import numpy as np
 from torch.utils.data import DataLoader, Sampler
@@ -19,30 +19,31 @@ from .medicalDataLoader import CachedLoader, DeviceSliceCache, MedicalImageDatas
 
 
 class PatientSampler(Sampler):
+    """Batch sampler whose batches are the slice indices of one patient scan (reference :27-60).  ``grp_regex``'s first
+    group names the scan a file stem belongs to; scans are served in first-seen file order (the reference iterates a
+    ``set``, whose order is hash-dependent), each with its slice indices in file order; ``shuffle`` permutes the scans with
+    ``random.sample`` -- one draw per iteration, as there."""
+
     def __init__(self, dataset: MedicalImageDataset, grp_regex, shuffle=False, quite=False) -> None:
-        filenames: List[str] = dataset.filenames[dataset.subfolders[0]]
+        names: List[str] = dataset.filenames[dataset.subfolders[0]]
         self.grp_regex = grp_regex
-        self.shuffle: bool = shuffle
-        self.shuffle_fn: Callable = (lambda x: random.sample(x, len(x))) if self.shuffle else (lambda x: x)
-        grouping_regex = re.compile(self.grp_regex)
-        stems = [Path(filename).stem for filename in filenames]
-        patients = [grouping_regex.match(s).group(1) for s in stems]
-        unique_patients = list(dict.fromkeys(patients))     # first-seen order (the reference's set() order is hash-dependent)
-        assert len(unique_patients) < len(filenames)
+        self.shuffle: bool = bool(shuffle)
+        scan_of = re.compile(grp_regex)
+        by_scan: Dict[str, List[int]] = defaultdict(list)        # insertion-ordered: scans in first-seen order
+        for index, name in enumerate(names):
+            by_scan[scan_of.match(Path(name).stem).group(1)].append(index)
+        if not len(by_scan) < len(names):
+            raise AssertionError("PatientSampler: the regex does not group the slices into scans")
         if not quite:
-            print(f"Found {len(unique_patients)} unique patients out of {len(filenames)} images")
-        self.idx_map: Dict[str, List[int]] = dict(zip(unique_patients, repeat(None)))
-        for i, patient in enumerate(patients):
-            if not self.idx_map[patient]:
-                self.idx_map[patient] = []
-            self.idx_map[patient] += [i]
-        assert sum(len(self.idx_map[k]) for k in unique_patients) == len(filenames)
+            print(f"Found {len(by_scan)} unique patients out of {len(names)} images")
+        self.idx_map: Dict[str, List[int]] = dict(by_scan)
 
     def __len__(self):
-        return len(self.idx_map.keys())
+        return len(self.idx_map)
 
     def __iter__(self):
-        return iter(self.shuffle_fn(list(self.idx_map.values())))
+        batches = list(self.idx_map.values())
+        return iter(random.sample(batches, len(batches)) if self.shuffle else batches)
 
 
 def get_ACDC_dataloaders(dataset_dict: dict, dataloader_dict: dict, quite=False, mode1='train', mode2='val'):
@@ -61,19 +62,25 @@ def get_ACDC_dataloaders(dataset_dict: dict, dataloader_dict: dict, quite=False,
 
 
 def create_partitions(config):
-    """Patient ids of the labeled partitions (one per model) and of the unlabeled set (:86-103)."""
-    partition_ratio = config['Lab_Partitions']['partition_sets']
-    lab_ids = [1, int(100 * partition_ratio + 1)]
-    unlab_ids = [int(100 * partition_ratio + 1), 101]
-    partition_overlap = config['Lab_Partitions']['partition_overlap']
-    rd_idx = np.random.permutation(range(*lab_ids))
-    overlap_idx = np.random.choice(rd_idx, size=int(float(partition_overlap) * len(range(*lab_ids))), replace=False)
-    exclusive_idx = [x for x in rd_idx if x not in overlap_idx]
-    n_splits = int(config['Lab_Partitions']['num_models'])
-    exclusive_samples = int(len(exclusive_idx) / n_splits)
-    excl_indx = [exclusive_idx[i * exclusive_samples: (i + 1) * exclusive_samples] for i in range(n_splits)]
-    lab_partitions = [np.hstack((overlap_idx, np.array(excl_indx[idx]))) for idx in range(n_splits)]
-    return lab_partitions, list(range(*unlab_ids))
+    """-> (one array of labeled patient ids per model, list of unlabeled patient ids) (reference :86-103).
+
+    ACDC's 100 training patients are cut at ``partition_sets``: ids 1..100*ratio are labeled, the rest unlabeled.  Every model
+    sees the ``partition_overlap`` share of the labeled ids; the remaining ids are dealt to the models in equal consecutive
+    runs (a remainder that does not divide is dropped, as in the reference).  The numpy global RNG is consumed in exactly this
+    order -- it decides which patient lands where, and tests/golden/g8_data.npz pins it:
+        1. ``np.random.permutation`` over the labeled ids,
+        2. ``np.random.choice(..., replace=False)`` of the shared ids out of that permutation."""
+    spec = config['Lab_Partitions']
+    first_unlabeled = int(100 * spec['partition_sets'] + 1)
+    labeled_ids = range(1, first_unlabeled)
+    shuffled = np.random.permutation(labeled_ids)                                                     # RNG draw 1
+    n_shared = int(float(spec['partition_overlap']) * len(labeled_ids))
+    shared = np.random.choice(shuffled, size=n_shared, replace=False)                                 # RNG draw 2
+    private = [pid for pid in shuffled if pid not in shared]       # keeps the permutation's order
+    n_models = int(spec['num_models'])
+    run = len(private) // n_models
+    partitions = [np.hstack((shared, np.array(private[m * run:(m + 1) * run]))) for m in range(n_models)]
+    return partitions, list(range(first_unlabeled, 101))
 
 
 def get_ACDC_split_dataloders(config, quite=True):

@@ -452,6 +452,91 @@ def g9_acdc(n_steps=600):
     print("reference val 3-D DSC", v3[..., 0])
 
 
+# ----------------------------------------------------------------------------- G10 reference co-training to a DSC that means something
+def g10_acdc_dsc(arch="enet", epochs=5, steps_per_epoch=500, bs=4, threads=None):
+    """`epochs` calls of the UNMODIFIED reference `CoTrainer._train_loop` (each cut to `steps_per_epoch` steps) on the vendored
+    ACDC subset with ALL FIVE training patients labeled for both models (Lab_Partitions fully overlapping) and serving as the
+    unlabeled pool as well, `_eval_loop` on validation patient 006 after every epoch.  Recorded: the slice names of every batch
+    (as a digest per step plus the first 60 steps verbatim), the supervised losses, the validation 2-D / 3-D Dice CURVE.
+    round-2's g9 stopped at a reference DSC of 0.1 (two labeled patients, 600 steps), where "within 0.2" cannot fail; this
+    one runs until the reference segments the heart.  tests/test_acdc_dsc_gpu.py trains the HIP nets over the same batches."""
+    import hashlib
+    import time
+    import generalframework.dataset.ACDC_helper as ref_helper
+    from generalframework.dataset import MedicalImageDataset as RefDataset
+    from torch.utils.data import DataLoader
+    sys.path.insert(0, REPO)
+    import dct_amd  # noqa: F401
+    from dct_amd.dataset.augment import segment_transform
+    if threads:
+        torch.set_num_threads(threads)
+    sub = os.path.join(OUT, "acdc_subset")
+    C, seeds = 4, (41, 42)
+    everyone = ["1", "2", "3", "4", "5"]
+    kw = dict(root_dir=sub, subfolders=["img", "gt"], transform=segment_transform((256, 256)), augment="PILaugment",
+              pin_memory=False, quite=True)
+    train_set, val_set = RefDataset(mode="train", **kw), RefDataset(mode="val", **kw)
+    base = DataLoader(train_set, batch_size=bs, shuffle=True, drop_last=True, num_workers=0)
+    labs = [ref_helper.extract_patients(base, everyone) for _ in range(2)]
+    unl = ref_helper.extract_patients(DataLoader(RefDataset(mode="train", **kw), batch_size=bs, shuffle=True, drop_last=True,
+                                                 num_workers=0), everyone)
+    val = DataLoader(val_set, batch_sampler=ref_helper.PatientSampler(val_set, r"(patient\d+_\d+)_\d+", shuffle=False, quite=True))
+    segs = []
+    for s in seeds:
+        seg = Segmentator({"name": arch, "num_classes": C}, {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                          {"name": "StepLR", "step_size": 90, "gamma": 0.1})
+        torch.manual_seed(s)
+        seg.torchnet.load_state_dict(oracle.build_net(arch, C).state_dict())
+        segs.append(seg)
+    sup_log, names_log = [], []
+    crit = {"sup": _Recorder(get_loss_fn("cross_entropy"), sup_log), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    tr = CoTrainer(segmentators=segs, labeled_dataloaders=labs, unlabeled_dataloader=unl, val_dataloader=val,
+                   criterions=crit, max_epoch=epochs, save_dir=tmp, device="cpu", axises=[1, 2, 3],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False)
+
+    def short_range(*a):
+        return range(steps_per_epoch) if a == (300,) else range(*a)
+    ref_trainer_mod.range = short_range
+    orig_iter = ref_trainer_mod.iterator_
+
+    class rec_iter(orig_iter):
+        def __next__(self):
+            b = super().__next__()
+            if isinstance(b, (list, tuple)) and len(b) == 3:     # (the progress-report toggle is an iterator_ over two strings)
+                names_log.append(",".join(b[2]))
+            return b
+    ref_trainer_mod.iterator_ = rec_iter
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    sup_train, v2s, v3s = [], [], []
+    t0 = time.time()
+    try:
+        for e in range(epochs):
+            n0 = len(sup_log)
+            tr._train_loop(labs, unl, epoch=e, mode=ModelMode.TRAIN, save=False, train_jsd=True, train_adv=False)
+            sup_train.append(torch.stack(sup_log[n0:n0 + 2 * steps_per_epoch]).reshape(steps_per_epoch, 2))
+            ref_trainer_mod.iterator_ = orig_iter
+            with torch.no_grad():
+                v2, v3 = tr._eval_loop(val, epoch=e, mode=ModelMode.EVAL, save=False)
+            ref_trainer_mod.iterator_ = rec_iter
+            v2s.append(v2)
+            v3s.append(v3)
+            print(f"[g10 {arch}] epoch {e} ({time.time() - t0:.0f} s): sup last20 {sup_train[-1][-20:].mean(0).tolist()}  "
+                  f"val 3-D foreground DSC {v3[:, 1:, 0].mean(1).tolist()}  2-D {v2[:, 1:, 0].mean(1).tolist()}", flush=True)
+    finally:
+        del ref_trainer_mod.range
+        ref_trainer_mod.iterator_ = orig_iter
+    n = epochs * steps_per_epoch
+    names = np.array(names_log).reshape(n, 3)
+    digest = np.array([hashlib.md5("|".join(row).encode()).hexdigest()[:12] for row in names])
+    save(f"g10_acdc_{arch}", arch=arch, epochs=epochs, steps_per_epoch=steps_per_epoch, bs=bs, C=C, net_seeds=np.array(seeds),
+         sup=torch.cat(sup_train), batch_names_head=names[:60], batch_digest=digest,
+         val_dice2d=torch.stack(v2s), val_dice3d=torch.stack(v3s))
+
+
 # ----------------------------------------------------------------------------- G5 full steps
 class _FakeDataset:
     training = ModelMode.EVAL
@@ -635,3 +720,7 @@ if __name__ == "__main__":
         g8_data()
     if "g9" in which:
         g9_acdc()
+    if "g10_enet" in which:
+        g10_acdc_dsc("enet", epochs=5, steps_per_epoch=500, bs=4, threads=4)
+    if "g10_unet" in which:
+        g10_acdc_dsc("unet", epochs=4, steps_per_epoch=250, bs=2, threads=4)
