@@ -85,7 +85,7 @@ class FlatParams:
     # -- gradients --------------------------------------------------------------------------
     def _grad_view(self, i: int) -> torch.Tensor:
         p = self.params[i]
-        return self.gflat.as_strided(p.shape, p.stride(), self.offsets[i])
+        return self.gflat.as_strided(p.shape, p.stride(), self.gflat.storage_offset() + self.offsets[i])   # gflat may be a slice (ddp arena)
 
     def grads_attached(self) -> bool:
         if self.gflat is None or self.gflat.device != self.flat.device:

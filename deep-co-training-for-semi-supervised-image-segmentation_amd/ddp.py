@@ -8,8 +8,9 @@ gradients summed onto device 0.  The MI355X-native equivalent here:
     (global batch = world x per-GPU batch; equal per-rank batch sizes make the gradient
     *average* equal to the global-batch mean gradient);
   * each model's gradients already live in ONE flat fp32 buffer (arch/flat.py), so the exchange
-    is one large all-reduce per model straight out of that buffer -- no bucket copies, and for
-    Enet-sized models no swarm of latency-bound tiny collectives.  xGMI is point-to-point
+    is one large all-reduce per model straight out of that buffer -- no bucket copies; the flat
+    buffers of SMALL models (Enet: 1.45 MB each) are laid out back to back in one arena and leave
+    as ONE collective per step for all S models, not S latency-bound ones.  xGMI is point-to-point
     (7 links x ~153 GB/s per GPU): a ring all-reduce of UNet's 124 MB takes ~1.4 ms at 8 GPUs, so
     model m's all-reduce is issued asynchronously right after model m's backward is enqueued
     and overlaps the backward of model m+1 (``begin`` / ``finish``);
@@ -33,8 +34,10 @@ class FlatGradSync(object):
     reads.  ``measure=True``: HIP events around every wait, ``exposed_ms()`` = time the model streams actually stalled on the
     exchange (what the overlap did not hide)."""
 
+    FUSE_BELOW = 4 << 20        # elements: models under 16 MiB of fp32 gradients share one arena and ONE all-reduce per step
+
     def __init__(self, segmentators, process_group=None, broadcast_weights: bool = True, compress: Optional[str] = None,
-                 measure: bool = False):
+                 measure: bool = False, fuse_small: bool = True):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("FlatGradSync needs an initialised torch.distributed process group")
         self.segmentators = list(segmentators)
@@ -51,6 +54,13 @@ class FlatGradSync(object):
         self.measure = measure
         self._events: List = []
         self.exchanged_bytes = 0
+        self.fuse_small = bool(fuse_small)
+        self._arena: Optional[torch.Tensor] = None      # gradient buffers of all small models, back to back (Enet -> single bucket)
+        self._arena_span = {}       # model index -> (lo, hi) elements of the arena
+        self._fused_ready: List[int] = []
+        self.collectives = 0        # all-reduce launches since construction (tests and bench read it)
+        self._prepared = False
+        self._pair_rng = None       # adversarial pair: one RandomState per job, same seed on every rank (draw_pair)
         if broadcast_weights:
             self.broadcast_weights()
         # decorrelate the ranks' dropout masks (same torch seed on every rank gives every rank the same Philox seed)
@@ -78,7 +88,64 @@ class FlatGradSync(object):
                 if b.dtype.is_floating_point:
                     dist.broadcast(b.data, src=0, group=self.group)
 
+    # -- the adversarial pair: identical on every rank ----------------------------------------------
+    def draw_pair(self, n_models: int):
+        """The (a, b) models of this step's adversarial block (reference cotraining_totalloss.py:230-234: ``np.random.choice``
+        on the process-global numpy RNG).  Under data parallelism every rank must train the SAME pair -- the gradient average
+        of a step mixes the ranks' adversarial terms -- but the ranks' global numpy states need not agree (loaders, user code).
+        So the job owns one RandomState: rank 0 draws its seed from ITS global RNG once (a user seed still controls the
+        sequence), broadcasts it, and every rank draws the per-step pairs from that private stream."""
+        import numpy as np
+        if self._pair_rng is None:
+            dev = "cpu"
+            if dist.get_backend(self.group) == "nccl":
+                dev = torch.device("cuda", torch.cuda.current_device())
+            seed = torch.tensor([int(np.random.randint(0, 2 ** 31 - 1)) if self.rank == 0 else 0], dtype=torch.int64, device=dev)
+            dist.broadcast(seed, src=0, group=self.group)
+            self._pair_rng = np.random.RandomState(int(seed.item()))
+        try:
+            choice = sorted(self._pair_rng.choice(list(range(n_models)), 2, replace=False).tolist())
+        except Exception:
+            choice = sorted(self._pair_rng.choice(list(range(n_models)), 2, replace=True).tolist())
+        return choice[0], choice[1]
+
     # -- gradients ---------------------------------------------------------------------------------
+    def _adopt_arena(self):
+        """Move the flat gradient buffers of all small flat-buffer models into one allocation (each a slice of it, the
+        ``p.grad`` views re-pointed), so that their exchange is a single collective with no copies.  Idempotent; re-adopts a
+        model whose buffer was re-allocated since (``.to(device)``, ``load_state_dict`` re-flattening)."""
+        small = []
+        for i, seg in enumerate(self.segmentators):
+            flat = getattr(seg.torchnet, "flat_params", None)
+            if flat is not None and flat.total < self.FUSE_BELOW:
+                flat.ensure()
+                small.append((i, flat))
+        if len(small) < 2:
+            self._arena, self._arena_span = None, {}
+            return
+        dev = small[0][1].flat.device
+        total = sum(f.total for _, f in small)
+        if self._arena is None or self._arena.numel() != total or self._arena.device != dev:
+            self._arena = torch.zeros(total, dtype=torch.float32, device=dev)
+            self._arena_span = {}
+            lo = 0
+            for i, f in small:
+                self._arena_span[i] = (lo, lo + f.total)
+                lo += f.total
+        base = self._arena.data_ptr()
+        for i, f in small:
+            lo, hi = self._arena_span[i]
+            if f.gflat is not None and f.gflat.data_ptr() == base + 4 * lo and f.grads_attached():
+                continue
+            piece = self._arena[lo:hi]
+            if f.gflat is not None and f.gflat.device == dev and f.grads_attached():
+                piece.copy_(f.gflat)            # gradients accumulated so far move with the buffer
+            else:
+                piece.zero_()
+            f.gflat = piece
+            for k, p in enumerate(f.params):
+                p.grad = f._grad_view(k)
+
     def _reduce_tensor(self, t: torch.Tensor, async_op: bool):
         if self._avg:
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), None
@@ -97,8 +164,26 @@ class FlatGradSync(object):
         else:
             wire = src
         self.exchanged_bytes += wire.numel() * wire.element_size()
+        self.collectives += 1
         work, scale = self._reduce_tensor(wire, True)
         return (model_index, work, scale, None, None, (wire, src) if wire is not src else None)
+
+    def _start_arena(self):
+        """ONE all-reduce over the arena (every small model's gradients); the pending record carries the key 'arena'."""
+        src = self._arena
+        if self.compress == "bf16":
+            buf = self._cbuf.get("arena")
+            if buf is None or buf.numel() != src.numel() or buf.device != src.device:
+                buf = torch.empty(src.numel(), dtype=torch.bfloat16, device=src.device)
+                self._cbuf["arena"] = buf
+            buf.copy_(src)
+            wire = buf
+        else:
+            wire = src
+        self.exchanged_bytes += wire.numel() * wire.element_size()
+        self.collectives += 1
+        work, scale = self._reduce_tensor(wire, True)
+        return ("arena", work, scale, None, None, (wire, src) if wire is not src else None)
 
     def begin_bucket(self, model_index: int, lo: int, hi: int):
         """Start the all-reduce of elements [lo, hi) of one model's flat gradient buffer -- called from inside the
@@ -119,6 +204,15 @@ class FlatGradSync(object):
             return
         net = self.segmentators[model_index].torchnet
         flat = getattr(net, "flat_params", None)
+        if self.fuse_small and model_index in self._arena_span and flat is not None and flat.grads_attached() and \
+                flat.gflat.data_ptr() == self._arena.data_ptr() + 4 * self._arena_span[model_index][0]:
+            # small model: its gradients sit in the shared arena -- the collective goes out when the LAST of them is ready
+            if model_index not in self._fused_ready:
+                self._fused_ready.append(model_index)
+            if len(self._fused_ready) == len(self._arena_span):
+                self._fused_ready = []
+                self._pending.append(self._start_arena())
+            return
         if flat is not None and flat.grads_attached():
             self._pending.append(self._start(model_index, flat, 0, flat.gflat.numel()))
             return
@@ -132,9 +226,16 @@ class FlatGradSync(object):
     @torch.no_grad()
     def finish(self, model_index: Optional[int] = None):
         """Wait for the pending all-reduces (of one model, or all) and finish the averaging."""
+        if self._fused_ready and (model_index is None or model_index in self._fused_ready):
+            # not every small model produced gradients this step: exchange the ready ones one by one (same result, more launches)
+            ready, self._fused_ready = self._fused_ready, []
+            for i in ready:
+                flat = self.segmentators[i].torchnet.flat_params
+                self._pending.append(self._start(i, flat, 0, flat.gflat.numel()))
         keep = []
         for ent in self._pending:
-            if model_index is not None and ent[0] != model_index:
+            fused_hit = ent[0] == "arena" and (model_index is None or model_index in self._arena_span)
+            if model_index is not None and ent[0] != model_index and not fused_hit:
                 keep.append(ent)
                 continue
             _, work, scale, buf, params, wire = ent
@@ -176,6 +277,13 @@ class FlatGradSync(object):
         for i in range(len(self.segmentators)):
             self.begin(i)
         self.finish()
+
+    def prepare(self):
+        """Call once the models sit on their device and before the first step (CoTrainer does): lays the small models'
+        gradient buffers out in the shared arena, outside any graph capture."""
+        if self.fuse_small:
+            self._adopt_arena()
+        self._prepared = True
 
 
 def init_from_env(backend: Optional[str] = None):

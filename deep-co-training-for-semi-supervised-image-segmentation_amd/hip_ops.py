@@ -12,8 +12,24 @@ from . import _lib
 from ._lib import BF16, DTYPE_OF, F32, EnetTf, call, conv_desc, ptr, stream, view
 
 
+_WS_CACHE = {}      # (device index, stream handle) -> uint8 workspace, grown geometrically
+
+
 def _ws(nbytes: int, device) -> Optional[torch.Tensor]:
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    """Scratch for one launch (split-K slabs, partial sums).  Eager launches reuse ONE buffer per stream -- launches of a
+    stream run in order, so the next one may overwrite it -- instead of hitting the allocator per call.  Under stream
+    capture the buffer comes from the graph's private pool as before: a cached buffer baked into a graph could be
+    replaced (and freed) by a later, larger request while the graph still replays."""
+    nbytes = max(int(nbytes), 16)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    buf = _WS_CACHE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 2 * buf.numel() if buf is not None else 1 << 20), dtype=torch.uint8, device=dev)
+        _WS_CACHE[key] = buf
+    return buf
 
 
 def _dt(t: torch.Tensor) -> int:

@@ -137,6 +137,8 @@ class CoTrainer(Trainer):
         self.to(self.device)
         self.use_tqdm = use_tqdm and tqdm_ is not None
         self.grad_sync = grad_sync          # dct_amd.ddp.FlatGradSync or None (single process)
+        if grad_sync is not None and hasattr(grad_sync, "prepare"):
+            grad_sync.prepare()             # small models' gradient buffers -> one arena, one collective per step
         self.batch_lab_unlab = True         # one B_l+B_u pass per batch-independent net (see _run_step_fused)
         self.model_streams = True           # one HIP stream per model in the fused step (see _streams)
         self._stream_pool = None
@@ -229,6 +231,8 @@ class CoTrainer(Trainer):
 
     def _draw_adv_choice(self) -> Tuple[int, int]:
         S = len(self.segmentators)
+        if self.grad_sync is not None and hasattr(self.grad_sync, "draw_pair"):
+            return self.grad_sync.draw_pair(S)       # data parallelism: the same pair on every rank
         try:
             choice = sorted(np.random.choice(list(range(S)), 2, replace=False).tolist())
         except Exception:
@@ -239,6 +243,8 @@ class CoTrainer(Trainer):
                   train_jsd: bool, train_adv: bool, adv_choice: Optional[Tuple[int, int]] = None) -> dict:
         """One co-training step == reference lines :207-248.  Returns
         dict(sup=[Tensor], jsd=Tensor|0, adv=Tensor|0, preds=[Tensor], unlab_probs=[Tensor])."""
+        if self.grad_sync is not None and not getattr(self.grad_sync, "_prepared", True):
+            self.grad_sync.prepare()        # (a grad_sync attached after construction) before anything is captured
         if train_adv and adv_choice is None:
             adv_choice = self._draw_adv_choice()
         # the kernels take raw pointers: images fp32, labels int64, both dense (a loader may hand over uint8 labels or

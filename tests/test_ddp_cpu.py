@@ -161,3 +161,73 @@ def test_two_rank_gloo_bucketed_exchange(tmp_path):
         want = (torch.arange(n, dtype=torch.float32) * 1 + 10 * m + torch.arange(n, dtype=torch.float32) * 2 + 10 * m) / 2
         assert torch.equal(g0[m], g1[m])
         np.testing.assert_allclose(g0[m].numpy(), want.numpy(), rtol=1e-6)
+
+
+def _arena_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import types
+    import torch.distributed as dist
+    from dct_amd import ddp
+    from dct_amd.arch.flat import FlatParams
+    ddp.init_from_env("gloo")
+    np.random.seed(1000 + 17 * rank)            # the ranks' global numpy states DIFFER (loaders, user code)
+    segs = []
+    for m in range(3):
+        net = torch.nn.Sequential(torch.nn.Linear(40, 30), torch.nn.Linear(30, 7 + m))
+        net.flat_params = FlatParams(list(net.parameters()))
+        segs.append(types.SimpleNamespace(torchnet=net))
+    sync = ddp.FlatGradSync(segs, broadcast_weights=False)
+    sync.prepare()
+    flats = [s.torchnet.flat_params for s in segs]
+    assert sync._arena is not None and sync._arena.numel() == sum(f.total for f in flats)
+    for m, f in enumerate(flats):
+        assert f.grads_attached() and f.gflat.data_ptr() == sync._arena.data_ptr() + 4 * sync._arena_span[m][0]
+    log = {"pairs": [], "collectives": []}
+    for step in range(3):
+        for m, f in enumerate(flats):
+            f.gflat.copy_(torch.arange(f.total, dtype=torch.float32) * (rank + 1) + 10 * m + step)
+        c0 = sync.collectives
+        for m in range(3):
+            sync.begin(m)               # the collective leaves with the LAST model's begin
+        for m in range(3):
+            sync.finish(m)
+        log["collectives"].append(sync.collectives - c0)
+        log["pairs"].append(sync.draw_pair(3))
+    # a model whose buffer was re-allocated (e.g. .to(device)) is re-adopted with its gradients
+    flats[1].gflat = flats[1].gflat.clone()
+    for k, p in enumerate(flats[1].params):
+        p.grad = flats[1]._grad_view(k)
+    keep = flats[1].gflat.clone()
+    sync.prepare()
+    assert flats[1].gflat.data_ptr() == sync._arena.data_ptr() + 4 * sync._arena_span[1][0] and torch.equal(flats[1].gflat, keep)
+    # only two of the three models have gradients this step: falls back to one exchange each, still the rank mean
+    for m in (0, 2):
+        flats[m].gflat.fill_(float(rank + 1))
+        sync.begin(m)
+    c0 = sync.collectives
+    sync.finish()
+    log["partial"] = (sync.collectives - c0, float(flats[0].gflat[0]), float(flats[2].gflat[-1]))
+    log["g"] = [f.gflat.clone() for f in flats]
+    torch.save(log, os.path.join(out, f"a{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_small_models_share_one_collective_and_one_adversarial_pair(tmp_path):
+    """the S Enet-sized models' gradients leave as ONE flat collective per step (FlatGradSync arena), and the
+    adversarial pair is identical on every rank although the ranks' global numpy RNG states differ (draw_pair)."""
+    world, port = 2, _free_port()
+    out = str(tmp_path)
+    mp.spawn(_arena_worker, args=(world, port, out), nprocs=world, join=True)
+    a0 = torch.load(os.path.join(out, "a0.pt"), weights_only=False)
+    a1 = torch.load(os.path.join(out, "a1.pt"), weights_only=False)
+    assert a0["collectives"] == [1, 1, 1] and a1["collectives"] == [1, 1, 1]
+    assert a0["pairs"] == a1["pairs"] and all(0 <= a < b <= 2 for a, b in a0["pairs"])
+    assert a0["partial"] == a1["partial"] == (2, 1.5, 1.5)
+    for m in range(3):
+        assert torch.equal(a0["g"][m], a1["g"][m])
+    n = a0["g"][1].numel()                      # model 1 kept the mean of step 2
+    want = (torch.arange(n, dtype=torch.float32) * 1 + torch.arange(n, dtype=torch.float32) * 2) / 2 + 10 + 2
+    np.testing.assert_allclose(a0["g"][1].numpy(), want.numpy(), rtol=1e-6)
