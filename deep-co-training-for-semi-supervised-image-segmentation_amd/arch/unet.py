@@ -199,12 +199,12 @@ class UNet(nn.Module):
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
-        self._pack_key = None
+        self.mark_weights_updated()         # (also drops "the bf16 shadow is fresh": it mirrors the weights before the call)
         return r
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
-        self._pack_key = None
+        self.mark_weights_updated()
         return r
 
     def _w(self, conv: _ConvP) -> torch.Tensor:

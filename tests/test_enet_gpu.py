@@ -118,35 +118,39 @@ def _bf16_points(onet):
 #        1-6 %.  In bf16 mode only the final transposed conv's gradients are compared (=> 0.2) and the rest
 #        must be finite; every kernel is checked on its own in mixed bf16 mode by
 #        tests/test_enet_kernels_gpu.py.  The parity claim is the fp32 mode.
-#  The oracle itself is part of that chaos: ATen's CPU reductions change their summation order with the thread count, and on
-#  the single-image case below the oracle's OWN gradients move by 5e-3 .. 1.7e-2 between 8 and 16+ threads (measured: against
-#  an oracle on the box's default thread count the fp32 kernels are within 5.4e-4 on every tensor, tools/debug_enet_margin.py;
-#  against the 16-thread oracle of tests/conftest.py the same kernels read 1.7e-2) => 3e-2 for fp32 gradients.
-@pytest.mark.parametrize("dtype,tol_logit,tol_grad", [(torch.float32, 2e-5, 3e-2), (torch.bfloat16, 0.2, 0.2)])
+#  The fp32 oracle itself is part of that chaos: ATen's CPU reductions change their summation order with the thread count, and
+#  on the single-image case below the fp32 oracle's OWN gradients move by 5e-3 .. 1.7e-2 between 8 and 16+ threads.  So the
+#  fp32 (parity) mode is held to the oracle evaluated in FLOAT64 -- same modules, same weights, rounding noise 1e-16: a
+#  deterministic reference whatever the host -- and the gate stays at 5e-3 (round 2 had widened it to 3e-2
+#  against the thread-dependent fp32 oracle).
+@pytest.mark.parametrize("dtype,tol_logit,tol_grad", [(torch.float32, 2e-5, 5e-3), (torch.bfloat16, 0.2, 0.2)])
 @pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 2), (1, 96, 128, 4)])
 def test_enet_vs_oracle_fwd_bwd_train(dtype, tol_logit, tol_grad, B, H, W, C):
     onet = _oracle_net(C, 7).train()
     net = _hip_net(onet, C, dtype).train()
+    f64 = dtype == torch.float32
     if dtype == torch.bfloat16:
         _bf16_points(onet)
     g = torch.Generator().manual_seed(3)
     x = torch.rand(B, 1, H, W, generator=g)
     t = torch.randint(0, C, (B, H, W), generator=g)
-    xo = x.clone().requires_grad_(True)
+    if f64:
+        onet = onet.double()
+    xo = (x.double() if f64 else x.clone()).requires_grad_(True)
     yo = onet(xo)
     oracle.cross_entropy_2d(yo, t).backward()
     xd = x.to(DEV).requires_grad_(True)
     y = net(xd)
-    assert _rel2(y.detach().float().cpu().numpy(), yo.detach().numpy()) < tol_logit
+    assert _rel2(y.detach().float().cpu().numpy(), yo.detach().float().numpy()) < tol_logit
     yo2 = yo.detach().clone().requires_grad_(True)
     gl = torch.autograd.grad(oracle.cross_entropy_2d(yo2, t), yo2)[0]
-    y.backward(gl.to(DEV))
-    errs = {"grad_x": _rel2(xd.grad.cpu().numpy(), xo.grad.numpy())}
+    y.backward(gl.float().to(DEV))
+    errs = {"grad_x": _rel2(xd.grad.cpu().numpy(), xo.grad.float().numpy())}
     for (k, p), (_, po) in zip(net.named_parameters(), onet.named_parameters()):
         if po.grad.norm() < 1e-6:      # biases in front of a BatchNorm: zero gradient up to rounding
             assert p.grad.norm().item() < (1e-5 if dtype == torch.float32 else 1e-2), k
             continue
-        errs[k] = _rel2(p.grad.cpu().numpy(), po.grad.numpy())
+        errs[k] = _rel2(p.grad.cpu().numpy(), po.grad.float().numpy())
     assert all(np.isfinite(v) for v in errs.values())
     if dtype == torch.bfloat16:
         errs = {k: v for k, v in errs.items() if k.startswith("decoder.layers.5")}
@@ -159,7 +163,7 @@ def test_enet_vs_oracle_fwd_bwd_train(dtype, tol_logit, tol_grad, B, H, W, C):
         sd, so = net.state_dict(), onet.state_dict()
         for k in so:
             if k.endswith("running_mean") or k.endswith("running_var"):
-                np.testing.assert_allclose(sd[k].cpu().numpy(), so[k].numpy(), rtol=2e-4, atol=1e-6, err_msg=k)
+                np.testing.assert_allclose(sd[k].cpu().numpy(), so[k].float().numpy(), rtol=2e-4, atol=1e-6, err_msg=k)
 
 
 def test_enet_rejects_bad_inputs():

@@ -100,10 +100,16 @@ def test_train_loop_fp32_matches_reference_golden(golden, tmp_path, tag):
             # meaningless for them: allow a fifth of the maximal Adam displacement on top
             atol = 1e-5 + (0.2 * n * 1e-3 * mult[~noise] if enet else 0.0)
             err = np.abs(df[~noise, col] - ref[~noise])
-            # (running statistics of the deepest blocks after three chaotic Adam steps: up to 3.05 % measured on one running
-            #  variance of the last encoder block => 5 %)
-            rtol = np.array([(5e-2 if (enet and "running_" in k) else 2e-3 * loose) for k in np.array(names)[~noise]])
+            # Running statistics after three chaotic Adam steps: 3 % for every BatchNorm; ONE running variance of the last
+            # encoder block (the deepest, smallest sample: 2 x 8 x 8) was measured at 3.05 % -- at most one such outlier is
+            # let through, and only up to 5 %.
+            kept = np.array(names)[~noise]
+            is_run = np.array([enet and "running_" in k for k in kept])
+            rtol = np.where(is_run, 3e-2, 2e-3 * loose)
             bad = err > rtol * np.abs(ref[~noise]) + atol
+            outliers = bad & is_run & (err <= 5e-2 * np.abs(ref[~noise]) + atol)
+            if outliers.sum() <= 1:
+                bad = bad & ~outliers
             assert not bad.any(), (col, [names[i] for i in np.flatnonzero(~noise)[bad]][:8], err[bad][:8], ref[~noise][bad][:8])
             assert np.all(np.abs(df[noise, col] - ref[noise]) <= step_bound * mult[noise] + 1e-6)
         st = seg.optimizer.state
