@@ -356,10 +356,15 @@ def main():
     caps = list(tr._step_graphs._graphs.values()) if getattr(tr, "_step_graphs", None) is not None else []
     if caps and getattr(caps[0], "program", None) is not None:
         prog = caps[0].program
-        from dct_amd.trainer.stream_sched import _QUEUE_GROUPS
+        from dct_amd.trainer.stream_sched import queue_probe_report
+        probe = queue_probe_report(device)
         result["config"]["step_execution"] = {"mode": "program of per-stream HIP graphs (trainer/stream_sched.py)", "graphs": prog.n_graphs,
                                               "kernel_nodes": prog.n_nodes, "ops": len(prog.ops),
-                                              "hardware_queue_groups_found": [len(g) for g in next(iter(_QUEUE_GROUPS.values()), [])]}
+                                              "hardware_queue_groups_found": probe.get("sizes", []),
+                                              # four groups are what the multi-queue layouts are dealt over; anything else means the
+                                              # timing probe was disturbed and the streams were dealt blindly (slower, still correct)
+                                              "hardware_queue_probe_ok": bool(probe.get("ok", probe.get("source") == "DCT_HW_QUEUES")),
+                                              "hardware_queue_probe": probe}
     elif caps:
         result["config"]["step_execution"] = {"mode": "one HIP graph"}
     else:

@@ -180,6 +180,11 @@ class StepGraphCache(object):
                     tr._sched = EagerSchedule()
                     for (o, n), v in zip(self._counters(), before):
                         setattr(o, n, v)
+                    for seg in tr.segmentators:      # weight packs "built" by recorded-only launches do not exist: rebuild next step
+                        if hasattr(seg.torchnet, "mark_weights_updated"):
+                            seg.torchnet.mark_weights_updated()
+                    if "capture" not in str(e).lower() and "graph" not in str(e).lower():
+                        raise                         # an argument / kernel error is not a refused capture: do not hide it
                     self._seen[sig] = -(1 << 30)
                     import warnings
                     warnings.warn(f"dct_amd: capturing the step as a program of HIP graphs failed ({e}); this step shape runs eagerly")

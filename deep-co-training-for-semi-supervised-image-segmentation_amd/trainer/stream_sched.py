@@ -256,6 +256,7 @@ class SegmentRecorder(object):
 
 # ---- which streams sit on different hardware queues ---------------------------------------------------
 _QUEUE_GROUPS = {}
+_QUEUE_PROBE = {}
 
 
 def _chain_graph(stream, x, links):
@@ -275,10 +276,20 @@ def queue_groups(device, candidates: int = 8, links: int = 150) -> List[List[tor
     HIP multiplexes its streams onto a few hardware queues (four by default) and does not say which: two streams of one queue
     run their graph launches one after the other.  One short captured chain per candidate stream; a candidate whose chain,
     launched together with a group's first stream, takes > 1.6 x one chain shares that group's queue."""
-    key = (torch.device(device).index or 0)
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())      # a bare "cuda" means the CURRENT device, not device 0
+    key = dev.index
     if key in _QUEUE_GROUPS:
         return _QUEUE_GROUPS[key]
-    dev = torch.device(device)
+    import os
+    forced = os.environ.get("DCT_HW_QUEUES")       # e.g. "4": skip the probe and deal fresh streams round-robin over that many groups
+    if forced:
+        n = max(1, int(forced))
+        out = [[own_stream(dev) for _ in range(max(1, candidates // n))] for _ in range(n)]
+        _QUEUE_GROUPS[key] = out
+        _QUEUE_PROBE[key] = dict(groups=n, sizes=[len(g) for g in out], attempts=0, source="DCT_HW_QUEUES")
+        return out
     streams = [own_stream(dev) for _ in range(candidates)]
     xs = [torch.ones(65536, device=dev) for _ in streams]
     graphs = [_chain_graph(s, x, links) for s, x in zip(streams, xs)]
@@ -313,8 +324,22 @@ def queue_groups(device, candidates: int = 8, links: int = 150) -> List[List[tor
         torch.cuda.set_stream(cur)
     del graphs
     out = [[streams[i] for i in g] for g in groups]
-    _QUEUE_GROUPS[key] = out
+    ok = len(groups) == 4 and max(len(g) for g in groups) <= 3
+    _QUEUE_PROBE[key] = dict(groups=len(groups), sizes=[len(g) for g in groups], attempts=attempt + 1, source="timing probe", ok=ok)
+    if ok:
+        _QUEUE_GROUPS[key] = out        # a failed probe is NOT cached: the next trainer probes again
+    else:
+        import warnings
+        warnings.warn(f"dct_amd: the hardware-queue probe found {len(groups)} groups {[len(g) for g in groups]} instead of 4 "
+                      "(shared or noisy GPU?); the multi-queue step layouts may run slower -- set DCT_HW_QUEUES=4 to skip the probe")
     return out
+
+
+def queue_probe_report(device=None) -> dict:
+    """What the last probe of ``device`` found (bench.py prints and asserts on it)."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    return dict(_QUEUE_PROBE.get(idx, {}))
 
 
 class StreamDealer(object):
