@@ -69,6 +69,7 @@ SIGNATURES = {
     "dct_bias_grad_workspace_bytes": (_sz, [_VP]),
     "dct_pack_weight": (_i, [_P, _P, _i, _i, _i, _i, _i, _i, _P]),
     "dct_pack_weights_batched": (_i, [_P, _i, _i, _i, _P]),
+    "dct_pack_weights_batched64": (_i, [_P, _i, _i, _P]),
     "dct_conv_cin1_fwd": (_i, [_VP, _P, _P, _VP, _DP, _i, _P]),
     "dct_conv_cin1_dgrad": (_i, [_VP, _P, _VP, _DP, _i, _P]),
     "dct_conv_cin1_wgrad_workspace_bytes": (_sz, [_VP, _DP]),

@@ -260,8 +260,8 @@ class UNet(nn.Module):
         tkey = (fp.version, fp.flat.data_ptr(), fp.shadow.data_ptr() if use_shadow else 0, dev, dt)
         if self._pack_table is None or self._pack_table[0] != tkey:
             self._pack_table = (tkey,) + K.pack_jobs_table(jobs, dev)
-        _, table, njobs, tiles = self._pack_table
-        K.pack_weights_batched(table, njobs, tiles, dt)
+        _, table, njobs, tiles, edge = self._pack_table
+        K.pack_weights_batched(table, njobs, tiles, dt, edge)
         self._pack_key = key
 
     # ------------------------------------------------------------------------------ forward

@@ -343,6 +343,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   if (kbeg < kend) stage(smem);
+  // bias of the tile's BN channels -> LDS now (behind the two stage buffers), so that the epilogue does not start with a
+  // global-memory round trip (stamps: 1.2k of the 2k cycles of "accumulators -> LDS" were the wait for these loads)
+  float* biasL = reinterpret_cast<float*>(smem + 2 * STAGE);
+  if (p.staged && tid < BN) {
+    int co = n0 + tid;
+    if (p.scatter) co %= p.cout;
+    biasL[tid] = p.bias ? p.bias[co] : 0.f;
+  }
   __syncthreads();
   int cur = 0;
   const int half = lane >> 5, l31 = lane & 31;
@@ -400,22 +408,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
     rowY[tid] = oy_; rowM[tid] = om_;
   }
 
-    // all bias vectors in ONE batch of loads (a load + wait per use costs a memory round trip each)
+    // bias vectors from the LDS copy made in the prologue
     f32x4 bv[TN][4];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bv[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int co = n0 + wn * WTN + i * 32 + 8 * q + 4 * half;
-          if (p.scatter) co %= p.cout;
-          bv[i][q] = *reinterpret_cast<const f32x4*>(p.bias + co);
-        }
-    }
+      for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const f32x4*>(biasL + wn * WTN + i * 32 + 8 * q + 4 * half);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int row = wm * WTM + j * 32 + l31;
@@ -630,6 +628,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
 #endif
   stageA(Abuf, 0);
   stageB(Bbuf, 0, 0);
+  float* biasL = reinterpret_cast<float*>(smem + ABUFS * A_BYTES + 2 * B_BYTES);   // bias -> LDS now: no memory round trip in the epilogue
+  if (tid < BN) biasL[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
   __syncthreads();
 #ifdef DCT_STAMPS
   st_pro = __builtin_amdgcn_s_memtime() - st_t0;
@@ -711,19 +711,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
 #endif
   {
     const int row = prow * TW + pcol;
-    // all bias vectors in ONE batch of loads (a load + wait per use costs a memory round trip each: 8 x ~450 cycles)
+    // bias vectors from the LDS copy made in the prologue
     f32x4 bv[TN][4];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bv[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          bv[i][q] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WTN + i * 32 + 8 * q + 4 * half);
-    }
+      for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const f32x4*>(biasL + wn * WTN + i * 32 + 8 * q + 4 * half);
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
 #pragma unroll
@@ -886,6 +879,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
   const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
   stageA(Abuf, 0);
   stageB(Bbuf, 0, 0);
+  float* biasL = reinterpret_cast<float*>(smem + ABUFS * A_BYTES + 2 * B_BYTES);   // bias -> LDS now: no memory round trip in the epilogue
+  if (tid < BN) biasL[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
   __syncthreads();
   int ab = 0, bb = 0;
   for (int c = 0; c < nch; ++c) {
@@ -947,11 +942,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
     // accumulator (i, j): channels wn * WTN + 16 * i + 4 * kq + {0..3} of pixel (patch row 2 * wm + j, column l15)
     f32x4 bv[TR];
 #pragma unroll
-    for (int i = 0; i < TR; ++i) bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-      for (int i = 0; i < TR; ++i) bv[i] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WTN + i * 16 + 4 * kq);
-    }
+    for (int i = 0; i < TR; ++i) bv[i] = *reinterpret_cast<const f32x4*>(biasL + wn * WTN + i * 16 + 4 * kq);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = (2 * wm + j) * TW + l15;
@@ -1319,7 +1310,7 @@ static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc*
 
 template <int BM, int BN, int WM, int WN, bool BOUNDS>
 static void launch_v2(const IgemmParams& p, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * 128 + (size_t)BN * 4;     // two stages + the tile's bias vector
   static bool attr_set = false;   // idempotent one-time opt-in to > 64 KiB dynamic LDS
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, BOUNDS>),
@@ -1339,7 +1330,7 @@ static void launch_v2(const IgemmParams& p, dim3 grid, hipStream_t st) {
 
 template <int BN, int NWN, int ABUFS>
 static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images, hipStream_t st) {
-  constexpr size_t lds = ABUFS * (size_t)(23 * 1024) + 2 * (size_t)BN * 128;
+  constexpr size_t lds = ABUFS * (size_t)(23 * 1024) + 2 * (size_t)BN * 128 + (size_t)BN * 4;   // halo stage(s), two weight stages, bias
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3_kernel<BN, 4, NWN, ABUFS>),

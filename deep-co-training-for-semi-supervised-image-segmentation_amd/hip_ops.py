@@ -88,8 +88,12 @@ def pack_weight(src_f32, dst, P, T, Q, transpose=False, flip_taps=False):
 
 def pack_jobs_table(jobs, device):
     """Device table for pack_weights_batched.  jobs: list of (src fp32 or bf16 tensor, dst tensor, P, T, Q, mode, flip) with
-    mode 1 -> dst[Q][T'][P], mode 2 -> dst[T'][Q][P] (dct_pack_weight's transpose codes).  Returns (table, n, tiles)."""
+    mode 1 -> dst[Q][T'][P], mode 2 -> dst[T'][Q][P] (dct_pack_weight's transpose codes).  Returns (table, n, tiles, edge):
+    edge 64 when every job is 16-bit -> 16-bit with P, Q multiples of 64 (the vectorised kernel), else 32."""
     import struct
+    wide = all(src.dtype == dst.dtype and src.element_size() == 2 and P % 64 == 0 and Q % 64 == 0 and
+               src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0 for src, dst, P, T, Q, mode, flip in jobs)
+    edge = 64 if wide else 32
     buf, tiles = bytearray(), 0
     for src, dst, P, T, Q, mode, flip in jobs:
         assert P % 32 == 0 and Q % 32 == 0 and mode in (1, 2)
@@ -97,13 +101,16 @@ def pack_jobs_table(jobs, device):
         assert src.dtype in (torch.float32, torch.bfloat16)
         buf += struct.pack("<QQiiiiqqii", src.data_ptr(), dst.data_ptr(), P, T, Q, int(bool(flip)), dq, dt, tiles,
                            int(src.dtype == torch.bfloat16))
-        tiles += (P // 32) * (Q // 32) * T
+        tiles += (P // edge) * (Q // edge) * T
     table = torch.frombuffer(buf, dtype=torch.uint8).clone().to(device)
-    return table, len(jobs), tiles
+    return table, len(jobs), tiles, edge
 
 
-def pack_weights_batched(table, njobs, tiles, dtype):
-    call("dct_pack_weights_batched", ptr(table), int(njobs), int(tiles), DTYPE_OF[dtype], stream())
+def pack_weights_batched(table, njobs, tiles, dtype, edge=32):
+    if edge == 64:
+        call("dct_pack_weights_batched64", ptr(table), int(njobs), int(tiles), stream())
+    else:
+        call("dct_pack_weights_batched", ptr(table), int(njobs), int(tiles), DTYPE_OF[dtype], stream())
 
 
 def conv_cin1_fwd(x, w, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=False):

@@ -116,6 +116,10 @@ int dct_pack_weight(const float* src, void* dst, int P, int T, int Q, int transp
  * multiples of 32) of dst[q*dq + t'*dt + p] = src[p][t][q]: (dq, dt) = (T*P, P) is dct_pack_weight's
  * transpose == 1, (P, Q*P) its transpose == 2.  total_tiles = tile_begin past the last job. */
 int dct_pack_weights_batched(const void* jobs_dev, int njobs, int total_tiles, int dtype, dct_stream stream);
+/* The same table for 16-bit (bf16 / f16) sources AND destinations, on 64 x 64 tiles with 16-byte accesses: every job has
+ * src_bf16 != 0, P and Q multiples of 64, dq and dt multiples of 8, 16-byte aligned src / dst; tile_begin counts 64 x 64
+ * tiles (P/64 * Q/64 * T per job).  This is the per-step re-pack of a bf16 UNet (arch/unet.py::_ensure_packs). */
+int dct_pack_weights_batched64(const void* jobs_dev, int njobs, int total_tiles, dct_stream stream);
 
 /* First layer, Cin = 1 (network.py:159 dec1 conv; enet.py:21 initial conv): direct conv.
  * x is fp32 [N,H,W,1]; w fp32 [Cout][R][S]; y in `dtype`. */

@@ -286,6 +286,28 @@ def test_conv_dgrad_via_packed_weights(ops, dtype):
     assert torch.equal(wf.float().cpu(), w.permute(0, 2, 3, 1).contiguous())
 
 
+@pytest.mark.parametrize("edge_ok", [True, False])
+def test_pack_weights_batched(ops, edge_ok):
+    """All transposed packs of a network in one launch (arch/unet.py::_ensure_packs): the 16-bit 64 x 64-tile kernel with
+    16-byte accesses (dct_pack_weights_batched64) when every job allows it, the 32 x 32 kernel otherwise -- bit-exact moves
+    against torch.permute for both pack layouts (conv dgrad [ci][flipped taps][co], convT forward [(a,b,co)][ci])."""
+    g = torch.Generator().manual_seed(16)
+    shapes = [(128, 9, 64, 1, True), (64, 9, 192, 1, True), (256, 4, 128, 2, False)] if edge_ok else [(96, 9, 64, 1, True), (64, 4, 32, 2, False)]
+    jobs, want = [], []
+    for P, T, Q, mode, flip in shapes:
+        src = torch.randn(P, T, Q, generator=g).to(torch.bfloat16).to(DEV)
+        dst = torch.empty(P * T * Q, dtype=torch.bfloat16, device=DEV)
+        jobs.append((src, dst, P, T, Q, mode, flip))
+        t = src.flip(1) if flip else src
+        want.append(t.permute(2, 1, 0).contiguous().flatten() if mode == 1 else t.permute(1, 2, 0).contiguous().flatten())
+    table, n, tiles, edge = ops.pack_jobs_table(jobs, torch.device(DEV))
+    assert edge == (64 if edge_ok else 32)
+    ops.pack_weights_batched(table, n, tiles, torch.bfloat16, edge)
+    torch.cuda.synchronize()
+    for (src, dst, *_), w in zip(jobs, want):
+        assert torch.equal(dst, w)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C", [64, 128, 512])
 def test_bias_grad(ops, dtype, C):

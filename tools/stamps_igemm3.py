@@ -27,6 +27,7 @@ def main():
     args = ap.parse_args()
     cin, hin, cout = LAYERS[args.layer]
     lib = _lib.load()
+    lib.dct_tune_set(11, 0)          # DCT_TUNE_IGEMM_MFMA16 = 0: the stamps sit in the 32x32x16 form (igemm3_kernel)
     fn = lib.dct_debug_stamps
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int]
