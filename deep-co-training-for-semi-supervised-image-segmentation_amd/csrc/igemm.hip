@@ -37,6 +37,7 @@ struct IgemmParams {
   int staged;  // v2: LDS-staged epilogue with 16-byte row stores (host-checked alignment / 32-bit offsets)
   int xcd_tiles, xcd_total;  // v3m / v2: XCD-aware 1-D tile order (0: plain grid)
   int xcd_gm, xcd_gn;        // v2: tiles along M and N of the plain grid (decode of the 1-D order)
+  int stagger;               // v3m / v3p: waves 4..7 issue their LDS-DMA pieces behind the step's first MFMA group (knob IGEMM_STAGGER)
 };
 
 template <typename T> struct Mfma;
@@ -345,8 +346,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
   if (kbeg < kend) stage(smem);
   // bias of the tile's BN channels -> LDS now (behind the two stage buffers), so that the epilogue does not start with a
   // global-memory round trip (stamps: 1.2k of the 2k cycles of "accumulators -> LDS" were the wait for these loads)
+  // (only where the extra BN * 4 bytes keep two blocks per CU: the 256 x 64 tile's stages are 80 KiB already)
+  constexpr bool BIAS_LDS = 2 * STAGE + BN * 4 <= 80 * 1024;
   float* biasL = reinterpret_cast<float*>(smem + 2 * STAGE);
-  if (p.staged && tid < BN) {
+  if (BIAS_LDS && p.staged && tid < BN) {
     int co = n0 + tid;
     if (p.scatter) co %= p.cout;
     biasL[tid] = p.bias ? p.bias[co] : 0.f;
@@ -408,12 +411,23 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
     rowY[tid] = oy_; rowM[tid] = om_;
   }
 
-    // bias vectors from the LDS copy made in the prologue
+    // bias vectors from the LDS copy made in the prologue (or, without one, in ONE batch of global loads)
     f32x4 bv[TN][4];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const f32x4*>(biasL + wn * WTN + i * 32 + 8 * q + 4 * half);
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (BIAS_LDS) {
+          bv[i][q] = *reinterpret_cast<const f32x4*>(biasL + wn * WTN + i * 32 + 8 * q + 4 * half);
+        } else {
+          bv[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.bias) {
+            int co = n0 + wn * WTN + i * 32 + 8 * q + 4 * half;
+            if (p.scatter) co %= p.cout;
+            bv[i][q] = *reinterpret_cast<const f32x4*>(p.bias + co);
+          }
+        }
+      }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int row = wm * WTM + j * 32 + l31;
@@ -874,6 +888,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
   const int l15 = lane & 15, kq = lane >> 4;
   const int rho0 = (2 * wm) * HW + l15;
   const int aswz = (l15 >> 1) & 7;
+  const bool late = p.stagger && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
 
   const int nch = p.Cin / 64;
   const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
@@ -886,9 +901,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
   for (int c = 0; c < nch; ++c) {
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {
-      if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
-      else if (c + 1 < nch) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
-      if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
+      // the step's LDS-DMA pieces (next weight tile, next halo at t == 0).  Issued by all eight waves right behind the barrier they
+      // queue up in the CU's one vector-memory path (stamps: ~500 of a step's ~1360 cycles per wave are spent ISSUING two or
+      // three pieces while no wave of the block feeds the matrix pipe); with p.stagger the second wave of every SIMD (waves
+      // 4..7) issues its pieces between the step's two MFMA groups instead.
+      auto stage_step = [&]() {
+        if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
+        else if (c + 1 < nch) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
+        if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
+      };
+      if (!late) stage_step();
       const int r = t / 3, s = t - 3 * r;
       const int rho = rho0 + r * HW + s;                      // column block 0; block 1 is one patch row (HW LDS rows) further
       const int pswz0 = (rho >> 1) & 7, pswz1 = ((rho + HW) >> 1) & 7;
@@ -916,6 +938,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[set][i], b[set][j], acc[i][j], 0, 0, 0);
+        if (k2 == 0 && late) stage_step();
       }
       __syncthreads();
       bb ^= 1;
@@ -1070,6 +1093,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
     rho0 = pr < PR ? pr * pitch + pc : 0;                      // slots past the tile read row 0 (never stored)
   }
   const int aswz = (l31 >> 1) & 7;
+  const bool late = p.stagger && wave >= NW / 2;
 
   const int nch = p.Cin / 64;
   const int cbeg = blockIdx.z * chunks_per_split, cend = min(nch, cbeg + chunks_per_split);
@@ -1081,9 +1105,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
   for (int c = cbeg; c < cend; ++c) {
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {
-      if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
-      else if (c + 1 < cend) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
-      if (t == 0 && c + 1 < cend) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
+      auto stage_step = [&]() {               // (see igemm3m_kernel: p.stagger moves the issue behind the first MFMA group for waves 4..7)
+        if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
+        else if (c + 1 < cend) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
+        if (t == 0 && c + 1 < cend) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
+      };
+      if (!late) stage_step();
       const int r = t / 3, s = t - 3 * r;
       const int rho = rho0 + r * pitch + s;
       const int pswz = (rho >> 1) & 7;
@@ -1106,6 +1133,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][i], b[set], acc[i], 0, 0, 0);
+        if (kk == 0 && late) stage_step();
       }
       __syncthreads();
       bb ^= 1;
@@ -1263,6 +1291,7 @@ int g_tune_igemm_xcd2 = 0;      // XCD-aware tile order of the per-tap kernel (w
 int g_tune_igemm_mfma16 = 1;    // shared-halo kernel on 16x16x32 MFMAs (igemm3m_kernel)
 int g_tune_igemm_halo_cover = 75;      // percent of the image the 8 x 16 patches must cover
 int g_tune_igemm_halo_min_blocks = 400;
+int g_tune_igemm_stagger = 0;   // shared-halo kernels: waves 4..7 issue their LDS-DMA pieces behind the step's first MFMA group
 int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3_kernel); 0: always v2
 
 static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int M, int N, Plan& pl) {
@@ -1310,7 +1339,8 @@ static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc*
 
 template <int BM, int BN, int WM, int WN, bool BOUNDS>
 static void launch_v2(const IgemmParams& p, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = 2 * (size_t)(BM + BN) * 128 + (size_t)BN * 4;     // two stages + the tile's bias vector
+  constexpr size_t stages = 2 * (size_t)(BM + BN) * 128;
+  constexpr size_t lds = stages + (stages + BN * 4 <= 80 * 1024 ? (size_t)BN * 4 : 0);     // two stages [+ the tile's bias vector]
   static bool attr_set = false;   // idempotent one-time opt-in to > 64 KiB dynamic LDS
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, BOUNDS>),
@@ -1503,6 +1533,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   p.partial = nullptr;
   p.staged = 0;
   p.xcd_tiles = 0; p.xcd_total = 0; p.xcd_gm = 0; p.xcd_gn = 0;
+  p.stagger = g_tune_igemm_stagger;
   if (pl.v2 && pl.splits == 1 && !d->accumulate && g_tune_igemm_staged) {
     const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
                      (long long)y->n * y->sn < (1ll << 31);
@@ -1608,6 +1639,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_ENET_BN_OWNER: g_enet_bn_owner = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_MFMA: if (value < 0 || value > 3) return DCT_ERR_BAD_ARG; g_enet_mfma = value; return DCT_OK;
     case DCT_TUNE_IGEMM_XCD2: g_tune_igemm_xcd2 = value ? 1 : 0; return DCT_OK;
+    case DCT_TUNE_IGEMM_STAGGER: g_tune_igemm_stagger = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_SPLIT: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_VEC: g_enet_reduce_vec = value ? 1 : 0; return DCT_OK;

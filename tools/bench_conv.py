@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--ab-packed", action="store_true", help="A/B the packed-rows shared-halo kernel (knob 10) on the deep levels")
     ap.add_argument("--ab-wgrad", action="store_true", help="A/B the filter-row weight-gradient kernel (knob 8) against the per-tap kernel")
     ap.add_argument("--ab", action="store_true", help="A/B the shared-halo 3x3 kernel against the per-tap kernel, interleaved in one process")
+    ap.add_argument("--ab-knob", action="append", default=[], metavar="KNOB=V0,V1[,...]",
+                    help="A/B any dct_tune_set knob: interleaved rounds of the listed values in one process (repeatable)")
+    ap.add_argument("--rounds", type=int, default=2)
     args = ap.parse_args()
     what = args.what.split(",")
     lib = _lib.load()
@@ -123,6 +126,14 @@ def main():
     run(args.batch, args.reps, what, "default", only)
     if args.ab_wgrad:
         ab_wgrad(args, lib, only)
+    for spec in args.ab_knob:
+        knob, vals = spec.split("=")
+        vals = [int(v) for v in vals.split(",")]
+        for rnd in range(args.rounds):
+            for v in vals:
+                assert lib.dct_tune_set(int(knob), v) == 0, (knob, v)
+                run(args.batch, args.reps, what, f"round {rnd}: knob {knob} = {v}", only)
+        lib.dct_tune_set(int(knob), vals[0])
     if args.ab_mfma16:
         for rnd in range(2):
             lib.dct_tune_set(11, 0)
