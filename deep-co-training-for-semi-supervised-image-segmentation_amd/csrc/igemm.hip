@@ -37,7 +37,6 @@ struct IgemmParams {
   int staged;  // v2: LDS-staged epilogue with 16-byte row stores (host-checked alignment / 32-bit offsets)
   int xcd_tiles, xcd_total;  // v3m / v2: XCD-aware 1-D tile order (0: plain grid)
   int xcd_gm, xcd_gn;        // v2: tiles along M and N of the plain grid (decode of the 1-D order)
-  int stagger;               // v3m / v3p: waves 4..7 issue their LDS-DMA pieces behind the step's first MFMA group (knob IGEMM_STAGGER)
 };
 
 template <typename T> struct Mfma;
@@ -256,6 +255,15 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((address_space(3))) const char* lptr_c;
 __device__ __forceinline__ void rd128(unsigned addr, bf16x8& dst) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); }
+template <int OFF> __device__ __forceinline__ void rd128o(unsigned addr, bf16x8& dst) {     // ds_read_b128 with an immediate byte offset
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int I, int N, int STRIDE> struct RdRows {      // dst[i] <- 16 bytes at addr + i * STRIDE, i = I .. N - 1 (immediate offsets)
+  __device__ static __forceinline__ void run(unsigned addr, bf16x8 (&dst)[N]) {
+    rd128o<I * STRIDE>(addr, dst[I]);
+    if constexpr (I + 1 < N) RdRows<I + 1, N, STRIDE>::run(addr, dst);
+  }
+};
 template <int N> __device__ __forceinline__ void lgkm_wait3() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void touch8(bf16x8& r) { asm volatile("" : "+v"(r)); }
 
@@ -605,18 +613,21 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
       }
     }
   };
-  // weight staging: piece = 8 cout rows
-  const bf16_t* wsrc[NPB];
+  // weight staging: piece = 8 cout rows.  The source is (wave-uniform base of the step's tap / channel slice) + (a lane's constant
+  // 32-bit byte offset): the global_load_lds takes the SGPR-base form and a step's staging costs no vector ALU work
+  // (the loop is bound by the SIMD's vector ISSUE -- MFMA issue slots plus VALU -- not by the matrix pipe: see DESIGN 4.1)
+  unsigned woffL[NPB];
 #pragma unroll
   for (int i = 0; i < NPB; ++i) {
     const int row = (wave + i * NW) * 8 + (lane >> 3);
-    wsrc[i] = reinterpret_cast<const bf16_t*>(p.w) + (long long)(n0 + row) * Ktot + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+    woffL[i] = (unsigned)(((long long)row * Ktot + (((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2);
   }
+  const char* wtile = p.w + (long long)n0 * Ktot * 2;
   auto stageB = [&](char* buf, int tap, int c0) {
-    const long long woff = (long long)tap * p.Cin + c0;
+    const char* wstep = wtile + ((long long)tap * p.Cin + c0) * 2;          // scalar
 #pragma unroll
     for (int i = 0; i < NPB; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + woff), (lptr_t)(buf + (wave + i * NW) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wstep + woffL[i]), (lptr_t)(buf + (wave + i * NW) * 1024), 16, 0, 0);
   };
 
   f32x16 acc[TN];
@@ -804,8 +815,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
 
 // igemm3_kernel on v_mfma_f32_16x16x32_bf16 (same FLOPs per cycle, same LDS traffic, 32-deep sub-steps): MI355X holds a
 // higher clock on this shape under load (MI355X_MICROARCH.md, DVFS item 7).  dct_tune_set(DCT_TUNE_IGEMM_MFMA16, 0/1).
+#ifndef DCT_V3M_WPE
+#define DCT_V3M_WPE 0          /* forcing four waves per SIMD through the attribute measured 1 % behind the compiler's own 100 registers */
+#endif
+#if DCT_V3M_WPE
+#define V3M_ATTR __attribute__((amdgpu_waves_per_eu(4, 8)))
+#else
+#define V3M_ATTR
+#endif
 template <int BN, int NWM, int NWN, int ABUFS>
-__global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmParams p, int tiles_x, int tiles_y) {
   constexpr int NW = NWM * NWN;
   constexpr int TH = 8, TW = 16, BM = TH * TW, HW = TW + 2, HROWS = (TH + 2) * HW;   // 180 halo rows of 128 B
   constexpr int APIECES = (HROWS + 7) / 8, A_BYTES = APIECES * 8 * 128;              // 23 pieces, 23552 B
@@ -817,7 +836,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
   char* Abuf = smem;                       // halo stage(s)
   char* Bbuf = smem + ABUFS * A_BYTES;     // two weight stages
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: LDS-DMA destinations and piece bookkeeping stay in SGPRs
   const int wn = wave / NWM, wm = wave % NWM;
   // XCD-aware tile order (knob DCT_TUNE_IGEMM_XCD): workgroups go round-robin over the 8 XCDs, each with its own L2.
   // Tile t of a 1-D grid is given to XCD t % 8's (t / 8)-th slot, and an XCD's slots cover a CONTIGUOUS range of
@@ -839,7 +859,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
   const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
 
   // halo staging: wave w issues pieces w, w + NW, ...; lane -> (row = piece * 8 + lane / 8, its swizzled source chunk)
-  long long aoff[NPA];
+  int aoff[NPA];                      // element offsets (the host admits this kernel only when x spans < 2^31 elements)
 #pragma unroll
   for (int i = 0; i < NPA; ++i) {
     const int piece = wave + i * NW;
@@ -849,7 +869,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
       const int hy = row / HW, hx = row - hy * HW;
       const int iy = y0 - p.pad_h + hy, ix = x0 - p.pad_w + hx;
       if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-        aoff[i] = img * p.xsN + iy * p.xsH + ix * p.xsW + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+        aoff[i] = (int)(img * p.xsN + iy * p.xsH + ix * p.xsW + (((lane & 7) ^ ((row >> 1) & 7)) * 8));
     }
   }
   auto stageA = [&](char* buf, int c0) {
@@ -888,7 +908,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
   const int l15 = lane & 15, kq = lane >> 4;
   const int rho0 = (2 * wm) * HW + l15;
   const int aswz = (l15 >> 1) & 7;
-  const bool late = p.stagger && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
 
   const int nch = p.Cin / 64;
   const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
@@ -897,51 +916,57 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
   float* biasL = reinterpret_cast<float*>(smem + ABUFS * A_BYTES + 2 * B_BYTES);   // bias -> LDS now: no memory round trip in the epilogue
   if (tid < BN) biasL[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
   __syncthreads();
+  // Fragment addresses with as little vector ALU work as the layout allows.  Weights: a lane's two sub-step addresses are
+  // constants of the lane (+ the stage, a scalar); the wave's 16-row blocks are reached through the read's immediate offset.
+  // Pixels: LDS row pi = rho0 + (tap offset, a literal once the nine taps are unrolled), 16-byte chunk (4 * k2 + kq) ^ ((pi >> 1) & 7);
+  // the second sub-step is the first with address bit 6 flipped, the second column block is HW rows further.
+  const unsigned Wb0 = smem_l + ABUFS * A_BYTES + (wn * WTN + l15) * 128 + ((kq ^ aswz) * 16);
+                                                             // (second sub-step: chunk (4 + kq) ^ aswz = the first address with bit 6 flipped)
   int ab = 0, bb = 0;
   for (int c = 0; c < nch; ++c) {
+    const unsigned Xs = smem_l + ab * A_BYTES;                // scalar
+#ifndef DCT_V3M_UNROLL
+#define DCT_V3M_UNROLL 1      /* measured (tools/gpu/r3f.sh): three unrolled taps per trip 13 % slower than one */
+#endif
 #pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-      // the step's LDS-DMA pieces (next weight tile, next halo at t == 0).  Issued by all eight waves right behind the barrier they
-      // queue up in the CU's one vector-memory path (stamps: ~500 of a step's ~1360 cycles per wave are spent ISSUING two or
-      // three pieces while no wave of the block feeds the matrix pipe); with p.stagger the second wave of every SIMD (waves
-      // 4..7) issues its pieces between the step's two MFMA groups instead.
-      auto stage_step = [&]() {
-        if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
-        else if (c + 1 < nch) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
-        if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
-      };
-      if (!late) stage_step();
-      const int r = t / 3, s = t - 3 * r;
-      const int rho = rho0 + r * HW + s;                      // column block 0; block 1 is one patch row (HW LDS rows) further
-      const int pswz0 = (rho >> 1) & 7, pswz1 = ((rho + HW) >> 1) & 7;
-      const unsigned Wl = smem_l + ABUFS * A_BYTES + bb * B_BYTES + (wn * WTN + l15) * 128;
-      const unsigned Xl = smem_l + ab * A_BYTES + rho * 128;
-      bf16x8 a[2][TR], b[2][2];
-      auto issue = [&](int set, int k2) {                      // k2: 32-deep sub-step (chunks 4 * k2 + kq)
-        const int ch = 4 * k2 + kq;
+    for (int r = 0; r < (DCT_V3M_UNROLL == 3 ? 3 : 9); ++r) {
 #pragma unroll
-        for (int i = 0; i < TR; ++i) rd128(Wl + i * 16 * 128 + ((ch ^ aswz) * 16), a[set][i]);
-        rd128(Xl + ((ch ^ pswz0) * 16), b[set][0]);
-        rd128(Xl + HW * 128 + ((ch ^ pswz1) * 16), b[set][1]);
-      };
-      issue(0, 0);
+    for (int sx0 = 0; sx0 < (DCT_V3M_UNROLL == 3 ? 3 : 1); ++sx0) {
+      const int t = DCT_V3M_UNROLL == 3 ? 3 * r + sx0 : r;
+      const int sx = DCT_V3M_UNROLL == 3 ? sx0 : r % 3;
+      const int rr = DCT_V3M_UNROLL == 3 ? r : r / 3;
+      if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
+      else if (c + 1 < nch) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
+      if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
+      const unsigned wa0 = Wb0 + bb * B_BYTES, wa1 = wa0 ^ 64u;
+      unsigned rho_t = rho0;
+      asm volatile("" : "+v"(rho_t));                        // recompute the tap's two addresses here (6 VALU) instead of keeping hoisted ones in registers
+      const unsigned pi0 = rho_t + rr * HW + sx, pi1 = pi0 + HW;
+      const unsigned x00 = (Xs + (pi0 << 7)) | (((kq ^ (pi0 >> 1)) & 7) << 4);
+      const unsigned x10 = (Xs + (pi0 << 7)) | (((kq ^ (pi1 >> 1)) & 7) << 4);     // (+ HW * 128 through the read's offset)
+      bf16x8 a[2][TR], b[2][2];
+      RdRows<0, TR, 16 * 128>::run(wa0, a[0]);
+      rd128o<0>(x00, b[0][0]);
+      rd128o<HW * 128>(x10, b[0][1]);
+      RdRows<0, TR, 16 * 128>::run(wa1, a[1]);
+      rd128o<0>(x00 ^ 64u, b[1][0]);
+      rd128o<HW * 128>(x10 ^ 64u, b[1][1]);
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        const int set = k2 & 1;
-        if (k2 + 1 < 2) { issue(set ^ 1, k2 + 1); lgkm_wait3<TR + 2>(); } else { lgkm_wait3<0>(); }
+        if (k2 == 0) lgkm_wait3<TR + 2>(); else lgkm_wait3<0>();
 #pragma unroll
-        for (int i = 0; i < TR; ++i) touch8(a[set][i]);
-        touch8(b[set][0]); touch8(b[set][1]);
+        for (int i = 0; i < TR; ++i) touch8(a[k2][i]);
+        touch8(b[k2][0]); touch8(b[k2][1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TR; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[set][i], b[set][j], acc[i][j], 0, 0, 0);
-        if (k2 == 0 && late) stage_step();
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k2][i], b[k2][j], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
       bb ^= 1;
+    }
     }
     ab ^= 1;
   }
@@ -1093,7 +1118,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
     rho0 = pr < PR ? pr * pitch + pc : 0;                      // slots past the tile read row 0 (never stored)
   }
   const int aswz = (l31 >> 1) & 7;
-  const bool late = p.stagger && wave >= NW / 2;
 
   const int nch = p.Cin / 64;
   const int cbeg = blockIdx.z * chunks_per_split, cend = min(nch, cbeg + chunks_per_split);
@@ -1105,12 +1129,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
   for (int c = cbeg; c < cend; ++c) {
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {
-      auto stage_step = [&]() {               // (see igemm3m_kernel: p.stagger moves the issue behind the first MFMA group for waves 4..7)
-        if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
-        else if (c + 1 < cend) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
-        if (t == 0 && c + 1 < cend) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
-      };
-      if (!late) stage_step();
+      if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
+      else if (c + 1 < cend) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
+      if (t == 0 && c + 1 < cend) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
       const int r = t / 3, s = t - 3 * r;
       const int rho = rho0 + r * pitch + s;
       const int pswz = (rho >> 1) & 7;
@@ -1133,7 +1154,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][i], b[set], acc[i], 0, 0, 0);
-        if (kk == 0 && late) stage_step();
       }
       __syncthreads();
       bb ^= 1;
@@ -1291,7 +1311,6 @@ int g_tune_igemm_xcd2 = 0;      // XCD-aware tile order of the per-tap kernel (w
 int g_tune_igemm_mfma16 = 1;    // shared-halo kernel on 16x16x32 MFMAs (igemm3m_kernel)
 int g_tune_igemm_halo_cover = 75;      // percent of the image the 8 x 16 patches must cover
 int g_tune_igemm_halo_min_blocks = 400;
-int g_tune_igemm_stagger = 0;   // shared-halo kernels: waves 4..7 issue their LDS-DMA pieces behind the step's first MFMA group
 int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3_kernel); 0: always v2
 
 static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int M, int N, Plan& pl) {
@@ -1533,7 +1552,6 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   p.partial = nullptr;
   p.staged = 0;
   p.xcd_tiles = 0; p.xcd_total = 0; p.xcd_gm = 0; p.xcd_gn = 0;
-  p.stagger = g_tune_igemm_stagger;
   if (pl.v2 && pl.splits == 1 && !d->accumulate && g_tune_igemm_staged) {
     const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
                      (long long)y->n * y->sn < (1ll << 31);
@@ -1560,7 +1578,9 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     const long long blocks = (long long)y->n * tiles_y * tiles_x * (p.N / bn);
     const double cover = (double)p.Ho * p.Wo / ((double)tiles_y * 8 * tiles_x * 16);
     // measured (tools/bench_conv.py --ab): the 64-channel tile only pays with a single channel slice (four blocks per CU)
-    if (y16 && m16 && cover >= g_tune_igemm_halo_cover * 0.01 && blocks >= g_tune_igemm_halo_min_blocks && (bn == 128 || x->c == 64)) {
+    // 32-bit addressing inside the kernel: x within 2^31 elements, a weight tile's rows within 2^32 bytes of its first
+    const bool x32 = (long long)x->n * x->sn < (1ll << 31) && (long long)bn * 9 * x->c * 2 < (1ll << 32);
+    if (y16 && m16 && x32 && cover >= g_tune_igemm_halo_cover * 0.01 && blocks >= g_tune_igemm_halo_min_blocks && (bn == 128 || x->c == 64)) {
       if (bn == 128) {
         if (x->c == 64) launch_v3<128, 2, 1>(p, tiles_x, tiles_y, y->n, st); else launch_v3<128, 2, 2>(p, tiles_x, tiles_y, y->n, st);
       } else launch_v3<64, 1, 1>(p, tiles_x, tiles_y, y->n, st);
@@ -1639,7 +1659,6 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_ENET_BN_OWNER: g_enet_bn_owner = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_MFMA: if (value < 0 || value > 3) return DCT_ERR_BAD_ARG; g_enet_mfma = value; return DCT_OK;
     case DCT_TUNE_IGEMM_XCD2: g_tune_igemm_xcd2 = value ? 1 : 0; return DCT_OK;
-    case DCT_TUNE_IGEMM_STAGGER: g_tune_igemm_stagger = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_SPLIT: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_VEC: g_enet_reduce_vec = value ? 1 : 0; return DCT_OK;

@@ -495,7 +495,6 @@ struct Wgrad3Params {
   int direct, accumulate, with_bias;
   float* bias;
   long long slab_stride;
-  int stagger;
 };
 
 template <int RB> __device__ __forceinline__ int swz3(int k) {       // in 16-B chunks
@@ -644,10 +643,7 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
 
   for (int it = 0; it < per_group; ++it) {
     const int gi = gbeg + it;
-    // (pr.stagger: the second wave group -- the SIMD partners of the first -- issues its pieces behind the step's first MFMA
-    //  group, so that the block's eight waves do not queue up in the vector-memory path right behind the barrier)
-    const bool late = G > 1 && pr.stagger && grp == G - 1 && gi < gend;
-    if (gi + 1 < gend && !late) stage(smem + (cur ^ 1) * STAGE);
+    if (gi + 1 < gend) stage(smem + (cur ^ 1) * STAGE);
     if (gi < gend) {                    // wave-uniform: a group with one step fewer only keeps the barrier     // all pieces up front: spreading them between the MFMA groups lands the stage later and was 8 % slower
     const unsigned Pl = smem_off + cur * STAGE;
     bf16x4 fa[2][TP][2], fb[2][3][TQ][2];
@@ -694,7 +690,6 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) accb[i] += (float)a[i][e];
       }
-      if (kk == 0 && late && gi + 1 < gend) stage(smem + (cur ^ 1) * STAGE);
     }
     }
     __syncthreads();
@@ -796,7 +791,6 @@ int g_tune_wgrad_target = 384;     // block target of the per-tap kernel (slab b
                                    // fastest; on the whole step (tools/ab_step.py --knob 14) 256-768 are level and 1.5 % ahead of 1150
 int g_tune_wgrad3_target = 768;    // same for the filter-row kernel, in 4-wave units
 int g_tune_wgrad_groups = 2;       // wave groups per wgrad3 block (1 | 2)
-int g_tune_wgrad_stagger = 0;      // wgrad3 with two wave groups: the second group issues its LDS-DMA pieces behind the step's first MFMA group
 int g_tune_wgrad_rows_fill = 70;   // percent: minimum fill of the 64-row K-steps for the filter-row kernel
 int g_tune_wgrad_rows = 1;     // 3x3 stride-1 layers on wide images: three taps of a filter row per block (wgrad3_kernel)
 int g_tune_wgrad_v2 = 1;       // dct_tune_set(DCT_TUNE_WGRAD_V2, 0): register-staged kernel
@@ -979,7 +973,6 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float
     pr.pitch = pl.pitch; pr.nr = pl.nr; pr.units_per_image = pl.units;
     pr.direct = pl.direct; pr.accumulate = d->accumulate;
     pr.bias = db; pr.with_bias = db ? 1 : 0; pr.slab_stride = slab_stride;
-    pr.stagger = g_tune_wgrad_stagger;
     launch_w3(pr, pl, st);
   } else if (pl.v2) {
     Wgrad2Params pr;
@@ -1008,6 +1001,5 @@ int dct_tune_set_wgrad(int knob, int value) {
   if (knob == DCT_TUNE_WGRAD_GROUPS) { g_tune_wgrad_groups = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD3_TARGET) { if (value < 64) return DCT_ERR_BAD_ARG; g_tune_wgrad3_target = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_TARGET) { if (value < 64) return DCT_ERR_BAD_ARG; g_tune_wgrad_target = value; return DCT_OK; }
-  if (knob == DCT_TUNE_WGRAD_STAGGER) { g_tune_wgrad_stagger = value ? 1 : 0; return DCT_OK; }
   return DCT_ERR_BAD_ARG;
 }

@@ -417,11 +417,8 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
                                                 with whole 8-channel groups (measured slower); 0 (default): split reduction + fold [+ apply] */
        DCT_TUNE_ENET_MWGRAD_WAVES = 28,      /* >= 64 (default 2048): waves an MFMA weight-gradient launch aims for */
        DCT_TUNE_ENET_MWGRAD_MIN_STEPS = 29,  /* multiple of 4 (default 4): least 16-pixel MFMA steps per pixel slice */
-       DCT_TUNE_ENET_APPLY_VEC = 30,         /* 1: BatchNorm-backward apply kernel on 8 channels per thread (measured slower in the step);
+       DCT_TUNE_ENET_APPLY_VEC = 30 };       /* 1: BatchNorm-backward apply kernel on 8 channels per thread (measured slower in the step);
                                                 0 (default): one element per thread */
-       DCT_TUNE_IGEMM_STAGGER = 31,          /* 1: in the shared-halo conv kernels the second wave of every SIMD (waves 4..7) issues its
-                                                LDS-DMA pieces between the step's MFMA groups instead of right behind the barrier */
-       DCT_TUNE_WGRAD_STAGGER = 32 };        /* 1: the same for the second wave group of the filter-row weight-gradient kernel */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 

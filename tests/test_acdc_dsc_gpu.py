@@ -94,3 +94,91 @@ def test_acdc_subset_dsc_matches_reference_at_equal_steps(golden, tmp_path, dtyp
         print(what, "foreground DSC  HIP", a, " reference", b)
         assert np.all(np.abs(a - b) <= 0.2), (what, a, b)
         assert abs(a.mean() - b.mean()) <= 0.1
+
+
+# ------------------------------------------------------------------------------------------------ a DSC check with teeth
+def _loaders_all_labeled(device, bs):
+    from torch.utils.data import DataLoader
+    from dct_amd.dataset import MedicalImageDataset, PatientSampler, extract_patients, segment_transform, to_cached_loaders
+    everyone = ["1", "2", "3", "4", "5"]
+    kw = dict(root_dir=SUB, subfolders=["img", "gt"], transform=segment_transform((256, 256)), augment="PILaugment",
+              pin_memory=False, quite=True)
+    train_set, val_set = MedicalImageDataset(mode="train", **kw), MedicalImageDataset(mode="val", **kw)
+    base = DataLoader(train_set, batch_size=bs, shuffle=True, drop_last=True, num_workers=0)
+    labs = [extract_patients(base, everyone) for _ in range(2)]
+    unl = extract_patients(DataLoader(MedicalImageDataset(mode="train", **kw), batch_size=bs, shuffle=True, drop_last=True, num_workers=0),
+                           everyone)
+    val = DataLoader(val_set, batch_sampler=PatientSampler(val_set, REGEX, shuffle=False, quite=True))
+    return to_cached_loaders(labs, unl, val, device=device)
+
+
+@pytest.mark.parametrize("arch", ["enet", "unet"])
+def test_acdc_dsc_curve_matches_a_reference_that_learned(arch, tmp_path):
+    """BASELINE.json: "DSC within 0.2 of the reference on ACDC at equal steps", against a reference run that actually segments
+    the heart.  tests/golden/g10_acdc_<arch>.npz (tools/capture_golden.py::g10_acdc_dsc) is the UNMODIFIED reference CoTrainer,
+    2 x Enet (5 epochs of 500 steps, bs 4 + 4) or 2 x UNet (the metric's network; 4 epochs of 250 steps, bs 2 + 2), all five
+    vendored training patients labeled for both models, CE + JSD, validated on patient 006 after every epoch.  The HIP bf16
+    trainer runs the same epochs from the same initial weights on the same batches (digests compared step by step) and must
+      * end within 0.2 of the reference's foreground DSC, per model, 3-D and 2-D,
+      * reach a foreground DSC >= 0.3 itself (a net that predicts background scores ~0),
+    and the fixture itself must show the reference at >= 0.5 on its best model (otherwise the comparison has no teeth)."""
+    import hashlib
+    from dct_amd import ModelMode
+    from dct_amd.loss import get_loss_fn
+    from dct_amd.models import Segmentator
+    from dct_amd.trainer import CoTrainer
+    from dct_amd.trainer import cotraining_totalloss as mod
+    path = os.path.join(GOLDEN, f"g10_acdc_{arch}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not captured yet (tools/capture_golden.py g10_{arch})")
+    g = np.load(path, allow_pickle=False)
+    E, n, bs, C = int(g["epochs"]), int(g["steps_per_epoch"]), int(g["bs"]), int(g["C"])
+    ref3 = g["val_dice3d"][:, :, 1:, 0].mean(2)          # [epoch, model] foreground mean
+    ref2 = g["val_dice2d"][:, :, 1:, 0].mean(2)
+    assert ref3[-1].max() >= 0.5, ("the reference never learned: the fixture cannot discriminate", ref3)
+    labs, unl, val = _loaders_all_labeled(DEV, bs)
+    segs = []
+    for s in g["net_seeds"]:
+        torch.manual_seed(int(s))
+        sd = oracle.build_net(arch, C).state_dict()
+        seg = Segmentator({"name": arch, "num_classes": C, "compute_dtype": torch.bfloat16}, {"name": "Adam", "lr": 1e-3, "weight_decay": 1e-4},
+                          {"name": "StepLR", "step_size": 90, "gamma": 0.1})
+        seg.torchnet.load_state_dict(sd)
+        segs.append(seg)
+    crit = {"sup": get_loss_fn("cross_entropy"), "jsd": get_loss_fn("jsd"), "adv": get_loss_fn("jsd")}
+    tr = CoTrainer(segs, labs, unl, val, crit, max_epoch=E, save_dir=str(tmp_path), device=DEV, axises=[1, 2, 3],
+                   cot_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.5},
+                   adv_scheduler_dict={"name": "ConstantScheduler", "begin_epoch": 0, "max_value": 0.05},
+                   adv_training_dict={"eplision": 0.03}, use_tqdm=False, steps_per_epoch=n)
+    names = []
+    orig_iter = mod.iterator_
+
+    class rec_iter(orig_iter):
+        def __next__(self):
+            b = super().__next__()
+            if isinstance(b, (list, tuple)) and len(b) == 3:
+                names.append(",".join(b[2]))
+            return b
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    mine3, mine2 = [], []
+    for e in range(E):
+        mod.iterator_ = rec_iter
+        try:
+            tr._train_loop(labs, unl, epoch=e, mode=ModelMode.TRAIN, save=False, train_jsd=True, train_adv=False)
+        finally:
+            mod.iterator_ = orig_iter
+        with torch.no_grad():
+            v2, v3 = tr._eval_loop(val, epoch=e, mode=ModelMode.EVAL, save=False)
+        mine3.append(v3[:, 1:, 0].mean(1).numpy())
+        mine2.append(v2[:, 1:, 0].mean(1).numpy())
+        print(f"{arch} epoch {e}: 3-D foreground DSC HIP {mine3[-1]} reference {ref3[e]}   2-D HIP {mine2[-1]} reference {ref2[e]}", flush=True)
+    # the data path served the reference's batches, step by step
+    rows = np.array(names).reshape(E * n, 3)
+    assert rows[:60].tolist() == [[str(x) for x in r] for r in g["batch_names_head"]]
+    digest = np.array([hashlib.md5("|".join(r).encode()).hexdigest()[:12] for r in rows])
+    assert (digest == g["batch_digest"]).all()
+    mine3, mine2 = np.array(mine3), np.array(mine2)
+    for mine, ref, what in ((mine3, ref3, "3-D"), (mine2, ref2, "2-D")):
+        assert np.all(np.abs(mine[-1] - ref[-1]) <= 0.2), (what, mine[-1], ref[-1])
+        assert mine[-1].max() >= 0.3, (what, mine[-1], ref[-1])
