@@ -189,7 +189,17 @@ class Enet(nn.Module):
         self.flat_params = FlatParams(list(self.parameters()))
         self._pidx = {id(p): i for i, p in enumerate(self.flat_params.params)}
         self._grad_target = None
-        self._bn_stats = []                  # (bn, batch mean, unbiased batch variance) of the forward pass being planned
+        # Batch statistics of a training-mode forward pass: ONE flat buffer per pass, layer k's five vectors (scale, shift, mean,
+        # invstd, unbiased variance; c floats each) at element 5 * _bn_off[k] -- so that the running-statistics bookkeeping of all
+        # 84 layers is one launch over a static record table (dct_bn_running_update) instead of four torch._foreach launches
+        self._bn_list = [m for m in self.modules() if isinstance(m, _BN)]
+        self._bn_off, off = {}, 0
+        for m in self._bn_list:
+            self._bn_off[id(m)] = off
+            off += (m.num_features + 3) // 4 * 4            # (16-byte aligned vectors)
+        self._bn_total = off
+        self._bn_stats = None                # flat statistics buffer of the forward pass being planned
+        self._bn_table = None                # (key, device record table)
         self._defer_running = False
         self.fuse_bn_stats = os.environ.get("DCT_ENET_FUSE_BN_STATS", "1") != "0"     # BatchNorm partial sums from the conv epilogue
         # ... and the backward sums from the data-gradient epilogue (dct_enet_conv_bnbwd_stats): -270 launches per cfg4 step but level
@@ -244,19 +254,29 @@ class Enet(nn.Module):
 
     supports_deferred_running_stats = True
 
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._bn_table = None                # the buffers may have moved
+        return r
+
     def _apply_running(self, stats):
-        """r <- (1 - momentum) r + momentum b for every BatchNorm of one forward pass: four multi-tensor launches.  Every
-        training-mode forward goes through here (immediately, or deferred), so the arithmetic does not depend on the schedule."""
-        if not stats:
+        """r <- (1 - momentum) r + momentum b for every BatchNorm of one forward pass and num_batches_tracked += 1, in one launch
+        (csrc/bn.hip::bn_running_update_kernel).  Every training-mode forward goes through here (immediately, or deferred), so
+        the arithmetic does not depend on the schedule.  ``stats``: the pass's flat statistics buffer."""
+        if stats is None:
             return
-        torch._foreach_add_(self._nbt, 1)       # nn.BatchNorm2d bookkeeping (num_batches_tracked), one launch for all 84 layers
-        mom = stats[0][0].momentum
-        assert all(bn.momentum == mom for bn, _, _ in stats)
-        rms, rvs = [bn.running_mean for bn, _, _ in stats], [bn.running_var for bn, _, _ in stats]
-        torch._foreach_mul_(rms, 1.0 - mom)
-        torch._foreach_add_(rms, [m for _, m, _ in stats], alpha=mom)
-        torch._foreach_mul_(rvs, 1.0 - mom)
-        torch._foreach_add_(rvs, [v for _, _, v in stats], alpha=mom)
+        bns = self._bn_list
+        key = tuple(b.running_mean.data_ptr() for b in bns[:2]) + (bns[-1].running_var.data_ptr(), stats.device)
+        if self._bn_table is None or self._bn_table[0] != key:
+            mom = bns[0].momentum
+            assert all(bn.momentum == mom for bn in bns)
+            recs = []
+            for bn in bns:
+                c, base = bn.num_features, 5 * self._bn_off[id(bn)]
+                cp = (c + 3) // 4 * 4
+                recs.append((bn.running_mean, bn.running_var, bn.num_batches_tracked, c, base + 2 * cp, base + 4 * cp))
+            self._bn_table = (key, K.bn_running_table(recs, stats.device), mom)
+        K.bn_running_update(self._bn_table[1], len(bns), stats, self._bn_table[2])
 
     def apply_running_updates(self, tapes):
         """The deferred running-statistics updates of ``tapes`` (plan_forward(defer_running=True)), in the order given."""
@@ -306,10 +326,12 @@ class Enet(nn.Module):
         c = conv.cout
         if self.training:
             # batch statistics only: the running statistics are updated by _apply_running from (mean, unbiased variance)
-            vec = torch.empty(5, c, dtype=torch.float32, device=dev)
+            if self._bn_stats is None:
+                self._bn_stats = torch.empty(5 * self._bn_total, dtype=torch.float32, device=dev)
+            cp, base = (c + 3) // 4 * 4, 5 * self._bn_off[id(bn)]
+            vec = self._bn_stats[base:base + 5 * cp].view(5, cp)[:, :c]
             K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, None, None,
                                 True, vec[0], vec[1], vec[2], vec[3], save_var=vec[4], partial=stats, partial_rows=rows)
-            self._bn_stats.append((bn, vec[2], vec[4]))
         else:
             vec = torch.empty(4, c, dtype=torch.float32, device=dev)
             K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, bn.running_mean, bn.running_var,
@@ -460,7 +482,7 @@ class Enet(nn.Module):
         fin = self.decoder.layers[5]
         logits = torch.empty(B, H, W, self.num_classes, dtype=torch.float32, device=dev)
         self._conv_fwd(h, None, fin, logits)
-        stats, self._bn_stats = self._bn_stats, []
+        stats, self._bn_stats = self._bn_stats, None
         if save:
             tape.append({"kind": "final", "x": h, "training": self.training})
         if self.training:

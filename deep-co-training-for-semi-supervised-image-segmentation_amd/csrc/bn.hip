@@ -275,3 +275,44 @@ extern "C" int dct_bn_bwd(const dct_view* raw, const dct_view* g, const float* s
                          (const float*)c1c2, (const float*)(c1c2 + raw->c), vo));
   return dct_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// nn.BatchNorm2d bookkeeping of a whole network in ONE launch (Enet: 84 layers; the reference does it inside every
+// F.batch_norm call, arch/enet.py:22,55-122): r <- (1 - momentum) r + momentum b for running mean / variance from the batch
+// statistics a forward pass left in one flat buffer, and num_batches_tracked += 1.  One block per layer.
+namespace {
+struct BnRunRec { float* running_mean; float* running_var; long long* num_batches_tracked; int c, mean_off, var_off, pad_; };
+__global__ __launch_bounds__(128) void bn_running_update_kernel(const BnRunRec* recs, const float* stats, float momentum) {
+  const BnRunRec r = recs[blockIdx.x];
+  for (int i = threadIdx.x; i < r.c; i += 128) {
+    r.running_mean[i] = __fmaf_rn(momentum, stats[r.mean_off + i], r.running_mean[i] * (1.f - momentum));
+    r.running_var[i] = __fmaf_rn(momentum, stats[r.var_off + i], r.running_var[i] * (1.f - momentum));
+  }
+  if (threadIdx.x == 0 && r.num_batches_tracked) *r.num_batches_tracked += 1;
+}
+
+// out = a + b (+ c) over n floats, 16 bytes per lane: the flat gradient buffers of a model's concurrent backward passes,
+// added in pass order (trainer/cotraining_totalloss.py::_finish_step)
+__global__ __launch_bounds__(256) void flat_sum_kernel(float* out, const float* a, const float* b, const float* c, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+  float4 o = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  if (c) { const float4 z = reinterpret_cast<const float4*>(c)[i]; o.x += z.x; o.y += z.y; o.z += z.z; o.w += z.w; }
+  reinterpret_cast<float4*>(out)[i] = o;
+}
+}  // namespace
+
+extern "C" int dct_bn_running_update(const void* records_dev, int n_layers, const float* stats, float momentum, dct_stream stream) {
+  if (!records_dev || n_layers < 1 || !stats) return DCT_ERR_BAD_ARG;
+  DCT_LAUNCH(DCT_PROF_OTHER, bn_running_update_kernel, dim3(n_layers), dim3(128), 0, (hipStream_t)stream,
+             (const BnRunRec*)records_dev, stats, momentum);
+  return dct_check_launch();
+}
+
+extern "C" int dct_flat_sum(float* out, const float* a, const float* b, const float* c, long long n, dct_stream stream) {
+  if (!out || !a || !b || n < 1 || (n & 3) || ((uintptr_t)out & 15) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15) || ((uintptr_t)c & 15))
+    return DCT_ERR_BAD_ARG;
+  DCT_LAUNCH(DCT_PROF_OTHER, flat_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, a, b, c, n / 4);
+  return dct_check_launch();
+}

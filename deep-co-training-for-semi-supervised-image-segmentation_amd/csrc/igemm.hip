@@ -1044,6 +1044,243 @@ __global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmP
   }
 }
 
+// igemm3m_kernel with a RING of four 32-channel weight half-stages filled three half-steps ahead (counted vmcnt waits, raw
+// s_barrier) instead of two 64-channel stages drained with vmcnt(0) at every barrier.  Same tile, same LDS bytes, same
+// fragment maps and the same order of accumulation (slice, tap, 32-channel half), so the results are bit-identical to
+// igemm3m_kernel.  dct_tune_set(DCT_TUNE_IGEMM_RING, 0/1).
+__device__ __forceinline__ void wait_vm(int n) {       // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the count is an immediate)
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+template <int BN, int NWM, int NWN, int ABUFS>
+__global__ __launch_bounds__(NWM * NWN * 64) void igemm3r_kernel(IgemmParams p, int tiles_x, int tiles_y) {
+  constexpr int NW = NWM * NWN;
+  constexpr int TH = 8, TW = 16, BM = TH * TW, HW = TW + 2, HROWS = (TH + 2) * HW;   // 180 halo rows of 128 B
+  constexpr int APIECES = (HROWS + 7) / 8, A_BYTES = APIECES * 8 * 128;              // 23 pieces, 23552 B
+  constexpr int B_BYTES = BN * 64, BPIECES = BN / 16, NB = 4, PF = 3;              // weight stage: BN rows x 32 channels; ring of NB, PF half-steps ahead
+  constexpr int NPA = (APIECES + NW - 1) / NW;
+  static_assert(BPIECES == NW, "one weight piece per wave and half-step");
+  constexpr int WTN = BN / NWN, TN = WTN / 32;
+  static_assert(NWM == 4 && TN >= 1, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  char* Abuf = smem;                       // halo stage(s)
+  char* Bbuf = smem + ABUFS * A_BYTES;     // ring of four weight half-stages
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: LDS-DMA destinations and piece bookkeeping stay in SGPRs
+  const int wn = wave / NWM, wm = wave % NWM;
+  // XCD-aware tile order (knob DCT_TUNE_IGEMM_XCD): workgroups go round-robin over the 8 XCDs, each with its own L2.
+  // Tile t of a 1-D grid is given to XCD t % 8's (t / 8)-th slot, and an XCD's slots cover a CONTIGUOUS range of
+  // (patch, channel tile) pairs with the channel tile fastest: the N tiles of one patch and neighbouring patches
+  // (shared halo rows) read their input through the same L2.
+  int bx, ntile;
+  if (p.xcd_tiles > 0) {
+    const int per_xcd = p.xcd_tiles;                          // ceil(total tiles / 8)
+    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int nt = p.N / BN;
+    if ((blockIdx.x >> 3) >= per_xcd || t >= p.xcd_total) return;
+    bx = t / nt; ntile = t - bx * nt;
+  } else { bx = blockIdx.x; ntile = blockIdx.y; }
+  const int tx = bx % tiles_x; bx /= tiles_x;
+  const int ty = bx % tiles_y; const int img = bx / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = ntile * BN;
+  const long long Ktot = 9ll * p.Cin;
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
+
+  // halo staging: wave w issues pieces w, w + NW, ...; lane -> (row = piece * 8 + lane / 8, its swizzled source chunk)
+  int aoff[NPA];                      // element offsets (the host admits this kernel only when x spans < 2^31 elements)
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    const int piece = wave + i * NW;
+    const int row = piece * 8 + (lane >> 3);
+    aoff[i] = -1;
+    if (piece < APIECES && row < HROWS) {
+      const int hy = row / HW, hx = row - hy * HW;
+      const int iy = y0 - p.pad_h + hy, ix = x0 - p.pad_w + hx;
+      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+        aoff[i] = (int)(img * p.xsN + iy * p.xsH + ix * p.xsW + (((lane & 7) ^ ((row >> 1) & 7)) * 8));
+    }
+  }
+  auto stageA = [&](char* buf, int c0) {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int piece = wave + i * NW;
+      if (piece < APIECES) {
+        const char* src = aoff[i] >= 0 ? reinterpret_cast<const char*>(xb + aoff[i] + c0) : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + piece * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // weight staging: ONE piece per wave and half-step = 16 cout rows x 64 bytes (32 input channels of one tap).  16-byte chunk c of
+  // row r sits at chunk c ^ (((r >> 2) & 1) << 1): with 64-byte rows that makes the ds_read_b128 lane groups (16 consecutive rows at
+  // one logical chunk, or two runs of them) hit 16 distinct 16-byte slots of the 256-byte bank row.
+  unsigned woffL;
+  {
+    const int row = wave * 16 + (lane >> 2);
+    woffL = (unsigned)(((long long)row * Ktot + (((lane & 3) ^ (((row >> 2) & 1) << 1)) * 8)) * 2);
+  }
+  const char* wtile = p.w + (long long)n0 * Ktot * 2;
+  // half-step q of the tile (0 .. 18 * nch - 1): channel slice q / 18, tap (q % 18) / 2, 32-channel half q % 2
+  auto stageBq = [&](int q) {
+    const int c = q / 18, rem = q - 18 * c, tap = rem >> 1, hh = rem & 1;
+    const char* wstep = wtile + ((long long)tap * p.Cin + c * 64 + hh * 32) * 2;          // scalar
+    __builtin_amdgcn_global_load_lds((gptr_t)(wstep + woffL), (lptr_t)(Bbuf + (q & (NB - 1)) * B_BYTES + wave * 1024), 16, 0, 0);
+  };
+
+  constexpr int TR = WTN / 16;                 // 16-channel row blocks per wave
+  f32x4 acc[TR][2];
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // v_mfma_f32_16x16x32_bf16 fragments: lane l holds row / column l % 16 and the 16-byte K chunk l / 16 of a 32-deep
+  // sub-step.  Column block j of the wave's 32 pixels is patch row 2 * wm + j, columns 0..15 in lane order.
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int rho0 = (2 * wm) * HW + l15;
+  const int aswz = (l15 >> 1) & 7;
+
+  const int nch = p.Cin / 64, nq = 18 * nch;
+  const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
+  // this wave's halo pieces per slice (pieces wave, wave + NW, ... below APIECES): the LDS-DMA bookkeeping below counts them
+  int nA = 0;
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) nA += (wave + i * NW < APIECES) ? 1 : 0;
+  stageA(Abuf, 0);
+#pragma unroll
+  for (int q = 0; q < PF; ++q) stageBq(q);                  // (nq >= 18 > PF)
+  float* biasL = reinterpret_cast<float*>(smem + ABUFS * A_BYTES + NB * B_BYTES);   // bias -> LDS now: no memory round trip in the epilogue
+  if (tid < BN) biasL[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+  // Fragment addresses (see igemm3m_kernel).  Weights: 64-byte rows, a lane's address is a constant + the ring slot.
+  const unsigned Wb = smem_l + ABUFS * A_BYTES + (wn * WTN + l15) * 64 + ((kq ^ ((l15 >> 1) & 2)) * 16);
+  // The weight ring runs PF half-steps ahead of the MFMAs; a wave waits (counted vmcnt: LDS-DMA pieces retire in issue order)
+  // only for the pieces of the half-step it is about to read, then the block meets at a raw s_barrier -- never a vmcnt(0) in the
+  // loop (PMC on the two-stage kernel: its waves sat parked at "vmcnt(0) + barrier" for 43 % of every K-step, the DMA of step
+  // t + 1 being issued only one step -- 0.6 us -- before it is needed).
+  int h1 = 1, h2 = 1;                                        // pieces this wave issued in the previous half-step and the one before
+  int ab = 0;
+  for (int c = 0; c < nch; ++c) {
+    const unsigned Xs = smem_l + ab * A_BYTES;                // scalar
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      unsigned rho_t = rho0;
+      asm volatile("" : "+v"(rho_t));                        // the tap's addresses are recomputed here (6 VALU), not kept hoisted in registers
+      const unsigned pi0 = rho_t + (t / 3) * HW + (t % 3), pi1 = pi0 + HW;
+      const unsigned x00 = (Xs + (pi0 << 7)) | (((kq ^ (pi0 >> 1)) & 7) << 4);
+      const unsigned x10 = (Xs + (pi0 << 7)) | (((kq ^ (pi1 >> 1)) & 7) << 4);     // (+ HW * 128 through the read's offset)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int q = (c * 9 + t) * 2 + hh;
+        wait_vm(h1 + h2);                                    // the pieces of half-step q (and, at a slice's first step, its halo) have landed
+        __builtin_amdgcn_s_barrier();                        // ... for every wave; and every wave is done reading half-step q - 1
+        int issued = 0;
+        if (ABUFS == 2 && t == 0 && hh == 0 && c + 1 < nch) { stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64); issued += nA; }
+        if (q + PF < nq) { stageBq(q + PF); issued += 1; }
+        h2 = h1; h1 = issued;
+        const unsigned wa = Wb + (q & (NB - 1)) * B_BYTES;
+        bf16x8 a[TR], b[2];
+        RdRows<0, TR, 16 * 64>::run(wa, a);
+        rd128o<0>(hh ? (x00 ^ 64u) : x00, b[0]);
+        rd128o<HW * 128>(hh ? (x10 ^ 64u) : x10, b[1]);
+        lgkm_wait3<0>();
+#pragma unroll
+        for (int i = 0; i < TR; ++i) touch8(a[i]);
+        touch8(b[0]); touch8(b[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TR; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    ab ^= 1;
+  }
+  __syncthreads();                                           // every wave is done with the stages: the epilogue reuses them
+
+  // ---- epilogue (staged through LDS as in v2): tile row = patch pixel py * 16 + px
+  constexpr int CPR = BN / 8;
+  static_assert(BM * BN * 2 <= ABUFS * A_BYTES + (NB * B_BYTES - BM * 8), "epilogue tile does not fit");
+  char* tile = smem;                                   // BM * BN * 2 bytes: the halo stage(s) and, if needed, the head of the weight stages
+  int* rowY = reinterpret_cast<int*>(smem + ABUFS * A_BYTES + NB * B_BYTES - BM * 8);   // tail of the weight stages
+  int* rowM = rowY + BM;
+  if (tid < BM) {
+    const int oy = y0 + (tid >> 4), ox = x0 + (tid & 15);
+    int oy_ = -1, om_ = -1;
+    if (oy < p.Ho && ox < p.Wo) {
+      oy_ = (int)(img * p.ysN + oy * p.ysH + ox * p.ysW);
+      om_ = (int)(img * p.msN + oy * p.msH + ox * p.msW);
+    }
+    rowY[tid] = oy_; rowM[tid] = om_;
+  }
+  {
+    // accumulator (i, j): channels wn * WTN + 16 * i + 4 * kq + {0..3} of pixel (patch row 2 * wm + j, column l15)
+    f32x4 bv[TR];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) bv[i] = *reinterpret_cast<const f32x4*>(biasL + wn * WTN + i * 16 + 4 * kq);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (2 * wm + j) * TW + l15;
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        const int cl = wn * WTN + i * 16 + 4 * kq;
+        float v[4] = {acc[i][j][0] + bv[i][0], acc[i][j][1] + bv[i][1], acc[i][j][2] + bv[i][2], acc[i][j][3] + bv[i][3]};
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+        const int chunk = (cl >> 3) ^ (row & (CPR - 1));
+        *reinterpret_cast<bf16x4*>(tile + row * (BN * 2) + chunk * 16 + (cl & 4) * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NCH = BM * CPR / (NW * 64);
+  // the mask / old-value loads of all NCH chunks go out together, then the stores
+  int yo[NCH];
+  bf16x8 mk[NCH], old[NCH];
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    const int id = t * (NW * 64) + tid;
+    const int row = id / CPR, co = n0 + (id % CPR) * 8;
+    yo[t] = rowY[row];
+    if (yo[t] >= 0) {
+      if (p.mask && co < p.mask_channels) mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
+      if (p.accumulate) old[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.y) + yo[t] + co);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    const int id = t * (NW * 64) + tid;
+    const int row = id / CPR, cc = id % CPR;
+    if (yo[t] < 0) continue;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
+    const int co = n0 + cc * 8;
+    if (p.mask && co < p.mask_channels) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
+    }
+    if (p.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
+    }
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Shared-halo kernel for SMALL images ("v3p"): the 128-pixel tile is PR whole output rows of one image, packed in LDS
 // at a pitch of Wo + 2 rows (pixel m = (m / Wo, m % Wo) sits at LDS row (m / Wo) * pitch + m % Wo + tap offset
@@ -1311,6 +1548,7 @@ int g_tune_igemm_xcd2 = 0;      // XCD-aware tile order of the per-tap kernel (w
 int g_tune_igemm_mfma16 = 1;    // shared-halo kernel on 16x16x32 MFMAs (igemm3m_kernel)
 int g_tune_igemm_halo_cover = 75;      // percent of the image the 8 x 16 patches must cover
 int g_tune_igemm_halo_min_blocks = 400;
+int g_tune_igemm_ring = 1;      // shared-halo kernel with the four-slot weight ring (igemm3r_kernel); 0: two stages, vmcnt(0) per step
 int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3_kernel); 0: always v2
 
 static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int M, int N, Plan& pl) {
@@ -1400,6 +1638,16 @@ static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3m_kernel<BN, 4, NWN, ABUFS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr16 = true;
+    }
+    if (g_tune_igemm_ring) {
+      static bool attrr = false;
+      if (!attrr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3r_kernel<BN, 4, NWN, ABUFS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attrr = true;
+      }
+      DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3r_kernel<BN, 4, NWN, ABUFS>), g1, dim3(4 * NWN * 64), lds, st, q, tiles_x, tiles_y);
+      return;
     }
     DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 4, NWN, ABUFS>), g1, dim3(4 * NWN * 64), lds, st, q, tiles_x, tiles_y);
     return;
@@ -1659,6 +1907,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_ENET_BN_OWNER: g_enet_bn_owner = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_MFMA: if (value < 0 || value > 3) return DCT_ERR_BAD_ARG; g_enet_mfma = value; return DCT_OK;
     case DCT_TUNE_IGEMM_XCD2: g_tune_igemm_xcd2 = value ? 1 : 0; return DCT_OK;
+    case DCT_TUNE_IGEMM_RING: g_tune_igemm_ring = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_SPLIT: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_VEC: g_enet_reduce_vec = value ? 1 : 0; return DCT_OK;

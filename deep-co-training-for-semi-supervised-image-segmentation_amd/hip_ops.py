@@ -113,6 +113,28 @@ def pack_weights_batched(table, njobs, tiles, dtype, edge=32):
         call("dct_pack_weights_batched", ptr(table), int(njobs), int(tiles), DTYPE_OF[dtype], stream())
 
 
+def bn_running_table(layers, device):
+    """Device record table for bn_running_update.  layers: list of (running_mean, running_var, num_batches_tracked or None, c,
+    mean_off, var_off) -- offsets in elements into the flat statistics buffer of a forward pass."""
+    import struct
+    buf = bytearray()
+    for rm, rv, nbt, c, moff, voff in layers:
+        assert rm.dtype == torch.float32 and rv.dtype == torch.float32 and rm.is_contiguous() and rv.is_contiguous()
+        assert nbt is None or nbt.dtype == torch.int64
+        buf += struct.pack("<QQQiiii", rm.data_ptr(), rv.data_ptr(), nbt.data_ptr() if nbt is not None else 0, int(c), int(moff), int(voff), 0)
+    return torch.frombuffer(buf, dtype=torch.uint8).clone().to(device)
+
+
+def bn_running_update(table, n_layers, stats, momentum):
+    call("dct_bn_running_update", ptr(table), int(n_layers), ptr(stats), float(momentum), stream())
+
+
+def flat_sum(out, a, b, c=None):
+    """out = a + b (+ c): flat fp32 buffers of equal length (multiple of 4 elements)."""
+    call("dct_flat_sum", ptr(out), ptr(a), ptr(b), ptr(c), out.numel(), stream())
+    return out
+
+
 def conv_cin1_fwd(x, w, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=False):
     d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu)
     vx, vy = view(x), view(y)

@@ -371,12 +371,15 @@ class CoTrainer(Trainer):
             # (gradient exchange, optimizers) is queued on the origin stream
             self._pass_join()
             for idx, (flat, bufs) in sorted(self._pass_pending.items()):
+                from .. import hip_ops as K
                 if len(bufs) == 1:
                     flat.gflat.copy_(bufs[0])
+                elif len(bufs) <= 3 and flat.gflat.is_cuda and flat.gflat.numel() % 4 == 0:
+                    K.flat_sum(flat.gflat, bufs[0], bufs[1], bufs[2] if len(bufs) == 3 else None)      # ((lab + unl) + adv), one launch
                 else:
                     torch.add(bufs[0], bufs[1], out=flat.gflat)
-                for buf in bufs[2:]:
-                    flat.gflat.add_(buf)
+                    for buf in bufs[2:]:
+                        flat.gflat.add_(buf)
                 if self.grad_sync is not None:
                     self._sched.call(lambda idx=idx: self.grad_sync.begin(idx))
             streams = None

@@ -285,6 +285,16 @@ int dct_enet_conv_stats(const dct_view* x, const float* w, const float* bias, co
                         int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
                         double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream);
 
+/* nn.BatchNorm2d bookkeeping for all layers of a network in one launch: layer k (record k of records_dev)
+ *   { float* running_mean; float* running_var; int64* num_batches_tracked (nullable); int32 c, mean_off, var_off, pad; }  (40 bytes)
+ * gets r <- (1 - momentum) r + momentum * stats[off + i] for both running statistics (stats: the flat buffer a forward pass
+ * left its batch means / UNBIASED variances in) and num_batches_tracked += 1 -- what F.batch_norm does per call in the
+ * reference (arch/enet.py:22,55-122).  Replaces four torch._foreach launches per forward pass. */
+int dct_bn_running_update(const void* records_dev, int n_layers, const float* stats, float momentum, dct_stream stream);
+/* out = a + b (+ c if non-NULL) over n floats (n % 4 == 0, 16-byte aligned): the per-pass flat gradient buffers of one model,
+ * added in pass order -- ((labeled + unlabeled) + adversarial), bit for bit the in-place accumulation of sequential passes. */
+int dct_flat_sum(float* out, const float* a, const float* b, const float* c, long long n, dct_stream stream);
+
 size_t dct_enet_reduce_workspace_bytes(int channels);
 /* nn.BatchNorm2d(eps 1e-3, momentum 0.1) forward statistics of a raw conv output (enet.py:22,55-122):
  * training: batch mean / biased var (double accumulation, fixed-order fold), running stats updated
@@ -417,8 +427,10 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
                                                 with whole 8-channel groups (measured slower); 0 (default): split reduction + fold [+ apply] */
        DCT_TUNE_ENET_MWGRAD_WAVES = 28,      /* >= 64 (default 2048): waves an MFMA weight-gradient launch aims for */
        DCT_TUNE_ENET_MWGRAD_MIN_STEPS = 29,  /* multiple of 4 (default 4): least 16-pixel MFMA steps per pixel slice */
-       DCT_TUNE_ENET_APPLY_VEC = 30 };       /* 1: BatchNorm-backward apply kernel on 8 channels per thread (measured slower in the step);
+       DCT_TUNE_ENET_APPLY_VEC = 30,         /* 1: BatchNorm-backward apply kernel on 8 channels per thread (measured slower in the step);
                                                 0 (default): one element per thread */
+       DCT_TUNE_IGEMM_RING = 31 };           /* 1 (default): shared-halo conv kernel with a four-slot ring of 32-channel weight half-stages filled three
+                                                half-steps ahead (counted vmcnt, raw barrier); 0: two 64-channel stages, vmcnt(0) at every barrier */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 

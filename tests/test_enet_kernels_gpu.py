@@ -363,3 +363,35 @@ def test_enet_dgrad_epilogue_bn_backward_sums(K, dt, cg, cx, k, act):
     if act == 2:
         close(ds2, ds1, torch.float32, "dslope", r32=2e-5)
     close(d2, d1, dt, "draw", r32=1e-5, r16=1e-2)
+
+
+def test_bn_running_update_and_flat_sum():
+    """One launch for the BatchNorm bookkeeping of a whole network (dct_bn_running_update) == nn.BatchNorm2d's
+    r <- (1 - m) r + m b and num_batches_tracked += 1 per layer; dct_flat_sum == ((a + b) + c) bit for bit."""
+    from dct_amd import hip_ops as K
+    g = torch.Generator().manual_seed(21)
+    cs = [13, 16, 64, 128, 5]
+    offs, off = [], 0
+    for c in cs:
+        offs.append(off)
+        off += (c + 3) // 4 * 4
+    stats = torch.randn(5 * off, generator=g).to(DEV)
+    layers, want = [], []
+    for c, o in zip(cs, offs):
+        rm, rv = torch.randn(c, generator=g).to(DEV), (torch.rand(c, generator=g) + 0.5).to(DEV)
+        nbt = torch.tensor(7, dtype=torch.int64, device=DEV)
+        cp, base = (c + 3) // 4 * 4, 5 * o
+        layers.append((rm, rv, nbt, c, base + 2 * cp, base + 4 * cp))
+        want.append((0.9 * rm.cpu().double() + 0.1 * stats[base + 2 * cp:base + 2 * cp + c].cpu().double(),
+                     0.9 * rv.cpu().double() + 0.1 * stats[base + 4 * cp:base + 4 * cp + c].cpu().double()))
+    table = K.bn_running_table(layers, torch.device(DEV))
+    K.bn_running_update(table, len(layers), stats, 0.1)
+    torch.cuda.synchronize()
+    for (rm, rv, nbt, *_), (wm, wv) in zip(layers, want):
+        np.testing.assert_allclose(rm.cpu().numpy(), wm.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(rv.cpu().numpy(), wv.numpy(), rtol=1e-6, atol=1e-7)
+        assert int(nbt) == 8
+    a, b, c = (torch.randn(4096 + 64, generator=g).to(DEV) for _ in range(3))
+    out = torch.empty_like(a)
+    assert torch.equal(K.flat_sum(out, a, b, c), (a + b) + c)
+    assert torch.equal(K.flat_sum(out, a, b), a + b)
