@@ -264,6 +264,12 @@ template <int I, int N, int STRIDE> struct RdRows {      // dst[i] <- 16 bytes a
     if constexpr (I + 1 < N) RdRows<I + 1, N, STRIDE>::run(addr, dst);
   }
 };
+template <int J, int N, int STRIDE> struct RdCols {      // dst[j] <- 16 bytes at (addr[j] ^ flip) + j * STRIDE, j = J .. N - 1
+  __device__ static __forceinline__ void run(const unsigned (&addr)[N], unsigned flip, bf16x8 (&dst)[N]) {
+    rd128o<J * STRIDE>(addr[J] ^ flip, dst[J]);
+    if constexpr (J + 1 < N) RdCols<J + 1, N, STRIDE>::run(addr, flip, dst);
+  }
+};
 template <int N> __device__ __forceinline__ void lgkm_wait3() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void touch8(bf16x8& r) { asm volatile("" : "+v"(r)); }
 
@@ -831,7 +837,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmP
   constexpr int B_BYTES = BN * 128, BPIECES = BN / 8;
   constexpr int NPA = (APIECES + NW - 1) / NW, NPB = BPIECES / NW;
   constexpr int WTN = BN / NWN, TN = WTN / 32;
-  static_assert(NWM == 4 && BPIECES % NW == 0 && TN >= 1, "tile/wave mismatch");
+  static_assert((NWM == 4 || NWM == 2) && BPIECES % NW == 0 && TN >= 1, "tile/wave mismatch");
+  constexpr int PXB = 8 / NWM;             // 16-pixel column blocks (patch rows) per wave: 2 with eight waves, 4 with four
   extern __shared__ __attribute__((aligned(128))) char smem[];
   char* Abuf = smem;                       // halo stage(s)
   char* Bbuf = smem + ABUFS * A_BYTES;     // two weight stages
@@ -897,16 +904,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmP
   };
 
   constexpr int TR = WTN / 16;                 // 16-channel row blocks per wave
-  f32x4 acc[TR][2];
+  f32x4 acc[TR][PXB];
 #pragma unroll
   for (int i = 0; i < TR; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < PXB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // v_mfma_f32_16x16x32_bf16 fragments: lane l holds row / column l % 16 and the 16-byte K chunk l / 16 of a 32-deep
   // sub-step.  Column block j of the wave's 32 pixels is patch row 2 * wm + j, columns 0..15 in lane order.
   const int l15 = lane & 15, kq = lane >> 4;
-  const int rho0 = (2 * wm) * HW + l15;
+  const int rho0 = (PXB * wm) * HW + l15;
   const int aswz = (l15 >> 1) & 7;
 
   const int nch = p.Cin / 64;
@@ -941,27 +948,28 @@ __global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmP
       const unsigned wa0 = Wb0 + bb * B_BYTES, wa1 = wa0 ^ 64u;
       unsigned rho_t = rho0;
       asm volatile("" : "+v"(rho_t));                        // recompute the tap's two addresses here (6 VALU) instead of keeping hoisted ones in registers
-      const unsigned pi0 = rho_t + rr * HW + sx, pi1 = pi0 + HW;
-      const unsigned x00 = (Xs + (pi0 << 7)) | (((kq ^ (pi0 >> 1)) & 7) << 4);
-      const unsigned x10 = (Xs + (pi0 << 7)) | (((kq ^ (pi1 >> 1)) & 7) << 4);     // (+ HW * 128 through the read's offset)
-      bf16x8 a[2][TR], b[2][2];
+      const unsigned pi0 = rho_t + rr * HW + sx;
+      const unsigned xrow = Xs + (pi0 << 7);
+      unsigned xj[PXB];                                      // column block j: LDS row pi0 + j * HW (+ j * HW * 128 through the read's offset)
+#pragma unroll
+      for (int j = 0; j < PXB; ++j) xj[j] = xrow | (((kq ^ ((pi0 + j * HW) >> 1)) & 7) << 4);
+      bf16x8 a[2][TR], b[2][PXB];
       RdRows<0, TR, 16 * 128>::run(wa0, a[0]);
-      rd128o<0>(x00, b[0][0]);
-      rd128o<HW * 128>(x10, b[0][1]);
+      RdCols<0, PXB, HW * 128>::run(xj, 0u, b[0]);
       RdRows<0, TR, 16 * 128>::run(wa1, a[1]);
-      rd128o<0>(x00 ^ 64u, b[1][0]);
-      rd128o<HW * 128>(x10 ^ 64u, b[1][1]);
+      RdCols<0, PXB, HW * 128>::run(xj, 64u, b[1]);
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        if (k2 == 0) lgkm_wait3<TR + 2>(); else lgkm_wait3<0>();
+        if (k2 == 0) lgkm_wait3<TR + PXB>(); else lgkm_wait3<0>();
 #pragma unroll
         for (int i = 0; i < TR; ++i) touch8(a[k2][i]);
-        touch8(b[k2][0]); touch8(b[k2][1]);
+#pragma unroll
+        for (int j = 0; j < PXB; ++j) touch8(b[k2][j]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TR; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < PXB; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k2][i], b[k2][j], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
@@ -987,13 +995,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmP
     rowY[tid] = oy_; rowM[tid] = om_;
   }
   {
-    // accumulator (i, j): channels wn * WTN + 16 * i + 4 * kq + {0..3} of pixel (patch row 2 * wm + j, column l15)
+    // accumulator (i, j): channels wn * WTN + 16 * i + 4 * kq + {0..3} of pixel (patch row PXB * wm + j, column l15)
     f32x4 bv[TR];
 #pragma unroll
     for (int i = 0; i < TR; ++i) bv[i] = *reinterpret_cast<const f32x4*>(biasL + wn * WTN + i * 16 + 4 * kq);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = (2 * wm + j) * TW + l15;
+    for (int j = 0; j < PXB; ++j) {
+      const int row = (PXB * wm + j) * TW + l15;
 #pragma unroll
       for (int i = 0; i < TR; ++i) {
         const int cl = wn * WTN + i * 16 + 4 * kq;
@@ -1548,7 +1556,9 @@ int g_tune_igemm_xcd2 = 0;      // XCD-aware tile order of the per-tap kernel (w
 int g_tune_igemm_mfma16 = 1;    // shared-halo kernel on 16x16x32 MFMAs (igemm3m_kernel)
 int g_tune_igemm_halo_cover = 75;      // percent of the image the 8 x 16 patches must cover
 int g_tune_igemm_halo_min_blocks = 400;
-int g_tune_igemm_ring = 1;      // shared-halo kernel with the four-slot weight ring (igemm3r_kernel); 0: two stages, vmcnt(0) per step
+int g_tune_igemm_ring = 0;      // 1: shared-halo kernel with a four-slot ring of 32-channel weight half-stages, counted vmcnt (igemm3r_kernel):
+                                // bit-identical, measured 15 % SLOWER than two 64-channel stages (twice the barriers for the same MFMAs)
+int g_tune_igemm_waves4h = 0;   // 1: the 128-channel shared-halo tile on four waves of 64 x 64 instead of eight of 32 x 64
 int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3_kernel); 0: always v2
 
 static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int M, int N, Plan& pl) {
@@ -1648,6 +1658,18 @@ static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images
       }
       DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3r_kernel<BN, 4, NWN, ABUFS>), g1, dim3(4 * NWN * 64), lds, st, q, tiles_x, tiles_y);
       return;
+    }
+    if constexpr (BN == 128) {
+      if (g_tune_igemm_waves4h) {       // the same tile on FOUR waves of 64 pixels x 64 channels (two blocks per CU = two waves per SIMD)
+        static bool attr4 = false;
+        if (!attr4) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3m_kernel<BN, 2, NWN, ABUFS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          attr4 = true;
+        }
+        DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 2, NWN, ABUFS>), g1, dim3(2 * NWN * 64), lds, st, q, tiles_x, tiles_y);
+        return;
+      }
     }
     DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 4, NWN, ABUFS>), g1, dim3(4 * NWN * 64), lds, st, q, tiles_x, tiles_y);
     return;
@@ -1908,6 +1930,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_ENET_MFMA: if (value < 0 || value > 3) return DCT_ERR_BAD_ARG; g_enet_mfma = value; return DCT_OK;
     case DCT_TUNE_IGEMM_XCD2: g_tune_igemm_xcd2 = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM_RING: g_tune_igemm_ring = value ? 1 : 0; return DCT_OK;
+    case DCT_TUNE_IGEMM_HALO_WAVES4: g_tune_igemm_waves4h = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_SPLIT: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_VEC: g_enet_reduce_vec = value ? 1 : 0; return DCT_OK;

@@ -429,8 +429,9 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
        DCT_TUNE_ENET_MWGRAD_MIN_STEPS = 29,  /* multiple of 4 (default 4): least 16-pixel MFMA steps per pixel slice */
        DCT_TUNE_ENET_APPLY_VEC = 30,         /* 1: BatchNorm-backward apply kernel on 8 channels per thread (measured slower in the step);
                                                 0 (default): one element per thread */
-       DCT_TUNE_IGEMM_RING = 31 };           /* 1 (default): shared-halo conv kernel with a four-slot ring of 32-channel weight half-stages filled three
-                                                half-steps ahead (counted vmcnt, raw barrier); 0: two 64-channel stages, vmcnt(0) at every barrier */
+       DCT_TUNE_IGEMM_RING = 31,             /* 1: shared-halo conv kernel with a four-slot ring of 32-channel weight half-stages filled three half-steps
+                                                ahead (counted vmcnt, raw barrier) -- bit-identical, measured 15 % slower; 0 (default): two 64-channel stages */
+       DCT_TUNE_IGEMM_HALO_WAVES4 = 32 };    /* 1: the 128-channel shared-halo tile on four waves of 64 pixels x 64 channels; 0: eight of 32 x 64 */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 

@@ -113,28 +113,29 @@ def test_conv2d_epilogue_mask_accumulate_views(ops, dtype):
     (16, 256, 18, 16, 256, 2),      # packed rows, data-gradient form (pad 2), ragged last tile, unsplit
     (16, 1024, 13, 13, 128, 0),     # packed rows: one 11 x 11 tile per image, four-way split
 ])
-@pytest.mark.parametrize("mfma16", [0, 1, 2])          # 2: the 16x16x32 form with the two-stage weight pipeline (knob 31 = 0) instead of the ring
+@pytest.mark.parametrize("mfma16", [0, 1, 2])          # 2: the 16x16x32 form with the four-slot weight ring (knob 31 = 1)
 def test_conv2d_3x3_shared_halo(ops, B, Cin, H, W, Cout, pad, mfma16):
     from dct_amd import _lib
     if mfma16 and H < 90:
         pytest.skip("the 16x16x32 variant exists for the patch kernel only")
     _lib.load().dct_tune_set(11, 1 if mfma16 else 0)
-    _lib.load().dct_tune_set(31, 0 if mfma16 == 2 else 1)
+    _lib.load().dct_tune_set(31, 1 if mfma16 == 2 else 0)
     _lib.load().dct_tune_set(10, 1)          # small images: the packed-rows kernel is what these cases test
     try:
         _shared_halo_case(ops, B, Cin, H, W, Cout, pad)
     finally:
         _lib.load().dct_tune_set(11, _MFMA16_DEFAULT)
-        _lib.load().dct_tune_set(31, 1)
+        _lib.load().dct_tune_set(31, 0)
         _lib.load().dct_tune_set(10, _PACKED_DEFAULT)
 
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [(4, 64, 130, 130, 128, 0), (4, 64, 101, 117, 64, 0), (5, 128, 122, 90, 128, 2),
                                                 (3, 192, 96, 96, 256, 0), (16, 256, 59, 59, 256, 0)])
-def test_conv2d_3x3_weight_ring_is_bit_identical_to_two_stages(ops, B, Cin, H, W, Cout, pad):
-    """igemm3r_kernel (four-slot ring of 32-channel weight half-stages, counted vmcnt, raw barriers) accumulates in the order of
-    igemm3m_kernel (slice, tap, 32-channel half): every output bit must agree, with and without the mask / accumulate epilogue,
-    and a second launch must reproduce the first (a missed wait shows as run-to-run differences)."""
+def test_conv2d_3x3_shared_halo_variants_are_bit_identical(ops, B, Cin, H, W, Cout, pad):
+    """The A/B variants of the shared-halo kernel accumulate in one order (slice, tap, 32-channel half), so every output bit must
+    agree with the default (eight waves, two 64-channel weight stages): the four-slot weight ring with counted vmcnt waits and raw
+    barriers (knob 31), and the four-wave 64 x 64 form of the 128-channel tile (knob 32) -- with and without the mask /
+    accumulate epilogue; a second launch must reproduce the first (a missed wait shows as run-to-run differences)."""
     from dct_amd import _lib
     lib = _lib.load()
     dtype = torch.bfloat16
@@ -144,22 +145,22 @@ def test_conv2d_3x3_weight_ring_is_bit_identical_to_two_stages(ops, B, Cin, H, W
     b = torch.randn(Cout, generator=g).to(DEV)
     Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
     mask = to_dev(q(torch.randn(B, Cout, Ho, Wo, generator=g), dtype), dtype)
-    outs = {}
+    outs = []
     try:
-        for ring in (1, 0, 1):
+        for ring, waves4 in ((0, 0), (1, 0), (0, 1), (1, 0), (0, 1)):
             lib.dct_tune_set(31, ring)
+            lib.dct_tune_set(32, waves4)
             y = torch.empty(B, Ho, Wo, Cout, dtype=dtype, device=DEV)
             ops.conv2d(x, w, b, y, pad_h=pad, pad_w=pad, relu=True)
             z = torch.ones(B, Ho, Wo, Cout, dtype=dtype, device=DEV)
             ops.conv2d(x, w, None, z, pad_h=pad, pad_w=pad, mask=mask, mask_scale=2.0, accumulate=True)
             torch.cuda.synchronize()
-            outs.setdefault(ring, []).append((y, z))
+            outs.append((y, z))
     finally:
-        lib.dct_tune_set(31, 1)
-    (y1, z1), (y1b, z1b) = outs[1]
-    (y0, z0), = outs[0]
-    assert torch.equal(y1, y1b) and torch.equal(z1, z1b)
-    assert torch.equal(y1, y0) and torch.equal(z1, z0)
+        lib.dct_tune_set(31, 0)
+        lib.dct_tune_set(32, 0)
+    for y, z in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(z, outs[0][1])
 
 
 _MFMA16_DEFAULT = 1
