@@ -188,6 +188,9 @@ def main():
     ap.add_argument("--force-ddp", action="store_true",
                     help="run the N > 1 code path (RCCL process group, gradient exchange, its report) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=0,
+                    help="extra (untimed) training steps before the warm-up: the timed network is then that many Adam steps old "
+                         "(operand statistics of a trained net; profiles/r03_cfg2_after_300_steps.json)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight gradients on a second stream per model (eager only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
@@ -250,7 +253,7 @@ def main():
     # Setup (not part of the W warm-up steps or of the timed region): first-touch allocations, kernel attribute setup
     # and the one-time HIP-graph capture of the step (two eager steps, the capture, and the first replays, which upload
     # the graph) -- the equivalent of a JIT / engine-build phase.  Then W untimed warm-up steps, then exactly K timed.
-    for i in range(SETUP_STEPS):
+    for i in range(SETUP_STEPS + args.train_steps):
         one_step(i)
     torch.cuda.synchronize()
     for i in range(args.warmup):
@@ -350,7 +353,8 @@ def main():
         "config": {"workload": f"{args.config}: {cfg['desc']}", "imgs_per_step_per_gpu": imgs_per_step,
                    "global_batch": f"{cfg['B_l'] * world}+{cfg['B_u'] * world}", "parallelism": f"dp{world}",
                    "weights": "random init (xavier_normal), reference architecture; trained for the setup + warm-up steps on "
-                              "blob-structured synthetic slices (tests/helpers.py::blob_batches)"},
+                              "blob-structured synthetic slices (tests/helpers.py::blob_batches)",
+                   "adam_steps_before_the_timed_region": SETUP_STEPS + args.train_steps + args.warmup},
         "losses_last_step": losses,
     }
     caps = list(tr._step_graphs._graphs.values()) if getattr(tr, "_step_graphs", None) is not None else []

@@ -656,6 +656,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
   const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
 #ifdef DCT_STAMPS
   unsigned long long st_issue = 0, st_comp = 0, st_vm = 0, st_bar = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_pro;
+  const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz reference: shader clock = d(memtime) / d(memrealtime) x 100 MHz
 #endif
   stageA(Abuf, 0);
   stageB(Bbuf, 0, 0);
@@ -815,6 +816,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
     o[0] += 1ull; o[1] += st_pro; o[2] += st_issue; o[3] += st_comp; o[4] += st_vm; o[5] += st_bar;
     o[6] += st_end - st_loop_end; o[7] += st_end - st_t0; o[8] += (unsigned long long)(nch * 9);
     o[9] += e0 - st_loop_end; o[10] += e1 - e0; o[11] += e2 - e1; o[12] += st_end - e2;
+    o[13] += __builtin_amdgcn_s_memrealtime() - st_r0;
   }
 #endif
 }

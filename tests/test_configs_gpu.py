@@ -333,7 +333,7 @@ def test_enet_configs_full_size_vs_oracle(config, dtype):
     every step (so the captured / replayed steps are held as tightly as step 0).
 
     fp32 mode vs the oracle in FLOAT64 (deterministic whatever the host's thread count).  Bounds, with what was measured on
-    the MI355X (profiles/r03_enet_full_size_parity.txt):
+    the MI355X (profiles/r03_full_size_parity_and_dsc.txt):
       supervised losses <= 1e-5 (2.4e-6), JSD <= 1e-4 (1.6e-6);
       adversarial KL <= 5e-3 (1.8e-3): FGSM takes sign(d loss / d x), which flips wherever the two arithmetics put a
         near-zero gradient on different sides of 0, and every flipped pixel moves x_adv by 2 eps;

@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layer", default="dec2b")
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--zeros", type=float, default=0.0, help="fraction of exactly-zero input activations (a ReLU network's operands)")
+    ap.add_argument("--spin", type=float, default=2.0, help="seconds of back-to-back launches before the stamped ones (the clock settles)")
     args = ap.parse_args()
     cin, hin, cout = LAYERS[args.layer]
     lib = _lib.load()
@@ -33,12 +35,19 @@ def main():
     fn.argtypes = [C.c_void_p, C.c_int]
     dev = "cuda:0"
     B, ho = args.batch, hin - 2
-    x = torch.randn(B, hin, hin, cin, device=dev).to(torch.bfloat16)
+    x = torch.randn(B, hin, hin, cin, device=dev)
+    if args.zeros > 0:
+        x = x.abs() * (torch.rand_like(x) >= args.zeros)          # non-negative with the given share of exact zeros, like a ReLU output
+    x = x.to(torch.bfloat16)
     w = (torch.randn(cout, 3, 3, cin, device=dev) / (3 * cin ** 0.5)).to(torch.bfloat16)
     bias = torch.randn(cout, device=dev)
     y = torch.empty(B, ho, ho, cout, device=dev, dtype=torch.bfloat16)
-    for _ in range(3):
-        K.conv2d(x, w, bias, y, relu=True)
+    import time
+    t_end = time.time() + args.spin
+    while time.time() < t_end:
+        for _ in range(50):
+            K.conv2d(x, w, bias, y, relu=True)
+        torch.cuda.synchronize()
     buf = (C.c_ulonglong * 16)()
     fn(buf, 1)
     n = 10
@@ -50,6 +59,9 @@ def main():
         raise SystemExit("no stamps: not a DCT_STAMPS build, or the layer did not take the shared-halo kernel")
     spw = steps / waves
     print(f"{args.layer}: {waves // n} waves/launch, {spw:.0f} K-steps per wave")
+    if buf[13]:
+        print(f"  in-kernel shader clock: {buf[7] / buf[13] * 0.1:.3f} GHz  (s_memtime / s_memrealtime x 100 MHz over whole wave lifetimes; "
+              f"input zeros {args.zeros:.0%})")
     print(f"  per wave: prologue {buf[1] / waves:8.0f}  loop {(buf[2] + buf[3] + buf[4] + buf[5]) / waves:8.0f}  "
           f"epilogue {buf[6] / waves:8.0f}  total {buf[7] / waves:8.0f} cycles")
     print(f"  epilogue: row table {buf[9] / waves:6.0f}  acc -> LDS {buf[10] / waves:6.0f}  barrier {buf[11] / waves:6.0f}  "
