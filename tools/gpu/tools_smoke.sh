@@ -18,7 +18,7 @@ t probe_graph_chains python tools/probe_graph_chains.py
 t probe_step_program python tools/probe_step_program.py cfg4
 t probe_stream_pairs python tools/probe_stream_pairs.py
 t probe_uninit       python tools/probe_uninit.py
-t run_steps          python tools/run_steps.py
+t run_steps          python tools/run_steps.py cfg4 4
 t pmc_layer          python tools/pmc_layer.py --layer dec3b --n 2
 tail -3 $O/*.log | grep -E "==>|Error|error|Traceback" | head -60
 cat $O/summary.txt
