@@ -91,6 +91,27 @@ def pmc_traffic(config):
     return None
 
 
+def pmc_mfma_busy(config):
+    """MFMA-pipe busy share per kernel class and the in-kernel shader clock from the committed round-3 counter passes
+    (profiles/r03_<config>_pmc_mfma_busy.txt, profiles/r03_in_kernel_clock.txt); None when absent."""
+    out = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", f"r03_{config}_pmc_mfma_busy.txt")) as f:
+            for line in f:
+                t = line.split()
+                if len(t) >= 4 and t[2].endswith("%"):
+                    out[t[0]] = float(t[2].rstrip("%")) / 100.0
+        clocks = []
+        with open(os.path.join(ROOT, "profiles", "r03_in_kernel_clock.txt")) as f:
+            for line in f:
+                if "in-kernel shader clock" in line and "zeros 0%" in line:
+                    clocks.append(float(line.split("clock:")[1].split("GHz")[0]))
+        return {"mfma_pipe_busy_share_of_simd_cycles": out, "in_kernel_clock_ghz_dense_inputs": clocks,
+                "source": f"profiles/r03_{config}_pmc_mfma_busy.txt, profiles/r03_in_kernel_clock.txt (rocprofv3 --pmc passes of this command, round 3)"}
+    except Exception:
+        return None
+
+
 def make_trainer(cfg, dtype, device, rank, world, grad_sync_factory, n_batches=4):
     from dct_amd.loss import get_loss_fn
     from dct_amd.models import Segmentator
@@ -404,6 +425,10 @@ def main():
                                "unit": "TFLOP/s"},
                 "per_class_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in per.items()},
                 "measured": "HIP events around every launch on the launch stream, over the same K steps re-run right after the timed region",
+                # the same FLOPs over the timed step (both model streams overlapping): what the job as a whole makes of the matrix peak
+                "step_level": {"achieved": (flops["igemm"] + flops["wgrad"]) / (ms_per_step * 1e-3) / 1e12, "unit": "TFLOP/s",
+                               "frac": (flops["igemm"] + flops["wgrad"]) / (ms_per_step * 1e-3) / 1e12 / peak},
+                "counters": pmc_mfma_busy(args.config),
             }
         elif prof is not None:
             # Enet: HBM bound.  Algorithmic bytes = conv in+out activation elements x 2 B (bf16) x 3 (fwd, dgrad, wgrad)
@@ -423,6 +448,10 @@ def main():
                 "avg_launch_us": 1e3 * ms / max(launches, 1), "launches_per_step": launches,
                 "per_class_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in prof.items()},
                 "measured": "HIP events around every launch on the launch stream, over the same K steps re-run right after the timed region",
+                # `frac` above divides by the SERIALISED kernel time of the eager single-stream leg; the timed step runs its chains on
+                # four hardware queues, so the job-level figure is the same bytes over ms_per_step:
+                "step_level": {"achieved": alg_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                               "frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0},
             }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg)
