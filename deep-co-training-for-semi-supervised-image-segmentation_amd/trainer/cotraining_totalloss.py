@@ -43,16 +43,23 @@ from .trainer import Trainer
 # dozens of trainers, and stream objects that die with an old trainer would be destroyed whenever the cyclic GC runs --
 # including in the middle of a later trainer's graph capture, where hipStreamDestroy is not permitted.
 _STREAM_POOL = {}
-POOL_STREAMS = os.environ.get("DCT_POOL_STREAMS", "0") == "1"
+POOL_STREAMS = os.environ.get("DCT_POOL_STREAMS", "1") != "0"
 
 
 def _pooled_stream(device, *key, dealer=None):
+    """The stream of role ``key`` (("model", i), ("pass", i, k), ...) on ``device``.  With a dealer it comes from the cached,
+    bounded set of probe streams (one per hardware queue in turn); otherwise ONE own stream per (device, role) for the life of
+    the process -- a long-lived process that builds many trainers (sweeps, the test suite) must not create streams without
+    bound: they are never destroyed and all map onto the same four hardware queues.  Two live trainers then share
+    their role streams, which only serialises them against each other.  DCT_POOL_STREAMS=0 restores a fresh stream per request."""
+    if dealer is not None:
+        return dealer.take()
+    if not POOL_STREAMS:
+        return own_stream(device)
     k = (str(device),) + key
-    st = _STREAM_POOL.get(k) if POOL_STREAMS else None
+    st = _STREAM_POOL.get(k)
     if st is None:
-        st = dealer.take() if dealer is not None else own_stream(device)
-        if POOL_STREAMS:
-            _STREAM_POOL[k] = st
+        st = _STREAM_POOL[k] = own_stream(device)
     return st
 
 

@@ -85,6 +85,20 @@ def own_stream(device) -> torch.cuda.Stream:
     return st
 
 
+_RECORDER_MAIN = {}
+
+
+def _recorder_main(device) -> torch.cuda.Stream:
+    """The stream a SegmentRecorder records the caller's work on: one per device for the life of the process (a fresh one per
+    capture leaked a HIP stream per capture)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _RECORDER_MAIN.get(idx)
+    if st is None:
+        st = _RECORDER_MAIN[idx] = own_stream(torch.device("cuda", idx))
+    return st
+
+
 def _graph_node_count(graph: torch.cuda.CUDAGraph) -> int:
     """Number of nodes of a captured (keep_graph) graph, -1 when it cannot be asked."""
     try:
@@ -136,7 +150,7 @@ class SegmentRecorder(object):
 
     def __init__(self, device):
         self.device = device
-        self.main = own_stream(device)                 # stands in for the caller's stream while recording
+        self.main = _recorder_main(device)             # stands in for the caller's stream while recording (one per device, reused)
         self.ops: List[tuple] = []
         self._pools = {}
         self._empty: List[torch.cuda.CUDAGraph] = []
