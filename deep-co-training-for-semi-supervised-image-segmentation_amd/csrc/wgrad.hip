@@ -504,7 +504,10 @@ template <int RB> __device__ __forceinline__ int swz3(int k) {       // in 16-B 
 // G: wave groups per block.  Each group of NW waves is a complete copy of the tile machinery (own stages, own half of the
 // block's K-steps); the groups' accumulators are added through LDS before the slab is written.  Two groups halve the
 // number of slabs (written once, read once by the fold: 38 MB per layer at 768 four-wave blocks) at the same waves per CU.
-template <int BP, int BQ, int NW, bool NARROW, int G>
+// QSHIFT: the x fragments of a row's three taps come from ONE 12-pixel window per lane (three transposing reads) -- tap 2 is the
+// window moved by one dword, tap 1 four v_alignbit_b32 -- instead of three separate 8-pixel reads: 5 instead of 8 fragment reads per
+// sub-step (0.83 KiB of LDS per MFMA instead of 1.33; the kernel is LDS-bandwidth bound).  Same MFMA operands bit for bit.
+template <int BP, int BQ, int NW, bool NARROW, int G, bool QSHIFT>
 __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   const WgradParams& p = pr.w;
   constexpr int RBP = BP * 2, RBQ = BQ * 2;
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
       }
   }
   constexpr int P_KK = 16 * RBP, P_HI = 4 * RBP, Q_KK = 16 * RBQ, Q_HI = 4 * RBQ;
-  constexpr int NRD = 2 * (TP + 3 * TQ);
+  constexpr int NRD = 2 * TP + (QSHIFT ? 3 : 6) * TQ;
   const unsigned smem_off = lds_off(smem);
   const bool do_bias = pr.with_bias && tr == 0 && qt == 0 && wq == 0;
   // bias gradient = column sums of dy: a lane's dy fragment is 8 pixels of ONE channel (row l31 of the MFMA A operand),
@@ -646,7 +649,8 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
     if (gi + 1 < gend) stage(smem + (cur ^ 1) * STAGE);
     if (gi < gend) {                    // wave-uniform: a group with one step fewer only keeps the barrier     // all pieces up front: spreading them between the MFMA groups lands the stage later and was 8 % slower
     const unsigned Pl = smem_off + cur * STAGE;
-    bf16x4 fa[2][TP][2], fb[2][3][TQ][2];
+    constexpr int QF = QSHIFT ? 1 : 3, QR = QSHIFT ? 3 : 2;     // fragment groups per column block and transposing reads per group
+    bf16x4 fa[2][TP][2], fb[2][QF][TQ][QR];
     auto issue = [&](int set, int kk) {
 #pragma unroll
       for (int i = 0; i < TP; ++i) {
@@ -654,12 +658,11 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
         tr_issue(Pl + pbase[i] + kk * P_KK + P_HI, fa[set][i][1]);
       }
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < QF; ++s)
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) {
-          tr_issue(Pl + qbase[s][j] + kk * Q_KK, fb[set][s][j][0]);
-          tr_issue(Pl + qbase[s][j] + kk * Q_KK + Q_HI, fb[set][s][j][1]);
-        }
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+          for (int r = 0; r < QR; ++r) tr_issue(Pl + qbase[s][j] + kk * Q_KK + r * Q_HI, fb[set][s][j][r]);     // rows +0..3, +4..7 [, +8..11]
     };
     issue(0, 0);
 #pragma unroll
@@ -669,9 +672,11 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
 #pragma unroll
       for (int i = 0; i < TP; ++i) { touch(fa[set][i][0]); touch(fa[set][i][1]); }
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < QF; ++s)
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) { touch(fb[set][s][j][0]); touch(fb[set][s][j][1]); }
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+          for (int r = 0; r < QR; ++r) touch(fb[set][s][j][r]);
       __builtin_amdgcn_sched_barrier(0);
       bf16x8 a[TP];
 #pragma unroll
@@ -680,7 +685,23 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
       for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
-          const bf16x8 b = join(fb[set][s][j][0], fb[set][s][j][1]);
+          bf16x8 b;
+          if constexpr (QSHIFT) {
+            // the lane's 12 consecutive pixels of its x channel as six dwords (two pixels each, the earlier one in the low half)
+            union W { bf16x4 v; unsigned d[2]; };
+            W w0, w1, w2; w0.v = fb[set][0][j][0]; w1.v = fb[set][0][j][1]; w2.v = fb[set][0][j][2];
+            const unsigned D0 = w0.d[0], D1 = w0.d[1], D2 = w1.d[0], D3 = w1.d[1], D4 = w2.d[0];
+            union F { bf16x8 v; unsigned d[4]; } f;
+            if (s == 0) { f.d[0] = D0; f.d[1] = D1; f.d[2] = D2; f.d[3] = D3; }
+            else if (s == 2) { f.d[0] = D1; f.d[1] = D2; f.d[2] = D3; f.d[3] = D4; }
+            else {
+              f.d[0] = __builtin_amdgcn_alignbit(D1, D0, 16); f.d[1] = __builtin_amdgcn_alignbit(D2, D1, 16);
+              f.d[2] = __builtin_amdgcn_alignbit(D3, D2, 16); f.d[3] = __builtin_amdgcn_alignbit(D4, D3, 16);
+            }
+            b = f.v;
+          } else {
+            b = join(fb[set][s][j][0], fb[set][s][j][1]);
+          }
 #pragma unroll
           for (int i = 0; i < TP; ++i) acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[s][i][j], 0, 0, 0);
         }
@@ -896,16 +917,21 @@ static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
   }
   DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ, NW>), dim3(grid), dim3(NW * 64), lds, st, pr);
 }
-template <int BP, int BQ, int NW, bool NARROW, int G>
-static void launch_w3_t(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
+template <int BP, int BQ, int NW, bool NARROW, int G, bool QSHIFT>
+static void launch_w3_q(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
   constexpr size_t lds = G * 2 * (64 * (size_t)BP * 2 + 72 * (size_t)BQ * 2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<BP, BQ, NW, NARROW, G>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW, G>), dim3(grid), dim3(G * NW * 64), lds, st, pr);
+  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT>), dim3(grid), dim3(G * NW * 64), lds, st, pr);
+}
+int g_tune_wgrad3_shift = 1;       // filter-row kernel: the three taps' x fragments from one 12-pixel window per lane (5 reads per sub-step, not 8)
+template <int BP, int BQ, int NW, bool NARROW, int G>
+static void launch_w3_t(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
+  if (g_tune_wgrad3_shift) launch_w3_q<BP, BQ, NW, NARROW, G, true>(pr, grid, st); else launch_w3_q<BP, BQ, NW, NARROW, G, false>(pr, grid, st);
 }
 static void launch_w3(const Wgrad3Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, 3);
@@ -1001,5 +1027,6 @@ int dct_tune_set_wgrad(int knob, int value) {
   if (knob == DCT_TUNE_WGRAD_GROUPS) { g_tune_wgrad_groups = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD3_TARGET) { if (value < 64) return DCT_ERR_BAD_ARG; g_tune_wgrad3_target = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_TARGET) { if (value < 64) return DCT_ERR_BAD_ARG; g_tune_wgrad_target = value; return DCT_OK; }
+  if (knob == DCT_TUNE_WGRAD3_SHIFT) { g_tune_wgrad3_shift = value ? 1 : 0; return DCT_OK; }
   return DCT_ERR_BAD_ARG;
 }

@@ -431,7 +431,9 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
                                                 0 (default): one element per thread */
        DCT_TUNE_IGEMM_RING = 31,             /* 1: shared-halo conv kernel with a four-slot ring of 32-channel weight half-stages filled three half-steps
                                                 ahead (counted vmcnt, raw barrier) -- bit-identical, measured 15 % slower; 0 (default): two 64-channel stages */
-       DCT_TUNE_IGEMM_HALO_WAVES4 = 32 };    /* 1: the 128-channel shared-halo tile on four waves of 64 pixels x 64 channels; 0: eight of 32 x 64 */
+       DCT_TUNE_IGEMM_HALO_WAVES4 = 32,      /* 1: the 128-channel shared-halo tile on four waves of 64 pixels x 64 channels; 0: eight of 32 x 64 */
+       DCT_TUNE_WGRAD3_SHIFT = 33 };         /* 1 (default): filter-row weight gradient builds a row's three x fragments from one 12-pixel window per lane
+                                                (register shifts) instead of three LDS reads; 0: one read per tap */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 

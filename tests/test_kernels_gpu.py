@@ -282,6 +282,38 @@ def test_conv2d_wgrad_filter_row_kernel_narrow_images(ops, B, Cin, H, W, Cout, p
     close(db.cpu(), dy.sum((0, 2, 3)), dtype, "filter-row wgrad, packed rows: db", rtol16=1e-2)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [(4, 64, 130, 132, 64, 0), (3, 128, 70, 101, 128, 1), (8, 256, 27, 27, 128, 0), (16, 128, 18, 16, 256, 2)])
+def test_conv2d_wgrad_filter_row_window_is_bit_identical(ops, B, Cin, H, W, Cout, pad):
+    """wgrad3_kernel<..., QSHIFT>: a row's three x fragments from ONE 12-pixel window per lane (tap 2 = the window moved by a dword,
+    tap 1 = four v_alignbit_b32) feed the MFMAs the same operands as three separate LDS reads: dW and db must agree bit for bit
+    (knob DCT_TUNE_WGRAD3_SHIFT), on wide images (runs of a row) and narrow ones (packed rows), and against autograd."""
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(15)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    y = F.conv2d(x, w, padding=pad)
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    (ref,) = torch.autograd.grad(y, w, dy)
+    lib = _lib.load()
+    lib.dct_tune_set(9, 30)
+    outs = []
+    try:
+        for shift in (1, 0, 1):
+            lib.dct_tune_set(33, shift)
+            dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=DEV)
+            db = torch.full((Cout,), float("nan"), device=DEV)
+            ops.conv2d_wgrad(to_dev(dy, dtype), to_dev(x, dtype), dw, pad_h=pad, pad_w=pad, accumulate=False, db=db)
+            torch.cuda.synchronize()
+            outs.append((dw, db))
+    finally:
+        lib.dct_tune_set(9, 70)
+        lib.dct_tune_set(33, 1)
+    close(outs[0][0].cpu(), ref.permute(0, 2, 3, 1), dtype, "filter-row wgrad, window form")
+    for dw, db in outs[1:]:
+        assert torch.equal(dw, outs[0][0]) and torch.equal(db, outs[0][1])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_convT_wgrad_and_dgrad(ops, dtype):
     g = torch.Generator().manual_seed(5)
