@@ -206,6 +206,7 @@ def main():
                     help="N > 1: gradients travel as bf16 on the xGMI ring (half the bytes); default fp32, as the reference's sums are")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="dct_tune_set(KNOB, VALUE) before the run (A/B)")
     ap.add_argument("--attr", action="append", default=[], metavar="NAME=0|1", help="boolean CoTrainer switch (pass_streams, ...) (A/B)")
+    ap.add_argument("--net-attr", action="append", default=[], metavar="NAME=0|1", help="boolean switch of every network (relu_bits, pool_codes, ...) (A/B)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="run the N > 1 code path (RCCL process group, gradient exchange, its report) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -255,6 +256,11 @@ def main():
         k, v = kv.split("=")
         assert hasattr(tr, k), k
         setattr(tr, k, bool(int(v)))
+    for kv in args.net_attr:
+        k, v = kv.split("=")
+        for seg in tr.segmentators:
+            assert hasattr(seg.torchnet, k), k
+            setattr(seg.torchnet, k, bool(int(v)))
     S = cfg["S"]
     nb = len(unl)
     tr.model_streams = not args.single_stream

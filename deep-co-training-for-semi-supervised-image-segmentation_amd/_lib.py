@@ -28,7 +28,8 @@ class View(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32),
                 ("pad_h", C.c_int32), ("pad_w", C.c_int32), ("relu", C.c_int32), ("scatter2x2", C.c_int32),
-                ("accumulate", C.c_int32), ("mask_channels", C.c_int32), ("mask_scale", C.c_float)]
+                ("accumulate", C.c_int32), ("mask_channels", C.c_int32), ("mask_scale", C.c_float),
+                ("mask_bits", C.c_void_p), ("relu_bits_out", C.c_void_p)]
 
 
 class EnetTf(C.Structure):
@@ -36,9 +37,11 @@ class EnetTf(C.Structure):
 
 
 def conv_desc(R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=0, scatter2x2=0, accumulate=0,
-              mask_channels=0, mask_scale=1.0) -> ConvDesc:
+              mask_channels=0, mask_scale=1.0, mask_bits=None, relu_bits_out=None) -> ConvDesc:
     return ConvDesc(R, S, stride, dil, pad_h, pad_w, int(relu), int(scatter2x2), int(accumulate),
-                    int(mask_channels), float(mask_scale))
+                    int(mask_channels), float(mask_scale),
+                    mask_bits.data_ptr() if mask_bits is not None else None,
+                    relu_bits_out.data_ptr() if relu_bits_out is not None else None)
 
 
 def view(t: torch.Tensor) -> View:
@@ -81,6 +84,8 @@ SIGNATURES = {
     "dct_conv1x1_head_bwd": (_i, [_VP, _VP, _P, _VP, _P, _P, _i, _i, _i, _P, _sz, _P]),
     "dct_maxpool2x2_fwd": (_i, [_VP, _VP, _i, _P]),
     "dct_maxpool2x2_bwd": (_i, [_VP, _VP, _VP, _i, _f, _i, _P]),
+    "dct_maxpool2x2_fwd_codes": (_i, [_VP, _VP, _P, _i, _P]),
+    "dct_maxpool2x2_bwd_codes": (_i, [_P, _VP, _VP, _i, _f, _i, _P]),
     "dct_bilinear_fwd": (_i, [_VP, _VP, _i, _i, _P]),
     "dct_bilinear_bwd": (_i, [_VP, _VP, _i, _i, _i, _P]),
     "dct_dropout_fwd": (_i, [_VP, _VP, _P, _f, _u64, _u64, _i, _P]),

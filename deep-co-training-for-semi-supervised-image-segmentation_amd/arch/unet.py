@@ -188,6 +188,8 @@ class UNet(nn.Module):
         self.dropout_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         self._debug: Optional[dict] = None   # tools/debug_unet_layers.py stashes backward intermediates here
         self._grad_hook = None               # data parallelism: called with a bucket index as gradient ranges complete
+        self.relu_bits = True                # convolutions keep the ReLU-gate bits of activations whose consumer's data gradient masks by them
+        self.pool_codes = True               # max-pool keeps its routing codes for the backward pass (which then does not re-read its input)
         self.wgrad_side_stream = False       # opt-in: weight gradients on a second HIP stream (see _run_backward)
         self._wgrad_stream = None
 
@@ -339,8 +341,19 @@ class UNet(nn.Module):
             bn_recs[name] = (raw, vec, bn)
             return y
 
-        def conv3(src, conv, dst, bn=None, name=None):
-            K.conv2d(src, P[id(conv)]["fwd"], conv.bias, dst, relu=bn is None)
+        bits: Dict[int, torch.Tensor] = {}     # ReLU-gate bits of the activations whose consumer's data gradient masks by them
+
+        def want_bits(t, bn):
+            if not (save and self.relu_bits and bn is None):
+                return None
+            b = K.relu_bits_like(t)
+            if b is not None:
+                bits[id(t)] = b
+            return b
+
+        def conv3(src, conv, dst, bn=None, name=None, gate=False):
+            """``gate``: dst feeds a convolution whose data gradient is masked by (dst > 0) -- keep the one-bit image of it."""
+            K.conv2d(src, P[id(conv)]["fwd"], conv.bias, dst, relu=bn is None, relu_bits_out=want_bits(dst, bn) if gate else None)
             return dst if bn is None else bn_relu(dst, bn, name)
 
         xs = x.detach().to(torch.float32).reshape(B, H, W, 1)
@@ -374,20 +387,21 @@ class UNet(nn.Module):
             ca, bna, cb, _ = self._roles[f"dec{lvl}"]
             a = new(h - 2, w - 2, width)
             if lvl == 1:
-                K.conv_cin1_fwd(xs, self._w(ca), ca.bias, a, relu=bna is None)
+                K.conv_cin1_fwd(xs, self._w(ca), ca.bias, a, relu=bna is None, relu_bits_out=want_bits(a, bna))
                 if bna is not None:
                     a = bn_relu(a, bna, "a1")
             else:
-                a = conv3(src, ca, a, bna, f"a{lvl}")
+                a = conv3(src, ca, a, bna, f"a{lvl}", gate=True)
             d = conv3(a, cb, new(h - 4, w - 4, width))
             dd = dropout(d, 0) if lvl == 4 else d
             h, w = (h - 4 + 1) // 2, (w - 4 + 1) // 2
-            p = K.maxpool_fwd(dd, new(h, w, width))
-            A[f"a{lvl}"], A[f"d{lvl}"], A[f"p{lvl}"] = a, dd, p
+            codes = torch.empty(B, h, w, width, dtype=torch.uint8, device=dev) if (save and self.pool_codes) else None
+            p = K.maxpool_fwd(dd, new(h, w, width), codes=codes)
+            A[f"a{lvl}"], A[f"d{lvl}"], A[f"p{lvl}"], A[f"pc{lvl}"] = a, dd, p, codes
             src = p
         # center
         ca, bna, cb, bnb, ct = self._roles["center"]
-        c1 = conv3(src, ca, new(h - 2, w - 2, 1024), bna, "c1")
+        c1 = conv3(src, ca, new(h - 2, w - 2, 1024), bna, "c1", gate=True)
         c2 = conv3(c1, cb, new(h - 4, w - 4, 1024), bnb, "c2")
         c2d = dropout(c2, 1)
         h, w = 2 * (h - 4), 2 * (w - 4)
@@ -398,19 +412,19 @@ class UNet(nn.Module):
         # decoder ("enc")
         for lvl, feat, co in ((4, 512, 256), (3, 256, 128), (2, 128, 64)):
             ca, bna, cb, bnb, ct = self._roles[f"enc{lvl}"]
-            ea = conv3(cat, ca, new(h - 2, w - 2, feat), bna, f"e{lvl}a")
-            eb = conv3(ea, cb, new(h - 4, w - 4, feat), bnb, f"e{lvl}b")
+            ea = conv3(cat, ca, new(h - 2, w - 2, feat), bna, f"e{lvl}a", gate=True)
+            eb = conv3(ea, cb, new(h - 4, w - 4, feat), bnb, f"e{lvl}b", gate=True)
             h, w = 2 * (h - 4), 2 * (w - 4)
             cat = new(h, w, 2 * co)
             K.conv2d(eb, P[id(ct)]["fwd"], ct.bias, cat[..., :co], R=1, S=1, relu=True, scatter2x2=True)
             K.bilinear_fwd(A[f"p{lvl - 1}"], cat[..., co:])
             A[f"e{lvl}a"], A[f"e{lvl}b"], A[f"cat{lvl - 1}"] = ea, eb, cat
         ca, bna, cb, _ = self._roles["enc1"]
-        e1a = conv3(cat, ca, new(h - 2, w - 2, 64), bna, "e1a")
+        e1a = conv3(cat, ca, new(h - 2, w - 2, 64), bna, "e1a", gate=True)
         e1b = conv3(e1a, cb, new(h - 4, w - 4, 64))
         f = K.head_fwd(e1b, self._w(self.final), self.final.bias, new(h - 4, w - 4, self.num_classes, torch.float32))
         logits = K.bilinear_fwd(f, new(H, W, self.num_classes, torch.float32))
-        A["bn"], A["bn_training"] = bn_recs, bool(self.training)
+        A["bn"], A["bn_training"], A["bits"] = bn_recs, bool(self.training), bits
         if bn_recs and self.training:      # nn.BatchNorm2d bookkeeping: one multi-tensor launch for all thirteen layers
             torch._foreach_add_([rec[2].num_batches_tracked for rec in bn_recs.values()], 1)
         A["e1a"], A["e1b"] = e1a, e1b
@@ -440,6 +454,7 @@ class UNet(nn.Module):
         # are queued on a second stream, ordered after the producer of dy by an event, and joined at the end.
         # Their operands stay referenced until the join (`keep`), so the caching allocator cannot hand a dy
         # buffer to a later data-gradient while a weight-gradient kernel still reads it.
+        gate_bits = A.get("bits") or {}
         cur = torch.cuda.current_stream(dev)
         side = self._side_stream(dev) if need_dw else None
         keep: List[torch.Tensor] = []
@@ -462,7 +477,8 @@ class UNet(nn.Module):
                         K.bias_grad(dy, self._gb(conv), accumulate=gacc)
             if dx_out is not None:
                 K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, pad_h=2, pad_w=2, mask=mask,
-                         mask_channels=mask_channels, mask_scale=mask_scale, accumulate=accumulate)
+                         mask_channels=mask_channels, mask_scale=mask_scale, accumulate=accumulate,
+                         mask_bits=gate_bits.get(id(mask)) if mask is not None else None)
             return dx_out
 
         def convT_bwd(conv, x_in, dy, dx_out, mask, mask_scale=1.0):
@@ -470,7 +486,8 @@ class UNet(nn.Module):
                 with on_side(dy, x_in):
                     K.conv2d_wgrad(x_in, dy, self._gw(conv), R=2, S=2, stride=2, accumulate=gacc)
                     K.bias_grad(dy, self._gb(conv), accumulate=gacc)
-            K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, R=2, S=2, stride=2, mask=mask, mask_scale=mask_scale)
+            K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, R=2, S=2, stride=2, mask=mask, mask_scale=mask_scale,
+                     mask_bits=gate_bits.get(id(mask)))
             return dx_out
 
         def bn_back(name, g):
@@ -527,7 +544,7 @@ class UNet(nn.Module):
         for lvl in (4, 3, 2, 1):
             ca, _, cb, _ = self._roles[f"dec{lvl}"]
             a, d = A[f"a{lvl}"], A[f"d{lvl}"]
-            dd = K.maxpool_bwd(d, dp[lvl], new_like(d), relu_mask=True, scale=ds if lvl == 4 else 1.0)
+            dd = K.maxpool_bwd(d, dp[lvl], new_like(d), relu_mask=True, scale=ds if lvl == 4 else 1.0, codes=A.get(f"pc{lvl}"))
             da = bn_back(f"a{lvl}", conv_bwd(cb, a, dd, new_like(a), mask=a))
             if lvl > 1:
                 conv_bwd(ca, A[f"p{lvl - 1}"], da, dp[lvl - 1], accumulate=True)

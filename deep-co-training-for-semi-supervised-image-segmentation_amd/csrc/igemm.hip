@@ -23,6 +23,8 @@ namespace {
 
 struct IgemmParams {
   const char* x; const char* w; const float* bias; const char* mask; char* y;
+  const unsigned char* mask_bits;   // optional one-bit image of `mask` (dense [n][h][w][c/8]); the staged epilogues read it instead
+  unsigned char* bits_out;          // optional: ReLU-gate bits of y (dense y only)
   float* partial;
   int M, N, Cin, R, S;
   int Ho, Wo, Hi, Wi;
@@ -93,6 +95,61 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, int n, int
   } else {
     f32x4 o = {v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(yp) = o;
+  }
+}
+
+
+// ReLU-gate bits of eight bf16 values (bit e: element e > 0) -- the one-bit-per-element image of an activation that the data
+// gradient of the layer it feeds needs (1/16 of the bytes of the activation itself).
+__device__ __forceinline__ unsigned relu_bits8(const bf16x8& v) {
+  unsigned b = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) b |= ((float)v[e] > 0.f ? 1u : 0u) << e;
+  return b;
+}
+
+// Second half of the LDS-staged epilogue of the shared-halo kernels: the block streams the [pixel][channel] image of its tile
+// out in whole 16-byte chunks.  The mask / old-value loads of all NCH chunks go out together (one memory round trip), then the
+// stores.  The ReLU mask of a data gradient comes from `mask_bits` (one byte per chunk) where the caller has them, else from the
+// activation itself; a forward pass with `bits_out` leaves those bits for its consumer's data gradient.
+template <int BM, int BN, int NW>
+__device__ __forceinline__ void staged_rows_out(const IgemmParams& p, const char* tile, const int* rowY, const int* rowM, int n0, int tid) {
+  constexpr int CPR = BN / 8;
+  constexpr int NCH = BM * CPR / (NW * 64);
+  int yo[NCH];
+  bf16x8 mk[NCH], old[NCH];
+  unsigned mb[NCH];
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    const int id = t * (NW * 64) + tid;
+    const int row = id / CPR, co = n0 + (id % CPR) * 8;
+    yo[t] = rowY[row];
+    if (yo[t] >= 0) {
+      if (p.mask_bits) mb[t] = p.mask_bits[(unsigned)(rowM[row] + co) >> 3];
+      else if (p.mask && co < p.mask_channels) mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
+      if (p.accumulate) old[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.y) + yo[t] + co);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    const int id = t * (NW * 64) + tid;
+    const int row = id / CPR, cc = id % CPR;
+    if (yo[t] < 0) continue;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
+    const int co = n0 + cc * 8;
+    if (p.mask_bits) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ((mb[t] >> e) & 1u) ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
+    } else if (p.mask && co < p.mask_channels) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
+    }
+    if (p.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
+    }
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
+    if (p.bits_out) p.bits_out[(unsigned)(yo[t] + co) >> 3] = (unsigned char)relu_bits8(v);
   }
 }
 
@@ -469,6 +526,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
     // the mask loads of all NCH chunks go out together (one memory round trip instead of NCH), then the stores
     long long yoff[NCH];
     bf16x8 mk[NCH];
+    unsigned mb[NCH];
     bool use_mask[NCH];
 #pragma unroll
     for (int t = 0; t < NCH; ++t) {
@@ -488,7 +546,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
         moff += (ab >> 1) * p.msH + (ab & 1) * p.msW;
       }
       yoff[t] = off + co;
-      if (p.mask && co < p.mask_channels) {
+      if (p.mask_bits) mb[t] = p.mask_bits[(unsigned long long)(moff + co) >> 3];
+      else if (p.mask && co < p.mask_channels) {
         use_mask[t] = true;
         mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + moff + co);
       }
@@ -499,11 +558,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
       const int id = t * (NW * 64) + tid;
       const int row = id / CPR, cc = id % CPR;
       bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
-      if (use_mask[t]) {
+      if (p.mask_bits) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ((mb[t] >> e) & 1u) ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
+      } else if (use_mask[t]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
       }
       *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yoff[t]) = v;
+      if (p.bits_out) p.bits_out[(unsigned long long)yoff[t] >> 3] = (unsigned char)relu_bits8(v);
     }
     return;
   }
@@ -776,37 +839,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
 #ifdef DCT_STAMPS
   const unsigned long long e2 = __builtin_amdgcn_s_memtime();
 #endif
-  constexpr int NCH = BM * CPR / (NW * 64);
-  // the mask / old-value loads of all NCH chunks go out together, then the stores
-  int yo[NCH];
-  bf16x8 mk[NCH], old[NCH];
-#pragma unroll
-  for (int t = 0; t < NCH; ++t) {
-    const int id = t * (NW * 64) + tid;
-    const int row = id / CPR, co = n0 + (id % CPR) * 8;
-    yo[t] = rowY[row];
-    if (yo[t] >= 0) {
-      if (p.mask && co < p.mask_channels) mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
-      if (p.accumulate) old[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.y) + yo[t] + co);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < NCH; ++t) {
-    const int id = t * (NW * 64) + tid;
-    const int row = id / CPR, cc = id % CPR;
-    if (yo[t] < 0) continue;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
-    const int co = n0 + cc * 8;
-    if (p.mask && co < p.mask_channels) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-    }
-    if (p.accumulate) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
-    }
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
-  }
+  staged_rows_out<BM, BN, NW>(p, tile, rowY, rowM, n0, tid);
 #ifdef DCT_STAMPS
   if (lane == 0 && g_stamp_buf) {
     const unsigned long long st_end = __builtin_amdgcn_s_memtime();
@@ -1021,37 +1054,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmP
     }
   }
   __syncthreads();
-  constexpr int NCH = BM * CPR / (NW * 64);
-  // the mask / old-value loads of all NCH chunks go out together, then the stores
-  int yo[NCH];
-  bf16x8 mk[NCH], old[NCH];
-#pragma unroll
-  for (int t = 0; t < NCH; ++t) {
-    const int id = t * (NW * 64) + tid;
-    const int row = id / CPR, co = n0 + (id % CPR) * 8;
-    yo[t] = rowY[row];
-    if (yo[t] >= 0) {
-      if (p.mask && co < p.mask_channels) mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
-      if (p.accumulate) old[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.y) + yo[t] + co);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < NCH; ++t) {
-    const int id = t * (NW * 64) + tid;
-    const int row = id / CPR, cc = id % CPR;
-    if (yo[t] < 0) continue;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
-    const int co = n0 + cc * 8;
-    if (p.mask && co < p.mask_channels) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-    }
-    if (p.accumulate) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
-    }
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
-  }
+  staged_rows_out<BM, BN, NW>(p, tile, rowY, rowM, n0, tid);
 }
 
 // igemm3m_kernel with a RING of four 32-channel weight half-stages filled three half-steps ahead (counted vmcnt waits, raw
@@ -1258,37 +1261,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3r_kernel(IgemmParams p, 
     }
   }
   __syncthreads();
-  constexpr int NCH = BM * CPR / (NW * 64);
-  // the mask / old-value loads of all NCH chunks go out together, then the stores
-  int yo[NCH];
-  bf16x8 mk[NCH], old[NCH];
-#pragma unroll
-  for (int t = 0; t < NCH; ++t) {
-    const int id = t * (NW * 64) + tid;
-    const int row = id / CPR, co = n0 + (id % CPR) * 8;
-    yo[t] = rowY[row];
-    if (yo[t] >= 0) {
-      if (p.mask && co < p.mask_channels) mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
-      if (p.accumulate) old[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.y) + yo[t] + co);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < NCH; ++t) {
-    const int id = t * (NW * 64) + tid;
-    const int row = id / CPR, cc = id % CPR;
-    if (yo[t] < 0) continue;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
-    const int co = n0 + cc * 8;
-    if (p.mask && co < p.mask_channels) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-    }
-    if (p.accumulate) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
-    }
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
-  }
+  staged_rows_out<BM, BN, NW>(p, tile, rowY, rowM, n0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1488,36 +1461,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
     }
   }
   __syncthreads();
-  constexpr int NCH = BM * CPR / (NW * 64);
-  int yo[NCH];
-  bf16x8 mk[NCH], old[NCH];
-#pragma unroll
-  for (int t = 0; t < NCH; ++t) {
-    const int id = t * (NW * 64) + tid;
-    const int row = id / CPR, co = n0 + (id % CPR) * 8;
-    yo[t] = rowY[row];
-    if (yo[t] >= 0) {
-      if (p.mask && co < p.mask_channels) mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
-      if (p.accumulate) old[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.y) + yo[t] + co);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < NCH; ++t) {
-    const int id = t * (NW * 64) + tid;
-    const int row = id / CPR, cc = id % CPR;
-    if (yo[t] < 0) continue;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
-    const int co = n0 + cc * 8;
-    if (p.mask && co < p.mask_channels) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-    }
-    if (p.accumulate) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
-    }
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
-  }
+  staged_rows_out<BM, BN, NW>(p, tile, rowY, rowM, n0, tid);
 }
 
 // Sum split-K partial slabs and apply the epilogue.  One thread per (pixel, 4 channels).
@@ -1538,6 +1482,13 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmParams p, int
   IgemmParams q = p;
   q.partial = nullptr;
   epilogue_store4<T>(q, n, oy, ox, c, v);
+}
+
+// ReLU-gate bits of a dense bf16 tensor (the paths whose epilogue does not leave them behind: split-K, unstaged stores)
+__global__ __launch_bounds__(256) void relu_bits_kernel(const bf16_t* __restrict__ y, unsigned char* __restrict__ bits, long long chunks) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= chunks) return;
+  bits[i] = (unsigned char)relu_bits8(*reinterpret_cast<const bf16x8*>(y + 8 * i));
 }
 
 struct Plan {
@@ -1759,6 +1710,10 @@ static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
 
 }  // namespace
 
+void dct_relu_bits_launch(const void* y_bf16, unsigned char* bits, long long chunks, hipStream_t st) {
+  DCT_LAUNCH(DCT_PROF_POINTWISE, relu_bits_kernel, dim3(div_up(chunks, 256)), dim3(256), 0, st, (const bf16_t*)y_bf16, bits, chunks);
+}
+
 extern "C" size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype) {
   if (!x || !y || !d) return 0;
   const int Ho = d->scatter2x2 ? y->h / 2 : y->h, Wo = d->scatter2x2 ? y->w / 2 : y->w;
@@ -1818,6 +1773,22 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     if (p.mask_channels % 4) return DCT_ERR_UNSUPPORTED;
     p.mask_scale = d->mask_scale;
   }
+  p.mask_bits = nullptr; p.bits_out = nullptr;
+  const auto dense = [](const dct_view* v) { return v->sw == v->c && v->sh == (long long)v->w * v->c && v->sn == (long long)v->h * v->w * v->c; };
+  if (d->mask_bits) {
+    // a one-bit image of `mask` (which stays the source for the paths without a staged epilogue)
+    if (!mask || dtype != DCT_BF16 || !dense(mask) || mask->c != y->c || p.mask_channels != y->c || y->c % 8) return DCT_ERR_BAD_ARG;
+    p.mask_bits = d->mask_bits;
+  }
+  if (d->relu_bits_out) {
+    if (dtype != DCT_BF16 || !dense(y) || y->c % 8 || p.scatter || ((uintptr_t)y->ptr & 15)) return DCT_ERR_BAD_ARG;
+    p.bits_out = d->relu_bits_out;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const auto bits_after = [&]() {      // the launch just issued did not write the bits in its epilogue
+    if (!p.bits_out) return;
+    dct_relu_bits_launch(y->ptr, p.bits_out, (long long)y->n * y->h * y->w * (y->c / 8), st);
+  };
   p.relu = d->relu; p.accumulate = d->accumulate;
   p.kiters = pl.kiters; p.kiters_per_split = pl.kiters_per_split;
   p.cin_iters = x->c / pl.bk;
@@ -1837,7 +1808,6 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     if (!workspace || workspace_bytes < need) return DCT_ERR_WORKSPACE;
     p.partial = (float*)workspace;
   }
-  hipStream_t st = (hipStream_t)stream;
   if (pl.v2 && pl.splits == 1 && g_tune_igemm_halo && g_tune_igemm_staged && (!bias || !((uintptr_t)bias & 15)) && d->R == 3 && d->S == 3 && d->stride == 1 &&
       d->dil == 1 && !p.scatter) {
     // shared-halo kernel: 8 x 16 output patches; worth it when the patches cover the image well and fill the device
@@ -1871,11 +1841,14 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
         IgemmParams q = p;
         q.partial = pp.splits > 1 ? (float*)workspace : nullptr;
         launch_v3p(q, pp, y->n, st);
+        if (pp.splits > 1) bits_after();
         return dct_check_launch();
       }
     }
   }
-  return dtype == DCT_BF16 ? launch<bf16_t>(p, pl, st) : launch<float>(p, pl, st);
+  const int rc = dtype == DCT_BF16 ? launch<bf16_t>(p, pl, st) : launch<float>(p, pl, st);
+  if (rc == DCT_OK && !p.staged) bits_after();
+  return rc == DCT_OK ? dct_check_launch() : rc;
 }
 
 #ifdef DCT_STAMPS

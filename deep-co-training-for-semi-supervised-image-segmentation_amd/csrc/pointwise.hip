@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(View x, const float* w, c
 // slice).  The 3x6 input window and the slice's 9xVEC weights sit in registers, so a pixel costs its 9xVEC FMAs
 // plus a quarter of the address arithmetic; per channel the taps accumulate in the same order as stem_fwd_kernel.
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void stem_fwd3x3_kernel(View x, const float* w, const float* bias, View y, StemGeom g) {
+__global__ __launch_bounds__(256) void stem_fwd3x3_kernel(View x, const float* w, const float* bias, View y, StemGeom g,
+                                                          unsigned char* __restrict__ bits) {
   extern __shared__ float sw[];  // [9][cout], then bias[cout]
   for (int i = threadIdx.x; i < g.cout * 9; i += 256) { const int c = i / 9, t = i - c * 9; sw[t * g.cout + c] = w[i]; }
   for (int i = threadIdx.x; i < g.cout; i += 256) sw[g.cout * 9 + i] = bias ? bias[i] : 0.f;
@@ -293,6 +294,14 @@ __global__ __launch_bounds__(256) void stem_fwd3x3_kernel(View x, const float* w
       if (g.relu) out[i] = fmaxf(out[i], 0.f);
     }
     VecIO<T, VEC>::store(yp + p * y.sw, out);
+    if constexpr (VEC == 8) {
+      if (bits) {        // ReLU-gate bits of the ROUNDED outputs (dense y: one byte per pixel and slice), for the consumer's data gradient
+        unsigned b = 0;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) b |= (to_f32((T)out[i]) > 0.f ? 1u : 0u) << i;
+        bits[(((long long)id.n * y.h + id.y) * y.w + x0 + p) * cvecs + id.cv] = (unsigned char)b;
+      }
+    }
   }
 }
 
@@ -439,6 +448,66 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View x, View dy, View 
       out[i] = o;
     }
     const int iy = 2 * id.y + (k >> 1), ix = 2 * id.x + (k & 1);
+    VecIO<T, VEC>::store(reinterpret_cast<T*>(dx.ptr) + voff(dx, id.n, iy, ix) + id.cv * VEC, out);
+  }
+}
+
+// The same pair with the routing decision kept from the forward pass: one byte per pooled element -- bits 0-1 the window
+// position of the first maximum (scan order, as above), bit 2 "the maximum is > 0" (the ReLU / dropout gate of the pool's
+// input), bit 3 "no maximum" (a window of NaNs routes nothing, as above).  The backward pass then reads dy and the codes only:
+// 1/8 of the bytes of the pool's input, which it no longer re-reads (130 MB per network and step at the first UNet level).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_fwd_codes_kernel(View x, View y, unsigned char* __restrict__ codes) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const PixIdx id = decode(t, y.n, y.h, y.w, y.c / VEC);
+  if (!id.ok) return;
+  float m[VEC];
+  int arg[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { m[i] = -INFINITY; arg[i] = 8; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int iy = 2 * id.y + (k >> 1), ix = 2 * id.x + (k & 1);
+    if (iy < x.h && ix < x.w) {
+      float v[VEC];
+      VecIO<T, VEC>::load(reinterpret_cast<const T*>(x.ptr) + voff(x, id.n, iy, ix) + id.cv * VEC, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        if (v[i] > m[i]) { m[i] = v[i]; arg[i] = k; }
+    }
+  }
+  VecIO<T, VEC>::store(reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, id.x) + id.cv * VEC, m);
+  union { unsigned char b[VEC]; unsigned w[VEC / 4]; } cd;             // dense [n][h][w][c], same walk as `decode`
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) cd.b[i] = (unsigned char)(arg[i] | (m[i] > 0.f ? 4 : 0));
+  unsigned* cp = reinterpret_cast<unsigned*>(codes + t * VEC);
+  if constexpr (VEC == 8) *reinterpret_cast<uint2*>(cp) = make_uint2(cd.w[0], cd.w[1]);
+  else cp[0] = cd.w[0];
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_bwd_codes_kernel(const unsigned char* __restrict__ codes, View dy, View dx, int relu_mask,
+                                                                float scale) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const PixIdx id = decode(t, dy.n, dy.h, dy.w, dy.c / VEC);
+  if (!id.ok) return;
+  float g[VEC];
+  VecIO<T, VEC>::load(reinterpret_cast<const T*>(dy.ptr) + voff(dy, id.n, id.y, id.x) + id.cv * VEC, g);
+  union { unsigned char b[VEC]; unsigned w[VEC / 4]; } cu;
+  const unsigned* cp = reinterpret_cast<const unsigned*>(codes + t * VEC);
+  if constexpr (VEC == 8) { const uint2 q = *reinterpret_cast<const uint2*>(cp); cu.w[0] = q.x; cu.w[1] = q.y; }
+  else cu.w[0] = cp[0];
+  const unsigned char* cd = cu.b;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    if (relu_mask) g[i] = (cd[i] & 4) ? g[i] * scale : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int iy = 2 * id.y + (k >> 1), ix = 2 * id.x + (k & 1);
+    if (iy >= dx.h || ix >= dx.w) continue;
+    float out[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = (cd[i] & 11) == k ? g[i] : 0.f;
     VecIO<T, VEC>::store(reinterpret_cast<T*>(dx.ptr) + voff(dx, id.n, iy, ix) + id.cv * VEC, out);
   }
 }
@@ -639,6 +708,8 @@ extern "C" int dct_pack_weights_batched64(const void* jobs_dev, int njobs, int t
   return dct_check_launch();
 }
 
+void dct_relu_bits_launch(const void* y_bf16, unsigned char* bits, long long chunks, hipStream_t st);   // igemm.hip
+
 extern "C" int dct_conv_cin1_fwd(const dct_view* x, const float* w, const float* bias, const dct_view* y,
                                  const dct_conv_desc* d, int dtype, dct_stream stream) {
   if (!view_ok(x) || !view_ok(y) || !w || !d || x->c != 1 || x->n != y->n) return DCT_ERR_BAD_ARG;
@@ -646,17 +717,24 @@ extern "C" int dct_conv_cin1_fwd(const dct_view* x, const float* w, const float*
   const StemGeom g = stem_geom(d, y->c);
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = (size_t)(y->c * d->R * d->S + y->c) * sizeof(float);
+  unsigned char* bits = d->relu_bits_out;
+  bool bits_done = false;
+  if (bits && (dtype != DCT_BF16 || !d->relu || y->c % 8 || y->sw != y->c || y->sh != (long long)y->w * y->c ||
+               y->sn != (long long)y->h * y->w * y->c)) return DCT_ERR_BAD_ARG;
   DISPATCH_T(dtype, {
     if (!vec_ok(y, 1, sizeof(T)) || (y->sw % VEC) || (y->sh % VEC) || (y->sn % VEC) || ((uintptr_t)y->ptr % 16)) return DCT_ERR_UNSUPPORTED;
     const long long total = (long long)y->n * y->h * y->w * ((y->c + VEC - 1) / VEC);
     if (d->R == 3 && d->S == 3 && d->stride == 1 && d->dil == 1 && y->c % VEC == 0) {
       const long long quads = (long long)y->n * y->h * ((y->w + 3) / 4) * (y->c / VEC);
-      DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_fwd3x3_kernel<T, VEC>), dim3(div_up(quads, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), g);
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_fwd3x3_kernel<T, VEC>), dim3(div_up(quads, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), g,
+                 VEC == 8 ? bits : nullptr);
+      bits_done = VEC == 8;
     } else if (d->R == 3 && d->S == 3)
       DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_fwd_kernel<T, VEC, 3>), dim3(div_up(total, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), g);
     else
       DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_fwd_kernel<T, VEC, 0>), dim3(div_up(total, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), g);
   });
+  if (bits && !bits_done) dct_relu_bits_launch(y->ptr, bits, (long long)y->n * y->h * y->w * (y->c / 8), st);
   return dct_check_launch();
 }
 
@@ -734,6 +812,30 @@ extern "C" int dct_maxpool2x2_bwd(const dct_view* x, const dct_view* dy, const d
     if (!vec_ok(x, VEC, sizeof(T)) || !vec_ok(dy, VEC, sizeof(T)) || !vec_ok(dx, VEC, sizeof(T))) return DCT_ERR_UNSUPPORTED;
     const long long total = (long long)dy->n * dy->h * dy->w * (x->c / VEC);
     DCT_LAUNCH(DCT_PROF_POINTWISE, (maxpool_bwd_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), 0, st, to_view(x), to_view(dy), to_view(dx), relu_mask, scale);
+  });
+  return dct_check_launch();
+}
+
+extern "C" int dct_maxpool2x2_fwd_codes(const dct_view* x, const dct_view* y, uint8_t* codes, int dtype, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(y) || !codes || x->n != y->n || x->c != y->c) return DCT_ERR_BAD_ARG;
+  if (y->h != (x->h + 1) / 2 || y->w != (x->w + 1) / 2) return DCT_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, {
+    if (!vec_ok(x, VEC, sizeof(T)) || !vec_ok(y, VEC, sizeof(T)) || ((uintptr_t)codes % VEC)) return DCT_ERR_UNSUPPORTED;
+    const long long total = (long long)y->n * y->h * y->w * (y->c / VEC);
+    DCT_LAUNCH(DCT_PROF_POINTWISE, (maxpool_fwd_codes_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), 0, st, to_view(x), to_view(y), codes);
+  });
+  return dct_check_launch();
+}
+extern "C" int dct_maxpool2x2_bwd_codes(const uint8_t* codes, const dct_view* dy, const dct_view* dx, int relu_mask,
+                                        float scale, int dtype, dct_stream stream) {
+  if (!codes || !view_ok(dy) || !view_ok(dx) || dy->c != dx->c || dx->n != dy->n) return DCT_ERR_BAD_ARG;
+  if (dy->h != (dx->h + 1) / 2 || dy->w != (dx->w + 1) / 2) return DCT_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, {
+    if (!vec_ok(dy, VEC, sizeof(T)) || !vec_ok(dx, VEC, sizeof(T)) || ((uintptr_t)codes % VEC)) return DCT_ERR_UNSUPPORTED;
+    const long long total = (long long)dy->n * dy->h * dy->w * (dy->c / VEC);
+    DCT_LAUNCH(DCT_PROF_POINTWISE, (maxpool_bwd_codes_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), 0, st, codes, to_view(dy), to_view(dx), relu_mask, scale);
   });
   return dct_check_launch();
 }

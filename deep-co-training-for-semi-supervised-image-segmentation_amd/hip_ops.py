@@ -40,10 +40,29 @@ def _dt(t: torch.Tensor) -> int:
 
 
 # ------------------------------------------------------------------------------ conv family
+def relu_bits_like(t: torch.Tensor):
+    """Buffer for the ReLU-gate bits of a dense bf16 NHWC tensor (one bit per element), or None where bits do not apply."""
+    if t.dtype != torch.bfloat16 or t.shape[3] % 8 or not t.is_contiguous():
+        return None
+    return torch.empty(t.shape[0], t.shape[1], t.shape[2], t.shape[3] // 8, dtype=torch.uint8, device=t.device)
+
+
+def _bits_ok(bits, of):
+    if bits is None:
+        return None
+    assert of is not None and bits.dtype == torch.uint8 and bits.is_contiguous() and of.is_contiguous()
+    assert tuple(bits.shape) == (of.shape[0], of.shape[1], of.shape[2], of.shape[3] // 8), (bits.shape, of.shape)
+    return bits
+
+
 def conv2d(x, w_packed, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=False, mask=None,
-           mask_channels=0, mask_scale=1.0, accumulate=False, scatter2x2=False):
-    """y (NHWC view, written in place) = epilogue(conv(x, w_packed)); see include/dct.h dct_conv2d."""
-    d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu, scatter2x2, accumulate, mask_channels, mask_scale)
+           mask_channels=0, mask_scale=1.0, accumulate=False, scatter2x2=False, mask_bits=None, relu_bits_out=None):
+    """y (NHWC view, written in place) = epilogue(conv(x, w_packed)); see include/dct.h dct_conv2d.
+
+    ``relu_bits_out`` (uint8 [N,H,W,C/8], dense y): the launch also leaves the ReLU-gate bits of y there (`relu_bits_like`);
+    ``mask_bits``: such bits of ``mask`` -- the data gradient then reads 1/16 of the bytes where its epilogue can."""
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu, scatter2x2, accumulate, mask_channels, mask_scale,
+                  _bits_ok(mask_bits, mask), _bits_ok(relu_bits_out, y))
     vx, vy = view(x), view(y)
     lib = _lib.load()
     dt = _dt(x)
@@ -135,8 +154,8 @@ def flat_sum(out, a, b, c=None):
     return out
 
 
-def conv_cin1_fwd(x, w, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=False):
-    d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu)
+def conv_cin1_fwd(x, w, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=False, relu_bits_out=None):
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu, relu_bits_out=_bits_ok(relu_bits_out, y))
     vx, vy = view(x), view(y)
     call("dct_conv_cin1_fwd", C.byref(vx), ptr(w), ptr(bias), C.byref(vy), C.byref(d), _dt(y), stream())
     return y
@@ -174,14 +193,25 @@ def head_bwd(x, dy, w, dx, dw, db, relu_mask=True, accumulate=False):
 
 
 # ------------------------------------------------------------------------------ pointwise
-def maxpool_fwd(x, y):
+def maxpool_fwd(x, y, codes=None):
+    """``codes`` (uint8, dense, y's shape): also keep the routing decision (window position of the first maximum + its ReLU
+    gate) for `maxpool_bwd(codes=...)`, which then does not re-read x."""
     vx, vy = view(x), view(y)
-    call("dct_maxpool2x2_fwd", C.byref(vx), C.byref(vy), _dt(x), stream())
+    if codes is not None:
+        assert codes.dtype == torch.uint8 and codes.is_contiguous() and tuple(codes.shape) == tuple(y.shape)
+        call("dct_maxpool2x2_fwd_codes", C.byref(vx), C.byref(vy), ptr(codes), _dt(x), stream())
+    else:
+        call("dct_maxpool2x2_fwd", C.byref(vx), C.byref(vy), _dt(x), stream())
     return y
 
 
-def maxpool_bwd(x, dy, dx, relu_mask=False, scale=1.0):
-    vx, vdy, vdx = view(x), view(dy), view(dx)
+def maxpool_bwd(x, dy, dx, relu_mask=False, scale=1.0, codes=None):
+    vdy, vdx = view(dy), view(dx)
+    if codes is not None:
+        assert codes.dtype == torch.uint8 and codes.is_contiguous() and tuple(codes.shape) == tuple(dy.shape)
+        call("dct_maxpool2x2_bwd_codes", ptr(codes), C.byref(vdy), C.byref(vdx), int(relu_mask), float(scale), _dt(dy), stream())
+        return dx
+    vx = view(x)
     call("dct_maxpool2x2_bwd", C.byref(vx), C.byref(vdy), C.byref(vdx), int(relu_mask), float(scale), _dt(x), stream())
     return dx
 

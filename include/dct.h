@@ -79,6 +79,12 @@ typedef struct dct_conv_desc {
   int32_t accumulate;
   int32_t mask_channels;
   float mask_scale;
+  /* ReLU-gate bits: one bit per element of a DENSE bf16 NHWC tensor, byte (pixel * C/8 + c/8), bit c%8 = "element > 0".
+   * relu_bits_out (nullable): dct_conv2d / dct_conv_cin1_fwd also leave the bits of y there (y dense, C % 8 == 0, bf16).
+   * mask_bits (nullable, with `mask` still passed): the same information as `mask` (dense, mask_channels = all of y's
+   * channels) at 1/16 of the bytes; the kernels whose epilogue can, read it instead of the activation. */
+  const uint8_t* mask_bits;
+  uint8_t* relu_bits_out;
 } dct_conv_desc;
 
 size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype);
@@ -150,6 +156,13 @@ int dct_conv1x1_head_bwd(const dct_view* x, const dct_view* dy, const float* w, 
 int dct_maxpool2x2_fwd(const dct_view* x, const dct_view* y, int dtype, dct_stream stream);
 int dct_maxpool2x2_bwd(const dct_view* x, const dct_view* dy, const dct_view* dx, int relu_mask,
                        float scale, int dtype, dct_stream stream);
+
+/* The same pair with the routing kept from the forward pass instead of re-derived from x: codes (uint8, dense
+ * [N][y.h][y.w][C], 8-byte aligned) receives per pooled element bits 0-1 = window position (2*dy+dx) of the first maximum,
+ * bit 2 = "maximum > 0" (the ReLU / dropout gate), bit 3 = no maximum; the backward pass reads dy and codes only. */
+int dct_maxpool2x2_fwd_codes(const dct_view* x, const dct_view* y, uint8_t* codes, int dtype, dct_stream stream);
+int dct_maxpool2x2_bwd_codes(const uint8_t* codes, const dct_view* dy, const dct_view* dx, int relu_mask,
+                             float scale, int dtype, dct_stream stream);
 
 /* ---- K5: bilinear resize, align_corners=True -------------------------------------------
  * Replaces F.upsample_bilinear (network.py:232-240).  Any in/out size.  y may be a channel

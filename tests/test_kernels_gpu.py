@@ -203,6 +203,59 @@ def _shared_halo_case(ops, B, Cin, H, W, Cout, pad):
     close(to_cpu(yd), ref, dtype, "halo conv mask/accumulate/views")
 
 
+def _pack_bits(t_nhwc):
+    """ReLU-gate bits of a dense NHWC tensor as the kernels lay them out: byte (pixel, c // 8), bit c % 8."""
+    pos = (t_nhwc.float() > 0).to(torch.int32)
+    n, h, w, c = pos.shape
+    return (pos.view(n, h, w, c // 8, 8) << torch.arange(8, device=pos.device, dtype=torch.int32)).sum(-1).to(torch.uint8)
+
+
+# every conv path: shared halo (128- and 64-channel tiles), packed rows (with and without its split), per-tap staged, split-K
+@pytest.mark.parametrize("B,Cin,H,W,Cout,pad,k,stride", [
+    (4, 64, 130, 130, 128, 0, 3, 1), (4, 64, 101, 117, 64, 0, 3, 1), (5, 128, 122, 90, 128, 2, 3, 1),
+    (16, 512, 13, 13, 1024, 0, 3, 1), (16, 1024, 11, 11, 1024, 2, 3, 1), (16, 256, 29, 29, 512, 0, 3, 1),
+    (2, 64, 20, 22, 64, 0, 3, 1), (16, 256, 48, 48, 128, 0, 3, 1), (8, 128, 24, 24, 256, 0, 2, 2)])
+def test_conv2d_relu_gate_bits(ops, B, Cin, H, W, Cout, pad, k, stride):
+    """A forward launch with ``relu_bits_out`` leaves exactly the bits of (y > 0); a data-gradient launch with ``mask_bits``
+    gives bit for bit what the launch masked by the activation itself gives."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(23)
+    x = to_dev(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = kmajor(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y0 = torch.empty(B, Ho, Wo, Cout, dtype=dtype, device=DEV)
+    ops.conv2d(x, w, b, y0, R=k, S=k, stride=stride, pad_h=pad, pad_w=pad, relu=True)
+    y1 = torch.empty_like(y0)
+    bits = ops.relu_bits_like(y1)
+    bits.fill_(0xA5)
+    ops.conv2d(x, w, b, y1, R=k, S=k, stride=stride, pad_h=pad, pad_w=pad, relu=True, relu_bits_out=bits)
+    assert torch.equal(y1, y0)
+    assert torch.equal(bits, _pack_bits(y1))
+    assert 0.2 < (y1 > 0).float().mean().item() < 0.8
+    # the same launch as a masked one (what the data gradient of the NEXT layer does with y as its mask)
+    act = to_dev(torch.randn(B, Cout, Ho, Wo, generator=g), dtype)
+    want = torch.empty_like(y0)
+    ops.conv2d(x, w, None, want, R=k, S=k, stride=stride, pad_h=pad, pad_w=pad, mask=act, mask_scale=2.0)
+    got = torch.full_like(y0, float("nan"))
+    ops.conv2d(x, w, None, got, R=k, S=k, stride=stride, pad_h=pad, pad_w=pad, mask=act, mask_scale=2.0, mask_bits=_pack_bits(act))
+    assert torch.equal(got, want)
+
+
+def test_stem_relu_gate_bits(ops):
+    g = torch.Generator().manual_seed(24)
+    B, H, W, Cout = 3, 37, 30, 64
+    x = torch.rand(B, H, W, 1, generator=g).to(DEV)
+    w = (torch.randn(Cout, 9, generator=g) / 3).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    y0 = torch.empty(B, H - 2, W - 2, Cout, dtype=torch.bfloat16, device=DEV)
+    ops.conv_cin1_fwd(x, w, b, y0, relu=True)
+    y1 = torch.empty_like(y0)
+    bits = ops.relu_bits_like(y1)
+    ops.conv_cin1_fwd(x, w, b, y1, relu=True, relu_bits_out=bits)
+    assert torch.equal(y1, y0) and torch.equal(bits, _pack_bits(y1))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 128, 10, 9, 64), (1, 1024, 9, 9, 512)])
 def test_convT2x2_fwd_scatter(ops, dtype, B, Cin, H, W, Cout):
@@ -458,6 +511,15 @@ def test_maxpool(ops, dtype, H, W):
     assert torch.equal(to_cpu(dx)[pos], rx[pos])
     ops.maxpool_bwd(xd, to_dev(dy, dtype), dx, relu_mask=True, scale=2.0)
     close(to_cpu(dx), rx * pos * 2.0, dtype, "maxpool bwd masked", rtol16=1e-6, rtol32=1e-7)
+    # the routing codes kept by the forward pass give the same two gradients bit for bit, without x
+    codes = torch.empty(yd.shape, dtype=torch.uint8, device=DEV)
+    yc = torch.empty_like(yd)
+    ops.maxpool_fwd(xd, yc, codes=codes)
+    assert torch.equal(yc, yd)
+    for masked, scale in ((False, 1.0), (True, 2.0)):
+        want = ops.maxpool_bwd(xd, to_dev(dy, dtype), torch.empty_like(xd), relu_mask=masked, scale=scale)
+        got = ops.maxpool_bwd(None, to_dev(dy, dtype), torch.full_like(xd, float("nan")), relu_mask=masked, scale=scale, codes=codes)
+        assert torch.equal(got, want), (masked, scale)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -143,6 +143,27 @@ def test_unet_train_mode_dropout_replay():
     assert torch.equal(net(xd), net(xd))
 
 
+def test_unet_gate_bits_and_pool_codes_leave_every_gradient_bit_identical():
+    """The backward pass with ReLU-gate bits (instead of re-read activations) and max-pool routing codes (instead of the
+    re-read pool input) gives bit for bit the gradients of the plan without them -- train mode, with dropout."""
+    C = 4
+    onet = _oracle_net(C, 7, p=0.5).train()
+    x = torch.rand(2, 1, 192, 208, generator=torch.Generator().manual_seed(6)).to(DEV)
+    gl = torch.randn(2, C, 192, 208, generator=torch.Generator().manual_seed(7)).to(DEV)
+    grads = []
+    for flag in (False, True):
+        net = _hip_net(onet, C, torch.bfloat16, p=0.5).train()
+        net.relu_bits = net.pool_codes = flag
+        net.dropout_seed = 99
+        xd = x.clone().requires_grad_(True)
+        y = net(xd)
+        y.backward(gl)
+        grads.append([y.detach().clone(), xd.grad.clone()] + [p.grad.clone() for p in net.parameters()])
+    names = ["logits", "grad_x"] + [k for k, _ in net.named_parameters()]
+    for k, a, b in zip(names, *grads):
+        assert torch.equal(a, b), k
+
+
 def test_unet_rejects_small_and_cpu_inputs():
     from dct_amd.arch import get_arch
     net = get_arch("unet", {"num_classes": 4}).to(DEV)

@@ -41,7 +41,7 @@ def timeit(fn, reps):
     return a.elapsed_time(b) / reps * 1e-3
 
 
-def run(B, reps, what, label, only=None):
+def run(B, reps, what, label, only=None, use_mask=True):
     dt = torch.bfloat16
     rows = []
     tot = {k: [0.0, 0.0] for k in ("fwd", "dgrad", "wgrad")}
@@ -64,7 +64,7 @@ def run(B, reps, what, label, only=None):
             t = timeit(lambda: K.conv2d(x, w, bias, y, relu=True), reps)
             r["fwd"] = t; tot["fwd"][0] += fl; tot["fwd"][1] += t
         if "dgrad" in what:
-            t = timeit(lambda: K.conv2d(dy, wd, None, dx, pad_h=2, pad_w=2, mask=x), reps)
+            t = timeit(lambda: K.conv2d(dy, wd, None, dx, pad_h=2, pad_w=2, mask=x if use_mask else None), reps)
             r["dgrad"] = t; tot["dgrad"][0] += fl; tot["dgrad"][1] += t
         if "wgrad" in what:
             t = timeit(lambda: K.conv2d_wgrad(dy, x, dw, accumulate=True), reps)
@@ -87,7 +87,7 @@ def run(B, reps, what, label, only=None):
             t = timeit(lambda: K.conv2d(x, wf, bias, y, R=1, S=1, relu=True, scatter2x2=True), reps)
             r["fwd"] = t; tot["fwd"][0] += fl; tot["fwd"][1] += t
         if "dgrad" in what:
-            t = timeit(lambda: K.conv2d(dy, wd, None, dx, R=2, S=2, stride=2, mask=x), reps)
+            t = timeit(lambda: K.conv2d(dy, wd, None, dx, R=2, S=2, stride=2, mask=x if use_mask else None), reps)
             r["dgrad"] = t; tot["dgrad"][0] += fl; tot["dgrad"][1] += t
         if "wgrad" in what:
             t = timeit(lambda: K.conv2d_wgrad(x, dy, dw, R=2, S=2, stride=2, accumulate=True), reps)
@@ -119,10 +119,16 @@ def main():
     ap.add_argument("--ab-knob", action="append", default=[], metavar="KNOB=V0,V1[,...]",
                     help="A/B any dct_tune_set knob: interleaved rounds of the listed values in one process (repeatable)")
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--no-mask", action="store_true", help="data gradients without the ReLU mask re-read (timing study only)")
     args = ap.parse_args()
     what = args.what.split(",")
     lib = _lib.load()
     only = set(args.only.split(",")) if args.only else None
+    if args.no_mask:
+        for rnd in range(args.rounds):
+            run(args.batch, args.reps, ["dgrad"], f"round {rnd}: data gradient with the ReLU mask (re-reads the layer input)", only)
+            run(args.batch, args.reps, ["dgrad"], f"round {rnd}: data gradient WITHOUT the mask (timing study)", only, use_mask=False)
+        return
     run(args.batch, args.reps, what, "default", only)
     if args.ab_wgrad:
         ab_wgrad(args, lib, only)
