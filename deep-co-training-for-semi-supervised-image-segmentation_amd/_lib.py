@@ -36,6 +36,17 @@ class EnetTf(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_void_p), ("mode", C.c_int32)]
 
 
+class EnetBnFin(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("training", C.c_int32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
+                ("save_var", C.c_void_p)]
+
+
+class EnetBnBwdFin(C.Structure):
+    _fields_ = [("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dslope", C.c_void_p), ("c1c2", C.c_void_p), ("training", C.c_int32)]
+
+
 def conv_desc(R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=0, scatter2x2=0, accumulate=0,
               mask_channels=0, mask_scale=1.0, mask_bits=None, relu_bits_out=None) -> ConvDesc:
     return ConvDesc(R, S, stride, dil, pad_h, pad_w, int(relu), int(scatter2x2), int(accumulate),
@@ -120,11 +131,21 @@ SIGNATURES = {
     "dct_enet_bn_bwd": (_i, [_VP, _VP, _VP, _P, _P, _P, _i, _P, _P, _P, _P, _P, _P, _i, _VP, _i, _i, _P, _sz, _P]),
     "dct_enet_bn_bwd_rows": (_i, [_VP, _VP, _VP, _P, _P, _P, _i, _P, _P, _P, _P, _P, _P, _i, _VP, _i, _i, _P, _sz, _i, _P]),
     "dct_enet_conv_bnbwd_stats": (_i, [_VP, _P, _VP, _DP, _i, _i, _i, _i, _i, _i, _VP, _P, _P, _P, _i, _P, _P, _P, _i, _P, _P]),
+    "dct_enet_conv_stats_fin": (_i, [_VP, _P, _P, _TP, _VP, _DP, _i, _i, _i, _i, _i, _i, _P, _i, _P, _P, _P, _P]),
+    "dct_enet_conv_bnbwd_stats_fin": (_i, [_VP, _P, _VP, _DP, _i, _i, _i, _i, _i, _i, _VP, _P, _P, _P, _i, _P, _P, _P, _i, _P, _P, _P, _P]),
     "dct_enet_channel_sum": (_i, [_VP, _P, _i, _i, _P, _sz, _P]),
     "dct_enet_tail_fwd": (_i, [_VP, _TP, _VP, _VP, _TP, _P, _i, _i, _VP, _i, _i, _P]),
     "dct_enet_tail_bwd": (_i, [_VP, _VP, _P, _i, _i, _i, _VP, _i, _i, _P]),
     "dct_enet_wgrad_workspace_bytes": (_sz, [_VP, _VP, _DP]),
     "dct_enet_wgrad": (_i, [_VP, _TP, _VP, _TP, _P, _DP, _i, _i, _P, _sz, _P]),
+    "dct_group_begin": (_i, [_i]),
+    "dct_group_member": (_i, [_i]),
+    "dct_group_max": (_i, []),
+    "dct_group_abort": (_i, []),
+    "dct_group_end": (_i, [_P, _P, _P]),
+    "dct_leaves_begin": (_i, []),
+    "dct_leaves_flush": (_i, [_P, _P]),
+    "dct_leaves_end": (_i, [_P, _P]),
     "dct_bn_workspace_bytes": (_sz, [_i]),
     "dct_bn_fwd": (_i, [_VP, _P, _P, _f, _f, _P, _P, _i, _P, _P, _P, _P, _VP, _i, _i, _P, _sz, _P]),
     "dct_bn_bwd": (_i, [_VP, _VP, _P, _P, _P, _P, _P, _P, _i, _P, _i, _i, _VP, _i, _P, _sz, _P]),
@@ -175,7 +196,15 @@ def ptr(t) -> int:
     return t.data_ptr()
 
 
+# While a pass group is open (hip_ops.PassGroup) only the entry points that RECORD their launches may be called: anything
+# else would launch at once, ahead of the recorded launches it depends on.
+GROUP_OPEN = False
+_RECORDING = None
+
+
 def call(name: str, *args) -> None:
+    if GROUP_OPEN and not name.startswith(("dct_enet_", "dct_group_", "dct_leaves_")):
+        raise RuntimeError(f"dct_amd: {name} inside an open pass group (only the Enet entry points record their launches)")
     check(getattr(load(), name)(*args), name)
 
 

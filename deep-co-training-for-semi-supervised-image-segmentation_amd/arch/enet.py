@@ -169,6 +169,15 @@ class _Decoder(nn.Module):
             _EConvT(14, num_classes, 2, stride=2)])
 
 
+def _empty(*a, **k):
+    """Allocation of a plan: referenced until the launches are issued while the pass records into a K.PassGroup."""
+    return K.keep(torch.empty(*a, **k))
+
+
+def _empty_like(t):
+    return K.keep(torch.empty_like(t))
+
+
 class _Rec(object):
     """what one conv+BN(+act) unit leaves behind for its consumers and for the backward"""
     __slots__ = ("raw", "tf", "mean", "invstd", "bn", "act", "conv", "src", "src_tf")
@@ -253,6 +262,7 @@ class Enet(nn.Module):
             self._defer_running = False
 
     supports_deferred_running_stats = True
+    supports_pass_groups = True          # the plan's launches record into a hip_ops.PassGroup (grouped passes)
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
@@ -285,7 +295,8 @@ class Enet(nn.Module):
             if stats is not None:
                 self._apply_running(stats)
 
-    def plan_backward(self, tape, dlogits: torch.Tensor, need_dx: bool = False, need_dw: bool = True, grad_buffer=None):
+    def plan_backward(self, tape, dlogits: torch.Tensor, need_dx: bool = False, need_dw: bool = True, grad_buffer=None,
+                      leaf_hook=None, leaf_every: int = 7):
         """``grad_buffer``: flat fp32 tensor (flat_params.total elements, zeroed by the caller) that receives this pass's
         parameter gradients instead of the network's gradient buffer -- the 2-3 backward passes a model sees per step are
         independent apart from that accumulation, so the trainer runs them on separate streams and adds the buffers in a fixed
@@ -293,10 +304,12 @@ class Enet(nn.Module):
         if need_dw:
             self.flat_params.ensure_grads()
         self._grad_target = grad_buffer if need_dw else None
+        self._leaf_hook = (leaf_hook, max(1, int(leaf_every))) if (leaf_hook is not None and need_dw) else None
         try:
             dx = self._run_backward(tape, dlogits, need_dx, need_dw)
         finally:
             self._grad_target = None
+            self._leaf_hook = None
         return dx.reshape(dx.shape[0], 1, dx.shape[1], dx.shape[2]) if dx is not None else None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -311,29 +324,37 @@ class Enet(nn.Module):
         """conv (+bias) -> raw; BatchNorm statistics -> consumer transform."""
         dt, dev = self.compute_dtype, src.device
         B = src.shape[0]
-        raw = torch.empty(B, out_hw[0], out_hw[1], conv.cout, dtype=torch.float32, device=dev)   # raw: always fp32
+        raw = _empty(B, out_hw[0], out_hw[1], conv.cout, dtype=torch.float32, device=dev)   # raw: always fp32
         stats, rows = None, 0
         tiles = (B * out_hw[0] * out_hw[1] + 31) // 32
         if (self.training and self.fuse_bn_stats and dt != torch.float32 and conv.cin >= 16 and conv.cin % 16 == 0 and
                 conv.cout <= 128 and tiles <= 1024):
             # MFMA convolution: its epilogue writes the BatchNorm partial sums (one launch and one read of `raw` less per seam)
-            stats = torch.empty(tiles * conv.cout * 3, dtype=torch.float64, device=dev)
-            rows = self._conv_fwd(src, src_tf, conv, raw, stats=stats)
+            stats = _empty(tiles * conv.cout * 3, dtype=torch.float64, device=dev)
+            fused = True
         else:
-            self._conv_fwd(src, src_tf, conv, raw)
+            fused = False
         rec = _Rec()
         rec.raw, rec.conv, rec.bn, rec.act, rec.src, rec.src_tf = raw, conv, bn, act, src, src_tf
         c = conv.cout
         if self.training:
             # batch statistics only: the running statistics are updated by _apply_running from (mean, unbiased variance)
             if self._bn_stats is None:
-                self._bn_stats = torch.empty(5 * self._bn_total, dtype=torch.float32, device=dev)
+                self._bn_stats = _empty(5 * self._bn_total, dtype=torch.float32, device=dev)
             cp, base = (c + 3) // 4 * 4, 5 * self._bn_off[id(bn)]
             vec = self._bn_stats[base:base + 5 * cp].view(5, cp)[:, :c]
-            K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, None, None,
-                                True, vec[0], vec[1], vec[2], vec[3], save_var=vec[4], partial=stats, partial_rows=rows)
+            done = False
+            if fused:       # the BatchNorm's finalize rides in the convolution's last block where the library can (-> done)
+                rows, done = self._conv_fwd(src, src_tf, conv, raw, stats=stats,
+                                            fin=(self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, vec[0], vec[1], vec[2], vec[3], vec[4]))
+            else:
+                self._conv_fwd(src, src_tf, conv, raw)
+            if not done:
+                K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, None, None,
+                                    True, vec[0], vec[1], vec[2], vec[3], save_var=vec[4], partial=stats, partial_rows=rows)
         else:
-            vec = torch.empty(4, c, dtype=torch.float32, device=dev)
+            self._conv_fwd(src, src_tf, conv, raw)
+            vec = _empty(4, c, dtype=torch.float32, device=dev)
             K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, bn.running_mean, bn.running_var,
                                 False, vec[0], vec[1], vec[2], vec[3])
         if isinstance(act, _PReLU):
@@ -345,7 +366,7 @@ class Enet(nn.Module):
         rec.mean, rec.invstd = vec[2], vec[3]
         return rec
 
-    def _conv_fwd(self, src, src_tf, conv, dst, stats=None):
+    def _conv_fwd(self, src, src_tf, conv, dst, stats=None, fin=None):
         """``stats`` (float64 scratch): the convolution's epilogue also writes the BatchNorm partial sums of ``dst`` where it can;
         -> number of partial rows (0: not written)."""
         w = self._w(conv.weight)
@@ -354,8 +375,8 @@ class Enet(nn.Module):
         if stats is not None:
             kw = dict(R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1], compute=self.compute_dtype)
             if conv.transposed:
-                return K.enet_conv_stats(src, w, b, src_tf, dst, stats, transposed=True, ws=(1, conv.cout, t * conv.cout), **kw)
-            return K.enet_conv_stats(src, w, b, src_tf, dst, stats, dil=conv.dil, ws=(t * conv.cin, conv.cin, 1), **kw)
+                return K.enet_conv_stats(src, w, b, src_tf, dst, stats, transposed=True, ws=(1, conv.cout, t * conv.cout), fin=fin, **kw)
+            return K.enet_conv_stats(src, w, b, src_tf, dst, stats, dil=conv.dil, ws=(t * conv.cin, conv.cin, 1), fin=fin, **kw)
         if conv.transposed:
             K.enet_conv(src, w, b, src_tf, dst, R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1],
                         transposed=True, ws=(1, conv.cout, t * conv.cout), compute=self.compute_dtype)
@@ -363,7 +384,7 @@ class Enet(nn.Module):
             K.enet_conv(src, w, b, src_tf, dst, R=conv.kh, S=conv.kw, stride=conv.stride, dil=conv.dil, pad_h=conv.pad[0],
                         pad_w=conv.pad[1], ws=(t * conv.cin, conv.cin, 1), compute=self.compute_dtype)
 
-    def _conv_dgrad(self, g, conv, dst, accumulate=False, resid=None, bn_of_dst=None):
+    def _conv_dgrad(self, g, conv, dst, accumulate=False, resid=None, bn_of_dst=None, need_dw=True):
         """dst (+)= d(loss)/d(conv input) given g = d/d(conv output).
 
         ``bn_of_dst`` (a _Rec): dst is the gradient wrt act(BN(rec.raw)); where the MFMA form runs, its epilogue also writes that
@@ -376,15 +397,19 @@ class Enet(nn.Module):
             cin_g = g.shape[3]
             if (self.fuse_bn_bwd_stats and self._tape_training and self.compute_dtype != torch.float32 and cin_g >= 16 and cin_g % 16 == 0 and
                     dst.shape[3] <= 128 and tiles <= 1024 and not accumulate and resid is None):
-                stats = torch.empty(tiles * dst.shape[3] * 3, dtype=torch.float64, device=dst.device)
+                stats = _empty(tiles * dst.shape[3] * 3, dtype=torch.float64, device=dst.device)
                 kw = dict(R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1], compute=self.compute_dtype)
+                # the BatchNorm-backward finalize (parameter gradients + the apply pass's two means) rides in the launch where it can
+                scratch = _empty(2 * dst.shape[3], dtype=torch.float32, device=dst.device)
+                fin = (self._g(rec.bn.weight) if need_dw else None, self._g(rec.bn.bias) if need_dw else None,
+                       self._g(rec.act.weight) if (need_dw and isinstance(rec.act, _PReLU)) else None, scratch, self._tape_training)
                 if conv.transposed:
-                    rows = K.enet_conv_bnbwd_stats(g, w, dst, stats, rec.raw, rec.tf, rec.mean, rec.invstd,
-                                                   ws=(t * conv.cout, conv.cout, 1), **kw)
+                    rows, done = K.enet_conv_bnbwd_stats(g, w, dst, stats, rec.raw, rec.tf, rec.mean, rec.invstd,
+                                                         ws=(t * conv.cout, conv.cout, 1), fin=fin, **kw)
                 else:
-                    rows = K.enet_conv_bnbwd_stats(g, w, dst, stats, rec.raw, rec.tf, rec.mean, rec.invstd, dil=conv.dil,
-                                                   transposed=True, ws=(1, conv.cin, t * conv.cin), **kw)
-                return dst, stats, rows
+                    rows, done = K.enet_conv_bnbwd_stats(g, w, dst, stats, rec.raw, rec.tf, rec.mean, rec.invstd, dil=conv.dil,
+                                                         transposed=True, ws=(1, conv.cin, t * conv.cin), fin=fin, **kw)
+                return dst, (stats, scratch), (-1 if (done and rows > 0) else rows)
             self._conv_dgrad(g, conv, dst)
             return dst, None, 0
         rg, rm = resid if resid is not None else (None, None)
@@ -430,7 +455,7 @@ class Enet(nn.Module):
         core = mb.at(0)
         if blk.kind == "asym":
             c5, c15 = core.at(0), core.at(1)
-            mid_raw = torch.empty(B, oh, ow, c5.cout, dtype=torch.float32, device=dev)
+            mid_raw = _empty(B, oh, ow, c5.cout, dtype=torch.float32, device=dev)
             self._conv_fwd(r1.raw, r1.tf, c5, mid_raw)
             r2 = self._cba(mid_raw, None, c15, mb.at(1), mb.at(2), (oh, ow), save)
             st["mid_raw"] = mid_raw
@@ -438,10 +463,10 @@ class Enet(nn.Module):
             r2 = self._cba(r1.raw, r1.tf, core, mb.at(1), mb.at(2), (oh, ow), save)
         s3 = blk.block1x1_2
         r3 = self._cba(r2.raw, r2.tf, s3.at(0), s3.at(1), s3.at(2), (oh, ow), save)
-        out = torch.empty(B, oh, ow, blk.cout, dtype=dt, device=dev)
+        out = _empty(B, oh, ow, blk.cout, dtype=dt, device=dev)
         idx_out = None
         if blk.kind == "down":
-            idx_out = torch.empty(B, oh, ow, blk.cin, dtype=torch.uint8, device=dev)
+            idx_out = _empty(B, oh, ow, blk.cin, dtype=torch.uint8, device=dev)
             K.enet_tail_fwd(r3.raw, r3.tf, x, None, None, idx_out, blk.cin, 1, out)
         elif blk.kind == "up":
             cb = blk.conv_before_unpool
@@ -463,7 +488,7 @@ class Enet(nn.Module):
             xs = xs.contiguous()
         ini = self.encoder.initial
         r0 = self._cba(xs, None, ini.conv, ini.batch_norm, ini.prelu, (H // 2, W // 2), save)   # the image stays fp32
-        h = torch.empty(B, H // 2, W // 2, 14, dtype=dt, device=dev)
+        h = _empty(B, H // 2, W // 2, 14, dtype=dt, device=dev)
         K.enet_tail_fwd(r0.raw, r0.tf, xs, None, None, None, 13, 3, h)
         tape = [{"kind": "initial", "x": xs, "r0": r0, "out": h}] if save else None
         stack = []
@@ -480,7 +505,7 @@ class Enet(nn.Module):
             if save:
                 tape.append(st)
         fin = self.decoder.layers[5]
-        logits = torch.empty(B, H, W, self.num_classes, dtype=torch.float32, device=dev)
+        logits = _empty(B, H, W, self.num_classes, dtype=torch.float32, device=dev)
         self._conv_fwd(h, None, fin, logits)
         stats, self._bn_stats = self._bn_stats, None
         if save:
@@ -498,8 +523,11 @@ class Enet(nn.Module):
         partial sums, already written by the data-gradient convolution that produced g (_conv_dgrad(bn_of_dst=rec))."""
         dev = rec.raw.device
         c = rec.raw.shape[3]
-        draw = torch.empty(rec.raw.shape, dtype=self.compute_dtype, device=dev)
-        scratch = torch.empty(2 * c, dtype=torch.float32, device=dev)
+        draw = _empty(rec.raw.shape, dtype=self.compute_dtype, device=dev)
+        if partial is not None:          # (_conv_dgrad: the rows and the scratch its fused finalize may have filled already; rows < 0)
+            partial, scratch = partial
+        else:
+            scratch = _empty(2 * c, dtype=torch.float32, device=dev)
         dg = self._g(rec.bn.weight) if need_dw else None
         db = self._g(rec.bn.bias) if need_dw else None
         ds = self._g(rec.act.weight) if (need_dw and isinstance(rec.act, _PReLU)) else None
@@ -517,32 +545,32 @@ class Enet(nn.Module):
         d3 = self._bn_bwd(r3, dout, out, need_dw)
         if need_dw:
             self._conv_wgrad(d3, r3.conv, r2.raw, r2.tf, before_bn=True)
-        g2, p2, n2 = self._conv_dgrad(d3, r3.conv, torch.empty(r2.raw.shape, dtype=dt, device=r2.raw.device), bn_of_dst=r2)
+        g2, p2, n2 = self._conv_dgrad(d3, r3.conv, _empty(r2.raw.shape, dtype=dt, device=r2.raw.device), bn_of_dst=r2, need_dw=need_dw)
         d2 = self._bn_bwd(r2, g2, None, need_dw, partial=p2, rows=n2)
         if blk.kind == "asym":
             c5, c15 = blk.middle_block.at(0).at(0), blk.middle_block.at(0).at(1)
             mid_raw = st["mid_raw"]
             if need_dw:
                 self._conv_wgrad(d2, c15, mid_raw, None, before_bn=True)
-            gmid = self._conv_dgrad(d2, c15, torch.empty(mid_raw.shape, dtype=dt, device=mid_raw.device))
+            gmid = self._conv_dgrad(d2, c15, _empty(mid_raw.shape, dtype=dt, device=mid_raw.device))
             if need_dw:
                 self._conv_wgrad(gmid, c5, r1.raw, r1.tf)
-            g1, p1, n1 = self._conv_dgrad(gmid, c5, torch.empty(r1.raw.shape, dtype=dt, device=r1.raw.device), bn_of_dst=r1)
+            g1, p1, n1 = self._conv_dgrad(gmid, c5, _empty(r1.raw.shape, dtype=dt, device=r1.raw.device), bn_of_dst=r1, need_dw=need_dw)
         else:
             if need_dw:
                 self._conv_wgrad(d2, r2.conv, r1.raw, r1.tf, before_bn=True)
-            g1, p1, n1 = self._conv_dgrad(d2, r2.conv, torch.empty(r1.raw.shape, dtype=dt, device=r1.raw.device), bn_of_dst=r1)
+            g1, p1, n1 = self._conv_dgrad(d2, r2.conv, _empty(r1.raw.shape, dtype=dt, device=r1.raw.device), bn_of_dst=r1, need_dw=need_dw)
         d1 = self._bn_bwd(r1, g1, None, need_dw, partial=p1, rows=n1)
         if need_dw:
             self._conv_wgrad(d1, r1.conv, x, None, before_bn=True)
         # ---- input gradient = extension branch + main branch
-        dx = torch.empty_like(x)
+        dx = _empty_like(x)
         if blk.kind == "down":
             K.enet_tail_bwd(dout, out, st["idx"], blk.cin, 1, dx)
             self._conv_dgrad(d1, r1.conv, dx, accumulate=True)
         elif blk.kind == "up":
             rm: _Rec = st["rm"]
-            gm = K.enet_tail_bwd(dout, out, st["idx"], blk.cout, 2, torch.empty(rm.raw.shape, dtype=dt, device=rm.raw.device))
+            gm = K.enet_tail_bwd(dout, out, st["idx"], blk.cout, 2, _empty(rm.raw.shape, dtype=dt, device=rm.raw.device))
             dm = self._bn_bwd(rm, gm, None, need_dw)
             if need_dw:
                 self._conv_wgrad(dm, rm.conv, x, None, before_bn=True)
@@ -557,13 +585,16 @@ class Enet(nn.Module):
         fin = self.decoder.layers[5]
         st = tape[-1]
         self._tape_training = st["training"]
-        dl = dlogits if dt == torch.float32 else K.cast(dlogits, torch.empty(dlogits.shape, dtype=dt, device=dev))
+        dl = dlogits if dlogits.dtype == dt else K.cast(dlogits, _empty(dlogits.shape, dtype=dt, device=dev))
         if need_dw:
             self._conv_wgrad(dl, fin, st["x"], None)
-        g = torch.empty_like(st["x"])
+        g = _empty_like(st["x"])
         self._conv_dgrad(dl, fin, g)
-        for st in reversed(tape[1:-1]):
+        hook = getattr(self, "_leaf_hook", None)
+        for k, st in enumerate(reversed(tape[1:-1])):
             g = self._bottleneck_bwd(st, g, need_dw)
+            if hook is not None and (k + 1) % hook[1] == 0:
+                hook[0]()           # (K.LeafSide: the weight gradients held back so far go out on another queue)
         st = tape[0]
         r0 = st["r0"]
         d0 = self._bn_bwd(r0, g[..., :13], None, need_dw)
@@ -572,7 +603,7 @@ class Enet(nn.Module):
             self._conv_wgrad(d0, ini.conv, st["x"], None, before_bn=True)
         dx = None
         if need_dx:
-            dx = torch.empty_like(st["x"])
+            dx = _empty_like(st["x"])
             self._conv_dgrad(d0, ini.conv, dx)
             K.enet_tail_bwd(g, st["x"], None, 13, 3, dx, accumulate=True)
         return dx

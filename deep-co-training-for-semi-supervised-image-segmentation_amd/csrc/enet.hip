@@ -14,6 +14,7 @@
 //     max-unpool / zero-channel-pad of the down- and up-sampling bottlenecks.
 // Activations are NHWC in `dtype` (bf16 or f32); all per-channel vectors and the math are fp32.
 #include <algorithm>
+#include <vector>
 #include "dct_common.h"
 
 int g_enet_reduce_ppt = 8;           // pixels per thread of a per-channel reduction (sets the number of partial rows)
@@ -32,6 +33,68 @@ int g_enet_wgrad_slices = 1;          // 0: one pixel slice per round whatever t
 int g_enet_wgrad_max_blocks = 1024;   // dct_tune_set(DCT_TUNE_ENET_WGRAD_BLOCKS, n); <= WG_MAX_BLOCKS
 
 namespace {
+
+
+// ---- launch plumbing: single and GROUPED launches of the same kernel body -------------------------------------------
+// Every Enet kernel body is a functor F { using Args; THREADS; static __device__ run(const Args&) } with ALL of its
+// arguments in one struct.  enet_one<F> launches it as before.  enet_grp<F> runs up to GROUP_MAX independent argument
+// sets in ONE launch (blockIdx.z picks the set): the 2S forward (or backward) passes of a co-training step have identical
+// shapes and no dependencies among themselves, each underfills the device and each of their ~200-500 launches is a seam on
+// its queue -- grouped, they are one chain of launches instead of 2S (trainer/cotraining_totalloss.py::_run_step_wide).
+// The bodies are the same code on the same operands, so a grouped pass is bit-identical to the pass launched alone.
+// Recording (dct_group_begin / _member / _end): while a group is open the entry points below do not launch; they append
+// {body, grid, block, LDS bytes, argument blob} to the current member's list.  dct_group_end zips the lists: entry k of
+// all members becomes one grouped launch when body and launch geometry agree, else one launch per member.
+constexpr int GROUP_MAX = 6;
+template <typename A> struct GroupArgs { A m[GROUP_MAX]; };
+template <typename F> __global__ __launch_bounds__(F::THREADS) void enet_one(typename F::Args a) { F::run(a); }
+template <typename F> __global__ __launch_bounds__(F::THREADS) void enet_grp(GroupArgs<typename F::Args> g) { F::run(g.m[blockIdx.z]); }
+
+struct GroupRec {
+  void (*launch)(const void* const* args, int n, dim3 grid, dim3 block, size_t lds, hipStream_t st, int cls);
+  dim3 grid, block;
+  size_t lds;
+  int cls;
+  std::vector<char> blob;
+};
+struct GroupState {
+  bool active = false;
+  bool leaves_only = false;   // "side" recording: only the launches of LEAF work (weight gradients, bias sums -- nothing downstream
+                              // in the pass reads their results) are held back, everything else launches at once
+  int member = 0;
+  std::vector<std::vector<GroupRec>> recs;
+};
+GroupState g_grp;
+bool g_leaf_scope = false;    // set by the entry points whose launches are leaves (dct_enet_wgrad, dct_enet_channel_sum)
+struct LeafScope { bool was; LeafScope() : was(g_leaf_scope) { g_leaf_scope = true; } ~LeafScope() { g_leaf_scope = was; } };
+
+template <typename F>
+void enet_launch_n(const void* const* args, int n, dim3 grid, dim3 block, size_t lds, hipStream_t st, int cls) {
+  using A = typename F::Args;
+  static_assert(sizeof(GroupArgs<A>) <= 4000, "grouped kernel arguments exceed the kernarg segment");
+  if (n == 1) {
+    DCT_LAUNCH(cls, enet_one<F>, grid, block, lds, st, *reinterpret_cast<const A*>(args[0]));
+    return;
+  }
+  GroupArgs<A> g;
+  for (int i = 0; i < n; ++i) g.m[i] = *reinterpret_cast<const A*>(args[i]);
+  for (int i = n; i < GROUP_MAX; ++i) g.m[i] = g.m[0];
+  grid.z = (unsigned)n;
+  DCT_LAUNCH(cls, enet_grp<F>, grid, block, lds, st, g);
+}
+
+template <typename F>
+void enet_launch(int cls, dim3 grid, dim3 block, size_t lds, hipStream_t st, const typename F::Args& a) {
+  if (g_grp.active && (!g_grp.leaves_only || g_leaf_scope)) {
+    GroupRec r;
+    r.launch = &enet_launch_n<F>; r.grid = grid; r.block = block; r.lds = lds; r.cls = cls;
+    r.blob.assign(reinterpret_cast<const char*>(&a), reinterpret_cast<const char*>(&a) + sizeof(a));
+    g_grp.recs[g_grp.member].push_back(std::move(r));
+    return;
+  }
+  const void* one[1] = {&a};
+  enet_launch_n<F>(one, 1, grid, block, lds, st, cls);
+}
 
 // Element access through a view whose storage is `T` or, when its bit of the call's f32 mask is set, fp32
 // (raw conv outputs stay fp32 in bf16 mode: BatchNorm subtracts their mean, which would cancel bf16's 8 bits).
@@ -80,6 +143,197 @@ static inline Tf to_tf(const dct_enet_tf* t) {
   return r;
 }
 
+// ---- per-channel partial sums -> per-channel results: the fold and the three "finalize" bodies ------------------------------
+// Fixed-order fold of the per-block partials: thread (c, part) sums blocks part, part+NP, ... and the NP
+// partial sums of a channel are then added in ascending `part` -- deterministic, and blockDim/CP-way parallel
+// instead of one thread walking all blocks.  Result valid for threads with part == 0.
+constexpr int FT = 1024;      // threads of the one-block finalize kernels: with 256 a 128-channel fold walked 128 partial rows per
+                              // thread (11 us of dependent loads, 16 % of a cfg4 step's kernel time); 1024 threads walk 32
+// SC1: the rows were written by OTHER blocks of this same launch (the finalize rides in the producing kernel's last block, see
+// last_block_arrived): every load of them is an agent-scope (sc1) load, which bypasses this CU's L1.
+template <bool SC1> __device__ __forceinline__ double ld_partial(const double* p) {
+  if constexpr (SC1) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  } else {
+    return *p;
+  }
+}
+template <bool SC1> __device__ __forceinline__ void st_partial(double* p, double v) {
+  if constexpr (SC1) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *p = v;
+  }
+}
+template <bool SC1>
+__device__ __forceinline__ void fold_partials(const double* partial, int blocks, int C, double* red, double s[3]) {
+  int CP = 1;
+  while (CP < C) CP <<= 1;
+  const int NP = (int)blockDim.x / CP;        // blockDim.x = g_enet_fold_threads (256 ... FT), or the producing kernel's block
+  const int c = threadIdx.x % CP, part = threadIdx.x / CP;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (c < C && part < NP) {
+    // eight rows per round trip (the rolled loop is load -> wait -> add per row: one L2 latency per partial row).  The adds keep
+    // their order, so the sums are bit for bit those of the rolled loop.
+    int b = part;
+    for (; b + 7 * NP < blocks; b += 8 * NP) {
+      double q[8][3];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double* p = partial + ((long long)(b + u * NP) * C + c) * 3;
+        q[u][0] = ld_partial<SC1>(p); q[u][1] = ld_partial<SC1>(p + 1); q[u][2] = ld_partial<SC1>(p + 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a0 += q[u][0]; a1 += q[u][1]; a2 += q[u][2]; }
+    }
+    for (; b < blocks; b += NP) {
+      const double* q = partial + ((long long)b * C + c) * 3;
+      a0 += ld_partial<SC1>(q); a1 += ld_partial<SC1>(q + 1); a2 += ld_partial<SC1>(q + 2);
+    }
+  }
+  if (threadIdx.x < NP * CP) { red[threadIdx.x * 3] = a0; red[threadIdx.x * 3 + 1] = a1; red[threadIdx.x * 3 + 2] = a2; }
+  __syncthreads();
+  s[0] = s[1] = s[2] = 0.0;
+  if (part == 0 && c < C)
+    for (int k = 0; k < NP; ++k) { s[0] += red[(k * CP + c) * 3]; s[1] += red[(k * CP + c) * 3 + 1]; s[2] += red[(k * CP + c) * 3 + 2]; }
+}
+
+// BatchNorm forward finalize: statistics -> scale/shift (+ running statistics)
+struct FinP {
+  const double* partial; int blocks, C; double count;
+  const float* gamma; const float* beta; float eps, momentum;
+  float* running_mean; float* running_var; int training;
+  float* scale; float* shift; float* save_mean; float* save_invstd; float* save_var;
+};
+// red: >= blockDim.x * 3 doubles of LDS
+template <bool SC1> __device__ __forceinline__ void bn_fin_body(const FinP& p, double* red) {
+  double s[3];
+  fold_partials<SC1>(p.partial, p.training ? p.blocks : 0, p.C, red, s);
+  const int c = threadIdx.x;
+  int CP = 1;
+  while (CP < p.C) CP <<= 1;
+  if (c >= p.C || threadIdx.x >= CP) return;
+  float mean, var;
+  if (p.training) {
+    const double m = s[0] / p.count;
+    double v = s[1] / p.count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m; var = (float)v;
+    const double unbiased = p.count > 1.0 ? v * p.count / (p.count - 1.0) : v;
+    if (p.running_mean) {
+      p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+      p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
+    }
+    if (p.save_var) p.save_var[c] = (float)unbiased;       // what a deferred running-statistics update needs
+  } else {
+    mean = p.running_mean[c]; var = p.running_var[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + p.eps);
+  const float sc = p.gamma[c] * invstd;
+  p.scale[c] = sc;
+  p.shift[c] = p.beta[c] - mean * sc;
+  if (p.save_mean) { p.save_mean[c] = mean; p.save_invstd[c] = invstd; }
+}
+struct BnFinK {
+  using Args = FinP;
+  static constexpr int THREADS = FT;
+  static __device__ __forceinline__ void run(const Args& p) {
+    __shared__ double red[FT * 3];
+    bn_fin_body<false>(p, red);
+  }
+};
+
+// BatchNorm backward finalize: dgamma/dbeta/dslope (+=) and the two per-channel means the apply pass needs
+struct BFinP {
+  const double* partial; int blocks, C; double count; int training;
+  float* dgamma; float* dbeta; float* dslope; float* c1; float* c2;
+};
+template <bool SC1> __device__ __forceinline__ void bn_bwd_fin_body(const BFinP& p, double* red) {
+  double s[3];
+  fold_partials<SC1>(p.partial, p.blocks, p.C, red, s);
+  const int c = threadIdx.x;
+  int CP = 1;
+  while (CP < p.C) CP <<= 1;
+  if (c >= p.C || threadIdx.x >= CP) return;
+  if (p.dbeta) p.dbeta[c] += (float)s[0];
+  if (p.dgamma) p.dgamma[c] += (float)s[1];
+  if (p.dslope) p.dslope[c] += (float)s[2];
+  // eval mode: mean / invstd are constants (running statistics), so no correction terms
+  p.c1[c] = p.training ? (float)(s[0] / p.count) : 0.f;
+  p.c2[c] = p.training ? (float)(s[1] / p.count) : 0.f;
+}
+struct BnBwdFinK {
+  using Args = BFinP;
+  static constexpr int THREADS = FT;
+  static __device__ __forceinline__ void run(const Args& p) {
+    __shared__ double red[FT * 3];
+    bn_bwd_fin_body<false>(p, red);
+  }
+};
+
+// plain per-channel sum finalize (bias gradient): out[c] += sum_b partial[b][c][0]
+struct SFinP { const double* partial; int blocks, C; float* out; };
+template <bool SC1> __device__ __forceinline__ void sum_fin_body(const SFinP& p, double* red) {
+  double s[3];
+  fold_partials<SC1>(p.partial, p.blocks, p.C, red, s);
+  const int c = threadIdx.x;
+  int CP = 1;
+  while (CP < p.C) CP <<= 1;
+  if (c >= p.C || threadIdx.x >= CP) return;
+  p.out[c] += (float)s[0];
+}
+struct SumFinK {
+  using Args = SFinP;
+  static constexpr int THREADS = FT;
+  static __device__ __forceinline__ void run(const Args& p) {
+    __shared__ double red[FT * 3];
+    sum_fin_body<false>(p, red);
+  }
+};
+
+// A finalize riding in its producer: the block of a launch that arrives LAST (every other block has published its partial rows)
+// runs the fold + finalize in place of a one-block launch of its own -- one seam less per BatchNorm on the chain, and a chain of
+// these ~8 us launches is what an Enet step is made of.  Visibility follows MI355X_MICROARCH.md "inter-workgroup visibility",
+// first row of the hand-off table: every partial row is stored sc1 (st_partial<true>), every storing wave drains its stores
+// (s_waitcnt vmcnt(0)), a workgroup barrier, ONE lane adds to the launch's ticket (agent scope); the workgroup whose add returns
+// total - 1 is last, its other waves join behind a barrier, and every load of the rows is an sc1 load (fold_partials<true>).
+// The ticket resets itself, so a replayed graph finds it at zero.
+struct FinU {
+  int mode;                   // 0: none (the caller launches the finalize kernel), 1: BnFinK, 2: BnBwdFinK, 3: SumFinK
+  int* ticket;
+  union { FinP f; BFinP b; SFinP s; };
+};
+// The ticket is a two-level tree: block b adds to shard b % S (each shard on a 64-byte line of its own), the last arrival of a
+// shard adds to the root, the last arrival at the root is the launch's last block.  (One counter for a whole launch serialises
+// its 500-1200 agent-scope adds on one line: ~20 ns each, i.e. 10-25 us on every fused launch -- measured, cfg4 15.5 -> 18.5 ms.)
+constexpr int TICKET_SHARDS = 32;
+constexpr int TICKET_INTS = 16 * (TICKET_SHARDS + 1);
+__device__ __forceinline__ bool last_block_arrived(int* ticket, unsigned total, int* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's sc1 partial stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int last = 0;
+    const unsigned S = total < (unsigned)TICKET_SHARDS ? total : (unsigned)TICKET_SHARDS, s = blockIdx.x % S;
+    const unsigned mine = (total - s + S - 1) / S;        // blocks that report to shard s
+    int* sub = ticket + 16 * (1 + s);
+    if (__hip_atomic_fetch_add(sub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)mine - 1) {
+      __hip_atomic_store(sub, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)S - 1) {
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
+    }
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+__device__ __forceinline__ void run_fused_finalize(const FinU& u, double* red) {
+  if (u.mode == 1) bn_fin_body<true>(u.f, red);
+  else if (u.mode == 2) bn_bwd_fin_body<true>(u.b, red);
+  else sum_fin_body<true>(u.s, red);
+}
+
 struct ConvP {
   View x, y, rg, rm;              // input, output, residual grad + its ReLU mask (optional)
   const float* w; const float* bias;
@@ -95,11 +349,15 @@ struct ConvP {
   // MFMA form, optional (data gradients): the outputs are g = d/d act(BN(braw)) of the producing layer; per-tile BatchNorm-backward
   // sums {sum dz, sum dz xhat, sum g z [z<0]} (enet_reduce kind 1) go to stats instead
   View braw; const float* bscale; const float* bshift; const float* bslope; const float* bmean; const float* binvstd; int bact; int bn_bwd;
+  int ngroups;       // MFMA form: output-channel groups of 32 NT (blockIdx.x = pixel tile * ngroups + group)
+  FinU fin;          // MFMA form with stats: the consumer's finalize rides in the last block (mode != 0)
 };
 
 // One thread = one output pixel x 8 output channels.  Weights live in LDS as [tap][i][G*8].
-template <typename T>
-__global__ __launch_bounds__(256) void enet_conv_kernel(ConvP p) {
+template <typename T> struct ConvK {
+  using Args = ConvP;
+  static constexpr int THREADS = 256;
+  static __device__ __forceinline__ void run(const Args& p) {
   extern __shared__ float Ws[];
   const int Cin = p.x.c, Cout = p.y.c, taps = p.R * p.S, CO = p.G * 8;
   for (int e = threadIdx.x; e < taps * Cin * CO; e += 256) {
@@ -183,6 +441,7 @@ __global__ __launch_bounds__(256) void enet_conv_kernel(ConvP p) {
     stv<T>(p.y, yo + c, p.fm & 2, v);
   }
 }
+};
 
 // 8 consecutive channels of one pixel as one (T) or two (fp32) 16-byte loads
 template <typename T> __device__ __forceinline__ void ld8(const View& v, long long off, int f32, float o[8]) {
@@ -461,17 +720,21 @@ __device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, fl
             d2 += (double)srd[((w * NT + j) * 32 + r) * 3 + 2];
           }
           double* o = p.stats + (row * Cout + c) * 3;
-          o[0] = a; o[1] = b; o[2] = d2;
+          if (p.fin.mode) { st_partial<true>(o, a); st_partial<true>(o + 1, b); st_partial<true>(o + 2, d2); }
+          else { o[0] = a; o[1] = b; o[2] = d2; }
         }
       }
     }
   }
 }
 
-template <typename T, int NT>
-__global__ __launch_bounds__(64 * MC_W) void enet_mconv_kernel(ConvP p, int ngroups) {
+template <typename T, int NT> struct MconvK {
+  using Args = ConvP;
+  static constexpr int THREADS = 64 * MC_W;
+  static __device__ __forceinline__ void run(const Args& p) {
+    const int ngroups = p.ngroups;
   __shared__ __attribute__((aligned(16))) float tfs[3 * 128];
-  __shared__ float red[MC_W * NT * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float red[MC_W * NT * 16 * 64];      // >= 256 * 3 doubles: the fused finalize folds through it
   __shared__ float srd[MC_W * NT * 32 * 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -508,7 +771,12 @@ __global__ __launch_bounds__(64 * MC_W) void enet_mconv_kernel(ConvP p, int ngro
   __syncthreads();
   if (p.fm & 2) mconv_store<T, NT, true>(p, red, srd, cbase, wbase, P, r, h, wave);
   else mconv_store<T, NT, false>(p, red, srd, cbase, wbase, P, r, h, wave);
+  if (p.fin.mode) {        // (block-uniform) the statistics' finalize, in the block that arrives last; `red` is free again
+    __shared__ int s_last;
+    if (last_block_arrived(p.fin.ticket, gridDim.x, &s_last)) run_fused_finalize(p.fin, reinterpret_cast<double*>(red));
+  }
 }
+};
 
 // ---- per-channel sums over pixels: partial[blk][c][k], k < NS, double accumulators -------------
 // kind 0: {sum x, sum x^2}                                  (BatchNorm statistics; bias grad uses k = 0)
@@ -519,6 +787,8 @@ struct RedP {
   int act;                       // activation after the BN: 0 none, 2 PReLU, 3 ReLU
   int has_mask, kind, ppb;
   int fm;                        // f32 mask: bit0 x (raw), bit1 g, bit2 g mask, bit3 draw
+  double* partial;               // reductions: [block][C][3] partial sums
+  FinU fin;                      // the finalize of these sums rides in the last block (mode != 0)
 };
 
 template <typename T>
@@ -530,8 +800,11 @@ __device__ __forceinline__ float grad_in(const RedP& p, int n, int y, int x, int
   return g;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void enet_reduce_kernel(RedP p, double* partial) {
+template <typename T> struct ReduceK {
+  using Args = RedP;
+  static constexpr int THREADS = 256;
+  static __device__ __forceinline__ void run(const Args& p) {
+    double* partial = p.partial;
   __shared__ double red[256 * 3];
   const int C = p.x.c;
   int CP = 1;
@@ -567,16 +840,25 @@ __global__ __launch_bounds__(256) void enet_reduce_kernel(RedP p, double* partia
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int r = 0; r < rows; ++r) { s0 += red[(r * CP + c) * 3]; s1 += red[(r * CP + c) * 3 + 1]; s2 += red[(r * CP + c) * 3 + 2]; }
     double* o = partial + ((long long)blockIdx.x * C + c) * 3;
-    o[0] = s0; o[1] = s1; o[2] = s2;
+    if (p.fin.mode) { st_partial<true>(o, s0); st_partial<true>(o + 1, s1); st_partial<true>(o + 2, s2); }
+    else { o[0] = s0; o[1] = s1; o[2] = s2; }
+  }
+  if (p.fin.mode) {
+    __shared__ int s_last;
+    if (last_block_arrived(p.fin.ticket, gridDim.x, &s_last)) run_fused_finalize(p.fin, red);
   }
 }
+};
 
 // Same partial sums for channel counts that are multiples of 8 (Enet's 16 / 32 / 64 / 128-wide tensors: most of them): a thread
 // owns 8 consecutive channels and loads them as one or two 16-byte vectors per pixel (the scalar kernel above issues one 2- or
 // 4-byte load per element and a 64-bit-capable index decode per pixel); fp32 running sums over runs of 32 pixels are flushed
 // into doubles, rows of threads are folded through LDS in a fixed order.  Same partial layout, same finalize kernels.
-template <typename T>
-__global__ __launch_bounds__(256) void enet_reduce_vec_kernel(RedP p, double* partial) {
+template <typename T> struct ReduceVecK {
+  using Args = RedP;
+  static constexpr int THREADS = 256;
+  static __device__ __forceinline__ void run(const Args& p) {
+    double* partial = p.partial;
   extern __shared__ double redv[];                // [rows][C][3]
   const int C = p.x.c, CV = C / 8;                // CV in {2, 4, 8, 16}
   const int rows = 256 / CV;
@@ -639,101 +921,27 @@ __global__ __launch_bounds__(256) void enet_reduce_vec_kernel(RedP p, double* pa
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int r = 0; r < rows; ++r) { const double* q = redv + ((long long)r * C + c) * 3; s0 += q[0]; s1 += q[1]; s2 += q[2]; }
     double* o = partial + ((long long)blockIdx.x * C + c) * 3;
-    o[0] = s0; o[1] = s1; o[2] = s2;
+    if (p.fin.mode) { st_partial<true>(o, s0); st_partial<true>(o + 1, s1); st_partial<true>(o + 2, s2); }
+    else { o[0] = s0; o[1] = s1; o[2] = s2; }
+  }
+  if (p.fin.mode) {        // redv ([rows][C][3] doubles = 48 KiB) is free again behind the barrier inside
+    __shared__ int s_last;
+    if (last_block_arrived(p.fin.ticket, gridDim.x, &s_last)) run_fused_finalize(p.fin, redv);
   }
 }
-
-// Fixed-order fold of the per-block partials: thread (c, part) sums blocks part, part+NP, ... and the NP
-// partial sums of a channel are then added in ascending `part` -- deterministic, and 256/CP-way parallel
-// instead of one thread walking all blocks.  Result valid for threads with part == 0.
-constexpr int FT = 1024;      // threads of the one-block finalize kernels: with 256 a 128-channel fold walked 128 partial rows per
-                              // thread (11 us of dependent loads, 16 % of a cfg4 step's kernel time); 1024 threads walk 32
-__device__ __forceinline__ void fold_partials(const double* partial, int blocks, int C, double* red, double s[3]) {
-  int CP = 1;
-  while (CP < C) CP <<= 1;
-  const int NP = (int)blockDim.x / CP;        // blockDim.x = g_enet_fold_threads (256 ... FT)
-  const int c = threadIdx.x % CP, part = threadIdx.x / CP;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  if (c < C)
-    for (int b = part; b < blocks; b += NP) {
-      const double* q = partial + ((long long)b * C + c) * 3;
-      a0 += q[0]; a1 += q[1]; a2 += q[2];
-    }
-  red[threadIdx.x * 3] = a0; red[threadIdx.x * 3 + 1] = a1; red[threadIdx.x * 3 + 2] = a2;
-  __syncthreads();
-  s[0] = s[1] = s[2] = 0.0;
-  if (part == 0 && c < C)
-    for (int k = 0; k < NP; ++k) { s[0] += red[(k * CP + c) * 3]; s[1] += red[(k * CP + c) * 3 + 1]; s[2] += red[(k * CP + c) * 3 + 2]; }
-}
-
-// BatchNorm forward finalize (one block of 256): statistics -> scale/shift (+ running statistics)
-__global__ __launch_bounds__(FT) void enet_bn_finalize_kernel(const double* partial, int blocks, int C, double count,
-                                        const float* gamma, const float* beta, float eps, float momentum,
-                                        float* running_mean, float* running_var, int training,
-                                        float* scale, float* shift, float* save_mean, float* save_invstd, float* save_var) {
-  __shared__ double red[FT * 3];
-  double s[3];
-  fold_partials(partial, training ? blocks : 0, C, red, s);
-  const int c = threadIdx.x;
-  int CP = 1;
-  while (CP < C) CP <<= 1;
-  if (c >= C || threadIdx.x >= CP) return;
-  float mean, var;
-  if (training) {
-    const double m = s[0] / count;
-    double v = s[1] / count - m * m;
-    if (v < 0.0) v = 0.0;
-    mean = (float)m; var = (float)v;
-    const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
-    if (running_mean) {
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-    }
-    if (save_var) save_var[c] = (float)unbiased;       // what a deferred running-statistics update needs
-  } else {
-    mean = running_mean[c]; var = running_var[c];
-  }
-  const float invstd = 1.0f / sqrtf(var + eps);
-  const float sc = gamma[c] * invstd;
-  scale[c] = sc;
-  shift[c] = beta[c] - mean * sc;
-  if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
-}
-
-// BatchNorm backward finalize: dgamma/dbeta/dslope (+=) and the two per-channel means the apply pass needs
-__global__ __launch_bounds__(FT) void enet_bn_bwd_finalize_kernel(const double* partial, int blocks, int C, double count, int training,
-                                            float* dgamma, float* dbeta, float* dslope, float* c1, float* c2) {
-  __shared__ double red[FT * 3];
-  double s[3];
-  fold_partials(partial, blocks, C, red, s);
-  const int c = threadIdx.x;
-  int CP = 1;
-  while (CP < C) CP <<= 1;
-  if (c >= C || threadIdx.x >= CP) return;
-  if (dbeta) dbeta[c] += (float)s[0];
-  if (dgamma) dgamma[c] += (float)s[1];
-  if (dslope) dslope[c] += (float)s[2];
-  // eval mode: mean / invstd are constants (running statistics), so no correction terms
-  c1[c] = training ? (float)(s[0] / count) : 0.f;
-  c2[c] = training ? (float)(s[1] / count) : 0.f;
-}
-
-// plain per-channel sum finalize (bias gradient): out[c] += sum_b partial[b][c][0]
-__global__ __launch_bounds__(FT) void enet_sum_finalize_kernel(const double* partial, int blocks, int C, float* out) {
-  __shared__ double red[FT * 3];
-  double s[3];
-  fold_partials(partial, blocks, C, red, s);
-  const int c = threadIdx.x;
-  int CP = 1;
-  while (CP < C) CP <<= 1;
-  if (c >= C || threadIdx.x >= CP) return;
-  out[c] += (float)s[0];
-}
+};
 
 // The same for whole 8-channel groups (every BatchNorm of stages 1-3): a thread owns 8 consecutive channels of one pixel -- one or
 // two 16-byte loads per operand and one 16-byte store instead of eight scalar round trips, an eighth of the threads.
-template <typename T>
-__global__ __launch_bounds__(256) void enet_bn_bwd_apply_vec_kernel(RedP p, const float* c1, const float* c2, View out) {
+struct ApplyP { RedP p; const float* c1; const float* c2; View out; };
+template <typename T> struct BnApplyVecK {
+  using Args = ApplyP;
+  static constexpr int THREADS = 256;
+  static __device__ __forceinline__ void run(const Args& a) {
+    const RedP& p = a.p;
+    const float* c1 = a.c1; const float* c2 = a.c2;
+    const View& out = a.out;
+
   const int C = p.x.c, CV = C >> 3;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)p.x.n * p.x.h * p.x.w * CV;
@@ -776,6 +984,7 @@ __global__ __launch_bounds__(256) void enet_bn_bwd_apply_vec_kernel(RedP p, cons
     *reinterpret_cast<V8*>(reinterpret_cast<T*>(out.ptr) + oo) = q;
   }
 }
+};
 
 // ---- channel-owner BatchNorm kernels for small tensors -----------------------------------------------
 // Stage-2/3 tensors (8 x 25 x 25 x 32...128, 8 x 50 x 50 x 16...64) hold 0.3 - 2.5 MB: the split reduction above is three
@@ -943,8 +1152,14 @@ __global__ __launch_bounds__(OWN_T) void enet_bn_bwd_owner_kernel(RedP p, double
 }
 
 // draw = scale * (dz - c1 - xhat * c2)
-template <typename T>
-__global__ __launch_bounds__(256) void enet_bn_bwd_apply_kernel(RedP p, const float* c1, const float* c2, View out) {
+template <typename T> struct BnApplyK {
+  using Args = ApplyP;
+  static constexpr int THREADS = 256;
+  static __device__ __forceinline__ void run(const Args& a) {
+    const RedP& p = a.p;
+    const float* c1 = a.c1; const float* c2 = a.c2;
+    const View& out = a.out;
+
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const int C = p.x.c;
   const long long total = (long long)p.x.n * p.x.h * p.x.w * C;
@@ -961,6 +1176,7 @@ __global__ __launch_bounds__(256) void enet_bn_bwd_apply_kernel(RedP p, const fl
   const float r = p.scale[c] * (dz - c1[c] - xh * c2[c]);
   stv<T>(out, voff(out, n, y, x) + c, p.fm & 8, r);
 }
+};
 
 // ---- bottleneck tail --------------------------------------------------------------------------
 struct TailP {
@@ -984,8 +1200,10 @@ __device__ __forceinline__ float pool4(const View& v, int n, int oy, int ox, int
   return best;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void enet_tail_fwd_kernel(TailP p) {
+template <typename T> struct TailFwdK {
+  using Args = TailP;
+  static constexpr int THREADS = 256;
+  static __device__ __forceinline__ void run(const Args& p) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const int C = p.out.c;
   const long long total = (long long)p.out.n * p.out.h * p.out.w * C;
@@ -1017,6 +1235,7 @@ __global__ __launch_bounds__(256) void enet_tail_fwd_kernel(TailP p) {
   }
   stv<T>(p.out, oo, p.fm & 8, fmaxf(mainv + ext, 0.f));
 }
+};
 
 // backward of the main branch of down / up / initial blocks
 struct TailBP {
@@ -1029,8 +1248,10 @@ struct TailBP {
   int fm;                         // f32 mask: bit0 dout, bit1 out, bit2 dst
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void enet_tail_bwd_kernel(TailBP p) {
+template <typename T> struct TailBwdK {
+  using Args = TailBP;
+  static constexpr int THREADS = 256;
+  static __device__ __forceinline__ void run(const Args& p) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const int C = p.dst.c;
   const long long total = (long long)p.dst.n * p.dst.h * p.dst.w * C;
@@ -1057,6 +1278,7 @@ __global__ __launch_bounds__(256) void enet_tail_bwd_kernel(TailBP p) {
   if (p.accumulate) g += ldv<T>(p.dst, dof, p.fm & 4);
   stv<T>(p.dst, dof, p.fm & 4, g);
 }
+};
 
 // ---- weight gradient: dW[o][tap][i] (physical index e, see ws_* strides of the forward) -------------
 // A pixel p = (n, ay, ax) of view A pairs with pixel (ay*stride - pad + r*dil, ...) of view B.
@@ -1068,6 +1290,7 @@ struct WgP {
   int R, S, stride, dil, pad_h, pad_w;
   int ppb;
   int fm;                         // f32 mask: bit0 a, bit1 b
+  float* partial; int E, pps, mtiles, ntiles;      // slabs [slice][E]; MFMA form: pixels per slice, 32 x 32 tiles
 };
 constexpr int WG_MAX_BLOCKS = 1024;
 constexpr int WG_PB = 32;          // pixels staged per round
@@ -1079,8 +1302,11 @@ constexpr int WG_TPT = 2;          // 4x8 register tiles per thread (<= 512 tile
 // SL pixel slices: when the gradient has <= 256 / SL register tiles, SL thread groups each take 32 / SL of a round's pixels
 // for every tile and their accumulators are added through LDS at the end -- otherwise most of the block idles in the FMA
 // phase (a 16 x 16 x 9 gradient has 72 tiles).
-template <typename T, int SL>
-__global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, int E) {
+template <typename T, int SL> struct WgradK {
+  using Args = WgP;
+  static constexpr int THREADS = 256;
+  static __device__ __forceinline__ void run(const Args& p) {
+    float* partial = p.partial; const int E = p.E;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Ca = p.a.c, Cb = p.b.c, taps = p.R * p.S;
   const int kb = taps * Cb;
@@ -1191,6 +1417,7 @@ __global__ __launch_bounds__(256) void enet_wgrad_kernel(WgP p, float* partial, 
     }
   }
 }
+};
 
 // MFMA form of the weight gradient (bf16 / f16 compute modes).  dW[o][k] = sum over pixels of A[pixel][o] * B[pixel + tap(k)][c(k)]
 // is a GEMM whose reduction runs over PIXELS, the strided dimension of both NHWC operands, so a v_mfma_f32_32x32x16 fragment
@@ -1289,8 +1516,11 @@ __device__ __forceinline__ void mwgrad_body(const WgP& p, float* partial, int E,
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(64) void enet_mwgrad_kernel(WgP p, float* partial, int E, int pps, int mtiles, int ntiles) {
+template <typename T> struct MwgradK {
+  using Args = WgP;
+  static constexpr int THREADS = 64;
+  static __device__ __forceinline__ void run(const Args& p) {
+    float* partial = p.partial; const int E = p.E, pps = p.pps, mtiles = p.mtiles, ntiles = p.ntiles;
   if (p.fm & 1) {
     if (p.fm & 2) mwgrad_body<T, true, true>(p, partial, E, pps, mtiles, ntiles);
     else mwgrad_body<T, true, false>(p, partial, E, pps, mtiles, ntiles);
@@ -1299,14 +1529,33 @@ __global__ __launch_bounds__(64) void enet_mwgrad_kernel(WgP p, float* partial, 
     else mwgrad_body<T, false, false>(p, partial, E, pps, mtiles, ntiles);
   }
 }
+};
 
 // dw[e] += sum_b partial[b][e]: 16 entries per block, 16 strided partial sums each, folded in fixed order
-__global__ __launch_bounds__(256) void enet_wgrad_reduce_kernel(const float* partial, float* dw, int E, int blocks) {
+struct WRedP { const float* partial; float* dw; int E, blocks; };
+struct WgradRedK {
+  using Args = WRedP;
+  static constexpr int THREADS = 256;
+  static __device__ __forceinline__ void run(const Args& p) {
+    const auto partial = p.partial;
+    const auto dw = p.dw;
+    const auto E = p.E;
+    const auto blocks = p.blocks;
+
   __shared__ float red[256];
   const int e = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
   float s = 0.f;
-  if (e < E)
-    for (int b = part; b < blocks; b += 16) s += partial[(long long)b * E + e];
+  if (e < E) {
+    int b = part;
+    for (; b + 7 * 16 < blocks; b += 8 * 16) {       // eight slabs per round trip, adds in the rolled loop's order (see fold_partials)
+      float q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = partial[(long long)(b + u * 16) * E + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += q[u];
+    }
+    for (; b < blocks; b += 16) s += partial[(long long)b * E + e];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (part == 0 && e < E) {
@@ -1316,6 +1565,7 @@ __global__ __launch_bounds__(256) void enet_wgrad_reduce_kernel(const float* par
     dw[e] += t;
   }
 }
+};
 
 static inline bool ok_dtype(int d) { return d == DCT_F32 || d == DCT_BF16 || d == DCT_F16; }
 static inline int red_plan(long long P, int C, int& ppb) {
@@ -1333,6 +1583,33 @@ static inline int red_plan(long long P, int C, int& ppb) {
 
 }  // namespace
 
+// Tickets of the fused finalizes: zeroed device ints handed out round-robin; a launch's last block resets its ticket, so a
+// replayed graph (which keeps the address it was captured with) finds it at zero.  2^15 of them: two launches in flight
+// could only meet on one after 32768 fused launches in between (a cfg4 step has ~1600).
+int g_enet_fuse_finalize = 0;       // dct_tune_set(DCT_TUNE_ENET_FUSE_FINALIZE, 1): finalizes ride in their producers' last blocks.  OFF: measured
+                                    // SLOWER (cfg4 15.4 -> 17.9 ms, cfg5 36.3 -> 40.7): a third fewer launches on every chain, but each fused launch
+                                    // grows by ~8 us -- the sc1 stores' drain, the ticket round trips, and above all one block folding 0.2-0.5 MB of
+                                    // rows it must fetch from memory at the ~65 GB/s a single block gets.  An in-launch hand-off between blocks
+                                    // costs as much as the launch seam it replaces.
+static int* enet_next_ticket(hipStream_t st) {
+  static int* pool = nullptr;
+  static unsigned next = 0;
+  constexpr unsigned N = 1u << 15;           // tickets of TICKET_INTS ints each: 69 MB
+  if (!g_enet_fuse_finalize) return nullptr;
+  if (!pool) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    int* p = nullptr;
+    const size_t bytes = (size_t)N * TICKET_INTS * sizeof(int);
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    pool = p;
+  }
+  return pool + (size_t)(next++ & (N - 1)) * TICKET_INTS;
+}
+
 #define ENET_T(dtype, ...) do { if ((dtype) == DCT_BF16) { using T = bf16_t; __VA_ARGS__; } else if ((dtype) == DCT_F16) { using T = f16_t; __VA_ARGS__; } \
                                else { using T = float; __VA_ARGS__; } } while (0)
 
@@ -1342,8 +1619,10 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
                           const dct_view* resid_grad, const dct_view* resid_mask,
                           int f32_mask, int dtype, double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream,
                           const dct_view* bn_raw = nullptr, const float* bn_scale = nullptr, const float* bn_shift = nullptr,
-                          const float* bn_slope = nullptr, int bn_act = 0, const float* bn_mean = nullptr, const float* bn_invstd = nullptr) {
+                          const float* bn_slope = nullptr, int bn_act = 0, const float* bn_mean = nullptr, const float* bn_invstd = nullptr,
+                          const FinU* fin = nullptr, int* finalized = nullptr) {
   if (stats_rows) *stats_rows = 0;
+  if (finalized) *finalized = 0;
   if (!view_ok(x) || !view_ok(y) || !w || !d || !ok_dtype(dtype) || x->n != y->n) return DCT_ERR_BAD_ARG;
   if (d->R < 1 || d->S < 1 || d->stride < 1 || d->dil < 1) return DCT_ERR_BAD_ARG;
   if (y->c > 128 || x->c > 128) return DCT_ERR_UNSUPPORTED;
@@ -1354,6 +1633,7 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
   p.transposed = transposed ? 1 : 0; p.accumulate = d->accumulate ? 1 : 0;
   p.ws_out = ws_out; p.ws_tap = ws_tap; p.ws_in = ws_in;
   p.has_resid = 0; p.wvec = 0; p.stats = nullptr; p.bn_bwd = 0; p.bact = 0; p.braw = p.y;
+  p.fin.mode = 0; p.fin.ticket = nullptr; p.ngroups = 0;
   p.bscale = p.bshift = p.bslope = p.bmean = p.binvstd = nullptr;
   p.rg = p.y; p.rm = p.y;
   if (resid_grad) {
@@ -1390,6 +1670,16 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
         }
       }
       if (ok) { p.stats = stats_partial; *stats_rows = (int)ptiles; }
+      if (ok && fin && finalized && fin->mode == (p.bn_bwd ? 2 : 1)) {
+        int* ticket = enet_next_ticket(st0);
+        if (ticket) {               // the consumer BatchNorm's finalize rides in this launch's last block
+          p.fin = *fin; p.fin.ticket = ticket;
+          const double count = (double)Pm;
+          if (p.fin.mode == 1) { p.fin.f.partial = stats_partial; p.fin.f.blocks = (int)ptiles; p.fin.f.C = y->c; p.fin.f.count = count; }
+          else { p.fin.b.partial = stats_partial; p.fin.b.blocks = (int)ptiles; p.fin.b.C = y->c; p.fin.b.count = count; }
+          *finalized = 1;
+        }
+      }
     }
     int nt = 1;
     if (ntiles >= 4 && ptiles >= 2048) nt = 4;
@@ -1397,9 +1687,10 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
     const int ngroups = (ntiles + nt - 1) / nt;
     if (ptiles * ngroups > 0x7fffffffLL) return DCT_ERR_UNSUPPORTED;
     const unsigned gridm = (unsigned)(ptiles * ngroups);
-    if (nt == 1) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 1>), dim3(gridm), dim3(64 * MC_W), 0, st0, p, ngroups));
-    else if (nt == 2) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 2>), dim3(gridm), dim3(64 * MC_W), 0, st0, p, ngroups));
-    else ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_mconv_kernel<T, 4>), dim3(gridm), dim3(64 * MC_W), 0, st0, p, ngroups));
+    p.ngroups = ngroups;
+    if (nt == 1) ENET_T(dtype, (enet_launch<MconvK<T, 1>>(DCT_PROF_OTHER, dim3(gridm), dim3(64 * MC_W), 0, st0, p)));
+    else if (nt == 2) ENET_T(dtype, (enet_launch<MconvK<T, 2>>(DCT_PROF_OTHER, dim3(gridm), dim3(64 * MC_W), 0, st0, p)));
+    else ENET_T(dtype, (enet_launch<MconvK<T, 4>>(DCT_PROF_OTHER, dim3(gridm), dim3(64 * MC_W), 0, st0, p)));
     return dct_check_launch();
   }
   const size_t lds = (size_t)d->R * d->S * x->c * Gp * 8 * sizeof(float);
@@ -1407,7 +1698,8 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
   const long long P = (long long)y->n * y->h * y->w;
   const unsigned grid = div_up(P, 256 / Gp);
   hipStream_t st = (hipStream_t)stream;
-  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_conv_kernel<T>, dim3(grid), dim3(256), lds, st, p));
+  p.ngroups = 0;
+  ENET_T(dtype, enet_launch<ConvK<T>>(DCT_PROF_OTHER, dim3(grid), dim3(256), lds, st, p));
   return dct_check_launch();
 }
 
@@ -1439,13 +1731,44 @@ extern "C" int dct_enet_conv_stats(const dct_view* x, const float* w, const floa
                         stats_capacity_rows, stats_rows, stream);
 }
 
+extern "C" int dct_enet_conv_stats_fin(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
+                                       const dct_view* y, const dct_conv_desc* d, int transposed,
+                                       int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
+                                       double* stats_partial, int stats_capacity_rows, int* stats_rows,
+                                       const dct_enet_bn_fin* fin, int* finalized, dct_stream stream) {
+  if (!stats_partial || !stats_rows || stats_capacity_rows < 1 || !fin || !finalized) return DCT_ERR_BAD_ARG;
+  if (!fin->gamma || !fin->beta || !fin->scale || !fin->shift || !fin->training) return DCT_ERR_BAD_ARG;
+  FinU u;
+  u.mode = 1; u.ticket = nullptr;
+  u.f = FinP{nullptr, 0, 0, 0.0, fin->gamma, fin->beta, fin->eps, fin->momentum, fin->running_mean, fin->running_var, 1,
+             fin->scale, fin->shift, fin->save_mean, fin->save_invstd, fin->save_var};
+  return enet_conv_impl(x, w, bias, tf, y, d, transposed, ws_out, ws_tap, ws_in, nullptr, nullptr, f32_mask, dtype, stats_partial,
+                        stats_capacity_rows, stats_rows, stream, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, &u, finalized);
+}
+
+extern "C" int dct_enet_conv_bnbwd_stats_fin(const dct_view* x, const float* w, const dct_view* y, const dct_conv_desc* d, int transposed,
+                                             int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
+                                             const dct_view* bn_raw, const float* bn_scale, const float* bn_shift, const float* bn_slope,
+                                             int bn_act, const float* bn_mean, const float* bn_invstd,
+                                             double* stats_partial, int stats_capacity_rows, int* stats_rows,
+                                             const dct_enet_bn_bwd_fin* fin, int* finalized, dct_stream stream) {
+  if (!stats_partial || !stats_rows || stats_capacity_rows < 1 || !bn_raw || !fin || !finalized || !fin->c1c2) return DCT_ERR_BAD_ARG;
+  FinU u;
+  u.mode = 2; u.ticket = nullptr;
+  u.b = BFinP{nullptr, 0, 0, 0.0, fin->training ? 1 : 0, fin->dgamma, fin->dbeta, bn_act == 2 ? fin->dslope : nullptr, fin->c1c2,
+              fin->c1c2 + y->c};
+  return enet_conv_impl(x, w, nullptr, nullptr, y, d, transposed, ws_out, ws_tap, ws_in, nullptr, nullptr, f32_mask, dtype, stats_partial,
+                        stats_capacity_rows, stats_rows, stream, bn_raw, bn_scale, bn_shift, bn_slope, bn_act, bn_mean, bn_invstd, &u,
+                        finalized);
+}
+
 extern "C" size_t dct_enet_reduce_workspace_bytes(int channels) {
   return (size_t)256 * (channels > 0 ? channels : 1) * 3 * sizeof(double);
 }
 
 // channel-owner form: whole 8-channel groups, vector-loadable views, few enough pixels for one block per group
 static bool enet_owner_ok(const RedP& p, int dtype, const View* out) {
-  if (!g_enet_bn_owner) return false;
+  if (!g_enet_bn_owner || (g_grp.active && !g_grp.leaves_only)) return false;      // (the owner kernels have no grouped form)
   const long long P = (long long)p.x.n * p.x.h * p.x.w;
   if (P > OWN_MAX_PIXELS || p.x.c % 8 != 0 || p.x.c < 8) return false;
   auto v8 = [&](const View& v, int f32) {
@@ -1458,13 +1781,28 @@ static bool enet_owner_ok(const RedP& p, int dtype, const View* out) {
   return true;
 }
 
-static int enet_reduce_launch(const RedP& p0, int dtype, void* workspace, size_t workspace_bytes, hipStream_t st, int& blocks_out) {
+// fin (nullable; mode + everything but partial / blocks / C / count filled in): the finalize of these sums rides in the launch's last
+// block where a ticket can be had -> *fused = true; otherwise the caller launches the finalize kernel as before
+static int enet_reduce_launch(const RedP& p0, int dtype, void* workspace, size_t workspace_bytes, hipStream_t st, int& blocks_out,
+                              const FinU* fin = nullptr, double count = 0.0, bool* fused = nullptr) {
   RedP p = p0;
+  p.fin.mode = 0; p.fin.ticket = nullptr;
+  if (fused) *fused = false;
   const long long P = (long long)p.x.n * p.x.h * p.x.w;
   int ppb;
   const int blocks = red_plan(P, p.x.c, ppb);
   if (!workspace || workspace_bytes < (size_t)blocks * p.x.c * 3 * sizeof(double)) return DCT_ERR_WORKSPACE;
   p.ppb = ppb;
+  if (fin && fused) {
+    int* ticket = enet_next_ticket(st);
+    if (ticket) {
+      p.fin = *fin; p.fin.ticket = ticket;
+      if (p.fin.mode == 1) { p.fin.f.partial = (const double*)workspace; p.fin.f.blocks = blocks; p.fin.f.C = p.x.c; p.fin.f.count = count; }
+      else if (p.fin.mode == 2) { p.fin.b.partial = (const double*)workspace; p.fin.b.blocks = blocks; p.fin.b.C = p.x.c; p.fin.b.count = count; }
+      else { p.fin.s.partial = (const double*)workspace; p.fin.s.blocks = blocks; p.fin.s.C = p.x.c; }
+      *fused = true;
+    }
+  }
   // 8-channel vector path: every view it reads has 8-aligned strides and a 16-byte (T) / 32-byte (fp32) aligned base
   auto v8 = [&](const View& v, int f32) {
     const int esz = (f32 || dtype == DCT_F32) ? 4 : 2;
@@ -1475,9 +1813,11 @@ static int enet_reduce_launch(const RedP& p0, int dtype, void* workspace, size_t
   if (vec && p.kind == 1) vec = v8(p.g, p.fm & 2) && (!p.has_mask || v8(p.m, p.fm & 4));
   if (vec) {
     const size_t lds = (size_t)(256 / (C / 8)) * C * 3 * sizeof(double);      // 48 KiB
-    ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_reduce_vec_kernel<T>, dim3(blocks), dim3(256), lds, st, p, (double*)workspace));
+    p.partial = (double*)workspace;
+    ENET_T(dtype, enet_launch<ReduceVecK<T>>(DCT_PROF_OTHER, dim3(blocks), dim3(256), lds, st, p));
   } else {
-    ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_reduce_kernel<T>, dim3(blocks), dim3(256), 0, st, p, (double*)workspace));
+    p.partial = (double*)workspace;
+    ENET_T(dtype, enet_launch<ReduceK<T>>(DCT_PROF_OTHER, dim3(blocks), dim3(256), 0, st, p));
   }
   blocks_out = blocks;
   return DCT_OK;
@@ -1506,19 +1846,25 @@ extern "C" int dct_enet_bn_fwd_stats_rows(const dct_view* raw, const float* gamm
   } else if (training) {
     RedP p; p.x = to_view(raw); p.g = p.x; p.m = p.x;
     p.scale = p.shift = p.slope = p.mean = p.invstd = nullptr;
-    p.act = 0; p.has_mask = 0; p.kind = 0; p.ppb = 0; p.fm = f32_mask & 1;
+    p.act = 0; p.has_mask = 0; p.kind = 0; p.ppb = 0; p.fm = f32_mask & 1; p.partial = nullptr;
     if (enet_owner_ok(p, dtype, nullptr)) {
       const double cnt = (double)raw->n * raw->h * raw->w;
       ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_fwd_owner_kernel<T>, dim3(raw->c / 8), dim3(OWN_T), 0, st, p, cnt, gamma, beta, eps,
                                momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, save_var));
       return dct_check_launch();
     }
-    const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
+    FinU u;
+    u.mode = 1; u.ticket = nullptr;
+    u.f = FinP{nullptr, 0, 0, 0.0, gamma, beta, eps, momentum, running_mean, running_var, 1, scale, shift, save_mean, save_invstd, save_var};
+    bool fused = false;
+    const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks, &u, (double)raw->n * raw->h * raw->w, &fused);
     if (rc != DCT_OK) return rc;
+    if (fused) return dct_check_launch();
   }
   const double count = (double)raw->n * raw->h * raw->w;
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_finalize_kernel, dim3(1), dim3(g_enet_fold_threads), 0, st, (const double*)workspace, blocks, raw->c, count,
-             gamma, beta, eps, momentum, running_mean, running_var, training ? 1 : 0, scale, shift, save_mean, save_invstd, save_var);
+  const FinP fp = {(const double*)workspace, blocks, raw->c, count, gamma, beta, eps, momentum, running_mean, running_var, training ? 1 : 0,
+                   scale, shift, save_mean, save_invstd, save_var};
+  enet_launch<BnFinK>(DCT_PROF_OTHER, dim3(1), dim3(g_enet_fold_threads), 0, st, fp);
   return dct_check_launch();
 }
 
@@ -1540,19 +1886,19 @@ extern "C" int dct_enet_bn_bwd_rows(const dct_view* raw, const dct_view* g, cons
                                     int partial_rows, dct_stream stream) {
   if (!view_ok(raw) || !view_ok(g) || !view_ok(draw) || !scale || !shift || !mean || !invstd || !c1c2 || !ok_dtype(dtype))
     return DCT_ERR_BAD_ARG;
-  if (partial_rows > 0 && g_mask) return DCT_ERR_BAD_ARG;
+  if (partial_rows != 0 && g_mask) return DCT_ERR_BAD_ARG;
   if (raw->c > 128 || (act == 2 && !slope)) return DCT_ERR_BAD_ARG;
   RedP p; p.x = to_view(raw); p.g = to_view(g); p.m = p.g;
   p.has_mask = 0;
   if (g_mask) { if (!view_ok(g_mask)) return DCT_ERR_BAD_ARG; p.m = to_view(g_mask); p.has_mask = 1; }
   p.scale = scale; p.shift = shift; p.slope = slope; p.mean = mean; p.invstd = invstd;
-  p.act = act; p.kind = 1; p.ppb = 0; p.fm = f32_mask;
+  p.act = act; p.kind = 1; p.ppb = 0; p.fm = f32_mask; p.partial = nullptr;
   hipStream_t st = (hipStream_t)stream;
   int blocks = 0;
   {
     const View vo0 = to_view(draw);
     const int oesz = ((f32_mask & 8) || dtype == DCT_F32) ? 4 : 2;
-    if (partial_rows <= 0 && enet_owner_ok(p, dtype, &vo0) && vo0.c == p.x.c && vo0.n == p.x.n && vo0.h == p.x.h && vo0.w == p.x.w &&
+    if (partial_rows == 0 && enet_owner_ok(p, dtype, &vo0) && vo0.c == p.x.c && vo0.n == p.x.n && vo0.h == p.x.h && vo0.w == p.x.w &&
         ((uintptr_t)vo0.ptr % oesz) == 0) {
       const double cnt = (double)raw->n * raw->h * raw->w;
       ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_owner_kernel<T>, dim3(raw->c / 8), dim3(OWN_T), 0, st, p, cnt, training ? 1 : 0,
@@ -1560,18 +1906,25 @@ extern "C" int dct_enet_bn_bwd_rows(const dct_view* raw, const dct_view* g, cons
       return dct_check_launch();
     }
   }
+  bool finalized = partial_rows < 0;    // < 0: dct_enet_conv_bnbwd_stats_fin has finalized already (c1c2 and the parameter gradients are set)
+  const double count = (double)raw->n * raw->h * raw->w;
   if (partial_rows > 0) {         // the data-gradient convolution that produced g wrote the partial rows (dct_enet_conv_bnbwd_stats)
     if (!workspace || workspace_bytes < (size_t)partial_rows * raw->c * 3 * sizeof(double)) return DCT_ERR_WORKSPACE;
     blocks = partial_rows;
-  } else {
-    const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
+  } else if (!finalized) {
+    FinU u;
+    u.mode = 2; u.ticket = nullptr;
+    u.b = BFinP{nullptr, 0, 0, 0.0, training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, c1c2 + raw->c};
+    const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks, &u, count, &finalized);
     if (rc != DCT_OK) return rc;
   }
-  const double count = (double)raw->n * raw->h * raw->w;
   const long long total = (long long)raw->n * raw->h * raw->w * raw->c;
   const View vo = to_view(draw);
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_finalize_kernel, dim3(1), dim3(g_enet_fold_threads), 0, st, (const double*)workspace, blocks, raw->c, count,
-             training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, c1c2 + raw->c);
+  if (!finalized) {
+    const BFinP bp = {(const double*)workspace, blocks, raw->c, count, training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, c1c2 + raw->c};
+    enet_launch<BnBwdFinK>(DCT_PROF_OTHER, dim3(1), dim3(g_enet_fold_threads), 0, st, bp);
+  }
+  const ApplyP ap = {p, (const float*)c1c2, (const float*)(c1c2 + raw->c), vo};
   {
     auto v8 = [&](const View& v, int f32) {
       const int esz = (f32 || dtype == DCT_F32) ? 4 : 2;
@@ -1579,27 +1932,32 @@ extern "C" int dct_enet_bn_bwd_rows(const dct_view* raw, const dct_view* g, cons
     };
     if (g_enet_apply_vec && v8(p.x, p.fm & 1) && v8(p.g, p.fm & 2) && (!p.has_mask || v8(p.m, p.fm & 4)) && v8(vo, p.fm & 8) &&
         vo.c == p.x.c) {
-      ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_apply_vec_kernel<T>, dim3(div_up(total / 8, 256)), dim3(256), 0, st, p,
-                               (const float*)c1c2, (const float*)(c1c2 + raw->c), vo));
+      ENET_T(dtype, enet_launch<BnApplyVecK<T>>(DCT_PROF_OTHER, dim3(div_up(total / 8, 256)), dim3(256), 0, st, ap));
       return dct_check_launch();
     }
   }
-  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_apply_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, p,
-                           (const float*)c1c2, (const float*)(c1c2 + raw->c), vo));
+  ENET_T(dtype, enet_launch<BnApplyK<T>>(DCT_PROF_OTHER, dim3(div_up(total, 256)), dim3(256), 0, st, ap));
   return dct_check_launch();
 }
 
 extern "C" int dct_enet_channel_sum(const dct_view* x, float* out, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
                                     dct_stream stream) {
   if (!view_ok(x) || !out || !ok_dtype(dtype) || x->c > 128) return DCT_ERR_BAD_ARG;
+  const LeafScope leaf;
   RedP p; p.x = to_view(x); p.g = p.x; p.m = p.x;
   p.scale = p.shift = p.slope = p.mean = p.invstd = nullptr;
-  p.act = 0; p.has_mask = 0; p.kind = 0; p.ppb = 0; p.fm = f32_mask & 1;
+  p.act = 0; p.has_mask = 0; p.kind = 0; p.ppb = 0; p.fm = f32_mask & 1; p.partial = nullptr;
   hipStream_t st = (hipStream_t)stream;
   int blocks = 0;
-  const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
+  FinU u;
+  u.mode = 3; u.ticket = nullptr;
+  u.s = SFinP{nullptr, 0, 0, out};
+  bool fused = false;
+  const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks, &u, 0.0, &fused);
   if (rc != DCT_OK) return rc;
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_sum_finalize_kernel, dim3(1), dim3(g_enet_fold_threads), 0, st, (const double*)workspace, blocks, x->c, out);
+  if (fused) return dct_check_launch();
+  const SFinP sp = {(const double*)workspace, blocks, x->c, out};
+  enet_launch<SumFinK>(DCT_PROF_OTHER, dim3(1), dim3(g_enet_fold_threads), 0, st, sp);
   return dct_check_launch();
 }
 
@@ -1619,7 +1977,7 @@ extern "C" int dct_enet_tail_fwd(const dct_view* raw, const dct_enet_tf* tf, con
   if (mode == 3 && (main_in->c != 1 || main_in->h != 2 * out->h || out->c != raw->c + 1)) return DCT_ERR_BAD_ARG;
   const long long total = (long long)out->n * out->h * out->w * out->c;
   hipStream_t st = (hipStream_t)stream;
-  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_tail_fwd_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, p));
+  ENET_T(dtype, enet_launch<TailFwdK<T>>(DCT_PROF_OTHER, dim3(div_up(total, 256)), dim3(256), 0, st, p));
   return dct_check_launch();
 }
 
@@ -1632,7 +1990,7 @@ extern "C" int dct_enet_tail_bwd(const dct_view* dout, const dct_view* out_mask,
   p.idx = idx; p.mode = mode; p.Cm = idx_channels; p.accumulate = accumulate ? 1 : 0; p.fm = f32_mask;
   const long long total = (long long)dst->n * dst->h * dst->w * dst->c;
   hipStream_t st = (hipStream_t)stream;
-  ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_tail_bwd_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, p));
+  ENET_T(dtype, enet_launch<TailBwdK<T>>(DCT_PROF_OTHER, dim3(div_up(total, 256)), dim3(256), 0, st, p));
   return dct_check_launch();
 }
 
@@ -1645,6 +2003,7 @@ extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const d
                               float* dw, const dct_conv_desc* d, int f32_mask, int dtype,
                               void* workspace, size_t workspace_bytes, dct_stream stream) {
   if (!view_ok(a) || !view_ok(b) || !dw || !d || !ok_dtype(dtype) || a->n != b->n) return DCT_ERR_BAD_ARG;
+  const LeafScope leaf;
   const int E = a->c * d->R * d->S * b->c;
   if ((g_enet_mfma & 2) && dtype != DCT_F32) {
     WgP p;
@@ -1669,9 +2028,10 @@ extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const d
     if (pps > 0x7fffffffLL || nsl * mtiles * ntiles > 0x7fffffffLL) return DCT_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < (size_t)nsl * E * sizeof(float)) return DCT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_mwgrad_kernel<T>, dim3((unsigned)(nsl * mtiles * ntiles)), dim3(64), 0, st, p,
-                             (float*)workspace, E, (int)pps, mtiles, ntiles));
-    DCT_LAUNCH(DCT_PROF_OTHER, enet_wgrad_reduce_kernel, dim3(div_up(E, 16)), dim3(256), 0, st, (const float*)workspace, dw, E, (int)nsl);
+    p.partial = (float*)workspace; p.E = E; p.pps = (int)pps; p.mtiles = mtiles; p.ntiles = ntiles;
+    ENET_T(dtype, enet_launch<MwgradK<T>>(DCT_PROF_OTHER, dim3((unsigned)(nsl * mtiles * ntiles)), dim3(64), 0, st, p));
+    const WRedP wr = {(const float*)workspace, dw, E, (int)nsl};
+    enet_launch<WgradRedK>(DCT_PROF_OTHER, dim3(div_up(E, 16)), dim3(256), 0, st, wr);
     return dct_check_launch();
   }
   const int CaP = (a->c + 3) & ~3, kbP = (d->R * d->S * b->c + 7) & ~7;
@@ -1697,9 +2057,106 @@ extern "C" int dct_enet_wgrad(const dct_view* a, const dct_enet_tf* tfa, const d
   const int nb = (int)((P + ppb - 1) / ppb);
   if (!workspace || workspace_bytes < (size_t)nb * E * sizeof(float)) return DCT_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  if (SL == 4) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_wgrad_kernel<T, 4>), dim3(nb), dim3(256), lds, st, p, (float*)workspace, E));
-  else if (SL == 2) ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_wgrad_kernel<T, 2>), dim3(nb), dim3(256), lds, st, p, (float*)workspace, E));
-  else ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, (enet_wgrad_kernel<T, 1>), dim3(nb), dim3(256), lds, st, p, (float*)workspace, E));
-  DCT_LAUNCH(DCT_PROF_OTHER, enet_wgrad_reduce_kernel, dim3(div_up(E, 16)), dim3(256), 0, st, (const float*)workspace, dw, E, nb);
+  p.partial = (float*)workspace; p.E = E; p.pps = 0; p.mtiles = 0; p.ntiles = 0;
+  if (SL == 4) ENET_T(dtype, (enet_launch<WgradK<T, 4>>(DCT_PROF_OTHER, dim3(nb), dim3(256), lds, st, p)));
+  else if (SL == 2) ENET_T(dtype, (enet_launch<WgradK<T, 2>>(DCT_PROF_OTHER, dim3(nb), dim3(256), lds, st, p)));
+  else ENET_T(dtype, (enet_launch<WgradK<T, 1>>(DCT_PROF_OTHER, dim3(nb), dim3(256), lds, st, p)));
+  const WRedP wr = {(const float*)workspace, dw, E, nb};
+  enet_launch<WgradRedK>(DCT_PROF_OTHER, dim3(div_up(E, 16)), dim3(256), 0, st, wr);
+  return dct_check_launch();
+}
+
+// ---- grouped passes (see "launch plumbing" at the top) ----------------------------------------------------------------
+extern "C" int dct_group_begin(int members) {
+  if (members < 1 || members > GROUP_MAX || g_grp.active) return DCT_ERR_BAD_ARG;
+  g_grp.recs.assign((size_t)members, std::vector<GroupRec>());
+  g_grp.member = 0;
+  g_grp.active = true;
+  return DCT_OK;
+}
+// Side recording of LEAF launches: from dct_leaves_begin on, the launches of dct_enet_wgrad / dct_enet_channel_sum (weight and
+// bias gradients: leaves of a backward pass's data-gradient chain) are held back while everything else launches as usual;
+// dct_leaves_flush(stream) issues what has been held back so far on `stream` (another queue, after an event of the chain) and
+// keeps recording, dct_leaves_end(stream) issues the rest and stops.  Operands must stay allocated until their flush has been
+// issued AND `stream` has been joined.
+extern "C" int dct_leaves_begin(void) {
+  if (g_grp.active) return DCT_ERR_BAD_ARG;
+  g_grp.recs.assign(1, std::vector<GroupRec>());
+  g_grp.member = 0;
+  g_grp.leaves_only = true;
+  g_grp.active = true;
+  return DCT_OK;
+}
+extern "C" int dct_leaves_flush(dct_stream stream, int* launches_out) {
+  if (!g_grp.active || !g_grp.leaves_only) return DCT_ERR_BAD_ARG;
+  std::vector<GroupRec> recs;
+  recs.swap(g_grp.recs[0]);
+  g_grp.active = false;            // (the launches below must go out)
+  for (const GroupRec& a : recs) {
+    const void* one[1] = {a.blob.data()};
+    a.launch(one, 1, a.grid, a.block, a.lds, (hipStream_t)stream, a.cls);
+  }
+  g_grp.active = true;
+  if (launches_out) *launches_out = (int)recs.size();
+  return dct_check_launch();
+}
+extern "C" int dct_leaves_end(dct_stream stream, int* launches_out) {
+  const int rc = dct_leaves_flush(stream, launches_out);
+  g_grp.active = false;
+  g_grp.leaves_only = false;
+  g_grp.recs.clear();
+  return rc;
+}
+extern "C" int dct_group_member(int member) {
+  if (!g_grp.active || member < 0 || member >= (int)g_grp.recs.size()) return DCT_ERR_BAD_ARG;
+  g_grp.member = member;
+  return DCT_OK;
+}
+extern "C" int dct_group_max(void) { return GROUP_MAX; }
+extern "C" int dct_group_abort(void) {
+  g_grp.active = false;
+  g_grp.leaves_only = false;
+  g_grp.recs.clear();
+  return DCT_OK;
+}
+// Launches everything recorded since dct_group_begin on `stream`: entry k of every member in ONE launch where the members agree
+// on kernel, grid, block and LDS bytes (the same plan on the same shapes always does), otherwise member by member.
+// *grouped_out / *single_out (nullable): how many launches of either kind were issued.
+extern "C" int dct_group_end(dct_stream stream, int* grouped_out, int* single_out) {
+  if (!g_grp.active || g_grp.leaves_only) return DCT_ERR_BAD_ARG;
+  g_grp.active = false;
+  std::vector<std::vector<GroupRec>> recs;
+  recs.swap(g_grp.recs);
+  hipStream_t st = (hipStream_t)stream;
+  const int n = (int)recs.size();
+  size_t longest = 0;
+  bool same_len = true;
+  for (const auto& r : recs) { longest = std::max(longest, r.size()); same_len = same_len && r.size() == recs[0].size(); }
+  int grouped = 0, single = 0;
+  for (size_t k = 0; k < longest; ++k) {
+    bool same = same_len && n > 1;
+    for (int m = 1; same && m < n; ++m) {
+      const GroupRec& a = recs[0][k]; const GroupRec& b = recs[m][k];
+      same = a.launch == b.launch && a.grid.x == b.grid.x && a.grid.y == b.grid.y && a.grid.z == b.grid.z && a.block.x == b.block.x &&
+             a.lds == b.lds && a.blob.size() == b.blob.size();
+    }
+    if (same && recs[0][k].grid.z == 1) {
+      const void* args[GROUP_MAX];
+      for (int m = 0; m < n; ++m) args[m] = recs[m][k].blob.data();
+      const GroupRec& a = recs[0][k];
+      a.launch(args, n, a.grid, a.block, a.lds, st, a.cls);
+      ++grouped;
+    } else {
+      for (int m = 0; m < n; ++m) {
+        if (k >= recs[m].size()) continue;
+        const GroupRec& a = recs[m][k];
+        const void* one[1] = {a.blob.data()};
+        a.launch(one, 1, a.grid, a.block, a.lds, st, a.cls);
+        ++single;
+      }
+    }
+  }
+  if (grouped_out) *grouped_out = grouped;
+  if (single_out) *single_out = single;
   return dct_check_launch();
 }

@@ -1882,7 +1882,7 @@ extern int g_enet_reduce_vec;                 // enet.hip
 extern int g_enet_fold_threads;               // enet.hip
 extern int g_enet_mfma;                       // enet.hip
 extern int g_enet_bn_owner;                   // enet.hip
-extern int g_enet_mwgrad_waves, g_enet_mwgrad_min_steps, g_enet_apply_vec;
+extern int g_enet_mwgrad_waves, g_enet_mwgrad_min_steps, g_enet_apply_vec, g_enet_fuse_finalize;
 
 extern "C" int dct_tune_set(int knob, int value) {
   switch (knob) {
@@ -1910,6 +1910,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_VEC: g_enet_reduce_vec = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_FOLD_THREADS: if (value != 256 && value != 512 && value != 1024) return DCT_ERR_BAD_ARG; g_enet_fold_threads = value; return DCT_OK;
+    case DCT_TUNE_ENET_FUSE_FINALIZE: g_enet_fuse_finalize = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }

@@ -21,6 +21,8 @@ def _ws(nbytes: int, device) -> Optional[torch.Tensor]:
     capture the buffer comes from the graph's private pool as before: a cached buffer baked into a graph could be
     replaced (and freed) by a later, larger request while the graph still replays."""
     nbytes = max(int(nbytes), 16)
+    if _GROUP is not None:        # recorded launches of different members run at the same time: scratch of their own, kept until then
+        return keep(torch.empty(nbytes, dtype=torch.uint8, device=device))
     if torch.cuda.is_current_stream_capturing():
         return torch.empty(nbytes, dtype=torch.uint8, device=device)
     dev = torch.device(device)
@@ -30,6 +32,103 @@ def _ws(nbytes: int, device) -> Optional[torch.Tensor]:
         buf = torch.empty(max(nbytes, 2 * buf.numel() if buf is not None else 1 << 20), dtype=torch.uint8, device=dev)
         _WS_CACHE[key] = buf
     return buf
+
+
+class PassGroup(object):
+    """Records the Enet launches of ``members`` independent passes and issues them as one chain of grouped launches
+    (include/dct.h "grouped passes").  Use::
+
+        with K.PassGroup(n) as grp:
+            for m in range(n):
+                grp.member(m)
+                ... plan_forward / plan_backward of pass m ...
+        # leaving the block launches on the current stream
+
+    Everything a member allocates while recording (`keep`) -- activations, scratch -- stays referenced until the launches
+    are issued: the caching allocator would otherwise hand member m + 1 the blocks member m has already "freed" although
+    none of m's kernels has run."""
+
+    def __init__(self, members: int):
+        self.n = int(members)
+        self.kept: list = []
+        self.grouped = self.single = 0
+
+    def __enter__(self):
+        global _GROUP
+        assert _GROUP is None, "pass groups do not nest"
+        call("dct_group_begin", self.n)
+        _GROUP = self
+        _lib.GROUP_OPEN = True
+        return self
+
+    def member(self, m: int) -> None:
+        call("dct_group_member", int(m))
+
+    def __exit__(self, et, ev, tb):
+        global _GROUP
+        _GROUP = None
+        _lib.GROUP_OPEN = False
+        if et is not None:
+            _lib.load().dct_group_abort()
+            self.kept.clear()
+            return False
+        g, s = C.c_int(0), C.c_int(0)
+        call("dct_group_end", stream(), C.byref(g), C.byref(s))
+        self.grouped, self.single = g.value, s.value
+        self.kept.clear()
+        return False
+
+
+class LeafSide(object):
+    """Holds back the weight- and bias-gradient launches of a backward pass (the leaves of its data-gradient chain) so that
+    they can be issued on ANOTHER queue (include/dct.h dct_leaves_*)::
+
+        with K.LeafSide() as side:
+            net.plan_backward(..., leaf_hook=hook)     # hook(): event on the chain's stream; side stream waits; side.flush() there
+        keep = side.kept                                # stays referenced until the side stream has been joined
+
+    ``flush`` issues what is held so far on the CURRENT stream.  Leaving the block issues any rest on the current stream."""
+
+    def __init__(self):
+        self.kept: list = []
+        self.launches = 0
+
+    def __enter__(self):
+        global _GROUP
+        assert _GROUP is None, "pass groups / leaf sides do not nest"
+        call("dct_leaves_begin")
+        _GROUP = self
+        return self
+
+    def flush(self) -> None:
+        n = C.c_int(0)
+        call("dct_leaves_flush", stream(), C.byref(n))
+        self.launches += n.value
+
+    def __exit__(self, et, ev, tb):
+        global _GROUP
+        _GROUP = None
+        if et is not None:
+            _lib.load().dct_group_abort()
+            return False
+        n = C.c_int(0)
+        call("dct_leaves_end", stream(), C.byref(n))
+        self.launches += n.value
+        return False
+
+
+_GROUP = None
+
+
+def keep(t):
+    """Tensor ``t`` (allocated by a pass that may be recording into a PassGroup) -> t, referenced until the group launches."""
+    if _GROUP is not None:
+        _GROUP.kept.append(t)
+    return t
+
+
+def group_max() -> int:
+    return int(_lib.load().dct_group_max())
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -428,6 +527,8 @@ _red_ws = {}
 def _enet_ws(device, nbytes):
     """Reduction scratch, cached per (device, stream): kernels of two models queued on different streams must not
     share it.  While a HIP graph is being captured the buffer comes from the graph's own pool instead."""
+    if _GROUP is not None:        # members of a pass group run at the same time: scratch of their own, kept until the launches
+        return keep(torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device))
     if torch.cuda.is_current_stream_capturing():
         return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
@@ -471,10 +572,12 @@ def enet_conv(x, w, bias, tf, y, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, tra
     return y
 
 
-def enet_conv_stats(x, w, bias, tf, y, stats, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, transposed=False, ws=(0, 0, 0), compute=None):
+def enet_conv_stats(x, w, bias, tf, y, stats, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, transposed=False, ws=(0, 0, 0), compute=None,
+                    fin=None):
     """enet_conv with the consumer BatchNorm's partial sums written by the convolution's epilogue into ``stats`` (float64,
     >= tiles * C * 3 elements, tiles = ceil(pixels / 32)).  -> number of partial rows written, 0 when the call did not take the
-    MFMA form (the statistics then need the usual reduction)."""
+    MFMA form (the statistics then need the usual reduction).  With ``fin`` -> (rows, finalized): finalized = the launch's last
+    block has also run the BatchNorm's finalize (no `enet_bn_fwd_stats` call needed)."""
     d = conv_desc(R, S, stride, dil, pad_h, pad_w)
     vx, vy = view(x), view(y)
     keep, tfp = _tfp(tf)
@@ -483,6 +586,15 @@ def enet_conv_stats(x, w, bias, tf, y, stats, *, R, S, stride=1, dil=1, pad_h=0,
         dt = DTYPE_OF[compute]
     rows = C.c_int(0)
     cap = stats.numel() // (3 * y.shape[3])
+    if fin is not None:
+        # fin = (gamma, beta, eps, momentum, scale, shift, mean, invstd, save_var): the BatchNorm's finalize rides in the launch
+        gamma, beta, eps, momentum, scale, shift, mean, invstd, save_var = fin
+        f = _lib.EnetBnFin(ptr(gamma), ptr(beta), float(eps), float(momentum), None, None, 1, ptr(scale), ptr(shift), ptr(mean),
+                           ptr(invstd), ptr(save_var))
+        done = C.c_int(0)
+        call("dct_enet_conv_stats_fin", C.byref(vx), ptr(w), ptr(bias), tfp, C.byref(vy), C.byref(d), int(transposed),
+             int(ws[0]), int(ws[1]), int(ws[2]), fm, dt, ptr(stats), int(cap), C.byref(rows), C.byref(f), C.byref(done), stream())
+        return int(rows.value), bool(done.value)
     call("dct_enet_conv_stats", C.byref(vx), ptr(w), ptr(bias), tfp, C.byref(vy), C.byref(d), int(transposed),
          int(ws[0]), int(ws[1]), int(ws[2]), fm, dt, ptr(stats), int(cap), C.byref(rows), stream())
     return int(rows.value)
@@ -504,7 +616,7 @@ def enet_bn_fwd_stats(raw, gamma, beta, eps, momentum, running_mean, running_var
 
 
 def enet_conv_bnbwd_stats(x, w, y, stats, rec_raw, rec_tf, rec_mean, rec_invstd, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0,
-                          transposed=False, ws=(0, 0, 0), compute=None):
+                          transposed=False, ws=(0, 0, 0), compute=None, fin=None):
     """Data-gradient convolution y = dgrad(x) (enet_conv without bias / transform / residual) whose epilogue also writes the
     BatchNorm-backward partial sums of the layer that produced y's tensor (raw output ``rec_raw``, consumer transform ``rec_tf``,
     saved statistics) into ``stats`` (float64, >= tiles * C * 3).  -> partial rows written (0: the usual reduction is needed)."""
@@ -516,6 +628,15 @@ def enet_conv_bnbwd_stats(x, w, y, stats, rec_raw, rec_tf, rec_mean, rec_invstd,
     act = rec_tf.mode if rec_tf.mode in (2, 3) else 0
     rows = C.c_int(0)
     cap = stats.numel() // (3 * y.shape[3])
+    if fin is not None:
+        # fin = (dgamma, dbeta, dslope, c1c2, training): the BatchNorm-backward finalize rides in the launch -> (rows, finalized)
+        dgamma, dbeta, dslope, c1c2, training = fin
+        f = _lib.EnetBnBwdFin(ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(c1c2), int(training))
+        done = C.c_int(0)
+        call("dct_enet_conv_bnbwd_stats_fin", C.byref(vx), ptr(w), C.byref(vy), C.byref(d), int(transposed), int(ws[0]), int(ws[1]),
+             int(ws[2]), fm, dt, C.byref(vr), ptr(rec_tf.scale), ptr(rec_tf.shift), ptr(rec_tf.slope), int(act), ptr(rec_mean),
+             ptr(rec_invstd), ptr(stats), int(cap), C.byref(rows), C.byref(f), C.byref(done), stream())
+        return int(rows.value), bool(done.value)
     call("dct_enet_conv_bnbwd_stats", C.byref(vx), ptr(w), C.byref(vy), C.byref(d), int(transposed), int(ws[0]), int(ws[1]), int(ws[2]),
          fm, dt, C.byref(vr), ptr(rec_tf.scale), ptr(rec_tf.shift), ptr(rec_tf.slope), int(act), ptr(rec_mean), ptr(rec_invstd),
          ptr(stats), int(cap), C.byref(rows), stream())
@@ -527,7 +648,7 @@ def enet_bn_bwd(raw, g, g_mask, tf, mean, invstd, dgamma, dbeta, dslope, c1c2, d
     vm = view(g_mask) if g_mask is not None else None
     act = tf.mode if tf.mode in (2, 3) else 0
     dt, fm = _mixed(raw, g, g_mask, draw)
-    if partial is not None and partial_rows > 0:          # rows written by enet_conv_bnbwd_stats: fold + apply only
+    if partial is not None and partial_rows != 0:         # rows written by enet_conv_bnbwd_stats: fold + apply only (< 0: apply only)
         call("dct_enet_bn_bwd_rows", C.byref(vr), C.byref(vg), None,
              ptr(tf.scale), ptr(tf.shift), ptr(tf.slope), int(act), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(dslope),
              ptr(c1c2), int(training), C.byref(vd), fm, dt, ptr(partial), partial.numel() * partial.element_size(), int(partial_rows),

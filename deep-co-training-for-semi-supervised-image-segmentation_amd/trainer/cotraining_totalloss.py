@@ -155,6 +155,8 @@ class CoTrainer(Trainer):
         self.pass_streams = True            # nets that support it (Enet): the backward passes of one model run on separate streams
         self._pass_pool = None
         self._pass_bufs = {}
+        self.leaf_offload = True            # ... with the adversarial backward pass's weight gradients on the queue that leaves idle
+        self.group_passes = True            # ... and issue the 2S co-training passes as grouped launches where the networks can (Enet)
         self.wide_forward = True            # networks with deferred running statistics: lay the step out on four hardware queues
                                             # (see _run_step_wide)
         self._qstreams = None
@@ -704,6 +706,8 @@ class CoTrainer(Trainer):
             nets[i].plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=buf)
 
         adv, adv_tapes = 0, {}
+        grouped = self._group_passes_ok(nets, lab, unl)
+        leaf_keep = None
         if train_adv:                                                          # :233-244 -> :371-392
             a, b = adv_choice
             eps = float(self.adv_training_dict.get('eplision', 0.05))
@@ -714,8 +718,28 @@ class CoTrainer(Trainer):
                 adv = K.kl_logits_fwd(lp_adv, lp_real, C)[0]
                 if lam_adv != 0.0:
                     da = K.kl_logits_bwd(lp_adv, lp_real, C, torch.empty_like(lp_adv), **g_adv)
-                    backward(a, 2, atape, da)
+                    if grouped and self.leaf_offload:
+                        # the chain ends with model a's backward pass: its weight gradients (a third of its launches, leaves of
+                        # the data-gradient chain) go to the queue the grouped co-training passes leave idle, a few blocks at a time
+                        side_q = free[2]
+                        buf = bufs[a][2] = self._pass_buffer(a, 2, fp[a])
+                        buf.zero_()
+                        with K.LeafSide() as side:
+                            def leaves_out():
+                                ev = sched.record(adv_q)
+                                sched.wait_event(side_q, ev)
+                                with sched.on(side_q):
+                                    side.flush()
+                            nets[a].plan_backward(atape, da, need_dx=False, need_dw=True, grad_buffer=buf, leaf_hook=leaves_out)
+                            leaves_out()
+                        leaf_keep = side.kept          # referenced until the queues are joined (end of this function)
+                    else:
+                        backward(a, 2, atape, da)
             adv_tapes = {"fgsm": (b, ftape), "adv": (a, atape)}
+        if grouped:
+            out = self._wide_grouped_tail(lab, unl, train_adv, nets, gs, g_cot, lam_cot, ignore, free, bufs, tapes, fp, adv, adv_tapes)
+            del leaf_keep
+            return out
         sup, preds, lab_pass = [], [], []
         for i in range(S):                                                     # :208-218
             with sched.on(lab_q[i]):
@@ -754,6 +778,113 @@ class CoTrainer(Trainer):
             for i in range(S):
                 with sched.on(unl_q[i]):
                     backward(i, 1, utapes[i], dl_outs[i])
+        if train_adv:
+            tapes[adv_tapes["fgsm"][0]].append(adv_tapes["fgsm"][1])
+            tapes[adv_tapes["adv"][0]].append(adv_tapes["adv"][1])
+        self._pass_early = {i: (fp[i], [bf for bf in bufs[i] if bf is not None]) for i in range(S)}
+        self._overwrite_models = set(range(S))
+        try:
+            self._finish_step([], None)             # join, sum the pass buffers in order, [gradient exchange], optimizers
+        finally:
+            self._overwrite_models = set()
+            self._pass_early = {}
+            self._pass_join = None
+        for i in range(S):                          # running statistics: labeled, unlabeled, FGSM, adversarial (reference order)
+            nets[i].apply_running_updates(tapes[i])
+        return dict(sup=sup, jsd=jsd, adv=adv, preds=preds, unlab_probs=unlab_probs)
+
+    def _group_passes_ok(self, nets, lab, unl) -> bool:
+        """The 2S co-training passes as grouped launches (include/dct.h "grouped passes"): networks whose plan records into a
+        K.PassGroup, equal labeled batch shapes, and no more members per group than the library packs into one launch."""
+        from .. import hip_ops as K
+        if not (self.group_passes and all(getattr(n, "supports_pass_groups", False) for n in nets)):
+            return False
+        if len({tuple(b[0].shape) for b in lab}) != 1:
+            return False
+        return len(nets) <= K.group_max()
+
+    def _wide_grouped_tail(self, lab, unl, train_adv, nets, gs, g_cot, lam_cot, ignore, free, bufs, tapes, fp, adv, adv_tapes) -> dict:
+        """Co-training half of `_run_step_wide` with the 2S passes grouped: the S labeled and the S unlabeled forward passes (one
+        group of 2S when the two batch shapes agree, else two groups of S on two queues) are ONE chain of ~210 launches instead
+        of 2S chains sharing three queues, and so are the 2S backward passes (~530 launches).  Same kernel bodies on the same
+        operands, same per-pass gradient buffers summed in the same order: bit-identical to the ungrouped layout."""
+        from .. import hip_ops as K
+        from ..loss.loss import _nchw
+        S, C = len(nets), self.C
+        sched = self._sched
+        one = tuple(lab[0][0].shape) == tuple(unl[0].shape) and 2 * S <= K.group_max()
+        q_lab, q_unl = free[0], (free[0] if one else free[1])
+        for n in nets:
+            n.flat_params.ensure()
+        lab_out, unl_out = [None] * S, [None] * S
+
+        def forward_group(members):
+            with K.PassGroup(len(members)) as grp:
+                for m, (i, kind) in enumerate(members):
+                    grp.member(m)
+                    x = lab[i][0] if kind == 0 else unl[0]
+                    lp, tape = nets[i].plan_forward(x, True, defer_running=True)
+                    (lab_out if kind == 0 else unl_out)[i] = (lp, tape)
+
+        lab_members = [(i, 0) for i in range(S)]
+        unl_members = [(i, 1) for i in range(S)]
+        if one:
+            with sched.on(q_lab):
+                forward_group(lab_members + unl_members)
+        else:
+            with sched.on(q_lab):
+                forward_group(lab_members)
+            with sched.on(q_unl):
+                forward_group(unl_members)
+        for i in range(S):                      # tapes per model in the reference's forward order: labeled, unlabeled
+            tapes[i].append(lab_out[i][1])
+            tapes[i].append(unl_out[i][1])
+        sup, preds, dls = [], [], []
+        with sched.on(q_lab):                                                  # :208-218
+            for i in range(S):
+                lp, gt = lab_out[i][0], lab[i][1]
+                dl = torch.empty_like(lp)
+                t = gt.reshape(-1)
+                out = K.ce_fwd(lp, t, C, ignore)
+                K.ce_bwd(lp, t, C, out[1:2], dl, gmul=gs, ignore_index=ignore)
+                sup.append(out[0])
+                preds.append(_nchw(lp))
+                dls.append(dl)
+        lps = [unl_out[i][0] for i in range(S)]
+        dl_outs = [torch.empty_like(lp) for lp in lps]
+        with sched.on(q_unl):                                                  # :219-227
+            jsd = K.jsd_logits_fwd(lps, C)[0]
+            unlab_probs = [_nchw(K.softmax_fwd(lp, C)) for lp in lps]
+            if lam_cot != 0.0:
+                K.jsd_logits_bwd(lps, C, dl_outs, **g_cot)
+
+        def backward_group(members):
+            # what does not record (zero fill of the pass buffers, the cast of the loss gradients) goes first
+            prepared = []
+            for i, kind in members:
+                buf = bufs[i][kind] = self._pass_buffer(i, kind, fp[i])
+                buf.zero_()
+                dl = dls[i] if kind == 0 else dl_outs[i]
+                cd = nets[i].compute_dtype
+                if dl.dtype != cd:
+                    dl = K.cast(dl, torch.empty(dl.shape, dtype=cd, device=dl.device))
+                prepared.append((i, kind, buf, dl))
+            with K.PassGroup(len(members)) as grp:
+                for m, (i, kind, buf, dl) in enumerate(prepared):
+                    grp.member(m)
+                    tape = (lab_out if kind == 0 else unl_out)[i][1]
+                    nets[i].plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=buf)
+
+        unl_bwd = unl_members if lam_cot != 0.0 else []
+        if one:
+            with sched.on(q_lab):
+                backward_group(lab_members + unl_bwd)
+        else:
+            with sched.on(q_lab):
+                backward_group(lab_members)
+            if unl_bwd:
+                with sched.on(q_unl):
+                    backward_group(unl_bwd)
         if train_adv:
             tapes[adv_tapes["fgsm"][0]].append(adv_tapes["fgsm"][1])
             tapes[adv_tapes["adv"][0]].append(adv_tapes["adv"][1])

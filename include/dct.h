@@ -445,10 +445,58 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
        DCT_TUNE_IGEMM_RING = 31,             /* 1: shared-halo conv kernel with a four-slot ring of 32-channel weight half-stages filled three half-steps
                                                 ahead (counted vmcnt, raw barrier) -- bit-identical, measured 15 % slower; 0 (default): two 64-channel stages */
        DCT_TUNE_IGEMM_HALO_WAVES4 = 32,      /* 1: the 128-channel shared-halo tile on four waves of 64 pixels x 64 channels; 0: eight of 32 x 64 */
-       DCT_TUNE_WGRAD3_SHIFT = 33 };         /* 1 (default): filter-row weight gradient builds a row's three x fragments from one 12-pixel window per lane
+       DCT_TUNE_WGRAD3_SHIFT = 33,           /* 1 (default): filter-row weight gradient builds a row's three x fragments from one 12-pixel window per lane
                                                 (register shifts) instead of three LDS reads; 0: one read per tap */
+       DCT_TUNE_ENET_FUSE_FINALIZE = 34 };   /* 1: Enet BatchNorm / bias-sum finalizes ride in the producing launch's last block (measured slower:
+                                                csrc/enet.hip g_enet_fuse_finalize); 0 (default): one-block launches of their own */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
+
+/* The same two launches with the BatchNorm's one-block "finalize" (statistics -> scale / shift / saved statistics; backward sums ->
+ * parameter gradients and the apply pass's two means) riding in the producing launch's LAST block (csrc/enet.hip
+ * last_block_arrived): one launch less per BatchNorm on the chain.  *finalized = 1 when that happened -- then skip
+ * dct_enet_bn_fwd_stats_rows, resp. call dct_enet_bn_bwd_rows with partial_rows = -1 (apply only); 0: proceed as after the plain call.
+ * (dct_enet_bn_fwd_stats / dct_enet_bn_bwd / dct_enet_channel_sum fuse their own reduction + finalize the same way internally.) */
+typedef struct dct_enet_bn_fin {
+  const float* gamma; const float* beta; float eps, momentum;
+  float* running_mean; float* running_var;      /* nullable: deferred running statistics */
+  int32_t training;                              /* must be 1 */
+  float* scale; float* shift; float* save_mean; float* save_invstd; float* save_var;
+} dct_enet_bn_fin;
+typedef struct dct_enet_bn_bwd_fin { float* dgamma; float* dbeta; float* dslope; float* c1c2; int32_t training; } dct_enet_bn_bwd_fin;
+int dct_enet_conv_stats_fin(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
+                            const dct_view* y, const dct_conv_desc* d, int transposed,
+                            int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
+                            double* stats_partial, int stats_capacity_rows, int* stats_rows,
+                            const dct_enet_bn_fin* fin, int* finalized, dct_stream stream);
+int dct_enet_conv_bnbwd_stats_fin(const dct_view* x, const float* w, const dct_view* y, const dct_conv_desc* d, int transposed,
+                                  int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
+                                  const dct_view* bn_raw, const float* bn_scale, const float* bn_shift, const float* bn_slope,
+                                  int bn_act, const float* bn_mean, const float* bn_invstd,
+                                  double* stats_partial, int stats_capacity_rows, int* stats_rows,
+                                  const dct_enet_bn_bwd_fin* fin, int* finalized, dct_stream stream);
+
+/* ---- grouped passes -------------------------------------------------------------------------------------------
+ * Independent passes with identical shapes (the 2S forward, then the 2S backward passes of a co-training step:
+ * cotraining_totalloss.py:208-227,247) as ONE chain of launches: between dct_group_begin(members) and dct_group_end the
+ * dct_enet_* entry points record their launches for the member selected by dct_group_member(m) instead of issuing them
+ * (every other entry point still launches at once: do not call them inside a group); dct_group_end(stream, ...) issues
+ * entry k of all members as one launch (blockIdx.z = member) where kernel, grid, block and LDS bytes agree, else member by
+ * member.  Same kernel bodies on the same operands: bit-identical to the passes launched one after the other.  The
+ * operands of every recorded launch must stay allocated until dct_group_end returns.  members <= dct_group_max(). */
+int dct_group_begin(int members);
+int dct_group_member(int member);
+int dct_group_max(void);
+int dct_group_abort(void);
+int dct_group_end(dct_stream stream, int* grouped_launches, int* single_launches);
+/* Leaves of a backward pass on another queue: from dct_leaves_begin on, the launches of dct_enet_wgrad and dct_enet_channel_sum
+ * (weight / bias gradients: nothing later in the pass reads them) are held back while all other entry points launch as usual;
+ * dct_leaves_flush(stream, &n) issues what is held so far on `stream` and keeps recording; dct_leaves_end issues the rest.
+ * The caller orders `stream` after the producing chain (an event before the flush) and joins it before the gradients are read;
+ * operands stay allocated until then.  Not nestable with a group. */
+int dct_leaves_begin(void);
+int dct_leaves_flush(dct_stream stream, int* launches);
+int dct_leaves_end(dct_stream stream, int* launches);
 
 #ifdef __cplusplus
 }

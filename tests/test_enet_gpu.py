@@ -173,3 +173,139 @@ def test_enet_rejects_bad_inputs():
         net(torch.rand(1, 1, 60, 64, device=DEV))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.rand(1, 1, 64, 64))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_enet_grouped_passes_are_bit_identical(dtype):
+    """Three independent passes (two of one network, one of another) recorded into a K.PassGroup and issued as ONE chain of
+    grouped launches give bit for bit the logits, the statistics and the per-pass gradient buffers of the same passes
+    launched one after the other (include/dct.h "grouped passes")."""
+    from dct_amd import hip_ops as K
+    C = 2
+    nets = [_hip_net(_oracle_net(C, 31 + i), C, dtype).train() for i in range(2)]
+    for n in nets:
+        n.flat_params.ensure()
+    g = torch.Generator().manual_seed(9)
+    passes = [(nets[0], torch.rand(3, 1, 72, 88, generator=g).to(DEV)), (nets[0], torch.rand(3, 1, 72, 88, generator=g).to(DEV)),
+              (nets[1], torch.rand(3, 1, 72, 88, generator=g).to(DEV))]
+    dls = [torch.randn(3, 72, 88, C, generator=g).to(DEV) for _ in passes]
+    dls_c = [d if dtype == torch.float32 else d.to(dtype) for d in dls]
+
+    def run(grouped):
+        outs, tapes, bufs = [], [], []
+        if grouped:
+            with K.PassGroup(len(passes)) as grp:
+                for m, (net, x) in enumerate(passes):
+                    grp.member(m)
+                    lp, tape = net.plan_forward(x, True, defer_running=True)
+                    outs.append(lp); tapes.append(tape)
+            assert grp.grouped > 100 and grp.single == 0, (grp.grouped, grp.single)
+        else:
+            for net, x in passes:
+                lp, tape = net.plan_forward(x, True, defer_running=True)
+                outs.append(lp); tapes.append(tape)
+        stats = [t[-1]["bn_stats"].clone() for t in tapes]
+        for net, _ in passes:
+            bufs.append(torch.zeros(net.flat_params.total, dtype=torch.float32, device=DEV))
+        if grouped:
+            with K.PassGroup(len(passes)) as grp:
+                for m, (net, x) in enumerate(passes):
+                    grp.member(m)
+                    net.plan_backward(tapes[m], dls_c[m], need_dx=False, need_dw=True, grad_buffer=bufs[m])
+            assert grp.grouped > 250 and grp.single == 0, (grp.grouped, grp.single)
+        else:
+            for m, (net, x) in enumerate(passes):
+                net.plan_backward(tapes[m], dls_c[m], need_dx=False, need_dw=True, grad_buffer=bufs[m])
+        torch.cuda.synchronize()
+        return [o.clone() for o in outs], stats, bufs
+
+    a = run(False)
+    b = run(True)
+    for m in range(len(passes)):
+        assert torch.equal(a[0][m], b[0][m]), f"logits of pass {m}"
+        net = passes[m][0]
+        for bn in net._bn_list:                 # (the flat buffer pads every vector to 4 floats: compare the vectors)
+            c, base = bn.num_features, 5 * net._bn_off[id(bn)]
+            cp = (c + 3) // 4 * 4
+            va, vb = a[1][m][base:base + 5 * cp].view(5, cp)[:, :c], b[1][m][base:base + 5 * cp].view(5, cp)[:, :c]
+            assert torch.equal(va, vb), f"batch statistics of pass {m}"
+        assert torch.equal(a[2][m], b[2][m]), f"gradient buffer of pass {m}"
+        assert a[2][m].abs().max().item() > 0
+    # anything that launches at once is refused while a group is open
+    with pytest.raises(RuntimeError):
+        with K.PassGroup(2):
+            K.cast(dls[0], torch.empty_like(dls[0], dtype=torch.bfloat16))
+
+
+def test_enet_backward_leaves_on_a_side_stream_are_bit_identical():
+    """K.LeafSide: the weight / bias gradients of a backward pass held back and issued on another stream in four batches give the
+    gradient buffer of the plain pass bit for bit (and the data-gradient chain itself launches at once)."""
+    from dct_amd import hip_ops as K
+    C = 2
+    net = _hip_net(_oracle_net(C, 41), C, torch.bfloat16).train()
+    net.flat_params.ensure()
+    g = torch.Generator().manual_seed(10)
+    x = torch.rand(4, 1, 80, 96, generator=g).to(DEV)
+    dl = torch.randn(4, 80, 96, C, generator=g).to(DEV).to(torch.bfloat16)
+    lp, tape = net.plan_forward(x, True, defer_running=True)
+    want = torch.zeros(net.flat_params.total, dtype=torch.float32, device=DEV)
+    net.plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=want)
+    got = torch.zeros_like(want)
+    main, side_stream = torch.cuda.current_stream(), torch.cuda.Stream()
+    flushes = []
+    with K.LeafSide() as side:
+        def out():
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side_stream.wait_event(ev)
+            with torch.cuda.stream(side_stream):
+                before = side.launches
+                side.flush()
+                flushes.append(side.launches - before)
+        net.plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=got, leaf_hook=out)
+        out()
+    keep = side.kept
+    main.wait_stream(side_stream)
+    torch.cuda.synchronize()
+    assert len(flushes) >= 3 and all(n > 0 for n in flushes) and side.launches > 120, (flushes, side.launches)
+    assert torch.equal(got, want)
+    del keep
+
+
+def test_enet_finalize_in_the_last_block_matches_the_one_block_launches():
+    """Knob 34 (DCT_TUNE_ENET_FUSE_FINALIZE): the BatchNorm / bias-sum finalizes riding in their producers' last blocks give the
+    logits, statistics and gradients of the separate one-block launches up to the rounding of a different fold grouping (the rows
+    are folded by 256 instead of 1024 threads: same values, another association of the double sums), run after run."""
+    from dct_amd import _lib, hip_ops as K
+    C = 2
+    net = _hip_net(_oracle_net(C, 51), C, torch.bfloat16).train()
+    net.flat_params.ensure()
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(8, 1, 104, 96, generator=g).to(DEV)
+    dl = torch.randn(8, 104, 96, C, generator=g).to(DEV).to(torch.bfloat16)
+    lib = _lib.load()
+
+    def run():
+        lp, tape = net.plan_forward(x, True, defer_running=True)
+        buf = torch.zeros(net.flat_params.total, dtype=torch.float32, device=DEV)
+        dx = net.plan_backward(tape, dl, need_dx=True, need_dw=True, grad_buffer=buf)
+        torch.cuda.synchronize()
+        return lp.clone(), buf, dx.clone()
+
+    outs = {}
+    for knob in (0, 1):
+        assert lib.dct_tune_set(34, knob) == 0
+        try:
+            outs[knob] = [run() for _ in range(3)]
+        finally:
+            lib.dct_tune_set(34, 0)
+    for k in (0, 1):                              # either mode is deterministic
+        for r in outs[k][1:]:
+            for a, b in zip(outs[k][0], r):
+                assert torch.equal(a, b), f"knob {k}: run-to-run difference"
+    for a, b, what in zip(outs[0][0], outs[1][0], ("logits", "gradients", "dx")):
+        err = (a.float() - b.float()).abs().max().item()
+        scale = b.float().abs().max().item()
+        assert err <= 2e-3 * scale, f"{what}: {err:.3e} vs scale {scale:.3e}"
+    rel = (outs[0][0][1] - outs[1][0][1]).norm().item() / outs[1][0][1].norm().item()
+    assert rel < 1e-3, rel
