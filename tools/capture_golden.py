@@ -723,4 +723,4 @@ if __name__ == "__main__":
     if "g10_enet" in which:
         g10_acdc_dsc("enet", epochs=5, steps_per_epoch=500, bs=4, threads=4)
     if "g10_unet" in which:
-        g10_acdc_dsc("unet", epochs=4, steps_per_epoch=250, bs=2, threads=4)
+        g10_acdc_dsc("unet", epochs=int(os.environ.get("G10_UNET_EPOCHS", "8")), steps_per_epoch=250, bs=2, threads=6)
