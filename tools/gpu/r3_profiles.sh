@@ -22,10 +22,15 @@ timeout 600 python tools/bench_conv.py --batch 16 > $O/bench_conv_per_layer.txt 
 timeout 600 python bench.py --steps 30 --warmup 10 --no-cpu-baseline > $O/cfg2_bench.json 2> $O/bench.err
 timeout 600 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --train-steps 300 > $O/cfg2_after_300_steps.json 2>> $O/bench.err
 timeout 600 python bench.py --config cfg3 --steps 30 --warmup 10 --no-cpu-baseline > $O/cfg3_bench.json 2>> $O/bench.err
-P=$PWD/deep-co-training-for-semi-supervised-image-segmentation_amd
-for z in 0 0.5 0.9; do for L in dec2b dec3b; do
-  DCT_LIB_PATH=$P/libdct_hip_stamps.so timeout 120 python tools/stamps_igemm3.py --layer $L --zeros $z >> $O/in_kernel_clock.txt 2>&1
-done; done
+# (the in-kernel clock, profiles/r03_in_kernel_clock.txt, needs the diagnostic build: make EXTRA=-DDCT_STAMPS OUT=../libdct_hip_stamps.so, then
+#  DCT_LIB_PATH=.../libdct_hip_stamps.so python tools/stamps_igemm3.py --layer dec2b --zeros 0|0.5|0.9)
+# Enet configurations: kernel statistics of the default command, bench lines, the step program's timeline
+run kd_cfg4 --kernel-trace --stats -d $O/kd_cfg4 -o k --output-format csv -- python3 bench.py --config cfg4 --steps 20 --warmup 5 $B
+python3 tools/rocprof_summary.py $(find $O/kd_cfg4 -name "*kernel_trace.csv" | head -1) > $O/cfg4_default_command_kernel_stats.txt
+timeout 600 python bench.py --config cfg4 --steps 30 --warmup 10 --no-cpu-baseline > $O/cfg4_bench.json 2>> $O/bench.err
+timeout 600 python bench.py --config cfg5 --steps 30 --warmup 10 --no-cpu-baseline > $O/cfg5_bench.json 2>> $O/bench.err
+timeout 300 python tools/probe_step_program.py cfg4 > $O/cfg4_step_program_timeline.txt 2>&1
+timeout 300 python tools/probe_step_program.py cfg5 > $O/cfg5_step_program_timeline.txt 2>&1
 # PMC study of the three dominant kernels (one layer each)
 bash tools/gpu/pmc_layer.sh $O/pmc_igemm3m_dec2b "" dec2b fwd
 bash tools/gpu/pmc_layer.sh $O/pmc_igemm3p_dec4b "" dec4b fwd
