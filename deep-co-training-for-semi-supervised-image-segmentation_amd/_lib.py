@@ -47,6 +47,10 @@ class EnetBnBwdFin(C.Structure):
     _fields_ = [("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dslope", C.c_void_p), ("c1c2", C.c_void_p), ("training", C.c_int32)]
 
 
+class EnetBwdIn(C.Structure):
+    _fields_ = [("g", C.POINTER(View)), ("g_mask", C.POINTER(View)), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("c1c2", C.c_void_p)]
+
+
 def conv_desc(R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=0, scatter2x2=0, accumulate=0,
               mask_channels=0, mask_scale=1.0, mask_bits=None, relu_bits_out=None) -> ConvDesc:
     return ConvDesc(R, S, stride, dil, pad_h, pad_w, int(relu), int(scatter2x2), int(accumulate),
@@ -133,6 +137,9 @@ SIGNATURES = {
     "dct_enet_conv_bnbwd_stats": (_i, [_VP, _P, _VP, _DP, _i, _i, _i, _i, _i, _i, _VP, _P, _P, _P, _i, _P, _P, _P, _i, _P, _P]),
     "dct_enet_conv_stats_fin": (_i, [_VP, _P, _P, _TP, _VP, _DP, _i, _i, _i, _i, _i, _i, _P, _i, _P, _P, _P, _P]),
     "dct_enet_conv_bnbwd_stats_fin": (_i, [_VP, _P, _VP, _DP, _i, _i, _i, _i, _i, _i, _VP, _P, _P, _P, _i, _P, _P, _P, _i, _P, _P, _P, _P]),
+    "dct_enet_conv_bwd_in": (_i, [_VP, _P, _TP, _P, _VP, _DP, _i, _i, _i, _i, _VP, _VP, _i, _i, _VP, _P, _P, _P, _i, _P, _P, _P, _i, _P, _P]),
+    "dct_enet_bn_bwd_sums": (_i, [_VP, _VP, _VP, _P, _P, _P, _i, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _sz, _i, _P]),
+    "dct_enet_bn_bwd_apply": (_i, [_VP, _VP, _VP, _P, _P, _P, _i, _P, _P, _P, _VP, _i, _i, _i, _P]),
     "dct_enet_channel_sum": (_i, [_VP, _P, _i, _i, _P, _sz, _P]),
     "dct_enet_tail_fwd": (_i, [_VP, _TP, _VP, _VP, _TP, _P, _i, _i, _VP, _i, _i, _P]),
     "dct_enet_tail_bwd": (_i, [_VP, _VP, _P, _i, _i, _i, _VP, _i, _i, _P]),

@@ -178,6 +178,15 @@ def _empty_like(t):
     return K.keep(torch.empty_like(t))
 
 
+class _Draw(object):
+    """The BatchNorm-backward result of a layer (gradient wrt its raw conv output), possibly not materialised: the data-gradient
+    convolution it feeds computes it on load (K.enet_conv_bwd_in), and only a weight gradient needs the tensor -- as a leaf."""
+    __slots__ = ("rec", "g", "g_mask", "scratch", "tensor")
+
+    def __init__(self, rec, g, g_mask, scratch, tensor=None):
+        self.rec, self.g, self.g_mask, self.scratch, self.tensor = rec, g, g_mask, scratch, tensor
+
+
 class _Rec(object):
     """what one conv+BN(+act) unit leaves behind for its consumers and for the backward"""
     __slots__ = ("raw", "tf", "mean", "invstd", "bn", "act", "conv", "src", "src_tf")
@@ -211,10 +220,18 @@ class Enet(nn.Module):
         self._bn_table = None                # (key, device record table)
         self._defer_running = False
         self.fuse_bn_stats = os.environ.get("DCT_ENET_FUSE_BN_STATS", "1") != "0"     # BatchNorm partial sums from the conv epilogue
-        # ... and the backward sums from the data-gradient epilogue (dct_enet_conv_bnbwd_stats): -270 launches per cfg4 step but level
-        # on the step (17.05 vs 17.15 ms) -- off; tests/test_enet_kernels_gpu.py pins the kernel, tools/debug_fuse_bn.py compares a
+        # ... and the backward sums from the data-gradient epilogue (dct_enet_conv_bnbwd_stats): -270 launches per cfg4 step.  Level
+        # on the four-queue step of round 2 (17.05 vs 17.15 ms), -3..5 % with the grouped layout of round 3 (15.2-15.6 vs 16.0-16.2 ms
+        # on one box; cfg5 level) -- on; tests/test_enet_kernels_gpu.py pins the kernel, tools/debug_fuse_bn.py compares a
         # whole backward pass (3e-3 in fp16 / 3e-2 in bf16 on the smallest gradients: rounding ties of the 16-bit draw tensors)
-        self.fuse_bn_bwd_stats = os.environ.get("DCT_ENET_FUSE_BN_BWD", "0") == "1"
+        self.fuse_bn_bwd_stats = os.environ.get("DCT_ENET_FUSE_BN_BWD", "1") == "1"
+        # BatchNorm-backward apply computed ON LOAD by the data-gradient convolution it feeds (K.enet_conv_bwd_in), the tensor only
+        # materialised -- as a leaf -- for the weight gradient: bit-identical, 60-90 launches off the adversarial chain, and LEVEL on
+        # cfg4 (15.98-16.18 vs 15.91-16.03 ms on one box), +0.5 % on cfg5: the convolution pays in loads (raw fp32 + g + mask instead
+        # of one 16-bit tensor) what the chain saves in launches.  Off; kept for A/B.
+        self.denorm_on_load = os.environ.get("DCT_ENET_DENORM_ON_LOAD", "0") == "1"
+        self.denorm_on_load_all = False      # (A/B: also for 3x3 / dilated / asymmetric kernels)
+        self.stats_tiles_cap = int(os.environ.get("DCT_ENET_STATS_TILES", "1024"))       # most 32-pixel tiles (= partial rows) a fused layer may have
         self.skip_zero_bias_grads = os.environ.get("DCT_ENET_BIAS_GRADS", "0") != "1"    # see _conv_wgrad
 
     supports_pass_streams = True         # plan_backward(grad_buffer=...): concurrent backward passes of one model (trainer)
@@ -328,7 +345,7 @@ class Enet(nn.Module):
         stats, rows = None, 0
         tiles = (B * out_hw[0] * out_hw[1] + 31) // 32
         if (self.training and self.fuse_bn_stats and dt != torch.float32 and conv.cin >= 16 and conv.cin % 16 == 0 and
-                conv.cout <= 128 and tiles <= 1024):
+                conv.cout <= 128 and tiles <= self.stats_tiles_cap):
             # MFMA convolution: its epilogue writes the BatchNorm partial sums (one launch and one read of `raw` less per seam)
             stats = _empty(tiles * conv.cout * 3, dtype=torch.float64, device=dev)
             fused = True
@@ -385,42 +402,49 @@ class Enet(nn.Module):
                         pad_w=conv.pad[1], ws=(t * conv.cin, conv.cin, 1), compute=self.compute_dtype)
 
     def _conv_dgrad(self, g, conv, dst, accumulate=False, resid=None, bn_of_dst=None, need_dw=True):
-        """dst (+)= d(loss)/d(conv input) given g = d/d(conv output).
+        """dst (+)= d(loss)/d(conv input) given g = d/d(conv output) -- a tensor, or a _Draw that the convolution computes on load
+        where the library has that form (else it is materialised here, on the chain).
 
-        ``bn_of_dst`` (a _Rec): dst is the gradient wrt act(BN(rec.raw)); where the MFMA form runs, its epilogue also writes that
-        BatchNorm's backward partial sums -> (dst, stats, rows) for _bn_bwd (rows = 0: not written)."""
+        ``bn_of_dst`` (a _Rec): dst is the gradient wrt act(BN(rec.raw)); where the MFMA form runs (and fuse_bn_bwd_stats is on), its
+        epilogue also writes that BatchNorm's backward partial sums -> (dst, (stats, scratch) | None, rows) for _bn_bwd (rows = 0: not
+        written, < 0: finalized as well)."""
         w = self._w(conv.weight)
         t = conv.taps
-        if bn_of_dst is not None:
-            rec = bn_of_dst
-            tiles = (dst.shape[0] * dst.shape[1] * dst.shape[2] + 31) // 32
-            cin_g = g.shape[3]
-            if (self.fuse_bn_bwd_stats and self._tape_training and self.compute_dtype != torch.float32 and cin_g >= 16 and cin_g % 16 == 0 and
-                    dst.shape[3] <= 128 and tiles <= 1024 and not accumulate and resid is None):
-                stats = _empty(tiles * dst.shape[3] * 3, dtype=torch.float64, device=dst.device)
-                kw = dict(R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1], compute=self.compute_dtype)
-                # the BatchNorm-backward finalize (parameter gradients + the apply pass's two means) rides in the launch where it can
-                scratch = _empty(2 * dst.shape[3], dtype=torch.float32, device=dst.device)
-                fin = (self._g(rec.bn.weight) if need_dw else None, self._g(rec.bn.bias) if need_dw else None,
-                       self._g(rec.act.weight) if (need_dw and isinstance(rec.act, _PReLU)) else None, scratch, self._tape_training)
-                if conv.transposed:
-                    rows, done = K.enet_conv_bnbwd_stats(g, w, dst, stats, rec.raw, rec.tf, rec.mean, rec.invstd,
-                                                         ws=(t * conv.cout, conv.cout, 1), fin=fin, **kw)
-                else:
-                    rows, done = K.enet_conv_bnbwd_stats(g, w, dst, stats, rec.raw, rec.tf, rec.mean, rec.invstd, dil=conv.dil,
-                                                         transposed=True, ws=(1, conv.cin, t * conv.cin), fin=fin, **kw)
-                return dst, (stats, scratch), (-1 if (done and rows > 0) else rows)
-            self._conv_dgrad(g, conv, dst)
-            return dst, None, 0
         rg, rm = resid if resid is not None else (None, None)
+        kw = dict(R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1], compute=self.compute_dtype)
         if conv.transposed:
-            K.enet_conv(g, w, None, None, dst, R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1],
-                        ws=(t * conv.cout, conv.cout, 1), accumulate=accumulate, resid_grad=rg, resid_mask=rm, compute=self.compute_dtype)
+            kw.update(ws=(t * conv.cout, conv.cout, 1))
         else:
-            K.enet_conv(g, w, None, None, dst, R=conv.kh, S=conv.kw, stride=conv.stride, dil=conv.dil, pad_h=conv.pad[0],
-                        pad_w=conv.pad[1], transposed=True, ws=(1, conv.cin, t * conv.cin), accumulate=accumulate,
-                        resid_grad=rg, resid_mask=rm, compute=self.compute_dtype)
-        return dst
+            kw.update(dil=conv.dil, transposed=True, ws=(1, conv.cin, t * conv.cin))
+        cin_g = g.rec.raw.shape[3] if isinstance(g, _Draw) else g.shape[3]
+        stats = scratch = None
+        if bn_of_dst is not None:
+            tiles = (dst.shape[0] * dst.shape[1] * dst.shape[2] + 31) // 32
+            if (self.fuse_bn_bwd_stats and self._tape_training and self.compute_dtype != torch.float32 and cin_g >= 16 and cin_g % 16 == 0 and
+                    dst.shape[3] <= 128 and tiles <= self.stats_tiles_cap and not accumulate and resid is None):
+                stats = _empty(tiles * dst.shape[3] * 3, dtype=torch.float64, device=dst.device)
+                scratch = _empty(2 * dst.shape[3], dtype=torch.float32, device=dst.device)
+        rec = bn_of_dst
+        # on load only where every input element is read ONCE (1x1, or a kernel as large as its stride): a 3x3 would repeat the
+        # transform -- and its three loads -- nine times per element (measured: the chain got 92 launches shorter and 0.5 ms slower)
+        once = conv.kh * conv.kw == 1 or (conv.kh == conv.stride and conv.kw == conv.stride and conv.dil == 1)
+        if isinstance(g, _Draw) and g.tensor is None and (once or self.denorm_on_load_all):
+            d = g
+            rows = K.enet_conv_bwd_in(d.rec.raw, w, d.rec.tf, d.g, d.g_mask, d.rec.mean, d.rec.invstd, d.scratch, dst,
+                                      resid_grad=rg, resid_mask=rm, accumulate=accumulate,
+                                      bn=(stats, rec.raw, rec.tf, rec.mean, rec.invstd) if stats is not None else None, **kw)
+            if rows is not None:
+                return (dst, (stats, scratch) if stats is not None else None, rows) if bn_of_dst is not None else dst
+        gt = self._tensor_of(g, leaf=False)
+        if stats is not None:
+            # the BatchNorm-backward finalize (parameter gradients + the apply pass's two means) rides in the launch where it can
+            fin = (self._g(rec.bn.weight) if need_dw else None, self._g(rec.bn.bias) if need_dw else None,
+                   self._g(rec.act.weight) if (need_dw and isinstance(rec.act, _PReLU)) else None, scratch, self._tape_training)
+            kw2 = {k: v for k, v in kw.items()}
+            rows, done = K.enet_conv_bnbwd_stats(gt, w, dst, stats, rec.raw, rec.tf, rec.mean, rec.invstd, fin=fin, **kw2)
+            return dst, (stats, scratch), (-1 if (done and rows > 0) else rows)
+        K.enet_conv(gt, w, None, None, dst, accumulate=accumulate, resid_grad=rg, resid_mask=rm, **kw)
+        return (dst, None, 0) if bn_of_dst is not None else dst
 
     def _conv_wgrad(self, g, conv, src, src_tf, before_bn=False):
         """dW (+ db) += for a conv whose input was src (read through src_tf) and output gradient is g.
@@ -431,6 +455,7 @@ class Enet(nn.Module):
         It is taken as the exact zero here -- nothing to accumulate -- which saves one reduction + one fold launch per conv
         and pass (~860 of a cfg4 step's ~5600 launches).  Eval-mode BatchNorm (running statistics) does pass a bias gradient."""
         dw = self._g(conv.weight)
+        g = self._tensor_of(g, leaf=True)          # (a _Draw not needed by its data-gradient convolution is materialised as a leaf)
         if conv.transposed:
             K.enet_wgrad(src, src_tf, g, None, dw, R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1])
         else:
@@ -523,7 +548,6 @@ class Enet(nn.Module):
         partial sums, already written by the data-gradient convolution that produced g (_conv_dgrad(bn_of_dst=rec))."""
         dev = rec.raw.device
         c = rec.raw.shape[3]
-        draw = _empty(rec.raw.shape, dtype=self.compute_dtype, device=dev)
         if partial is not None:          # (_conv_dgrad: the rows and the scratch its fused finalize may have filled already; rows < 0)
             partial, scratch = partial
         else:
@@ -532,9 +556,26 @@ class Enet(nn.Module):
         db = self._g(rec.bn.bias) if need_dw else None
         ds = self._g(rec.act.weight) if (need_dw and isinstance(rec.act, _PReLU)) else None
         # FGSM pass (need_dw False): the finalize kernel skips null parameter gradients -- no throw-away zero buffers
+        if self.denorm_on_load and self.compute_dtype != torch.float32:
+            # sums only: the elementwise apply leaves the chain -- the data-gradient convolution computes the result on load
+            # (_conv_dgrad), a weight gradient materialises it as a leaf (_tensor_of)
+            K.enet_bn_bwd_sums(rec.raw, g, g_mask, rec.tf, rec.mean, rec.invstd, dg, db, ds, scratch, training=self._tape_training,
+                               partial=partial, partial_rows=rows)
+            return _Draw(rec, g, g_mask, scratch)
+        draw = _empty(rec.raw.shape, dtype=self.compute_dtype, device=dev)
         K.enet_bn_bwd(rec.raw, g, g_mask, rec.tf, rec.mean, rec.invstd, dg, db, ds, scratch, draw, training=self._tape_training,
                       partial=partial, partial_rows=rows)
-        return draw
+        return _Draw(rec, g, g_mask, scratch, draw)
+
+    def _tensor_of(self, d, leaf: bool):
+        """The gradient tensor behind ``d`` (a plain tensor, or a _Draw that is materialised now if it was not)."""
+        if not isinstance(d, _Draw):
+            return d
+        if d.tensor is None:
+            rec = d.rec
+            d.tensor = K.enet_bn_bwd_apply(rec.raw, d.g, d.g_mask, rec.tf, rec.mean, rec.invstd, d.scratch,
+                                           _empty(rec.raw.shape, dtype=self.compute_dtype, device=rec.raw.device), leaf=leaf)
+        return d.tensor
 
     def _bottleneck_bwd(self, st, dout, need_dw, need_dx=True):
         blk: _Bottleneck = st["blk"]
@@ -542,27 +583,26 @@ class Enet(nn.Module):
         r1, r2, r3 = st["r1"], st["r2"], st["r3"]
         dt = self.compute_dtype
         # ---- extension branch, last to first
+        # (every data gradient is issued BEFORE the weight gradient of the same layer: it computes the BatchNorm-backward result on
+        #  load, the weight gradient materialises it -- a leaf, like itself)
         d3 = self._bn_bwd(r3, dout, out, need_dw)
+        g2, p2, n2 = self._conv_dgrad(d3, r3.conv, _empty(r2.raw.shape, dtype=dt, device=r2.raw.device), bn_of_dst=r2, need_dw=need_dw)
         if need_dw:
             self._conv_wgrad(d3, r3.conv, r2.raw, r2.tf, before_bn=True)
-        g2, p2, n2 = self._conv_dgrad(d3, r3.conv, _empty(r2.raw.shape, dtype=dt, device=r2.raw.device), bn_of_dst=r2, need_dw=need_dw)
         d2 = self._bn_bwd(r2, g2, None, need_dw, partial=p2, rows=n2)
         if blk.kind == "asym":
             c5, c15 = blk.middle_block.at(0).at(0), blk.middle_block.at(0).at(1)
             mid_raw = st["mid_raw"]
-            if need_dw:
-                self._conv_wgrad(d2, c15, mid_raw, None, before_bn=True)
             gmid = self._conv_dgrad(d2, c15, _empty(mid_raw.shape, dtype=dt, device=mid_raw.device))
             if need_dw:
+                self._conv_wgrad(d2, c15, mid_raw, None, before_bn=True)
                 self._conv_wgrad(gmid, c5, r1.raw, r1.tf)
             g1, p1, n1 = self._conv_dgrad(gmid, c5, _empty(r1.raw.shape, dtype=dt, device=r1.raw.device), bn_of_dst=r1, need_dw=need_dw)
         else:
+            g1, p1, n1 = self._conv_dgrad(d2, r2.conv, _empty(r1.raw.shape, dtype=dt, device=r1.raw.device), bn_of_dst=r1, need_dw=need_dw)
             if need_dw:
                 self._conv_wgrad(d2, r2.conv, r1.raw, r1.tf, before_bn=True)
-            g1, p1, n1 = self._conv_dgrad(d2, r2.conv, _empty(r1.raw.shape, dtype=dt, device=r1.raw.device), bn_of_dst=r1, need_dw=need_dw)
         d1 = self._bn_bwd(r1, g1, None, need_dw, partial=p1, rows=n1)
-        if need_dw:
-            self._conv_wgrad(d1, r1.conv, x, None, before_bn=True)
         # ---- input gradient = extension branch + main branch
         dx = _empty_like(x)
         if blk.kind == "down":
@@ -572,12 +612,14 @@ class Enet(nn.Module):
             rm: _Rec = st["rm"]
             gm = K.enet_tail_bwd(dout, out, st["idx"], blk.cout, 2, _empty(rm.raw.shape, dtype=dt, device=rm.raw.device))
             dm = self._bn_bwd(rm, gm, None, need_dw)
+            self._conv_dgrad(dm, rm.conv, dx)
             if need_dw:
                 self._conv_wgrad(dm, rm.conv, x, None, before_bn=True)
-            self._conv_dgrad(dm, rm.conv, dx)
             self._conv_dgrad(d1, r1.conv, dx, accumulate=True)
         else:
             self._conv_dgrad(d1, r1.conv, dx, resid=(dout, out))
+        if need_dw:
+            self._conv_wgrad(d1, r1.conv, x, None, before_bn=True)
         return dx
 
     def _run_backward(self, tape, dlogits, need_dx, need_dw):
@@ -599,13 +641,13 @@ class Enet(nn.Module):
         r0 = st["r0"]
         d0 = self._bn_bwd(r0, g[..., :13], None, need_dw)
         ini = self.encoder.initial
-        if need_dw:
-            self._conv_wgrad(d0, ini.conv, st["x"], None, before_bn=True)
         dx = None
         if need_dx:
             dx = _empty_like(st["x"])
             self._conv_dgrad(d0, ini.conv, dx)
             K.enet_tail_bwd(g, st["x"], None, 13, 3, dx, accumulate=True)
+        if need_dw:
+            self._conv_wgrad(d0, ini.conv, st["x"], None, before_bn=True)
         return dx
 
 

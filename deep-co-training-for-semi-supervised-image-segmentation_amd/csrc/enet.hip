@@ -45,7 +45,7 @@ namespace {
 // Recording (dct_group_begin / _member / _end): while a group is open the entry points below do not launch; they append
 // {body, grid, block, LDS bytes, argument blob} to the current member's list.  dct_group_end zips the lists: entry k of
 // all members becomes one grouped launch when body and launch geometry agree, else one launch per member.
-constexpr int GROUP_MAX = 6;
+constexpr int GROUP_MAX = 4;        // (4 x sizeof(ConvP) must fit the 4 KB kernel-argument segment)
 template <typename A> struct GroupArgs { A m[GROUP_MAX]; };
 template <typename F> __global__ __launch_bounds__(F::THREADS) void enet_one(typename F::Args a) { F::run(a); }
 template <typename F> __global__ __launch_bounds__(F::THREADS) void enet_grp(GroupArgs<typename F::Args> g) { F::run(g.m[blockIdx.z]); }
@@ -334,6 +334,18 @@ __device__ __forceinline__ void run_fused_finalize(const FinU& u, double* red) {
   else sum_fin_body<true>(u.s, red);
 }
 
+// BatchNorm backward, one element: draw = scale (dz - c1 - xhat c2), dz = g act'(z), z = scale raw + shift, xhat = (raw - mean) invstd.
+// ONE definition for the apply kernels and for the data-gradient convolution that applies it on load (ConvP::bwd_in): the two must
+// agree to the bit, a convolution reading the stored draw and one computing it on load see the same operand.
+__device__ __forceinline__ float bn_bwd_draw(float v, float g, float sc, float sh, float sl, float mu, float is, float c1, float c2, int act) {
+  const float z = fmaf(sc, v, sh);
+  float dz = g;
+  if (act == 2) { if (!(z > 0.f)) dz = g * sl; }
+  else if (act == 3) { if (!(z > 0.f)) dz = 0.f; }
+  const float xh = (v - mu) * is;
+  return sc * (dz - c1 - xh * c2);
+}
+
 struct ConvP {
   View x, y, rg, rm;              // input, output, residual grad + its ReLU mask (optional)
   const float* w; const float* bias;
@@ -351,6 +363,12 @@ struct ConvP {
   View braw; const float* bscale; const float* bshift; const float* bslope; const float* bmean; const float* binvstd; int bact; int bn_bwd;
   int ngroups;       // MFMA form: output-channel groups of 32 NT (blockIdx.x = pixel tile * ngroups + group)
   FinU fin;          // MFMA form with stats: the consumer's finalize rides in the last block (mode != 0)
+  // MFMA form, optional ("de-normalise on load"): the input IS the BatchNorm-backward result of a layer -- x = that layer's raw fp32
+  // output, tf = its scale / shift / slope, ig = the gradient wrt its activation (im: ReLU mask of ig, optional) -- and a lane
+  // computes draw = bn_bwd_draw(...) for its 8 channels where it would load them: the elementwise apply launch leaves the chain
+  int bwd_in, i_act, i_has_mask;
+  View ig, im;
+  const float* i_mean; const float* i_invstd; const float* i_c1; const float* i_c2;
 };
 
 // One thread = one output pixel x 8 output channels.  Weights live in LDS as [tap][i][G*8].
@@ -525,7 +543,7 @@ constexpr int MC_U = 1;            // K-steps of one wave whose loads are issued
                                    // U = 4 / 3 / 2 / 1 read 18.1 / 17.4 / 16.9 / 16.4 and 44.6 / 41.8 / 39.9 / 38.2 -- registers and loads
                                    // in flight per wave are what the concurrent kernels compete for
 
-template <typename T, int NT, bool XF, bool WV>
+template <typename T, int NT, bool XF, bool WV, bool BI = false>
 __device__ __forceinline__ void mconv_main(const ConvP& p, const float* tfs, int cbase, bool pvalid, int n, int oy, int ox, int r, int h,
                                            int wave, f32x16 (&acc)[NT]) {
   typedef typename LowMfma<T>::frag frag;
@@ -533,6 +551,7 @@ __device__ __forceinline__ void mconv_main(const ConvP& p, const float* tfs, int
   const int taps = p.R * p.S, nsteps = taps * (Cin >> 4);
   for (int s0 = wave; s0 < nsteps; s0 += MC_W * MC_U) {
     float a8[MC_U][8], w8[MC_U][NT][8];
+    float g8[BI ? MC_U : 1][8], m8[BI ? MC_U : 1][8];
     bool v[MC_U];
     int cis[MC_U];
 #pragma unroll
@@ -555,6 +574,10 @@ __device__ __forceinline__ void mconv_main(const ConvP& p, const float* tfs, int
       ok = ok && (unsigned)iy < (unsigned)p.x.h && (unsigned)ix < (unsigned)p.x.w;
       v[u] = ok;
       ld8t<T, XF>(p.x.ptr, ok ? voff(p.x, n, iy, ix) + ci : 0, a8[u]);
+      if constexpr (BI) {
+        ld8t<T, false>(p.ig.ptr, ok ? voff(p.ig, n, iy, ix) + ci : 0, g8[u]);
+        if (p.i_has_mask) ld8t<T, false>(p.im.ptr, ok ? voff(p.im, n, iy, ix) + ci : 0, m8[u]);
+      }
       const long long wtap = (long long)tap * p.ws_tap + (long long)ci * p.ws_in;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -579,11 +602,31 @@ __device__ __forceinline__ void mconv_main(const ConvP& p, const float* tfs, int
       *reinterpret_cast<f32x4*>(sl) = *reinterpret_cast<const f32x4*>(tfs + 256 + cis[u]);
       *reinterpret_cast<f32x4*>(sl + 4) = *reinterpret_cast<const f32x4*>(tfs + 256 + cis[u] + 4);
       frag A;
+      if constexpr (BI) {
+        // de-normalise on load: this lane's 8 channels of draw, rounded to T as the stored tensor would have been
+        float mu[8], is[8], k1[8], k2[8];
+        *reinterpret_cast<f32x4*>(mu) = *reinterpret_cast<const f32x4*>(tfs + 384 + cis[u]);
+        *reinterpret_cast<f32x4*>(mu + 4) = *reinterpret_cast<const f32x4*>(tfs + 384 + cis[u] + 4);
+        *reinterpret_cast<f32x4*>(is) = *reinterpret_cast<const f32x4*>(tfs + 512 + cis[u]);
+        *reinterpret_cast<f32x4*>(is + 4) = *reinterpret_cast<const f32x4*>(tfs + 512 + cis[u] + 4);
+        *reinterpret_cast<f32x4*>(k1) = *reinterpret_cast<const f32x4*>(tfs + 640 + cis[u]);
+        *reinterpret_cast<f32x4*>(k1 + 4) = *reinterpret_cast<const f32x4*>(tfs + 640 + cis[u] + 4);
+        *reinterpret_cast<f32x4*>(k2) = *reinterpret_cast<const f32x4*>(tfs + 768 + cis[u]);
+        *reinterpret_cast<f32x4*>(k2 + 4) = *reinterpret_cast<const f32x4*>(tfs + 768 + cis[u] + 4);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float z = fmaf(sc[k], a8[u][k], sh[k]);
-        const float t = z > 0.f ? z : z * sl[k];
-        A[k] = from_f32<T>(v[u] ? t : 0.f);
+        for (int k = 0; k < 8; ++k) {
+          float g = g8[u][k];
+          if (p.i_has_mask && !(m8[u][k] > 0.f)) g = 0.f;
+          const float t = bn_bwd_draw(a8[u][k], g, sc[k], sh[k], sl[k], mu[k], is[k], k1[k], k2[k], p.i_act);
+          A[k] = from_f32<T>(v[u] ? t : 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float z = fmaf(sc[k], a8[u][k], sh[k]);
+          const float t = z > 0.f ? z : z * sl[k];
+          A[k] = from_f32<T>(v[u] ? t : 0.f);
+        }
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -733,7 +776,7 @@ template <typename T, int NT> struct MconvK {
   static constexpr int THREADS = 64 * MC_W;
   static __device__ __forceinline__ void run(const Args& p) {
     const int ngroups = p.ngroups;
-  __shared__ __attribute__((aligned(16))) float tfs[3 * 128];
+  __shared__ __attribute__((aligned(16))) float tfs[7 * 128];      // scale, shift, slope [, mean, invstd, c1, c2: bwd_in]
   __shared__ __attribute__((aligned(16))) float red[MC_W * NT * 16 * 64];      // >= 256 * 3 doubles: the fused finalize folds through it
   __shared__ float srd[MC_W * NT * 32 * 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -743,6 +786,11 @@ template <typename T, int NT> struct MconvK {
     tfs[c] = on ? p.tf.scale[c] : 1.f;
     tfs[128 + c] = on ? p.tf.shift[c] : 0.f;
     tfs[256 + c] = (on && p.tf.mode == 2) ? p.tf.slope[c] : ((on && p.tf.mode == 3) ? 0.f : 1.f);
+    if (p.bwd_in) {
+      const bool in = c < p.x.c;
+      tfs[384 + c] = in ? p.i_mean[c] : 0.f; tfs[512 + c] = in ? p.i_invstd[c] : 0.f;
+      tfs[640 + c] = in ? p.i_c1[c] : 0.f; tfs[768 + c] = in ? p.i_c2[c] : 0.f;
+    }
   }
   const long long P = (long long)p.y.n * p.y.h * p.y.w;                  // < 2^31 (host check)
   const int cbase = (int)(blockIdx.x % ngroups) * (32 * NT);             // first output channel of this block
@@ -757,7 +805,10 @@ template <typename T, int NT> struct MconvK {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
   __syncthreads();
-  if (p.fm & 1) {
+  if (p.bwd_in) {          // (x = raw fp32: host check)
+    if (p.wvec) mconv_main<T, NT, true, true, true>(p, tfs, cbase, pvalid, n, oy, ox, r, h, wave, acc);
+    else mconv_main<T, NT, true, false, true>(p, tfs, cbase, pvalid, n, oy, ox, r, h, wave, acc);
+  } else if (p.fm & 1) {
     if (p.wvec) mconv_main<T, NT, true, true>(p, tfs, cbase, pvalid, n, oy, ox, r, h, wave, acc);
     else mconv_main<T, NT, true, false>(p, tfs, cbase, pvalid, n, oy, ox, r, h, wave, acc);
   } else {
@@ -963,13 +1014,7 @@ template <typename T> struct BnApplyVecK {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = c0 + i;
-    const float sc = p.scale[c];
-    const float z = fmaf(sc, v[i], p.shift[c]);
-    float dz = g[i];
-    if (p.act == 2) { if (!(z > 0.f)) dz = g[i] * p.slope[c]; }
-    else if (p.act == 3) { if (!(z > 0.f)) dz = 0.f; }
-    const float xh = (v[i] - p.mean[c]) * p.invstd[c];
-    r[i] = sc * (dz - c1[c] - xh * c2[c]);
+    r[i] = bn_bwd_draw(v[i], g[i], p.scale[c], p.shift[c], p.act == 2 ? p.slope[c] : 0.f, p.mean[c], p.invstd[c], c1[c], c2[c], p.act);
   }
   const long long oo = voff(out, n, y, x) + c0;
   if ((p.fm & 8) || sizeof(T) == 4) {
@@ -1168,12 +1213,7 @@ template <typename T> struct BnApplyK {
   pix3(split_c(idx, C, c), p.x.h, p.x.w, n, y, x);
   const float v = ldv<T>(p.x, voff(p.x, n, y, x) + c, p.fm & 1);
   const float g = grad_in<T>(p, n, y, x, c);
-  const float z = fmaf(p.scale[c], v, p.shift[c]);
-  float dz = g;
-  if (p.act == 2) { if (!(z > 0.f)) dz = g * p.slope[c]; }
-  else if (p.act == 3) { if (!(z > 0.f)) dz = 0.f; }
-  const float xh = (v - p.mean[c]) * p.invstd[c];
-  const float r = p.scale[c] * (dz - c1[c] - xh * c2[c]);
+  const float r = bn_bwd_draw(v, g, p.scale[c], p.shift[c], p.act == 2 ? p.slope[c] : 0.f, p.mean[c], p.invstd[c], c1[c], c2[c], p.act);
   stv<T>(out, voff(out, n, y, x) + c, p.fm & 8, r);
 }
 };
@@ -1620,7 +1660,7 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
                           int f32_mask, int dtype, double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream,
                           const dct_view* bn_raw = nullptr, const float* bn_scale = nullptr, const float* bn_shift = nullptr,
                           const float* bn_slope = nullptr, int bn_act = 0, const float* bn_mean = nullptr, const float* bn_invstd = nullptr,
-                          const FinU* fin = nullptr, int* finalized = nullptr) {
+                          const FinU* fin = nullptr, int* finalized = nullptr, const dct_enet_bwd_in* bin = nullptr) {
   if (stats_rows) *stats_rows = 0;
   if (finalized) *finalized = 0;
   if (!view_ok(x) || !view_ok(y) || !w || !d || !ok_dtype(dtype) || x->n != y->n) return DCT_ERR_BAD_ARG;
@@ -1634,6 +1674,26 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
   p.ws_out = ws_out; p.ws_tap = ws_tap; p.ws_in = ws_in;
   p.has_resid = 0; p.wvec = 0; p.stats = nullptr; p.bn_bwd = 0; p.bact = 0; p.braw = p.y;
   p.fin.mode = 0; p.fin.ticket = nullptr; p.ngroups = 0;
+  p.bwd_in = 0; p.i_act = 0; p.i_has_mask = 0; p.ig = p.x; p.im = p.x;
+  p.i_mean = p.i_invstd = p.i_c1 = p.i_c2 = nullptr;
+  if (bin) {
+    // x is the raw fp32 output of a BatchNorm'd layer, tf its transform; the kernel computes that layer's BatchNorm-backward
+    // result on load from (x, bin->g [, bin->g_mask]) -- MFMA form only
+    if (!tf || !tf->mode || !(f32_mask & 1) || !view_ok(bin->g) || !bin->mean || !bin->invstd || !bin->c1c2) return DCT_ERR_BAD_ARG;
+    if (bin->g->n != x->n || bin->g->h != x->h || bin->g->w != x->w || bin->g->c != x->c) return DCT_ERR_BAD_ARG;
+    if (bin->g_mask && (!view_ok(bin->g_mask) || bin->g_mask->n != x->n || bin->g_mask->h != x->h || bin->g_mask->w != x->w ||
+                        bin->g_mask->c != x->c)) return DCT_ERR_BAD_ARG;
+    auto v8 = [&](const dct_view* v) {     // 16-bit storage, 8 channels per 16-byte load
+      return v->c % 8 == 0 && v->sw % 8 == 0 && v->sh % 8 == 0 && v->sn % 8 == 0 && ((uintptr_t)v->ptr % 16) == 0 &&
+             (long long)v->n * v->sn < 0x7fffffffLL;
+    };
+    if (dtype == DCT_F32 || !v8(bin->g) || (bin->g_mask && !v8(bin->g_mask)) || (((uintptr_t)bin->mean | (uintptr_t)bin->invstd |
+        (uintptr_t)bin->c1c2) % 16) || (x->c % 4)) return DCT_ERR_UNSUPPORTED;
+    p.bwd_in = 1; p.i_act = (tf->mode == 2 || tf->mode == 3) ? tf->mode : 0;
+    p.ig = to_view(bin->g);
+    if (bin->g_mask) { p.im = to_view(bin->g_mask); p.i_has_mask = 1; }
+    p.i_mean = bin->mean; p.i_invstd = bin->invstd; p.i_c1 = bin->c1c2; p.i_c2 = bin->c1c2 + x->c;
+  }
   p.bscale = p.bshift = p.bslope = p.bmean = p.binvstd = nullptr;
   p.rg = p.y; p.rm = p.y;
   if (resid_grad) {
@@ -1693,6 +1753,7 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
     else ENET_T(dtype, (enet_launch<MconvK<T, 4>>(DCT_PROF_OTHER, dim3(gridm), dim3(64 * MC_W), 0, st0, p)));
     return dct_check_launch();
   }
+  if (bin) return DCT_ERR_UNSUPPORTED;        // (the VALU kernel has no de-normalise-on-load form: the caller materialises draw)
   const size_t lds = (size_t)d->R * d->S * x->c * Gp * 8 * sizeof(float);
   if (lds > 64 * 1024) return DCT_ERR_UNSUPPORTED;
   const long long P = (long long)y->n * y->h * y->w;
@@ -1760,6 +1821,19 @@ extern "C" int dct_enet_conv_bnbwd_stats_fin(const dct_view* x, const float* w, 
   return enet_conv_impl(x, w, nullptr, nullptr, y, d, transposed, ws_out, ws_tap, ws_in, nullptr, nullptr, f32_mask, dtype, stats_partial,
                         stats_capacity_rows, stats_rows, stream, bn_raw, bn_scale, bn_shift, bn_slope, bn_act, bn_mean, bn_invstd, &u,
                         finalized);
+}
+
+extern "C" int dct_enet_conv_bwd_in(const dct_view* raw, const float* w, const dct_enet_tf* tf, const dct_enet_bwd_in* bin,
+                                    const dct_view* y, const dct_conv_desc* d, int transposed, int ws_out, int ws_tap, int ws_in,
+                                    const dct_view* resid_grad, const dct_view* resid_mask, int f32_mask, int dtype,
+                                    const dct_view* bn_raw, const float* bn_scale, const float* bn_shift, const float* bn_slope, int bn_act,
+                                    const float* bn_mean, const float* bn_invstd,
+                                    double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream) {
+  if (!bin) return DCT_ERR_BAD_ARG;
+  if (bn_raw && (!stats_partial || !stats_rows || stats_capacity_rows < 1)) return DCT_ERR_BAD_ARG;
+  return enet_conv_impl(raw, w, nullptr, tf, y, d, transposed, ws_out, ws_tap, ws_in, resid_grad, resid_mask, f32_mask, dtype,
+                        bn_raw ? stats_partial : nullptr, bn_raw ? stats_capacity_rows : 0, bn_raw ? stats_rows : nullptr, stream,
+                        bn_raw, bn_scale, bn_shift, bn_slope, bn_act, bn_mean, bn_invstd, nullptr, nullptr, bin);
 }
 
 extern "C" size_t dct_enet_reduce_workspace_bytes(int channels) {
@@ -1878,15 +1952,17 @@ extern "C" int dct_enet_bn_bwd(const dct_view* raw, const dct_view* g, const dct
                               dtype, workspace, workspace_bytes, 0, stream);
 }
 
-extern "C" int dct_enet_bn_bwd_rows(const dct_view* raw, const dct_view* g, const dct_view* g_mask,
-                                    const float* scale, const float* shift, const float* slope, int act,
-                                    const float* mean, const float* invstd,
-                                    float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
-                                    const dct_view* draw, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
-                                    int partial_rows, dct_stream stream) {
-  if (!view_ok(raw) || !view_ok(g) || !view_ok(draw) || !scale || !shift || !mean || !invstd || !c1c2 || !ok_dtype(dtype))
+// do_sums: reduction (or the rows a convolution wrote) + finalize; do_apply: draw from (raw, g, c1c2)
+static int enet_bn_bwd_impl(const dct_view* raw, const dct_view* g, const dct_view* g_mask,
+                            const float* scale, const float* shift, const float* slope, int act,
+                            const float* mean, const float* invstd,
+                            float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
+                            const dct_view* draw, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
+                            int partial_rows, dct_stream stream, bool do_sums, bool do_apply) {
+  if (!view_ok(raw) || !view_ok(g) || (do_apply && !view_ok(draw)) || !scale || !shift || !mean || !invstd || !c1c2 || !ok_dtype(dtype))
     return DCT_ERR_BAD_ARG;
-  if (partial_rows != 0 && g_mask) return DCT_ERR_BAD_ARG;
+  if (do_sums && partial_rows != 0 && g_mask) return DCT_ERR_BAD_ARG;     // (rows from a convolution's epilogue never carry a mask)
+  if (!do_sums) partial_rows = -1;
   if (raw->c > 128 || (act == 2 && !slope)) return DCT_ERR_BAD_ARG;
   RedP p; p.x = to_view(raw); p.g = to_view(g); p.m = p.g;
   p.has_mask = 0;
@@ -1895,7 +1971,7 @@ extern "C" int dct_enet_bn_bwd_rows(const dct_view* raw, const dct_view* g, cons
   p.act = act; p.kind = 1; p.ppb = 0; p.fm = f32_mask; p.partial = nullptr;
   hipStream_t st = (hipStream_t)stream;
   int blocks = 0;
-  {
+  if (do_sums && do_apply) {
     const View vo0 = to_view(draw);
     const int oesz = ((f32_mask & 8) || dtype == DCT_F32) ? 4 : 2;
     if (partial_rows == 0 && enet_owner_ok(p, dtype, &vo0) && vo0.c == p.x.c && vo0.n == p.x.n && vo0.h == p.x.h && vo0.w == p.x.w &&
@@ -1919,11 +1995,12 @@ extern "C" int dct_enet_bn_bwd_rows(const dct_view* raw, const dct_view* g, cons
     if (rc != DCT_OK) return rc;
   }
   const long long total = (long long)raw->n * raw->h * raw->w * raw->c;
-  const View vo = to_view(draw);
+  const View vo = do_apply ? to_view(draw) : p.x;
   if (!finalized) {
     const BFinP bp = {(const double*)workspace, blocks, raw->c, count, training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, c1c2 + raw->c};
     enet_launch<BnBwdFinK>(DCT_PROF_OTHER, dim3(1), dim3(g_enet_fold_threads), 0, st, bp);
   }
+  if (!do_apply) return dct_check_launch();
   const ApplyP ap = {p, (const float*)c1c2, (const float*)(c1c2 + raw->c), vo};
   {
     auto v8 = [&](const View& v, int f32) {
@@ -1938,6 +2015,38 @@ extern "C" int dct_enet_bn_bwd_rows(const dct_view* raw, const dct_view* g, cons
   }
   ENET_T(dtype, enet_launch<BnApplyK<T>>(DCT_PROF_OTHER, dim3(div_up(total, 256)), dim3(256), 0, st, ap));
   return dct_check_launch();
+}
+
+extern "C" int dct_enet_bn_bwd_rows(const dct_view* raw, const dct_view* g, const dct_view* g_mask,
+                                    const float* scale, const float* shift, const float* slope, int act,
+                                    const float* mean, const float* invstd,
+                                    float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
+                                    const dct_view* draw, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,
+                                    int partial_rows, dct_stream stream) {
+  return enet_bn_bwd_impl(raw, g, g_mask, scale, shift, slope, act, mean, invstd, dgamma, dbeta, dslope, c1c2, training, draw, f32_mask,
+                          dtype, workspace, workspace_bytes, partial_rows, stream, true, true);
+}
+
+extern "C" int dct_enet_bn_bwd_sums(const dct_view* raw, const dct_view* g, const dct_view* g_mask,
+                                    const float* scale, const float* shift, const float* slope, int act,
+                                    const float* mean, const float* invstd,
+                                    float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
+                                    int f32_mask, int dtype, void* workspace, size_t workspace_bytes, int partial_rows, dct_stream stream) {
+  if (partial_rows < 0) return DCT_OK;        // (finalized by the producing convolution already)
+  return enet_bn_bwd_impl(raw, g, g_mask, scale, shift, slope, act, mean, invstd, dgamma, dbeta, dslope, c1c2, training, nullptr, f32_mask,
+                          dtype, workspace, workspace_bytes, partial_rows, stream, true, false);
+}
+
+extern "C" int dct_enet_bn_bwd_apply(const dct_view* raw, const dct_view* g, const dct_view* g_mask,
+                                     const float* scale, const float* shift, const float* slope, int act,
+                                     const float* mean, const float* invstd, const float* c1c2,
+                                     const dct_view* draw, int f32_mask, int dtype, int leaf, dct_stream stream) {
+  const bool was = g_leaf_scope;
+  if (leaf) g_leaf_scope = true;
+  const int rc = enet_bn_bwd_impl(raw, g, g_mask, scale, shift, slope, act, mean, invstd, nullptr, nullptr, nullptr, const_cast<float*>(c1c2),
+                                  1, draw, f32_mask, dtype, nullptr, 0, -1, stream, false, true);
+  g_leaf_scope = was;
+  return rc;
 }
 
 extern "C" int dct_enet_channel_sum(const dct_view* x, float* out, int f32_mask, int dtype, void* workspace, size_t workspace_bytes,

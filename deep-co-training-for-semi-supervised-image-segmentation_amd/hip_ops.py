@@ -661,6 +661,72 @@ def enet_bn_bwd(raw, g, g_mask, tf, mean, invstd, dgamma, dbeta, dslope, c1c2, d
     return draw
 
 
+def enet_bn_bwd_sums(raw, g, g_mask, tf, mean, invstd, dgamma, dbeta, dslope, c1c2, training=True, partial=None, partial_rows=0):
+    """The sums half of `enet_bn_bwd`: parameter gradients (+=) and the apply pass's two means (c1c2).  partial_rows < 0: the
+    producing convolution has finalized already -- nothing to launch."""
+    if partial_rows < 0:
+        return
+    vr, vg = view(raw), view(g)
+    vm = view(g_mask) if g_mask is not None else None
+    act = tf.mode if tf.mode in (2, 3) else 0
+    dt, fm = _mixed(raw, g, g_mask)
+    if partial is not None and partial_rows > 0:
+        ws, nbytes = partial, partial.numel() * partial.element_size()
+    else:
+        ws = _enet_ws(raw.device, _lib.load().dct_enet_reduce_workspace_bytes(raw.shape[3]))
+        nbytes, partial_rows = ws.numel(), 0
+    call("dct_enet_bn_bwd_sums", C.byref(vr), C.byref(vg), C.byref(vm) if vm is not None else None,
+         ptr(tf.scale), ptr(tf.shift), ptr(tf.slope), int(act), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(dslope),
+         ptr(c1c2), int(training), fm, dt, ptr(ws), nbytes, int(partial_rows), stream())
+
+
+def enet_bn_bwd_apply(raw, g, g_mask, tf, mean, invstd, c1c2, draw, leaf=False):
+    """The apply half: draw = BatchNorm-backward of g (elementwise, from raw / g / c1c2).  ``leaf``: only weight gradients read the
+    result -- under a `LeafSide` the launch is held back with them."""
+    vr, vg, vd = view(raw), view(g), view(draw)
+    vm = view(g_mask) if g_mask is not None else None
+    act = tf.mode if tf.mode in (2, 3) else 0
+    dt, fm = _mixed(raw, g, g_mask, draw)
+    call("dct_enet_bn_bwd_apply", C.byref(vr), C.byref(vg), C.byref(vm) if vm is not None else None,
+         ptr(tf.scale), ptr(tf.shift), ptr(tf.slope), int(act), ptr(mean), ptr(invstd), ptr(c1c2), C.byref(vd), fm, dt, int(leaf), stream())
+    return draw
+
+
+def enet_conv_bwd_in(raw, w, tf, g, g_mask, mean, invstd, c1c2, y, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, transposed=False,
+                     ws=(0, 0, 0), resid_grad=None, resid_mask=None, accumulate=False, compute=None, bn=None):
+    """Data-gradient convolution whose input is the BatchNorm-backward result of the layer (raw, tf, saved mean / invstd) for the
+    upstream gradient g [masked by g_mask], computed ON LOAD (include/dct.h dct_enet_conv_bwd_in).  ``bn`` = (stats, rec_raw, rec_tf,
+    rec_mean, rec_invstd): also write the output side's BatchNorm-backward partial rows (as enet_conv_bnbwd_stats).
+    -> None when the library has no on-load form for this call (the caller materialises the tensor), else the rows written (0 without
+    ``bn``)."""
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w, accumulate=accumulate)
+    vx, vy, vg = view(raw), view(y), view(g)
+    vm = view(g_mask) if g_mask is not None else None
+    keep_tf, tfp = _tfp(tf)
+    vrg = view(resid_grad) if resid_grad is not None else None
+    vrm = view(resid_mask) if resid_mask is not None else None
+    dt, fm = _mixed(raw, y, resid_grad, resid_mask)
+    if dt == F32 and compute in (torch.bfloat16, torch.float16):
+        dt = DTYPE_OF[compute]
+    b = _lib.EnetBwdIn(C.pointer(vg), C.pointer(vm) if vm is not None else None, ptr(mean), ptr(invstd), ptr(c1c2))
+    rows = C.c_int(0)
+    if bn is not None:
+        stats, rec_raw, rec_tf, rec_mean, rec_invstd = bn
+        vr = view(rec_raw)
+        act = rec_tf.mode if rec_tf.mode in (2, 3) else 0
+        extra = (C.byref(vr), ptr(rec_tf.scale), ptr(rec_tf.shift), ptr(rec_tf.slope), int(act), ptr(rec_mean), ptr(rec_invstd),
+                 ptr(stats), int(stats.numel() // (3 * y.shape[3])), C.byref(rows))
+    else:
+        extra = (None, None, None, None, 0, None, None, None, 0, None)
+    rc = getattr(_lib.load(), "dct_enet_conv_bwd_in")(
+        C.byref(vx), ptr(w), tfp, C.byref(b), C.byref(vy), C.byref(d), int(transposed), int(ws[0]), int(ws[1]), int(ws[2]),
+        C.byref(vrg) if vrg is not None else None, C.byref(vrm) if vrm is not None else None, fm, dt, *extra, stream())
+    if rc == -2:            # DCT_ERR_UNSUPPORTED: no MFMA form for this call
+        return None
+    _lib.check(rc, "dct_enet_conv_bwd_in")
+    return int(rows.value)
+
+
 def bn_fwd(raw, gamma, beta, eps, momentum, running_mean, running_var, training, scale, shift, mean, invstd, y=None, relu=True):
     """Wide-channel BatchNorm2d (+ReLU) forward of unet_bn: statistics -> scale/shift (+ running statistics) -> y."""
     vr = view(raw)

@@ -476,6 +476,38 @@ int dct_enet_conv_bnbwd_stats_fin(const dct_view* x, const float* w, const dct_v
                                   double* stats_partial, int stats_capacity_rows, int* stats_rows,
                                   const dct_enet_bn_bwd_fin* fin, int* finalized, dct_stream stream);
 
+/* "De-normalise on load": a data-gradient convolution whose input is the BatchNorm-backward result of the layer in front of it
+ * computes that result where it would load it -- raw = that layer's fp32 output, tf = its scale / shift / slope (mode != 0),
+ * bin = {gradient wrt its activation g, optional ReLU mask of g, saved mean / invstd, c1c2 from dct_enet_bn_bwd_sums} -- so the
+ * elementwise apply launch is no longer on the chain between the sums and this convolution (arch/enet.py: it is only launched,
+ * as a leaf, where a weight gradient needs the tensor).  Same arithmetic as the apply kernel (one shared definition), rounded to
+ * the compute type as the stored tensor would be.  Optional residual gate / accumulate as dct_enet_conv; optional output-side
+ * BatchNorm-backward sums as dct_enet_conv_bnbwd_stats (bn_raw != NULL).  MFMA form only (bf16 / f16, >= 16 channels, 16-byte
+ * aligned views): DCT_ERR_UNSUPPORTED otherwise -- the caller then materialises the tensor (dct_enet_bn_bwd_apply) and calls
+ * dct_enet_conv. */
+typedef struct dct_enet_bwd_in {
+  const dct_view* g; const dct_view* g_mask;
+  const float* mean; const float* invstd; const float* c1c2;
+} dct_enet_bwd_in;
+int dct_enet_conv_bwd_in(const dct_view* raw, const float* w, const dct_enet_tf* tf, const dct_enet_bwd_in* bin,
+                         const dct_view* y, const dct_conv_desc* d, int transposed, int ws_out, int ws_tap, int ws_in,
+                         const dct_view* resid_grad, const dct_view* resid_mask, int f32_mask, int dtype,
+                         const dct_view* bn_raw, const float* bn_scale, const float* bn_shift, const float* bn_slope, int bn_act,
+                         const float* bn_mean, const float* bn_invstd,
+                         double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream);
+/* The two halves of dct_enet_bn_bwd[_rows] on their own: the sums (reduction, or the rows a convolution's epilogue wrote, + finalize:
+ * parameter gradients and c1c2) and the elementwise apply (draw from raw, g, c1c2).  leaf != 0: the apply's result is only read by
+ * weight gradients, so under dct_leaves_begin it is held back with them. */
+int dct_enet_bn_bwd_sums(const dct_view* raw, const dct_view* g, const dct_view* g_mask,
+                         const float* scale, const float* shift, const float* slope, int act,
+                         const float* mean, const float* invstd,
+                         float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
+                         int f32_mask, int dtype, void* workspace, size_t workspace_bytes, int partial_rows, dct_stream stream);
+int dct_enet_bn_bwd_apply(const dct_view* raw, const dct_view* g, const dct_view* g_mask,
+                          const float* scale, const float* shift, const float* slope, int act,
+                          const float* mean, const float* invstd, const float* c1c2,
+                          const dct_view* draw, int f32_mask, int dtype, int leaf, dct_stream stream);
+
 /* ---- grouped passes -------------------------------------------------------------------------------------------
  * Independent passes with identical shapes (the 2S forward, then the 2S backward passes of a co-training step:
  * cotraining_totalloss.py:208-227,247) as ONE chain of launches: between dct_group_begin(members) and dct_group_end the

@@ -309,3 +309,26 @@ def test_enet_finalize_in_the_last_block_matches_the_one_block_launches():
         assert err <= 2e-3 * scale, f"{what}: {err:.3e} vs scale {scale:.3e}"
     rel = (outs[0][0][1] - outs[1][0][1]).norm().item() / outs[1][0][1].norm().item()
     assert rel < 1e-3, rel
+
+
+@pytest.mark.parametrize("need_dw", [True, False])
+def test_enet_denormalise_on_load_is_bit_identical(need_dw):
+    """Data-gradient convolutions computing the BatchNorm-backward result of their input on load (K.enet_conv_bwd_in) give bit for
+    bit the gradients of the plan that materialises it with the apply kernel first (one shared device function for the arithmetic)."""
+    C = 2
+    outs = []
+    for on_load in (False, True):
+        net = _hip_net(_oracle_net(C, 61), C, torch.bfloat16).train()
+        net.denorm_on_load, net.denorm_on_load_all = on_load, True
+        net.flat_params.ensure()
+        g = torch.Generator().manual_seed(13)
+        x = torch.rand(4, 1, 96, 88, generator=g).to(DEV)
+        dl = torch.randn(4, 96, 88, C, generator=g).to(DEV).to(torch.bfloat16)
+        lp, tape = net.plan_forward(x, True, defer_running=True)
+        buf = torch.zeros(net.flat_params.total, dtype=torch.float32, device=DEV)
+        dx = net.plan_backward(tape, dl, need_dx=True, need_dw=need_dw, grad_buffer=buf)
+        torch.cuda.synchronize()
+        outs.append((lp.clone(), buf, dx.clone()))
+    for a, b, what in zip(outs[0], outs[1], ("logits", "gradients", "dx")):
+        assert torch.equal(a, b), what
+    assert outs[0][2].abs().max().item() > 0 and (not need_dw or outs[0][1].abs().max().item() > 0)
