@@ -155,6 +155,7 @@ class CoTrainer(Trainer):
         self.pass_streams = True            # nets that support it (Enet): the backward passes of one model run on separate streams
         self._pass_pool = None
         self._pass_bufs = {}
+        self.group_one = True               # labeled and unlabeled passes in ONE group where the batch shapes agree (False: two groups, two queues)
         self.leaf_offload = True            # ... with the adversarial backward pass's weight gradients on the queue that leaves idle
         self.group_passes = True            # ... and issue the 2S co-training passes as grouped launches where the networks can (Enet)
         self.wide_forward = True            # networks with deferred running statistics: lay the step out on four hardware queues
@@ -812,7 +813,7 @@ class CoTrainer(Trainer):
         from ..loss.loss import _nchw
         S, C = len(nets), self.C
         sched = self._sched
-        one = tuple(lab[0][0].shape) == tuple(unl[0].shape) and 2 * S <= K.group_max()
+        one = self.group_one and tuple(lab[0][0].shape) == tuple(unl[0].shape) and 2 * S <= K.group_max()
         q_lab, q_unl = free[0], (free[0] if one else free[1])
         for n in nets:
             n.flat_params.ensure()
