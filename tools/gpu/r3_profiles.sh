@@ -31,6 +31,11 @@ timeout 600 python bench.py --config cfg4 --steps 30 --warmup 10 --no-cpu-baseli
 timeout 600 python bench.py --config cfg5 --steps 30 --warmup 10 --no-cpu-baseline > $O/cfg5_bench.json 2>> $O/bench.err
 timeout 300 python tools/probe_step_program.py cfg4 > $O/cfg4_step_program_timeline.txt 2>&1
 timeout 300 python tools/probe_step_program.py cfg5 > $O/cfg5_step_program_timeline.txt 2>&1
+# fabric traffic of the Enet kernel families (the derived FETCH_SIZE metric crashes rocprofv3 on this workload; its base counter does not)
+RX="enet_one|enet_grp"
+run f_cfg4  --pmc TCC_EA0_RDREQ_sum --kernel-trace --kernel-include-regex "$RX" -d $O/f_cfg4 -o f --output-format csv -- python3 bench.py --config cfg4 --steps 4 --warmup 2 $B --single-stream --no-graph
+run w_cfg4  --pmc WRITE_SIZE --kernel-trace --kernel-include-regex "$RX" -d $O/w_cfg4 -o w --output-format csv -- python3 bench.py --config cfg4 --steps 4 --warmup 2 $B --single-stream --no-graph
+python3 tools/pmc_traffic_enet.py "$(find $O/f_cfg4 -name "*counter_collection.csv" | head -1)" "$(find $O/w_cfg4 -name "*counter_collection.csv" | head -1)" > $O/cfg4_pmc_traffic.json
 # PMC study of the three dominant kernels (one layer each)
 bash tools/gpu/pmc_layer.sh $O/pmc_igemm3m_dec2b "" dec2b fwd
 bash tools/gpu/pmc_layer.sh $O/pmc_igemm3p_dec4b "" dec4b fwd

@@ -17,7 +17,10 @@ def load(path, cname):
         for r in csv.DictReader(f):
             if r["Counter_Name"] != cname:
                 continue
-            m = re.search(r"enet_[a-z_]+", r["Kernel_Name"])
+            # round 3: every Enet kernel is enet_one<F> / enet_grp<F> of a body functor F (MconvK, ReduceVecK, BnFinK, ...)
+            m = re.search(r"(Mconv|Mwgrad|ReduceVec|Reduce|BnBwdFin|BnFin|BnApplyVec|BnApply|WgradRed|Wgrad|Conv|TailFwd|TailBwd|SumFin)K", r["Kernel_Name"])
+            if m is None:
+                m = re.search(r"enet_[a-z_]+", r["Kernel_Name"])
             k = m.group(0) if m else r["Kernel_Name"][:30]
             agg[k][0] += 1
             agg[k][1] += float(r["Counter_Value"])
@@ -27,7 +30,8 @@ def load(path, cname):
 def main():
     rd, wr = load(sys.argv[1], "TCC_EA0_RDREQ_sum"), load(sys.argv[2], "WRITE_SIZE")
     per_step = float(sys.argv[3]) if len(sys.argv) > 3 else 966.0
-    steps = rd["enet_mconv_kernel"][0] / per_step
+    conv = "MconvK" if "MconvK" in rd else "enet_mconv_kernel"
+    steps = rd[conv][0] / per_step
     out, tr, tw = {}, 0.0, 0.0
     for k in sorted(rd, key=lambda k: -rd[k][1]):
         r, w = rd[k][1] * 64 / steps, wr.get(k, [0, 0])[1] * 1024 / steps
