@@ -233,7 +233,9 @@ class Enet(nn.Module):
         # of one 16-bit tensor) what the chain saves in launches.  Off; kept for A/B.
         self.denorm_on_load = os.environ.get("DCT_ENET_DENORM_ON_LOAD", "0") == "1"
         self.denorm_on_load_all = False      # (A/B: also for 3x3 / dilated / asymmetric kernels)
-        self.stats_tiles_cap = int(os.environ.get("DCT_ENET_STATS_TILES", "1024"))       # most 32-pixel tiles (= partial rows) a fused layer may have
+        # most 32-pixel tiles (= partial rows the one-block finalize must fold) a fused layer may have.  1024 / 1280 / 2560 / 5120 on one
+        # box: cfg4 15.79 / 15.52 / 15.43 / 15.54 ms, cfg5 37.50 / - / 37.48 / 38.82 (profiles/r03_cfg4_grouped_passes.txt)
+        self.stats_tiles_cap = int(os.environ.get("DCT_ENET_STATS_TILES", "2560"))
         self.skip_zero_bias_grads = os.environ.get("DCT_ENET_BIAS_GRADS", "0") != "1"    # see _conv_wgrad
 
     supports_pass_streams = True         # plan_backward(grad_buffer=...): concurrent backward passes of one model (trainer)

@@ -709,3 +709,37 @@ def test_adam_flat(ops):
     np.testing.assert_allclose(md.cpu().numpy(), m.numpy(), rtol=2e-6, atol=1e-8)   # fma contraction: ~2 ulp
     np.testing.assert_allclose(vd.cpu().numpy(), v.numpy(), rtol=2e-6, atol=1e-12)
     assert torch.equal(shadow.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+def test_loss_kernels_are_exact_beside_the_conv_kernels(ops):
+    """Regression for the packed-FP32 hazard (csrc/Makefile NOPK): the reductions of the loss kernels launched on one
+    stream while MFMA convolutions run on another give bit for bit what they give on a quiet device.  (Before the library was built
+    without v_pk_*_f32, the JSD came out 5-50 % low beside a stream of dct_conv2d launches in 59 of 60 tries.)"""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    C = 4
+    lps = [torch.randn(8, 256, 256, C, device=DEV, generator=g) * 0.3 for _ in range(3)]
+    tgt = torch.randint(0, C, (8 * 256 * 256,), device=DEV)
+    x = torch.randn(16, 124, 124, 128, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(128, 3, 3, 128, device=DEV, generator=g) / 34).to(torch.bfloat16)
+    y = torch.empty(16, 122, 122, 128, device=DEV, dtype=torch.bfloat16)
+    dw = torch.zeros(128 * 9 * 128, device=DEV)
+    victims = {"jsd": lambda: ops.jsd_logits_fwd(lps[:2], C)[0], "jsd3": lambda: ops.jsd_logits_fwd(lps, C)[0],
+               "kl": lambda: ops.kl_logits_fwd(lps[0], lps[1], C)[0], "ce": lambda: ops.ce_fwd(lps[0].reshape(-1, C), tgt, C)[0],
+               "entropy": lambda: ops.entropy_fwd(torch.softmax(lps[0], 3).contiguous(), C).double().sum()}
+    quiet = {}
+    for k, f in victims.items():
+        quiet[k] = float(f())
+        torch.cuda.synchronize()
+    sa, sb, sc = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    for k, f in victims.items():
+        for it in range(25):
+            with torch.cuda.stream(sb):
+                for _ in range(6):
+                    ops.conv2d(x, w, None, y, relu=True)
+            with torch.cuda.stream(sc):
+                for _ in range(2):
+                    ops.conv2d_wgrad(y, x, dw, accumulate=True)
+            with torch.cuda.stream(sa):
+                v = f()
+            torch.cuda.synchronize()
+            assert float(v) == quiet[k], (k, it, float(v), quiet[k])

@@ -1,0 +1,76 @@
+"""Do packed-FP32 VALU instructions survive beside the MFMA conv kernels?  (csrc/Makefile NOPK.)
+
+victim.hip is the JSD forward kernel cut down to per-thread sums (variant 1: as the compiler emits it, with v_pk_mul_f32 /
+v_pk_add_f32; 2: without the entropies; 4: the same products behind asm barriers, i.e. without the packed multiplies; 5: logs only).
+Each variant is launched 60 times on one stream, alone and beside a stream of dct_conv2d launches, and every per-thread result is
+compared with the quiet run.  Built twice: as the compiler likes it, and with -Xclang -target-feature -Xclang -packed-fp32-ops.
+
+    python tools/probe_packed_fp32/probe.py          (needs a GPU; builds the two victim libraries next to this file)
+Measured (MI355X, ROCm 7.2): default build, beside convs: variants 1 and 3 wrong in 60/60 launches (<= 4900 of 262144 threads),
+2 / 4 / 5 exact; flag build: all exact; every build exact without the convs."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(here)))
+import dct_amd  # noqa: E402,F401
+from dct_amd import hip_ops as K  # noqa: E402
+
+dev = "cuda:0"
+
+
+def build(name, extra):
+    out = os.path.join(here, name)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] + extra +
+                          ["-o", out, os.path.join(here, "victim.hip")], stderr=subprocess.DEVNULL)
+    lib = ctypes.CDLL(out)
+    lib.run_var.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+g = torch.Generator(device=dev).manual_seed(0)
+P = 8 * 256 * 256
+a = torch.randn(P * 4, device=dev, generator=g) * 0.3
+b = torch.randn(P * 4, device=dev, generator=g) * 0.3
+x = torch.randn(16, 124, 124, 128, device=dev, generator=g).to(torch.bfloat16)
+w = (torch.randn(128, 3, 3, 128, device=dev, generator=g) / 34).to(torch.bfloat16)
+y = torch.empty(16, 122, 122, 128, device=dev, dtype=torch.bfloat16)
+sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+
+
+def run(lib, mode):
+    part = torch.zeros(2048, device=dev)
+    per = torch.zeros(1024 * 256, device=dev)
+    with torch.cuda.stream(sA):
+        part.zero_()
+        per.zero_()
+        lib.run_var(mode, a.data_ptr(), b.data_ptr(), P, part.data_ptr(), per.data_ptr(), sA.cuda_stream)
+    return per
+
+
+for label, extra in (("default build", []), ("-packed-fp32-ops", ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"])):
+    lib = build("victim_%s.so" % ("nopk" if extra else "pk"), extra)
+    refs = {}
+    for mode in (1, 2, 3, 4, 5):
+        r = run(lib, mode)
+        torch.cuda.synchronize()
+        refs[mode] = r.clone()
+        torch.cuda.synchronize()
+    for load in ("none", "conv"):
+        for mode in (1, 2, 3, 4, 5):
+            bad, nbad = 0, 0
+            for it in range(60):
+                if load == "conv":
+                    with torch.cuda.stream(sB):
+                        for _ in range(6):
+                            K.conv2d(x, w, None, y, relu=True)
+                t = run(lib, mode)
+                torch.cuda.synchronize()
+                if not torch.equal(t, refs[mode]):
+                    bad += 1
+                    nbad = max(nbad, int((t != refs[mode]).sum()))
+            print(f"{label:18s} load {load:5s} variant {mode}: {bad}/60 launches differ (at most {nbad} of {t.numel()} threads)", flush=True)
