@@ -40,6 +40,17 @@ x = torch.randn(16, 124, 124, 128, device=dev, generator=g).to(torch.bfloat16)
 w = (torch.randn(128, 3, 3, 128, device=dev, generator=g) / 34).to(torch.bfloat16)
 y = torch.empty(16, 122, 122, 128, device=dev, dtype=torch.bfloat16)
 sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+xt = torch.randn(16, 44, 44, 128, device=dev, generator=g).to(torch.bfloat16)
+wt = (torch.randn(4 * 64, 128, device=dev, generator=g) / 11).to(torch.bfloat16)
+yt = torch.empty(16, 88, 88, 64, device=dev, dtype=torch.bfloat16)
+dw = torch.zeros(128 * 9 * 128, device=dev)
+ex = torch.randn(8, 64, 64, 64, device=dev, generator=g)
+ew = torch.randn(64, 3, 3, 64, device=dev, generator=g) / 24
+ey = torch.empty(8, 64, 64, 64, device=dev)
+A = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+Bm = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+big = torch.rand(1 << 26, device=dev)
+LOADS = ("none", "conv", "convT (per-tap kernel)", "weight gradient", "enet MFMA conv", "rocBLAS bf16 GEMM", "elementwise")
 
 
 def run(lib, mode):
@@ -60,17 +71,32 @@ for label, extra in (("default build", []), ("-packed-fp32-ops", ["-Xclang", "-t
         torch.cuda.synchronize()
         refs[mode] = r.clone()
         torch.cuda.synchronize()
-    for load in ("none", "conv"):
-        for mode in (1, 2, 3, 4, 5):
+    for load in LOADS:
+        for mode in ((1, 2, 3, 4, 5) if load in ("none", "conv") else (1,)):
             bad, nbad = 0, 0
             for it in range(60):
-                if load == "conv":
-                    with torch.cuda.stream(sB):
+                with torch.cuda.stream(sB):
+                    if load == "conv":                      # shared-halo 3x3 kernel: LDS-DMA staging + v_mfma_f32_16x16x32_bf16
                         for _ in range(6):
                             K.conv2d(x, w, None, y, relu=True)
+                    elif load == "convT (per-tap kernel)":  # igemm2: LDS-DMA staging + v_mfma_f32_32x32x16_bf16
+                        for _ in range(6):
+                            K.conv2d(xt, wt, None, yt, R=1, S=1, relu=True, scatter2x2=True)
+                    elif load == "weight gradient":
+                        for _ in range(3):
+                            K.conv2d_wgrad(y, x, dw, accumulate=True)
+                    elif load == "enet MFMA conv":          # plain global loads + v_mfma_f32_32x32x16_bf16, no LDS-DMA
+                        for _ in range(12):
+                            K.enet_conv(ex, ew, None, None, ey, R=3, S=3, pad_h=1, pad_w=1, ws=(9 * 64, 64, 1), compute=torch.bfloat16)
+                    elif load == "rocBLAS bf16 GEMM":
+                        for _ in range(3):
+                            torch.matmul(A, Bm)
+                    elif load == "elementwise":
+                        for _ in range(6):
+                            big.mul_(1.0001)
                 t = run(lib, mode)
                 torch.cuda.synchronize()
                 if not torch.equal(t, refs[mode]):
                     bad += 1
                     nbad = max(nbad, int((t != refs[mode]).sum()))
-            print(f"{label:18s} load {load:5s} variant {mode}: {bad}/60 launches differ (at most {nbad} of {t.numel()} threads)", flush=True)
+            print(f"{label:18s} load {load:24s} variant {mode}: {bad}/60 launches differ (at most {nbad} of {t.numel()} threads)", flush=True)
