@@ -116,7 +116,8 @@ def _loaders_all_labeled(device, bs):
 def test_acdc_dsc_curve_matches_a_reference_that_learned(arch, tmp_path):
     """BASELINE.json: "DSC within 0.2 of the reference on ACDC at equal steps", against a reference run that actually segments
     the heart.  tests/golden/g10_acdc_<arch>.npz (tools/capture_golden.py::g10_acdc_dsc) is the UNMODIFIED reference CoTrainer,
-    2 x Enet (5 epochs of 500 steps, bs 4 + 4) or 2 x UNet (the metric's network; 4 epochs of 250 steps, bs 2 + 2), all five
+    2 x Enet (5 epochs of 500 steps, bs 4 + 4) or 2 x UNet (the metric's network; 8 epochs of 250 steps, bs 2 + 2: the reference needs five of
+    them to pass 0.5), all five
     vendored training patients labeled for both models, CE + JSD, validated on patient 006 after every epoch.  The HIP bf16
     trainer runs the same epochs from the same initial weights on the same batches (digests compared step by step) and must
       * end within 0.2 of the reference's foreground DSC, per model, 3-D and 2-D,
