@@ -90,6 +90,7 @@ SIGNATURES = {
     "dct_pack_weights_batched64": (_i, [_P, _i, _i, _P]),
     "dct_bn_running_update": (_i, [_P, _i, _P, C.c_float, _P]),
     "dct_flat_sum": (_i, [_P, _P, _P, _P, C.c_longlong, _P]),
+    "dct_flat_scale": (_i, [_P, C.c_float, C.c_longlong, _P]),
     "dct_conv_cin1_fwd": (_i, [_VP, _P, _P, _VP, _DP, _i, _P]),
     "dct_conv_cin1_dgrad": (_i, [_VP, _P, _VP, _DP, _i, _P]),
     "dct_conv_cin1_wgrad_workspace_bytes": (_sz, [_VP, _DP]),

@@ -301,7 +301,34 @@ __global__ __launch_bounds__(256) void flat_sum_kernel(float* out, const float* 
   if (c) { const float4 z = reinterpret_cast<const float4*>(c)[i]; o.x += z.x; o.y += z.y; o.z += z.z; o.w += z.w; }
   reinterpret_cast<float4*>(out)[i] = o;
 }
+// x *= s over n floats at any 4-byte alignment: 16-byte accesses over the aligned body, block 0 takes the < 4 head and tail floats.
+// (ddp.py: the gradient average after a SUM all-reduce -- RCCL's own averaging kernels multiply with packed-FP32 instructions,
+// which this build keeps away from the conv kernels: csrc/Makefile.)
+__global__ __launch_bounds__(256) void flat_scale_kernel(float* x, float s, long long n, int head) {
+  const long long n4 = (n - head) / 4;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) {
+    float4* p = reinterpret_cast<float4*>(x + head) + i;
+    float4 v = *p;
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    *p = v;
+  }
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < head) x[threadIdx.x] *= s;
+    const long long t = head + 4 * n4 + threadIdx.x;
+    if (threadIdx.x < 4 && t < n) x[t] *= s;
+  }
+}
 }  // namespace
+
+extern "C" int dct_flat_scale(float* x, float scale, long long n, dct_stream stream) {
+  if (!x || n < 1 || ((uintptr_t)x & 3)) return DCT_ERR_BAD_ARG;
+  int head = (int)(((16 - ((uintptr_t)x & 15)) & 15) / 4);
+  if (head > n) head = (int)n;
+  const long long n4 = (n - head) / 4;
+  DCT_LAUNCH(DCT_PROF_OTHER, flat_scale_kernel, dim3((unsigned)(n4 ? (n4 + 255) / 256 : 1)), dim3(256), 0, (hipStream_t)stream, x, scale, n, head);
+  return dct_check_launch();
+}
 
 extern "C" int dct_bn_running_update(const void* records_dev, int n_layers, const float* stats, float momentum, dct_stream stream) {
   if (!records_dev || n_layers < 1 || !stats) return DCT_ERR_BAD_ARG;

@@ -14,6 +14,13 @@ gradients summed onto device 0.  The MI355X-native equivalent here:
     (7 links x ~153 GB/s per GPU): a ring all-reduce of UNet's 124 MB takes ~1.4 ms at 8 GPUs, so
     model m's all-reduce is issued asynchronously right after model m's backward is enqueued
     and overlaps the backward of model m+1 (``begin`` / ``finish``);
+  * the collective is a SUM and the 1/world of the average is applied here, not by RCCL: ``ReduceOp.AVG`` runs RCCL's
+    pre-multiply kernels, whose gfx950 code multiplies with packed-FP32 instructions (``v_pk_mul_f32``: 8-48 per ring / tree
+    function in torch's librccl.so; the plain ring SUM of f32 and every bf16 kernel hold none), and packed-FP32 arithmetic is what
+    goes wrong in waves that share a CU with the conv kernels (tools/probe_packed_fp32) -- which is exactly where an
+    exchange overlapped with the backward pass runs.  Fused-Adam models get the factor folded into the optimizer's
+    ``grad_scale`` (no launch, ``defer_average``); everything else is scaled in its buffer by ``dct_flat_scale``.
+    ``init_from_env`` asks RCCL for its ring algorithm unless NCCL_ALGO is set (its tree SUM of f32 holds packed adds);
   * BatchNorm buffers stay per-rank (what DataParallel replicas do); FGSM's input-gradient pass
     produces no parameter gradients and therefore never touches the exchange.
 
@@ -37,7 +44,7 @@ class FlatGradSync(object):
     FUSE_BELOW = 4 << 20        # elements: models under 16 MiB of fp32 gradients share one arena and ONE all-reduce per step
 
     def __init__(self, segmentators, process_group=None, broadcast_weights: bool = True, compress: Optional[str] = None,
-                 measure: bool = False, fuse_small: bool = True):
+                 measure: bool = False, fuse_small: bool = True, defer_average: bool = True):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("FlatGradSync needs an initialised torch.distributed process group")
         self.segmentators = list(segmentators)
@@ -47,7 +54,9 @@ class FlatGradSync(object):
         self._pending: List = []
         self._bucketed = set()      # models whose gradients already went out bucket by bucket this step
         self.bucket_calls = 0
-        self._avg = dist.get_backend(process_group) == "nccl"   # RCCL supports ReduceOp.AVG; gloo does not
+        # defer_average: a model whose optimizer takes a gradient scale (fused Adam over a flat buffer) keeps the SUM in its
+        # buffer and CoTrainer folds ``optimizer_scale(i)`` = 1/world into the update; False: every buffer holds the mean after finish()
+        self.defer_average = bool(defer_average)
         assert compress in (None, "bf16"), compress
         self.compress = compress
         self._cbuf = {}             # model index -> bf16 image of its flat gradient buffer
@@ -147,9 +156,34 @@ class FlatGradSync(object):
                 p.grad = f._grad_view(k)
 
     def _reduce_tensor(self, t: torch.Tensor, async_op: bool):
-        if self._avg:
-            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), t
+
+    def _deferred(self, model_index) -> bool:
+        """True when the 1/world of model_index's average is left to its optimizer (a property of the model, not of the step:
+        captured optimizer launches bake the factor in).  Models that share the arena decide together."""
+        if not self.defer_average or self.world == 1:
+            return False
+
+        def one(i):
+            seg = self.segmentators[i]
+            flat = getattr(seg.torchnet, "flat_params", None)
+            return hasattr(getattr(seg, "optimizer", None), "grad_scale") and flat is not None and flat.grads_attached()
+        if model_index == "arena" or model_index in self._arena_span:
+            return all(one(i) for i in self._arena_span)
+        return one(model_index)
+
+    def optimizer_scale(self, model_index: int) -> float:
+        """Factor model_index's optimizer has to apply to the gradients finish() leaves in its buffer."""
+        return 1.0 / self.world if self._deferred(model_index) else 1.0
+
+    def _average(self, t: torch.Tensor):
+        if self.world == 1:
+            return
+        if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+            from . import hip_ops as K
+            K.flat_scale(t, 1.0 / self.world)
+        else:
+            t.mul_(1.0 / self.world)
 
     def _start(self, model_index: int, flat, lo: int, hi: int):
         """all-reduce of gflat[lo:hi], optionally through the bf16 image; returns the pending record"""
@@ -247,10 +281,11 @@ class FlatGradSync(object):
                 self._events.append((e0, e1))
             else:
                 work.wait()
-            if scale is not None:
-                scale.mul_(1.0 / self.world)
             if wire is not None:
                 wire[1].copy_(wire[0])         # bf16 image -> the fp32 gradient buffer
+                scale = wire[1]
+            if buf is not None or not self._deferred(ent[0]):
+                self._average(scale)
             if buf is not None:
                 off = 0
                 for p in params:
@@ -286,6 +321,14 @@ class FlatGradSync(object):
         self._prepared = True
 
 
+def prefer_ring():
+    """RCCL's ring all-reduce unless the user chose (NCCL_ALGO): on one node's xGMI mesh it is what RCCL picks for the large
+    buffers anyway, and its f32 SUM kernels hold no packed-FP32 instructions while the tree's do (module docstring).  Call before
+    the process group is created."""
+    import os
+    os.environ.setdefault("NCCL_ALGO", "Ring")
+
+
 def init_from_env(backend: Optional[str] = None):
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and initialise the
     process group: 'nccl' (= RCCL on ROCm) when a GPU is visible, else 'gloo'."""
@@ -299,6 +342,7 @@ def init_from_env(backend: Optional[str] = None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(local)
+        prefer_ring()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29512")
     if not dist.is_initialized():

@@ -253,6 +253,14 @@ def flat_sum(out, a, b, c=None):
     return out
 
 
+def flat_scale(x, scale):
+    """x *= scale in place: a dense fp32 buffer (or slice of one) of any length."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    if x.numel():
+        call("dct_flat_scale", ptr(x), float(scale), x.numel(), stream())
+    return x
+
+
 def conv_cin1_fwd(x, w, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=False, relu_bits_out=None):
     d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu, relu_bits_out=_bits_ok(relu_bits_out, y))
     vx, vy = view(x), view(y)

@@ -405,12 +405,15 @@ class CoTrainer(Trainer):
         def on(i):
             return self._sched.on(streams[i]) if streams is not None else contextlib.nullcontext()
         unscale = getattr(self, "_grad_unscale", 1.0)
+        sync = self.grad_sync if self.grad_sync is not None else getattr(self, "_opt_phase_sync", None)
         for i, seg in enumerate(self.segmentators):
             with on(i):
                 if self.grad_sync is not None:
                     self._sched.call(lambda i=i: self.grad_sync.finish(i))     # model i's all-reduce only: later ones overlap this Adam launch
                 if hasattr(seg.optimizer, "grad_scale"):
-                    seg.optimizer.grad_scale = unscale          # fused Adam: folded into the update
+                    # fused Adam: the inverse loss scale and, under data parallelism, the 1/world of the gradient average
+                    # (the exchange is a SUM: ddp.py) are folded into the update
+                    seg.optimizer.grad_scale = unscale * (sync.optimizer_scale(i) if hasattr(sync, "optimizer_scale") else 1.0)
                 elif unscale != 1.0:
                     flat = getattr(seg.torchnet, "flat_params", None)
                     if flat is not None and flat.grads_attached():

@@ -214,9 +214,11 @@ class StepGraphCache(object):
                         cap.out = tr._run_step_fused(cap.lab, cap.unl, train_jsd, train_adv, adv_choice, lam_dev=lam_dev)
                     tr._defer_optimizer = False
                     cap.graph_opt = torch.cuda.CUDAGraph()
+                    tr._opt_phase_sync = sync          # (the exchange leaves a SUM: the update folds its 1/world in)
                     with torch.cuda.graph(cap.graph_opt, capture_error_mode="thread_local"):
                         tr._optimizer_phase(None)      # S small launches on the capture stream
                 finally:
+                    tr._opt_phase_sync = None
                     tr.grad_sync, tr._defer_optimizer = sync, False
                     tr.pass_streams = keep_pass
         finally:

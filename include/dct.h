@@ -307,6 +307,9 @@ int dct_bn_running_update(const void* records_dev, int n_layers, const float* st
 /* out = a + b (+ c if non-NULL) over n floats (n % 4 == 0, 16-byte aligned): the per-pass flat gradient buffers of one model,
  * added in pass order -- ((labeled + unlabeled) + adversarial), bit for bit the in-place accumulation of sequential passes. */
 int dct_flat_sum(float* out, const float* a, const float* b, const float* c, long long n, dct_stream stream);
+/* x *= scale over n floats (any 4-byte aligned pointer, any n >= 1): the 1/world of a gradient average after a SUM all-reduce
+ * (ddp.py::FlatGradSync -- replaces ReduceOp.AVG, whose RCCL kernels multiply with packed-FP32 instructions). */
+int dct_flat_scale(float* x, float scale, long long n, dct_stream stream);
 
 size_t dct_enet_reduce_workspace_bytes(int channels);
 /* nn.BatchNorm2d(eps 1e-3, momentum 0.1) forward statistics of a raw conv output (enet.py:22,55-122):

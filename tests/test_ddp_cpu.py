@@ -126,21 +126,25 @@ def _bucket_worker(rank, world, port, out):
     from dct_amd.arch.flat import FlatParams
     ddp.init_from_env("gloo")
     segs = []
-    for m in range(2):
+    for m in range(3):
         net = torch.nn.Sequential(torch.nn.Linear(40, 30), torch.nn.Linear(30, 7))
         net.flat_params = FlatParams(list(net.parameters()))
         net.flat_params.ensure()
         net.flat_params.ensure_grads()
         net.flat_params.gflat.copy_(torch.arange(net.flat_params.total, dtype=torch.float32) * (rank + 1) + 10 * m)
         segs.append(types.SimpleNamespace(torchnet=net))
+    # model 2's optimizer takes a gradient scale (the fused Adam does): its buffer keeps the SUM, the 1/world goes to the update
+    segs[2].optimizer = types.SimpleNamespace(grad_scale=1.0)
     sync = ddp.FlatGradSync(segs, broadcast_weights=False)
+    assert [sync.optimizer_scale(m) for m in range(3)] == [1.0, 1.0, 1.0 / world]
     total = segs[0].torchnet.flat_params.total
     cuts = [(total // 2, total), (total // 5, total // 2), (0, total // 5)]     # completion order of a backward pass
     for lo, hi in cuts:
         sync.begin_bucket(0, lo, hi)
     sync.begin(0)                   # every bucket already went out: must not reduce a second time
     sync.begin(1)                   # model 1: one whole-buffer exchange
-    for m in range(2):
+    sync.begin(2)
+    for m in range(3):
         sync.finish(m)
     torch.save([s.torchnet.flat_params.gflat.clone() for s in segs], os.path.join(out, f"g{rank}.pt"))
     dist.barrier()
@@ -150,15 +154,16 @@ def _bucket_worker(rank, world, port, out):
 @pytest.mark.timeout(300)
 def test_two_rank_gloo_bucketed_exchange(tmp_path):
     """FlatGradSync.begin_bucket (the in-backward exchange of UNet's gradient buckets): three slices of model 0 and the
-    whole buffer of model 1 end as the rank mean on both ranks, each element reduced exactly once."""
+    whole buffer of model 1 end as the rank mean on both ranks, each element reduced exactly once; model 2, whose optimizer
+    folds the 1/world into its update (FlatGradSync.optimizer_scale), keeps the rank SUM."""
     world, port = 2, _free_port()
     out = str(tmp_path)
     mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
     g0 = torch.load(os.path.join(out, "g0.pt"), weights_only=False)
     g1 = torch.load(os.path.join(out, "g1.pt"), weights_only=False)
-    for m in range(2):
+    for m in range(3):
         n = g0[m].numel()
-        want = (torch.arange(n, dtype=torch.float32) * 1 + 10 * m + torch.arange(n, dtype=torch.float32) * 2 + 10 * m) / 2
+        want = (torch.arange(n, dtype=torch.float32) * 1 + 10 * m + torch.arange(n, dtype=torch.float32) * 2 + 10 * m) / (2 if m < 2 else 1)
         assert torch.equal(g0[m], g1[m])
         np.testing.assert_allclose(g0[m].numpy(), want.numpy(), rtol=1e-6)
 

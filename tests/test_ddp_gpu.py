@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _trainer(tmp, rank, with_sync):
+def _trainer(tmp, rank, with_sync, defer=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import FakeLoader, batches
@@ -47,20 +47,21 @@ def _trainer(tmp, rank, with_sync):
         s.train()
     if with_sync:
         from dct_amd.ddp import FlatGradSync
-        tr.grad_sync = FlatGradSync(segs)
+        tr.grad_sync = FlatGradSync(segs, defer_average=defer)
     return tr, lab, unl, n
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, defer=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    tr, lab, unl, n = _trainer(os.path.join(out, f"r{rank}"), rank, True)
+    tr, lab, unl, n = _trainer(os.path.join(out, f"r{rank}"), rank, True, defer=defer)
     for k in range(n):
         lb = [(lab[i][k][0][0], lab[i][k][0][1]) for i in range(2)]
         o = tr._run_step(lb, (unl[k][0][0], unl[k][0][1]), True, True, (0, 1))
         assert all(torch.isfinite(v) for v in o["sup"])
+    assert [tr.grad_sync.optimizer_scale(i) for i in range(2)] == ([0.5, 0.5] if defer else [1.0, 1.0])
     torch.cuda.synchronize()
     w = [torch.cat([p.detach().flatten() for p in s.torchnet.parameters()]).cpu() for s in tr.segmentators]
     torch.save(dict(w=w, buckets=tr.grad_sync.bucket_calls), os.path.join(out, f"w{rank}.pt"))
@@ -70,14 +71,22 @@ def _worker(rank, world, port, out):
 
 @pytest.mark.timeout(600)
 def test_two_ranks_one_gpu_fused_step_stays_in_sync(tmp_path):
-    world, port, out = 2, _free_port(), str(tmp_path)
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    r0 = torch.load(os.path.join(out, "w0.pt"), weights_only=False)
-    r1 = torch.load(os.path.join(out, "w1.pt"), weights_only=False)
-    assert r0["buckets"] == r1["buckets"] == 3 * 2 * 3          # 3 buckets x 2 models x 3 steps, from inside the backward
-    for a, b in zip(r0["w"], r1["w"]):
-        assert torch.isfinite(a).all()
-        assert torch.equal(a, b)                                  # same start (broadcast) + same averaged gradients
+    """... and the two places the 1/world of the average can be applied -- folded into the fused Adam's gradient scale (default:
+    the buffers keep the SUM) or multiplied into the buffers by dct_flat_scale -- end in the same weights, bit for bit (world 2)."""
+    world, res = 2, {}
+    for defer in (True, False):
+        port, out = _free_port(), os.path.join(str(tmp_path), f"d{int(defer)}")
+        os.makedirs(out)
+        mp.spawn(_worker, args=(world, port, out, defer), nprocs=world, join=True)
+        r0 = torch.load(os.path.join(out, "w0.pt"), weights_only=False)
+        r1 = torch.load(os.path.join(out, "w1.pt"), weights_only=False)
+        assert r0["buckets"] == r1["buckets"] == 3 * 2 * 3          # 3 buckets x 2 models x 3 steps, from inside the backward
+        for a, b in zip(r0["w"], r1["w"]):
+            assert torch.isfinite(a).all()
+            assert torch.equal(a, b)                                  # same start (broadcast) + same averaged gradients
+        res[defer] = r0["w"]
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
 
 
 def _unet_prog_worker(rank, world, port, out, graph, backend):

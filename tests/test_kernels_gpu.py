@@ -743,3 +743,16 @@ def test_loss_kernels_are_exact_beside_the_conv_kernels(ops):
                 v = f()
             torch.cuda.synchronize()
             assert float(v) == quiet[k], (k, it, float(v), quiet[k])
+
+
+@pytest.mark.parametrize("n,off", [(1, 0), (3, 1), (4, 0), (7, 3), (1000, 0), (1001, 2), (1 << 20, 0), ((1 << 20) + 5, 1), (31_000_003, 3)])
+def test_flat_scale(ops, n, off):
+    """dct_flat_scale: x *= s over any 4-byte aligned slice (the gradient average after a SUM all-reduce, ddp.py): exactly the
+    fp32 product, and nothing outside the slice is touched."""
+    torch.manual_seed(n)
+    base = torch.randn(n + off + 9, device=DEV)
+    ref = base.clone()
+    ops.flat_scale(base[off:off + n], 1.0 / 3.0)
+    ref[off:off + n] = ref[off:off + n].cpu().mul(torch.tensor(1.0 / 3.0, dtype=torch.float32)).to(DEV)
+    torch.cuda.synchronize()
+    assert torch.equal(base, ref)

@@ -164,7 +164,7 @@ def test_bf16_step_tracks_oracle(tmp_path, golden):
 
 def test_rccl_gradient_exchange_single_rank(tmp_path, golden):
     """The N>1 code path of bench.py on the one GPU a test box has: a world_size-1 RCCL process group, flat
-    gradient all-reduce (ReduceOp.AVG, async) out of the flat buffers, per-model wait + fused Adam.  With one
+    gradient all-reduce (SUM, async; 1/world in Adam) out of the flat buffers, per-model wait + fused Adam.  With one
     rank the exchange must leave the step bit-identical to the single-process step."""
     import os
     import torch.distributed as dist
