@@ -302,8 +302,7 @@ __global__ __launch_bounds__(256) void flat_sum_kernel(float* out, const float* 
   reinterpret_cast<float4*>(out)[i] = o;
 }
 // x *= s over n floats at any 4-byte alignment: 16-byte accesses over the aligned body, block 0 takes the < 4 head and tail floats.
-// (ddp.py: the gradient average after a SUM all-reduce -- RCCL's own averaging kernels multiply with packed-FP32 instructions,
-// which this build keeps away from the conv kernels: csrc/Makefile.)
+// (ddp.py: the gradient average after a SUM all-reduce, for models whose optimizer does not fold 1/world into its update.)
 __global__ __launch_bounds__(256) void flat_scale_kernel(float* x, float s, long long n, int head) {
   const long long n4 = (n - head) / 4;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;

@@ -15,12 +15,12 @@ gradients summed onto device 0.  The MI355X-native equivalent here:
     model m's all-reduce is issued asynchronously right after model m's backward is enqueued
     and overlaps the backward of model m+1 (``begin`` / ``finish``);
   * the collective is a SUM and the 1/world of the average is applied here, not by RCCL: ``ReduceOp.AVG`` runs RCCL's
-    pre-multiply kernels, whose gfx950 code multiplies with packed-FP32 instructions (``v_pk_mul_f32``: 8-48 per ring / tree
-    function in torch's librccl.so; the plain ring SUM of f32 and every bf16 kernel hold none), and packed-FP32 arithmetic is what
-    goes wrong in waves that share a CU with the conv kernels (tools/probe_packed_fp32) -- which is exactly where an
-    exchange overlapped with the backward pass runs.  Fused-Adam models get the factor folded into the optimizer's
+    pre-multiply kernels, whose gfx950 code holds 8-48 packed-FP32 instructions per ring / tree function (the plain ring SUM of f32
+    and every bf16 kernel hold none), and an exchange overlapped with the backward pass runs beside the conv kernels -- the
+    neighbourhood in which one packed-FP32 operand form goes wrong (tools/probe_packed_fp32).  RCCL's kernels do not
+    use that form, so this is caution, but it is free: fused-Adam models get the factor folded into the optimizer's
     ``grad_scale`` (no launch, ``defer_average``); everything else is scaled in its buffer by ``dct_flat_scale``.
-    ``init_from_env`` asks RCCL for its ring algorithm unless NCCL_ALGO is set (its tree SUM of f32 holds packed adds);
+    ``init_from_env`` asks RCCL for its ring algorithm unless NCCL_ALGO is set;
   * BatchNorm buffers stay per-rank (what DataParallel replicas do); FGSM's input-gradient pass
     produces no parameter gradients and therefore never touches the exchange.
 

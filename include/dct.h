@@ -308,7 +308,7 @@ int dct_bn_running_update(const void* records_dev, int n_layers, const float* st
  * added in pass order -- ((labeled + unlabeled) + adversarial), bit for bit the in-place accumulation of sequential passes. */
 int dct_flat_sum(float* out, const float* a, const float* b, const float* c, long long n, dct_stream stream);
 /* x *= scale over n floats (any 4-byte aligned pointer, any n >= 1): the 1/world of a gradient average after a SUM all-reduce
- * (ddp.py::FlatGradSync -- replaces ReduceOp.AVG, whose RCCL kernels multiply with packed-FP32 instructions). */
+ * (ddp.py::FlatGradSync, for models whose optimizer does not fold the factor into its update). */
 int dct_flat_scale(float* x, float scale, long long n, dct_stream stream);
 
 size_t dct_enet_reduce_workspace_bytes(int channels);

@@ -6,8 +6,15 @@ Each variant is launched 60 times on one stream, alone and beside a stream of dc
 compared with the quiet run.  Built twice: as the compiler likes it, and with -Xclang -target-feature -Xclang -packed-fp32-ops.
 
     python tools/probe_packed_fp32/probe.py          (needs a GPU; builds the two victim libraries next to this file)
-Measured (MI355X, ROCm 7.2): default build, beside convs: variants 1 and 3 wrong in 60/60 launches (<= 4900 of 262144 threads),
-2 / 4 / 5 exact; flag build: all exact; every build exact without the convs."""
+Variants 6-8 are streaming kernels over float2 pairs: 6 = a * s + b * s (v_pk_mul_f32 + v_pk_add_f32: the arithmetic of a
+pre-multiplied sum, which is how RCCL forms ReduceOp.AVG), 7 = log2(a^2 + 1) * b (v_log_f32 results straight into
+v_pk_mul_f32), 8 = a * s + swap(b) (v_pk_fma_f32 with op_sel), 9 = a * s + b as
+v_pk_fma_f32 op_sel_hi:[0,1,1] in inline asm (RCCL's own instruction form; packed in both builds).
+Measured (MI355X, ROCm 7.2): default build, beside the shared-halo conv kernel: variants 1, 3 and 8 wrong in 60/60 launches
+(<= 5000 of 262144 / 2700 of 2097152 threads), beside the filter-row weight gradient 1 in 22-57 and 8 in 60 of 60; 2 / 4 / 5 / 6 / 7 / 9
+exact; flag build: all exact; every build exact without the convs and beside the other loads.  What variants 1, 3 and 8 share and the
+exact ones lack is a packed-FP32 instruction that reads a source pair with SWAPPED halves (op_sel:[..1..]); plain packed
+multiplies / adds (6), packed products of transcendental results (7) and the broadcast form op_sel_hi:[0,1,1] (9) survive."""
 import ctypes
 import os
 import subprocess
@@ -29,6 +36,7 @@ def build(name, extra):
                           ["-o", out, os.path.join(here, "victim.hip")], stderr=subprocess.DEVNULL)
     lib = ctypes.CDLL(out)
     lib.run_var.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.run_premul.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
     return lib
 
 
@@ -54,6 +62,11 @@ LOADS = ("none", "conv", "convT (per-tap kernel)", "weight gradient", "enet MFMA
 
 
 def run(lib, mode):
+    if mode >= 6:                   # streaming kernels over the 8 M floats of a and b: 6 = a / 8 + b / 8, 7 = log2(a^2 + 1) * b, 8 = a / 8 + swap(b), 9 = a / 8 + b (asm)
+        out = torch.empty_like(a)
+        with torch.cuda.stream(sA):
+            lib.run_premul(mode - 6, a.data_ptr(), b.data_ptr(), 0.125, a.numel() // 4, out.data_ptr(), sA.cuda_stream)
+        return out
     part = torch.zeros(2048, device=dev)
     per = torch.zeros(1024 * 256, device=dev)
     with torch.cuda.stream(sA):
@@ -63,16 +76,16 @@ def run(lib, mode):
     return per
 
 
-for label, extra in (("default build", []), ("-packed-fp32-ops", ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"])):
+for label, extra in (("default build", []), ("-packed-fp32-ops", ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVICTIM_NO_PK_ASM"])):
     lib = build("victim_%s.so" % ("nopk" if extra else "pk"), extra)
     refs = {}
-    for mode in (1, 2, 3, 4, 5):
+    for mode in (1, 2, 3, 4, 5, 6, 7, 8, 9):
         r = run(lib, mode)
         torch.cuda.synchronize()
         refs[mode] = r.clone()
         torch.cuda.synchronize()
     for load in LOADS:
-        for mode in ((1, 2, 3, 4, 5) if load in ("none", "conv") else (1,)):
+        for mode in ((1, 2, 3, 4, 5, 6, 7, 8, 9) if load in ("none", "conv") else (1, 6, 7, 8, 9)):
             bad, nbad = 0, 0
             for it in range(60):
                 with torch.cuda.stream(sB):

@@ -92,3 +92,47 @@ extern "C" int run_var(int mode, const float* a, const float* b, long long P, fl
   else hipLaunchKernelGGL(jsd_var<5>, dim3(1024), dim3(256), 0, st, pk, 2, P, partial, perthread);
   return (int)hipGetLastError();
 }
+
+// Variant 6: what a pre-multiplied sum of two gradient buffers does (RCCL's AVG = PreMulSum): out = a * s + b * s over float2 pairs,
+// which the default build turns into v_pk_mul_f32 + v_pk_add_f32 / v_pk_fma_f32 and the flag build into scalar multiplies and adds.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// Variants 7 / 8 narrow it down: 7 = packed products whose operands come straight from the transcendental unit (v_log_f32 ->
+// v_pk_mul_f32, the shape of p * log p), 8 = packed adds that read a swapped pair (op_sel forms, as the compiler emits for the
+// channel means), 9 = v_pk_fma_f32 with op_sel_hi:[0,1,1] written as inline asm (in both builds); variant 6 has neither.
+template <int KIND>
+__global__ __launch_bounds__(256) void premul_sum(const float* a, const float* b, float s, long long n4, float* out) {
+  const f32x2 s2 = {s, s};
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 x = reinterpret_cast<const f32x4*>(a)[i], y = reinterpret_cast<const f32x4*>(b)[i];
+    f32x2 x0 = {x[0], x[1]}, x1 = {x[2], x[3]}, y0 = {y[0], y[1]}, y1 = {y[2], y[3]};
+    f32x2 r0, r1;
+    if (KIND == 0) {
+      x0 = x0 * s2; x1 = x1 * s2; y0 = y0 * s2; y1 = y1 * s2;
+      asm volatile("" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));      // (the products stay products: no contraction into the sum)
+      r0 = x0 + y0; r1 = x1 + y1;
+    } else if (KIND == 1) {
+      const f32x2 l0 = {__log2f(x[0] * x[0] + 1.f), __log2f(x[1] * x[1] + 1.f)}, l1 = {__log2f(x[2] * x[2] + 1.f), __log2f(x[3] * x[3] + 1.f)};
+      r0 = l0 * y0; r1 = l1 * y1;
+    } else if (KIND == 2) {
+      const f32x2 ys0 = {y0[1], y0[0]}, ys1 = {y1[1], y1[0]};
+      r0 = x0 * s2 + ys0; r1 = x1 * s2 + ys1;
+    } else {      // the exact instruction form of RCCL's pre-multiplied sum (librccl.so, runRing<float, FuncPreMulSum<float>, ...>): low half of src0 for both lanes
+#ifdef VICTIM_NO_PK_ASM                      // (the flag build's assembler refuses the mnemonic)
+      r0 = x0 * s2 + y0; r1 = x1 * s2 + y1;
+#else
+      f32x2 sv = {s, 12345.f};
+      asm volatile("v_pk_fma_f32 %0, %2, %3, %4 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %1, %2, %5, %6 op_sel_hi:[0,1,1]"
+                   : "=&v"(r0), "=&v"(r1) : "v"(sv), "v"(x0), "v"(y0), "v"(x1), "v"(y1));
+#endif
+    }
+    const f32x4 r = {r0[0], r0[1], r1[0], r1[1]};
+    reinterpret_cast<f32x4*>(out)[i] = r;
+  }
+}
+extern "C" int run_premul(int kind, const float* a, const float* b, float s, long long n4, float* out, hipStream_t st) {
+  if (kind == 0) hipLaunchKernelGGL(premul_sum<0>, dim3(1024), dim3(256), 0, st, a, b, s, n4, out);
+  else if (kind == 1) hipLaunchKernelGGL(premul_sum<1>, dim3(1024), dim3(256), 0, st, a, b, s, n4, out);
+  else if (kind == 2) hipLaunchKernelGGL(premul_sum<2>, dim3(1024), dim3(256), 0, st, a, b, s, n4, out);
+  else hipLaunchKernelGGL(premul_sum<3>, dim3(1024), dim3(256), 0, st, a, b, s, n4, out);
+  return (int)hipGetLastError();
+}
