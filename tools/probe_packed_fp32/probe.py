@@ -14,7 +14,12 @@ Measured (MI355X, ROCm 7.2): default build, beside the shared-halo conv kernel: 
 (<= 5000 of 262144 / 2700 of 2097152 threads), beside the filter-row weight gradient 1 in 22-57 and 8 in 60 of 60; 2 / 4 / 5 / 6 / 7 / 9
 exact; flag build: all exact; every build exact without the convs and beside the other loads.  What variants 1, 3 and 8 share and the
 exact ones lack is a packed-FP32 instruction that reads a source pair with SWAPPED halves (op_sel:[..1..]); plain packed
-multiplies / adds (6), packed products of transcendental results (7) and the broadcast form op_sel_hi:[0,1,1] (9) survive."""
+multiplies / adds (6), packed products of transcendental results (7) and the broadcast form op_sel_hi:[0,1,1] (9) survive.
+Synthetic neighbours (victim.hip::neighbour) instead of the conv kernels: v_mfma_f32_16x16x32_bf16 back to back from registers is
+enough (1 / 3: 35 k of 262144 threads, 8: 135 k of 2097152, 60 of 60 launches); LDS reads, LDS-DMA, a dependent 32x32x16 chain
+and the 16x16x32 loop throttled by LDS reads are not.  Variants 10-17 (victim.hip::klass) are the other operand-routing
+instruction classes the library uses (DPP, v_pk_fma_f16 op_sel, bf16 converts, f64, v_perm / v_alignbit, fma, ds_bpermute, LDS):
+exact beside every load, in both builds."""
 import ctypes
 import os
 import subprocess
@@ -36,6 +41,8 @@ def build(name, extra):
                           ["-o", out, os.path.join(here, "victim.hip")], stderr=subprocess.DEVNULL)
     lib = ctypes.CDLL(out)
     lib.run_var.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.run_neighbour.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.run_class.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
     lib.run_premul.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
     return lib
 
@@ -58,10 +65,20 @@ ey = torch.empty(8, 64, 64, 64, device=dev)
 A = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
 Bm = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
 big = torch.rand(1 << 26, device=dev)
-LOADS = ("none", "conv", "convT (per-tap kernel)", "weight gradient", "enet MFMA conv", "rocBLAS bf16 GEMM", "elementwise")
+SYNTH = ("synthetic: LDS reads", "synthetic: MFMA 16x16x32", "synthetic: MFMA 32x32x16", "synthetic: MFMA 16x16x32 on LDS reads", "synthetic: LDS-DMA")
+LOADS = ("none", "conv", "convT (per-tap kernel)", "weight gradient", "enet MFMA conv", "rocBLAS bf16 GEMM", "elementwise") + SYNTH
+sink = torch.zeros(1024, device=dev)
+CLASSES = {10: "DPP row_shr", 11: "v_pk_fma_f16 op_sel", 12: "v_cvt_pk_bf16_f32", 13: "f64 mul / add", 14: "v_perm + v_alignbit", 15: "f32 fma",
+           16: "ds_bpermute", 17: "LDS write / read"}
+ALL = (1, 2, 3, 4, 5, 6, 7, 8, 9) + tuple(CLASSES)
 
 
 def run(lib, mode):
+    if mode >= 10:                  # other instruction classes (victim.hip::klass): DPP, packed f16 op_sel, bf16 converts, f64, v_perm / v_alignbit, fma, ds_bpermute, LDS
+        out = torch.empty_like(a)
+        with torch.cuda.stream(sA):
+            lib.run_class(mode - 10, a.data_ptr(), b.data_ptr(), 0.125, a.numel() // 4, out.data_ptr(), sA.cuda_stream)
+        return out
     if mode >= 6:                   # streaming kernels over the 8 M floats of a and b: 6 = a / 8 + b / 8, 7 = log2(a^2 + 1) * b, 8 = a / 8 + swap(b), 9 = a / 8 + b (asm)
         out = torch.empty_like(a)
         with torch.cuda.stream(sA):
@@ -79,13 +96,13 @@ def run(lib, mode):
 for label, extra in (("default build", []), ("-packed-fp32-ops", ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVICTIM_NO_PK_ASM"])):
     lib = build("victim_%s.so" % ("nopk" if extra else "pk"), extra)
     refs = {}
-    for mode in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+    for mode in ALL:
         r = run(lib, mode)
         torch.cuda.synchronize()
         refs[mode] = r.clone()
         torch.cuda.synchronize()
     for load in LOADS:
-        for mode in ((1, 2, 3, 4, 5, 6, 7, 8, 9) if load in ("none", "conv") else (1, 6, 7, 8, 9)):
+        for mode in (ALL if load in ("none", "conv", "weight gradient", SYNTH[1]) else (1, 8) if load in SYNTH else (1, 6, 7, 8, 9)):
             bad, nbad = 0, 0
             for it in range(60):
                 with torch.cuda.stream(sB):
@@ -104,6 +121,9 @@ for label, extra in (("default build", []), ("-packed-fp32-ops", ["-Xclang", "-t
                     elif load == "rocBLAS bf16 GEMM":
                         for _ in range(3):
                             torch.matmul(A, Bm)
+                    elif load in SYNTH:                     # victim.hip::neighbour: one ingredient of the conv kernels at a time
+                        for _ in range(3):
+                            lib.run_neighbour(SYNTH.index(load), big.data_ptr(), sink.data_ptr(), 400, sB.cuda_stream)
                     elif load == "elementwise":
                         for _ in range(6):
                             big.mul_(1.0001)
@@ -112,4 +132,4 @@ for label, extra in (("default build", []), ("-packed-fp32-ops", ["-Xclang", "-t
                 if not torch.equal(t, refs[mode]):
                     bad += 1
                     nbad = max(nbad, int((t != refs[mode]).sum()))
-            print(f"{label:18s} load {load:24s} variant {mode}: {bad}/60 launches differ (at most {nbad} of {t.numel()} threads)", flush=True)
+            print(f"{label:18s} load {load:24s} variant {mode}{' (' + CLASSES[mode] + ')' if mode in CLASSES else ''}: {bad}/60 launches differ (at most {nbad} of {t.numel()} threads)", flush=True)
