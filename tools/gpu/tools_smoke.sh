@@ -21,5 +21,5 @@ t probe_uninit       python tools/probe_uninit.py
 t run_steps          python tools/run_steps.py cfg4 4
 t pmc_layer          python tools/pmc_layer.py --layer dec3b --n 2
 t probe_packed_fp32  python tools/probe_packed_fp32/probe.py
-tail -3 $O/*.log | grep -E "==>|Error|error|Traceback" | head -60
+for f in $O/*.log; do echo "==> $f"; tail -n 3 "$f"; done | grep -E "==>|Error|error|Traceback" | tail -n 60
 cat $O/summary.txt
