@@ -309,6 +309,9 @@ class FlatGradSync(object):
         return float(t)
 
     def all_reduce(self):
+        """Exchange every model's gradients and wait.  Afterwards model i's buffer holds the rank mean times
+        ``1 / optimizer_scale(i)``: the SUM for fused-Adam models under ``defer_average`` (their update applies the 1/world),
+        the mean itself otherwise."""
         for i in range(len(self.segmentators)):
             self.begin(i)
         self.finish()
