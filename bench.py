@@ -238,8 +238,6 @@ def main():
     elif args.force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        from dct_amd import ddp
-        ddp.prefer_ring()
         dist.init_process_group(backend="nccl", rank=0, world_size=1)
 
     from dct_amd import _lib

@@ -20,7 +20,7 @@ gradients summed onto device 0.  The MI355X-native equivalent here:
     neighbourhood in which one packed-FP32 operand form goes wrong (tools/probe_packed_fp32).  RCCL's kernels do not
     use that form, so this is caution, but it is free: fused-Adam models get the factor folded into the optimizer's
     ``grad_scale`` (no launch, ``defer_average``); everything else is scaled in its buffer by ``dct_flat_scale``.
-    ``init_from_env`` asks RCCL for its ring algorithm unless NCCL_ALGO is set;
+    The algorithm choice stays RCCL's (``prefer_ring()`` is there for the cautious);
   * BatchNorm buffers stay per-rank (what DataParallel replicas do); FGSM's input-gradient pass
     produces no parameter gradients and therefore never touches the exchange.
 
@@ -325,9 +325,9 @@ class FlatGradSync(object):
 
 
 def prefer_ring():
-    """RCCL's ring all-reduce unless the user chose (NCCL_ALGO): on one node's xGMI mesh it is what RCCL picks for the large
-    buffers anyway, and its f32 SUM kernels hold no packed-FP32 instructions while the tree's do (module docstring).  Call before
-    the process group is created."""
+    """Optional: ask RCCL for its ring all-reduce (NCCL_ALGO=Ring unless the user chose) before the process group is created.
+    Its f32 SUM kernels hold no packed-FP32 instructions at all, the tree's hold 4-16 packed adds of the default operand form --
+    which the probe measured exact beside the conv kernels, so the algorithm choice is left to RCCL by default."""
     import os
     os.environ.setdefault("NCCL_ALGO", "Ring")
 
@@ -345,7 +345,6 @@ def init_from_env(backend: Optional[str] = None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(local)
-        prefer_ring()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29512")
     if not dist.is_initialized():
