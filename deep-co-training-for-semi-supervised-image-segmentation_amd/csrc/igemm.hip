@@ -17,29 +17,10 @@
 // bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  f32: v_mfma_f32_32x32x2_f32 -- exact
 // fp32 FMA chains, used by the parity path.
 #include <algorithm>
-#include "dct_common.h"
+#include "igemm_common.h"
 
 namespace {
 
-struct IgemmParams {
-  const char* x; const char* w; const float* bias; const char* mask; char* y;
-  const unsigned char* mask_bits;   // optional one-bit image of `mask` (dense [n][h][w][c/8]); the staged epilogues read it instead
-  unsigned char* bits_out;          // optional: ReLU-gate bits of y (dense y only)
-  float* partial;
-  int M, N, Cin, R, S;
-  int Ho, Wo, Hi, Wi;
-  int stride, dil, pad_h, pad_w;
-  long long xsN, xsH, xsW;
-  long long ysN, ysH, ysW;
-  long long msN, msH, msW;
-  int relu, scatter, accumulate, mask_channels;
-  float mask_scale;
-  int kiters, kiters_per_split, cin_iters;
-  int cout;  // real Cout (N/4 in scatter mode)
-  int staged;  // v2: LDS-staged epilogue with 16-byte row stores (host-checked alignment / 32-bit offsets)
-  int xcd_tiles, xcd_total;  // v3m / v2: XCD-aware 1-D tile order (0: plain grid)
-  int xcd_gm, xcd_gn;        // v2: tiles along M and N of the plain grid (decode of the 1-D order)
-};
 
 template <typename T> struct Mfma;
 template <> struct Mfma<bf16_t> {
@@ -99,59 +80,6 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, int n, int
 }
 
 
-// ReLU-gate bits of eight bf16 values (bit e: element e > 0) -- the one-bit-per-element image of an activation that the data
-// gradient of the layer it feeds needs (1/16 of the bytes of the activation itself).
-__device__ __forceinline__ unsigned relu_bits8(const bf16x8& v) {
-  unsigned b = 0;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) b |= ((float)v[e] > 0.f ? 1u : 0u) << e;
-  return b;
-}
-
-// Second half of the LDS-staged epilogue of the shared-halo kernels: the block streams the [pixel][channel] image of its tile
-// out in whole 16-byte chunks.  The mask / old-value loads of all NCH chunks go out together (one memory round trip), then the
-// stores.  The ReLU mask of a data gradient comes from `mask_bits` (one byte per chunk) where the caller has them, else from the
-// activation itself; a forward pass with `bits_out` leaves those bits for its consumer's data gradient.
-template <int BM, int BN, int NW>
-__device__ __forceinline__ void staged_rows_out(const IgemmParams& p, const char* tile, const int* rowY, const int* rowM, int n0, int tid) {
-  constexpr int CPR = BN / 8;
-  constexpr int NCH = BM * CPR / (NW * 64);
-  int yo[NCH];
-  bf16x8 mk[NCH], old[NCH];
-  unsigned mb[NCH];
-#pragma unroll
-  for (int t = 0; t < NCH; ++t) {
-    const int id = t * (NW * 64) + tid;
-    const int row = id / CPR, co = n0 + (id % CPR) * 8;
-    yo[t] = rowY[row];
-    if (yo[t] >= 0) {
-      if (p.mask_bits) mb[t] = p.mask_bits[(unsigned)(rowM[row] + co) >> 3];
-      else if (p.mask && co < p.mask_channels) mk[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.mask) + rowM[row] + co);
-      if (p.accumulate) old[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.y) + yo[t] + co);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < NCH; ++t) {
-    const int id = t * (NW * 64) + tid;
-    const int row = id / CPR, cc = id % CPR;
-    if (yo[t] < 0) continue;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
-    const int co = n0 + cc * 8;
-    if (p.mask_bits) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = ((mb[t] >> e) & 1u) ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-    } else if (p.mask && co < p.mask_channels) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-    }
-    if (p.accumulate) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
-    }
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
-    if (p.bits_out) p.bits_out[(unsigned)(yo[t] + co) >> 3] = (unsigned char)relu_bits8(v);
-  }
-}
 
 template <typename T, int BN, int BM>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
@@ -302,33 +230,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 // hit 16 distinct 16-B slots of the 256-B bank row.  Out-of-image taps (data-gradient halo) read a
 // 128-B zero page instead of branching around the DMA; rows past M are clamped to the last pixel
 // (their results are never stored).
-__device__ __attribute__((aligned(128))) const uint4 g_zero_page[8] = {};
 
 #ifdef DCT_STAMPS
 #define DCT_STAMP_WAVES 65536
 __device__ unsigned long long* g_stamp_buf = nullptr;   // diagnostic build only (make EXTRA=-DDCT_STAMPS): per-phase cycle sums
 #endif
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-typedef __attribute__((address_space(3))) const char* lptr_c;
-__device__ __forceinline__ void rd128(unsigned addr, bf16x8& dst) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); }
-template <int OFF> __device__ __forceinline__ void rd128o(unsigned addr, bf16x8& dst) {     // ds_read_b128 with an immediate byte offset
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-template <int I, int N, int STRIDE> struct RdRows {      // dst[i] <- 16 bytes at addr + i * STRIDE, i = I .. N - 1 (immediate offsets)
-  __device__ static __forceinline__ void run(unsigned addr, bf16x8 (&dst)[N]) {
-    rd128o<I * STRIDE>(addr, dst[I]);
-    if constexpr (I + 1 < N) RdRows<I + 1, N, STRIDE>::run(addr, dst);
-  }
-};
-template <int J, int N, int STRIDE> struct RdCols {      // dst[j] <- 16 bytes at (addr[j] ^ flip) + j * STRIDE, j = J .. N - 1
-  __device__ static __forceinline__ void run(const unsigned (&addr)[N], unsigned flip, bf16x8 (&dst)[N]) {
-    rd128o<J * STRIDE>(addr[J] ^ flip, dst[J]);
-    if constexpr (J + 1 < N) RdCols<J + 1, N, STRIDE>::run(addr, flip, dst);
-  }
-};
-template <int N> __device__ __forceinline__ void lgkm_wait3() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void touch8(bf16x8& r) { asm volatile("" : "+v"(r)); }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool BOUNDS>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmParams p) {
@@ -1710,6 +1616,11 @@ static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
 
 }  // namespace
 
+// igemm4.hip
+size_t dct_igemm4_workspace(int images, int Ho, int Wo, int Cin, int N);
+int dct_igemm4_launch(const void* params, int images, void* workspace, size_t workspace_bytes, hipStream_t st);
+extern int g_tune_igemm4, g_tune_igemm4_fill, g_tune_igemm4_min_blocks, g_tune_igemm4_split_below, g_tune_igemm4_ablate;
+
 void dct_relu_bits_launch(const void* y_bf16, unsigned char* bits, long long chunks, hipStream_t st) {
   DCT_LAUNCH(DCT_PROF_POINTWISE, relu_bits_kernel, dim3(div_up(chunks, 256)), dim3(256), 0, st, (const bf16_t*)y_bf16, bits, chunks);
 }
@@ -1724,6 +1635,8 @@ extern "C" size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* 
   size_t need = pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
   const PlanP pp = make_plan_p(x, y, d, dtype, N);
   if (pp.use && pp.splits > 1) need = std::max(need, (size_t)pp.splits * M * N * sizeof(float));
+  if (dtype == DCT_BF16 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil == 1 && !d->scatter2x2)
+    need = std::max(need, dct_igemm4_workspace(y->n, Ho, Wo, x->c, N));
   return need;
 }
 
@@ -1807,6 +1720,30 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     const size_t need = (size_t)pl.splits * p.M * p.N * sizeof(float);
     if (!workspace || workspace_bytes < need) return DCT_ERR_WORKSPACE;
     p.partial = (float*)workspace;
+  }
+  if (pl.v2 && g_tune_igemm_halo && g_tune_igemm_staged && (!bias || !((uintptr_t)bias & 15)) && d->R == 3 && d->S == 3 && d->stride == 1 &&
+      d->dil == 1 && !p.scatter) {
+    // one-block-per-CU ping-pong tile (igemm4.hip): 256 pixels x 128 channels, eight waves of 64 x 64
+    const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
+                     (long long)y->n * y->sn < (1ll << 31);
+    const bool m16 = !mask || (!((uintptr_t)mask->ptr & 15) && mask->sw % 8 == 0 && mask->sh % 8 == 0 && mask->sn % 8 == 0 &&
+                               p.mask_channels % 8 == 0 && (long long)mask->n * mask->sn < (1ll << 31));
+    const bool x32 = (long long)x->n * x->sn < (1ll << 31) && 128ll * 9 * x->c * 2 < (1ll << 32);
+    if (y16 && m16 && x32) {
+      IgemmParams q = p;
+      q.partial = nullptr;
+      const int took = dct_igemm4_launch(&q, y->n, workspace, workspace_bytes, st);
+      if (took == 1) return dct_check_launch();
+      if (took == 2) {
+        q.partial = (float*)workspace;
+        const long long work = (long long)p.M * (p.N / 4);
+        const size_t per = (size_t)p.M * p.N * sizeof(float);
+        DCT_LAUNCH(DCT_PROF_IGEMM, (splitk_epilogue_kernel<bf16_t>), dim3(div_up(work, 256)), dim3(256), 0, st, q,
+                   (int)(dct_igemm4_workspace(y->n, p.Ho, p.Wo, p.Cin, p.N) / per));
+        bits_after();
+        return dct_check_launch();
+      }
+    }
   }
   if (pl.v2 && pl.splits == 1 && g_tune_igemm_halo && g_tune_igemm_staged && (!bias || !((uintptr_t)bias & 15)) && d->R == 3 && d->S == 3 && d->stride == 1 &&
       d->dil == 1 && !p.scatter) {
@@ -1911,6 +1848,11 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_ENET_REDUCE_VEC: g_enet_reduce_vec = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_FOLD_THREADS: if (value != 256 && value != 512 && value != 1024) return DCT_ERR_BAD_ARG; g_enet_fold_threads = value; return DCT_OK;
     case DCT_TUNE_ENET_FUSE_FINALIZE: g_enet_fuse_finalize = value ? 1 : 0; return DCT_OK;
+    case DCT_TUNE_IGEMM4: g_tune_igemm4 = value ? 1 : 0; return DCT_OK;
+    case DCT_TUNE_IGEMM4_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm4_fill = value; return DCT_OK;
+    case DCT_TUNE_IGEMM4_MIN_BLOCKS: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm4_min_blocks = value; return DCT_OK;
+    case DCT_TUNE_IGEMM4_SPLIT_BELOW: if (value < 0) return DCT_ERR_BAD_ARG; g_tune_igemm4_split_below = value; return DCT_OK;
+    case 1000: g_tune_igemm4_ablate = value; return DCT_OK;      // diagnostic builds only
     case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }
