@@ -451,10 +451,11 @@ enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0
        DCT_TUNE_WGRAD3_SHIFT = 33,           /* 1 (default): filter-row weight gradient builds a row's three x fragments from one 12-pixel window per lane
                                                 (register shifts) instead of three LDS reads; 0: one read per tap */
        DCT_TUNE_ENET_FUSE_FINALIZE = 34,
-       DCT_TUNE_IGEMM4 = 35,                 /* 1 (default): 3x3 stride-1 bf16 layers on the one-block-per-CU ping-pong tile (csrc/igemm4.hip); 0: igemm.hip tiles */
+       DCT_TUNE_IGEMM4 = 35,                 /* 1: 3x3 stride-1 bf16 layers on the persistent one-block-per-CU ping-pong tile (csrc/igemm4.hip); 0 (default): igemm.hip tiles -- level on the step */
        DCT_TUNE_IGEMM4_FILL = 36,            /* percent (default 70): least fill of its 256-pixel tiles */
        DCT_TUNE_IGEMM4_MIN_BLOCKS = 37,      /* default 96: fewest blocks for which it is taken */
-       DCT_TUNE_IGEMM4_SPLIT_BELOW = 38 };   /* default 200: layers with fewer blocks are split over channel slices (fp32 slabs) */   /* 1: Enet BatchNorm / bias-sum finalizes ride in the producing launch's last block (measured slower:
+       DCT_TUNE_IGEMM4_SPLIT_BELOW = 38,     /* default 200: layers with fewer blocks are split over channel slices (fp32 slabs) */
+       DCT_TUNE_IGEMM4_BLOCKS = 39 };        /* persistent blocks per launch of that kernel; 0 (default): one per compute unit */   /* 1: Enet BatchNorm / bias-sum finalizes ride in the producing launch's last block (measured slower:
                                                 csrc/enet.hip g_enet_fuse_finalize); 0 (default): one-block launches of their own */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
