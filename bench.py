@@ -2,8 +2,9 @@
 """Headline benchmark: co-train imgs/sec (lab+unlab), 2xUNet ACDC-shaped 256x256 slices
 (BASELINE.json configs[1]: CE + JSD consistency, bs 8+8 per GPU, bf16), synthetic data.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --config cfg4 --global-batch 64+64   (fixed global batch split over the ranks: "scaling": "strong")
 
 A "step" is one pass of the hot path (CoTrainer._run_step) over one batch: 2 supervised
 forwards + CE, 2 unlabeled forwards + JSD, one backward through all four graphs, gradient
@@ -85,6 +86,7 @@ def pmc_traffic(config):
             with open(path) as f:
                 d = json.load(f)
             d["source"] = os.path.relpath(path, ROOT)
+            d["archived"] = "separate rocprofv3 --pmc passes of this command (committed file); not measured by this run"
             return d
         except Exception:
             continue
@@ -195,6 +197,62 @@ def cpu_baseline(cfg, seconds_budget=25.0):
                       f"{threads} threads"}
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) through torch.distributed.run and
+    pass their output through -- rank 0's JSON line stays the last line.  Runs BEFORE this process touches the GPU (a
+    process that has initialised HIP must not be replaced or forked into ranks); the reference's analogue is one command
+    driving N GPUs through nn.DataParallel (generalframework/models/segmentators.py:34-36)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(args, rank: int, world: int) -> None:
+    """`--dry-launch`: the N-rank plumbing of this script on CPU -- gloo process group, FlatGradSync, the barrier / max-over-ranks
+    timing and rank 0's JSON line -- around CoTrainer._run_step with oracle-injected networks (the product kernels are HIP-only;
+    tests/test_ddp_cpu.py builds the same trainer).  Not a measurement: it exists so that the launch path is testable without a GPU."""
+    import torch.distributed as dist
+    from dct_amd import ddp
+    from test_ddp_cpu import _build, _step
+    torch.set_num_threads(2)
+    ddp.init_from_env("gloo")
+    tr, lab, unl = _build(tempfile.mkdtemp(prefix=f"dct_dry_r{rank}_"), 100 * rank)
+    tr.grad_sync = ddp.FlatGradSync(tr.segmentators)
+    for _ in range(args.warmup):
+        _step(tr, lab, unl)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = _step(tr, lab, unl)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    imgs = 3            # tests/test_ddp_cpu.py::_build: 2 models x 1 labeled + 1 unlabeled slice per rank
+    line = {"metric": "co-train imgs/sec/node (lab+unlab), dry launch of the rank plumbing (CPU oracle networks over gloo)",
+            "value": imgs * world / (elapsed / args.steps), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": {"workload": "dry launch: 2xUNet 176x176 C=2 on CPU, bs 1+1 per rank (not a measurement)",
+                                            "global_batch": f"{world}+{world}", "parallelism": f"dp{world}"},
+            "losses_last_step": {"sup": [float(v) for v in out["sup"]], "jsd": float(out["jsd"])}}
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,14 +276,21 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
     ap.add_argument("--single-stream", action="store_true",
                     help="queue all models on one stream (the mode the per-kernel roofline leg and rocprofv3 kernel durations use)")
+    ap.add_argument("--global-batch", default="", metavar="L+U",
+                    help="fixed GLOBAL batch (labeled+unlabeled, e.g. 64+64 for cfg4: BASELINE.json configs[3]) split evenly over the "
+                         "ranks; the line then says \"scaling\": \"strong\".  Default: the configuration's per-GPU batch on every rank (weak)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="exercise the N-rank launch path on CPU (gloo, oracle-injected networks); prints one JSON line, measures nothing")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))       # (nothing above this line has touched the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_launch:
+        return dry_launch(args, rank, world)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
     torch.cuda.set_device(local)
@@ -241,7 +306,15 @@ def main():
         dist.init_process_group(backend="nccl", rank=0, world_size=1)
 
     from dct_amd import _lib
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    scaling = "weak"
+    if args.global_batch:
+        gl, gu = (int(v) for v in args.global_batch.split("+"))
+        if gl % world or gu % world or gl < world or gu < world:
+            raise SystemExit(f"--global-batch {args.global_batch} does not split evenly over {world} ranks")
+        cfg["B_l"], cfg["B_u"] = gl // world, gu // world
+        cfg["desc"] += f" -- fixed global batch {gl}+{gu} over {world} rank(s): {cfg['B_l']}+{cfg['B_u']} per GPU"
+        scaling = "strong"
     dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[args.dtype]
 
     def sync_factory(segs):
@@ -375,7 +448,7 @@ def main():
         "metric": "co-train imgs/sec/node (lab+unlab), 2xUNet ACDC 256x256" if args.config in ("cfg2", "cfg3")
         else f"co-train imgs/sec/node (lab+unlab), {cfg['S']}x{cfg['arch']} {cfg['H']}x{cfg['H']}",
         "value": value, "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.config}: {cfg['desc']}", "imgs_per_step_per_gpu": imgs_per_step,
                    "global_batch": f"{cfg['B_l'] * world}+{cfg['B_u'] * world}", "parallelism": f"dp{world}",
@@ -434,7 +507,8 @@ def main():
                 # the same FLOPs over the timed step (both model streams overlapping): what the job as a whole makes of the matrix peak
                 "step_level": {"achieved": (flops["igemm"] + flops["wgrad"]) / (ms_per_step * 1e-3) / 1e12, "unit": "TFLOP/s",
                                "frac": (flops["igemm"] + flops["wgrad"]) / (ms_per_step * 1e-3) / 1e12 / peak},
-                "counters": pmc_mfma_busy(args.config),
+                # counter evidence of an EARLIER run, read from the committed profile files (not measured by this run)
+                "archived_counters": pmc_mfma_busy(args.config),
             }
         elif prof is not None:
             # Enet: HBM bound.  Algorithmic bytes = conv in+out activation elements x 2 B (bf16) x 3 (fwd, dgrad, wgrad)

@@ -67,6 +67,7 @@ class FlatGradSync(object):
         self._arena: Optional[torch.Tensor] = None      # gradient buffers of all small models, back to back (Enet -> single bucket)
         self._arena_span = {}       # model index -> (lo, hi) elements of the arena
         self._fused_ready: List[int] = []
+        self._fused_events = {}     # model index -> event recorded on the stream that produced its arena slice (CUDA only)
         self.collectives = 0        # all-reduce launches since construction (tests and bench read it)
         self._prepared = False
         self._pair_rng = None       # adversarial pair: one RandomState per job, same seed on every rank (draw_pair)
@@ -109,7 +110,8 @@ class FlatGradSync(object):
             dev = "cpu"
             if dist.get_backend(self.group) == "nccl":
                 dev = torch.device("cuda", torch.cuda.current_device())
-            seed = torch.tensor([int(np.random.randint(0, 2 ** 31 - 1)) if self.rank == 0 else 0], dtype=torch.int64, device=dev)
+            drawn = int(np.random.randint(0, 2 ** 31 - 1))     # every rank draws (and all but rank 0 discard): the ranks' global numpy streams stay aligned
+            seed = torch.tensor([drawn if self.rank == 0 else 0], dtype=torch.int64, device=dev)
             dist.broadcast(seed, src=0, group=self.group)
             self._pair_rng = np.random.RandomState(int(seed.item()))
         try:
@@ -126,7 +128,11 @@ class FlatGradSync(object):
         small = []
         for i, seg in enumerate(self.segmentators):
             flat = getattr(seg.torchnet, "flat_params", None)
-            if flat is not None and flat.total < self.FUSE_BELOW:
+            # only models whose optimizer (if one is attached) is the fused flat one: re-pointing p.grad gives parameters without a gradient a zero
+            # view, which a torch optimizer would treat as "has a gradient" (weight decay / moments on untouched parameters)
+            opt = getattr(seg, "optimizer", None)
+            fused_opt = opt is None or hasattr(opt, "grad_scale")
+            if flat is not None and flat.total < self.FUSE_BELOW and fused_opt:
                 flat.ensure()
                 small.append((i, flat))
         if len(small) < 2:
@@ -203,8 +209,15 @@ class FlatGradSync(object):
         return (model_index, work, scale, None, None, (wire, src) if wire is not src else None)
 
     def _start_arena(self):
-        """ONE all-reduce over the arena (every small model's gradients); the pending record carries the key 'arena'."""
+        """ONE all-reduce over the arena (every small model's gradients); the pending record carries the key 'arena'.
+        The models' backward passes may have run on different streams (CoTrainer's per-model streams): the launching stream
+        first waits for the event each of them recorded in begin(), so the collective reads no slice that is still being written."""
         src = self._arena
+        if src.is_cuda:
+            cur = torch.cuda.current_stream(src.device)
+            for ev in self._fused_events.values():
+                cur.wait_event(ev)
+        self._fused_events = {}
         if self.compress == "bf16":
             buf = self._cbuf.get("arena")
             if buf is None or buf.numel() != src.numel() or buf.device != src.device:
@@ -217,7 +230,8 @@ class FlatGradSync(object):
         self.exchanged_bytes += wire.numel() * wire.element_size()
         self.collectives += 1
         work, scale = self._reduce_tensor(wire, True)
-        return ("arena", work, scale, None, None, (wire, src) if wire is not src else None)
+        # the record stays pending until EVERY arena model (or finish(None)) has waited for the collective on its own stream
+        return ["arena", work, scale, None, None, (wire, src) if wire is not src else None, set()]
 
     def begin_bucket(self, model_index: int, lo: int, hi: int):
         """Start the all-reduce of elements [lo, hi) of one model's flat gradient buffer -- called from inside the
@@ -243,6 +257,10 @@ class FlatGradSync(object):
             # small model: its gradients sit in the shared arena -- the collective goes out when the LAST of them is ready
             if model_index not in self._fused_ready:
                 self._fused_ready.append(model_index)
+            if self._arena.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self._arena.device))
+                self._fused_events[model_index] = ev
             if len(self._fused_ready) == len(self._arena_span):
                 self._fused_ready = []
                 self._pending.append(self._start_arena())
@@ -263,13 +281,39 @@ class FlatGradSync(object):
         if self._fused_ready and (model_index is None or model_index in self._fused_ready):
             # not every small model produced gradients this step: exchange the ready ones one by one (same result, more launches)
             ready, self._fused_ready = self._fused_ready, []
+            self._fused_events = {}          # (each per-model collective below is launched on the calling stream, as begin() would)
             for i in ready:
                 flat = self.segmentators[i].torchnet.flat_params
                 self._pending.append(self._start(i, flat, 0, flat.gflat.numel()))
         keep = []
         for ent in self._pending:
-            fused_hit = ent[0] == "arena" and (model_index is None or model_index in self._arena_span)
-            if model_index is not None and ent[0] != model_index and not fused_hit:
+            if ent[0] == "arena":
+                # One collective, several consumers on (possibly) different streams: each model waits for it on ITS stream and
+                # finishes its own slice there (bf16 image -> fp32, the 1/world) -- model j's update is ordered behind the
+                # collective by its own wait, not by whichever model happened to call finish() first.
+                _, work, arena_wire, _, _, wire, done = ent
+                mine = [i for i in self._arena_span if i not in done] if model_index is None else \
+                       ([model_index] if model_index in self._arena_span and model_index not in done else [])
+                if mine:
+                    if self.measure and torch.cuda.is_available():
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        work.wait()
+                        e1.record()
+                        self._events.append((e0, e1))
+                    else:
+                        work.wait()
+                    for i in mine:
+                        lo, hi = self._arena_span[i]
+                        if wire is not None:
+                            wire[1][lo:hi].copy_(wire[0][lo:hi])
+                        if not self._deferred("arena"):
+                            self._average(self._arena[lo:hi])
+                        done.add(i)
+                if len(done) < len(self._arena_span):
+                    keep.append(ent)
+                continue
+            if model_index is not None and ent[0] != model_index:
                 keep.append(ent)
                 continue
             _, work, scale, buf, params, wire = ent

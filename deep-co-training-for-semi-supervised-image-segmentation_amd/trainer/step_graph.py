@@ -38,6 +38,17 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 
+
+def _is_refused_capture(err: BaseException) -> bool:
+    """True for the errors HIP / torch raise when a stream capture is refused or invalidated ("operation not permitted when stream is
+    capturing", "capturing stream has unjoined work", "... graph ..."), False for the library's own launch / argument errors
+    ("dct_amd: ... failed"), which must reach the user."""
+    msg = str(err).lower()
+    if "dct_amd:" in msg and "captur" not in msg:
+        return False
+    return "captur" in msg or "graph" in msg
+
+
 class _Captured(object):
     __slots__ = ("graph", "graph_opt", "program", "lab", "unl", "out", "counters")
 
@@ -183,7 +194,7 @@ class StepGraphCache(object):
                     for seg in tr.segmentators:      # weight packs "built" by recorded-only launches do not exist: rebuild next step
                         if hasattr(seg.torchnet, "mark_weights_updated"):
                             seg.torchnet.mark_weights_updated()
-                    if "capture" not in str(e).lower() and "graph" not in str(e).lower():
+                    if not _is_refused_capture(e):
                         raise                         # an argument / kernel error is not a refused capture: do not hide it
                     self._seen[sig] = -(1 << 30)
                     import warnings

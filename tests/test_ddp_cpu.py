@@ -236,3 +236,22 @@ def test_two_rank_gloo_small_models_share_one_collective_and_one_adversarial_pai
     n = a0["g"][1].numel()                      # model 1 kept the mean of step 2
     want = (torch.arange(n, dtype=torch.float32) * 1 + torch.arange(n, dtype=torch.float32) * 2) / 2 + 10 + 2
     np.testing.assert_allclose(a0["g"][1].numpy(), want.numpy(), rtol=1e-6)
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) must start its two ranks itself and leave ONE JSON line with
+    n_gpus = 2 as the last line of its output: --dry-launch runs that path on CPU (gloo, oracle-injected networks)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"] == "dp2" and line["value"] > 0
+    assert all(v == v for v in line["losses_last_step"]["sup"])

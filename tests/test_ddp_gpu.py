@@ -196,16 +196,20 @@ def _enet_trainer(tmp, rank, compress, graph):
     return tr, lab, unl, n
 
 
-def _enet_worker(rank, world, port, out, compress, graph):
+def _enet_worker(rank, world, port, out, compress, graph, sup_only=False, model_streams=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     tr, lab, unl, n = _enet_trainer(os.path.join(out, f"r{rank}"), rank, compress, graph)
+    tr.model_streams = model_streams
     sups = []
     for k in range(n):
         lb = [(lab[i][k][0][0], lab[i][k][0][1]) for i in range(2)]
-        o = tr._run_step(lb, (unl[k][0][0], unl[k][0][1]), True, True, (0, 1))
+        if sup_only:
+            o = tr._run_step(lb, (unl[k][0][0], unl[k][0][1]), False, False, None)
+        else:
+            o = tr._run_step(lb, (unl[k][0][0], unl[k][0][1]), True, True, (0, 1))
         sups.append([float(v) for v in o["sup"]])
     torch.cuda.synchronize()
     g = tr._step_graphs
@@ -262,3 +266,25 @@ def test_enet_two_ranks_bf16_gradient_exchange(tmp_path):
     for a, b in zip(res[None]["w"], res["bf16"]["w"]):
         assert ((a - b).norm() / a.norm()).item() < 3e-2          # six Adam steps of lr 1e-3 on sign-like updates (measured 1.2e-2)
     assert res[None]["exposed"] >= 0.0
+
+
+@pytest.mark.timeout(900)
+def test_enet_two_ranks_supervised_only_arena_exchange_is_ordered_against_the_model_streams(tmp_path):
+    """Supervised-only steps (start_training's default: no JSD, no adversarial term) of 2 x Enet on per-model streams: each model's
+    ONE backward pass runs on its own stream and the fused arena collective is launched from the last model's -- it must wait for
+    the other model's stream (event per model in FlatGradSync.begin), and every model's Adam must wait for the collective on ITS
+    stream.  The weights must equal, bit for bit, the run with all models queued on one stream, and the ranks each other."""
+    res = {}
+    for streams in (False, True):
+        out = str(tmp_path / f"s{int(streams)}")
+        os.makedirs(out)
+        mp.spawn(_enet_worker, args=(2, _free_port(), out, None, False, True, streams), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(out, "w0.pt"), weights_only=False)
+        r1 = torch.load(os.path.join(out, "w1.pt"), weights_only=False)
+        for a, b in zip(r0["w"], r1["w"]):
+            assert torch.isfinite(a).all() and torch.equal(a, b)
+        assert r0["steps"] == [6, 6]
+        res[streams] = r0
+    assert res[False]["sups"] == res[True]["sups"]
+    for a, b in zip(res[False]["w"], res[True]["w"]):
+        assert torch.equal(a, b)

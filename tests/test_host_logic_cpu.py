@@ -356,3 +356,13 @@ def test_step_scheduling_switches_on_cpu_modules(tmp_path, monkeypatch):
     seen = []
     tr._sched.call(lambda: seen.append(1))
     assert seen == [1]
+
+
+def test_refused_capture_filter_recognises_the_runtime_messages():
+    """step_graph keeps a step shape on eager launches only for refused captures; the library's own launch errors propagate."""
+    from dct_amd.trainer.step_graph import _is_refused_capture
+    for msg in ("HIP error: operation not permitted when stream is capturing", "capturing stream has unjoined work",
+                "operation would make the legacy stream depend on a capturing blocking stream", "hipGraphInstantiate failed"):
+        assert _is_refused_capture(RuntimeError(msg)), msg
+    for msg in ("dct_amd: dct_conv2d failed (DCT_ERR_BAD_ARG)", "shape mismatch", "dct_amd: dct_enet_conv failed (DCT_ERR_LAUNCH)"):
+        assert not _is_refused_capture(RuntimeError(msg)), msg
