@@ -165,7 +165,9 @@ __global__ __launch_bounds__(256) void entropy_bwd_kernel(const float* probs, co
 }
 
 // ---- JSD ------------------------------------------------------------------------------------------
-struct PtrPack { const float* in[4]; float* out[4]; };
+// up to DCT_JSD_MAX_MODELS segmentators per call (the reference sweeps 2 / 4 / 6 views: script/GM/run_multiview.sh:2-6)
+constexpr int MAXS = 8;
+struct PtrPack { const float* in[MAXS]; float* out[MAXS]; };
 
 template <int C, bool FROM_LOGITS>
 __global__ __launch_bounds__(256) void jsd_fwd_kernel(PtrPack pk, int S, long long P, float* map, float* partial) {
@@ -197,18 +199,20 @@ __global__ __launch_bounds__(256) void jsd_fwd_kernel(PtrPack pk, int S, long lo
   if (partial) block_partial2(sum, 0.f, partial);
 }
 // FROM_LOGITS: dlogits_s (=|+=) g/P * softmax_bwd(dJ/dp_s);  else dprobs_s = dmap[pix] * dJ/dp_s
-template <int C, bool FROM_LOGITS>
+// SMAX: the models whose probabilities a thread keeps in registers (4: the co-training pairs / triples of the benchmark
+// configurations; 8: the multi-view sweeps)
+template <int C, bool FROM_LOGITS, int SMAX>
 __global__ __launch_bounds__(256) void jsd_bwd_kernel(PtrPack pk, int S, long long P, const float* dmap, const float* gscale,
                                                        float gmul, int acc) {
   const float invS = 1.f / (float)S;
   float g = 0.f;
   if constexpr (FROM_LOGITS) g = (gscale ? gscale[0] : 1.f) * gmul / (float)P;
   for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < P; pix += (long long)gridDim.x * 256) {
-    float p[4][C], mean[C];
+    float p[SMAX][C], mean[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) mean[c] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < SMAX; ++s) {
       if (s < S) {
         float x[C];
         load_px<C>(pk.in[s], pix, x);
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256) void jsd_bwd_kernel(PtrPack pk, int S, long lo
     for (int c = 0; c < C; ++c) { mean[c] *= invS; dm[c] = dent(mean[c]); }
     const float gp = FROM_LOGITS ? g : dmap[pix];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < SMAX; ++s) {
       if (s < S) {
         float d[C];
 #pragma unroll
@@ -491,8 +495,8 @@ extern "C" int dct_entropy_bwd(const float* probs, const float* dmap, float* dpr
 }
 
 static bool fill_pack(PtrPack& pk, const float* const* in, float* const* out, int S) {
-  if (S < 1 || S > 4 || !in) return false;
-  for (int s = 0; s < 4; ++s) { pk.in[s] = nullptr; pk.out[s] = nullptr; }
+  if (S < 1 || S > MAXS || !in) return false;
+  for (int s = 0; s < MAXS; ++s) { pk.in[s] = nullptr; pk.out[s] = nullptr; }
   for (int s = 0; s < S; ++s) {
     if (!in[s]) return false;
     pk.in[s] = in[s];
@@ -513,7 +517,8 @@ extern "C" int dct_jsd_map_bwd(const float* const* probs, int S, const float* dm
   PtrPack pk;
   if (!fill_pack(pk, probs, dprobs, S) || !dmap || !dprobs || pixels < 1) return DCT_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_bwd_kernel<C, false>), dim3(wide_grid(pixels)), dim3(256), 0, st, pk, S, (long long)pixels, dmap, (const float*)nullptr, 1.f, 0));
+  if (S <= 4) { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_bwd_kernel<C, false, 4>), dim3(wide_grid(pixels)), dim3(256), 0, st, pk, S, (long long)pixels, dmap, (const float*)nullptr, 1.f, 0)); }
+  else { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_bwd_kernel<C, false, MAXS>), dim3(wide_grid(pixels)), dim3(256), 0, st, pk, S, (long long)pixels, dmap, (const float*)nullptr, 1.f, 0)); }
   return dct_check_launch();
 }
 extern "C" int dct_jsd_logits_fwd(const float* const* logits, int S, int64_t pixels, int C_, float* out1,
@@ -532,7 +537,8 @@ extern "C" int dct_jsd_logits_bwd(const float* const* logits, int S, int64_t pix
   PtrPack pk;
   if (!fill_pack(pk, logits, dlogits, S) || !dlogits || pixels < 1) return DCT_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_bwd_kernel<C, true>), dim3(wide_grid(pixels)), dim3(256), 0, st, pk, S, (long long)pixels, (const float*)nullptr, gscale, gmul, accumulate));
+  if (S <= 4) { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_bwd_kernel<C, true, 4>), dim3(wide_grid(pixels)), dim3(256), 0, st, pk, S, (long long)pixels, (const float*)nullptr, gscale, gmul, accumulate)); }
+  else { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_bwd_kernel<C, true, MAXS>), dim3(wide_grid(pixels)), dim3(256), 0, st, pk, S, (long long)pixels, (const float*)nullptr, gscale, gmul, accumulate)); }
   return dct_check_launch();
 }
 

@@ -166,15 +166,19 @@ class _JSDMapFn(torch.autograd.Function):
         return tuple(_nchw(d) for d in dps)
 
 
+MAX_VIEWS = 8     # csrc/loss.hip MAXS
+
+
 class JSD_2D(nn.Module):
-    """H(mean_i p_i) - mean_i H(p_i) -> [B,H,W]; up to 4 views per call."""
+    """H(mean_i p_i) - mean_i H(p_i) -> [B,H,W]; up to 8 views per call (the reference's sweeps run 2, 4 and 6:
+    script/GM/run_multiview.sh:2-6, script/ACDC/5_run_multiple_view.sh:27-33)."""
 
     def __init__(self):
         super().__init__()
         self.entropy = Entropy_2D()
 
     def forward(self, input: List[torch.Tensor]):
-        assert 1 <= len(input) <= 4, "dct_amd JSD_2D handles up to 4 models per call"
+        assert 1 <= len(input) <= MAX_VIEWS, f"dct_amd JSD_2D handles up to {MAX_VIEWS} models per call"
         if DEBUG_ASSERTS:
             for inprob in input:
                 assert _simplex(inprob, 1)

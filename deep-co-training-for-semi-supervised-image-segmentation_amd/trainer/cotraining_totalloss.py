@@ -237,7 +237,7 @@ class CoTrainer(Trainer):
         if type(self.criterions['sup']) is not CrossEntropyLoss2d or type(self.criterions['jsd']) is not JSD_2D:
             return False
         return all(hasattr(s.torchnet, "flat_params") and hasattr(s.torchnet, "plan_forward")
-                   for s in self.segmentators) and len(self.segmentators) <= 4
+                   for s in self.segmentators) and len(self.segmentators) <= 8
 
     def _draw_adv_choice(self) -> Tuple[int, int]:
         S = len(self.segmentators)

@@ -695,7 +695,31 @@ def test_losses_match_golden(ops, golden):
     np.testing.assert_allclose(_back(dk, a).numpy(), g1["kl_grad_a"], rtol=2e-4, atol=1e-9)
 
 
-@pytest.mark.parametrize("S,C", [(2, 4), (3, 2), (4, 4)])
+def test_multiview_jsd_matches_golden(ops, golden):
+    """JSD over 4 and 6 models -- the reference's multi-view sweeps (script/GM/run_multiview.sh:2-6) -- against the maps and logit
+    gradients captured from the reference's JSD_2D (tests/golden/g1_multiview.npz), through both kernel forms."""
+    g = golden("g1_multiview")
+    torch.manual_seed(int(g["seed"]))
+    xs = [torch.randn(2, 3, 9, 7) * 1.5 for _ in range(6)]
+    for S in (4, 6):
+        lds = [_pc(x) for x in xs[:S]]
+        np.testing.assert_allclose(ops.jsd_logits_fwd(lds, 3).item(), g[f"jsd{S}_map"].mean(), rtol=1e-5)
+        pds = [ops.softmax_fwd(l, 3) for l in lds]
+        np.testing.assert_allclose(ops.jsd_map_fwd(pds, 3).cpu().reshape(2, 9, 7).numpy(), g[f"jsd{S}_map"], rtol=1e-4, atol=1e-7)
+        dls = [torch.zeros_like(l) for l in lds]
+        ops.jsd_logits_bwd(lds, 3, dls)
+        for k in range(S):
+            np.testing.assert_allclose(_back(dls[k], xs[0]).numpy(), g[f"jsd{S}_grad_{k}"], rtol=2e-4, atol=1e-9)
+    # the module API (what CoTrainer's unfused path and user code call)
+    from dct_amd.loss import JSD_2D
+    probs = [torch.softmax(x.to(DEV), 1).requires_grad_(True) for x in xs]
+    jm = JSD_2D()(probs)
+    np.testing.assert_allclose(jm.detach().cpu().numpy(), g["jsd6_map"], rtol=1e-4, atol=1e-7)
+    jm.mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in probs)
+
+
+@pytest.mark.parametrize("S,C", [(2, 4), (3, 2), (4, 4), (6, 2), (8, 3)])
 def test_jsd_kl_vs_oracle(ops, S, C):
     g = torch.Generator().manual_seed(14)
     ls = [(torch.randn(2, C, 33, 31, generator=g) * 2).requires_grad_(True) for _ in range(S)]

@@ -56,6 +56,19 @@ def test_g1_losses(golden):
     assert abs(ce.item() - 1.85805273) < 1e-6
 
 
+def test_g1_multiview_jsd(golden):
+    """JSD over 4 and 6 views as the reference computes it (script/GM/run_multiview.sh:2-6 run 2 / 4 / 6 segmentators)."""
+    g = golden("g1_multiview")
+    torch.manual_seed(int(g["seed"]))
+    xs = [torch.randn(2, 3, 9, 7) * 1.5 for _ in range(6)]
+    for S in (4, 6):
+        ls = [x.clone().requires_grad_(True) for x in xs[:S]]
+        jm = oracle.jsd_2d([oracle.softmax_channels(x) for x in ls])
+        np.testing.assert_allclose(jm.detach().numpy(), g[f"jsd{S}_map"], rtol=1e-5, atol=1e-7)
+        for k, gr in enumerate(torch.autograd.grad(jm.mean(), ls)):
+            np.testing.assert_allclose(gr.numpy(), g[f"jsd{S}_grad_{k}"], rtol=1e-5, atol=1e-8)
+
+
 def test_g2_schedulers(golden):
     g = golden("g2_schedulers")
     for tag in ("cot", "adv"):

@@ -155,6 +155,21 @@ def g1_losses():
     save("g1_losses", **out)
 
 
+def g1_multiview():
+    """JSD over 4 and 6 views (the reference's sweeps: script/GM/run_multiview.sh:2-6), 3 classes, maps and logit gradients."""
+    torch.manual_seed(3)
+    xs = [torch.randn(2, 3, 9, 7) * 1.5 for _ in range(6)]
+    out = dict(seed=3)
+    for S in (4, 6):
+        ls = [x.clone().requires_grad_(True) for x in xs[:S]]
+        ps = [torch.softmax(x, 1) for x in ls]
+        jm = JSD_2D()(ps)
+        out[f"jsd{S}_map"] = jm
+        for k, g in enumerate(torch.autograd.grad(jm.mean(), ls)):
+            out[f"jsd{S}_grad_{k}"] = g
+    save("g1_multiview", **out)
+
+
 # ----------------------------------------------------------------------------- G2 schedulers
 def g2_sched():
     out = {}
@@ -700,6 +715,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g3bn", "g5", "g6", "g7", "g8"]
     if "g1" in which:
         g1_losses()
+    if "g1mv" in which:
+        g1_multiview()
     if "g2" in which:
         g2_sched()
     if "g3" in which:
