@@ -66,22 +66,21 @@ class Segmentator(object):
         return self.torchnet.training
 
     def update(self, img: Tensor, gt: Tensor, criterion, mode=ModelMode.TRAIN) -> List[Tensor]:
-        assert img.shape.__len__() == 4
-        assert gt.shape.__len__() == 4
-        if mode == ModelMode.TRAIN:
-            self.train()
-            self.optimizer.zero_grad()
+        """One supervised step (TRAIN) or one loss evaluation (anything else) on a batch; returns [prediction, loss] detached and
+        leaves the network in training mode, as the reference's ``update`` does (segmentators.py:60-77)."""
+        if img.dim() != 4 or gt.dim() != 4:
+            raise AssertionError(f"expected [B, C, H, W] image and [B, 1, H, W] target, got {tuple(img.shape)} / {tuple(gt.shape)}")
+        learn = mode == ModelMode.TRAIN
+        self.torchnet.train(learn)
+        with torch.set_grad_enabled(learn):
             pred = self.predict(img)
             loss = criterion(pred, gt.squeeze(1))
+        if learn:
+            self.optimizer.zero_grad()
             loss.backward()
             self.optimizer.step()
-        else:
-            self.eval()
-            with torch.no_grad():
-                pred = self.predict(img)
-                loss = criterion(pred, gt.squeeze(1))
-        self.train()
-        return [pred.data, loss.data]
+        self.torchnet.train(True)
+        return [pred.detach(), loss.detach()]
 
     def schedulerStep(self):
         self.scheduler.step()
@@ -101,18 +100,18 @@ class Segmentator(object):
         self.scheduler.load_state_dict(state_dict['scheduler_state_dict'])
 
     def to(self, device: torch.device):
+        """network AND optimizer state (moment buffers; not the 0-d step counters) onto ``device``"""
         self.torchnet.to(device)
-        for state in self.optimizer.state.values():
-            for k, v in state.items():
-                if isinstance(v, torch.Tensor) and v.dim() > 0:
-                    state[k] = v.to(device)
+        for slot in self.optimizer.state.values():
+            moved = {name: t.to(device) for name, t in slot.items() if torch.is_tensor(t) and t.dim() > 0}
+            slot.update(moved)
+
+    _MODES = {ModelMode.TRAIN: True, 'train': True, ModelMode.EVAL: False, 'eval': False}
 
     def set_mode(self, mode):
-        assert mode in (ModelMode.TRAIN, ModelMode.EVAL) or mode in ('train', 'eval')
-        if mode in (ModelMode.TRAIN, 'train'):
-            self.train()
-        elif mode in (ModelMode.EVAL, 'eval'):
-            self.eval()
+        if mode not in self._MODES:
+            raise AssertionError(f"mode must be ModelMode.TRAIN / ModelMode.EVAL (or 'train' / 'eval'), got {mode!r}")
+        self.torchnet.train(self._MODES[mode])
 
     def eval(self):
         self.torchnet.eval()

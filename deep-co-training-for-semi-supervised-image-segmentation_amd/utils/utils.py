@@ -1,16 +1,19 @@
-"""Host-side helpers the step touches (reference: generalframework/utils/utils.py).
-``iterator_`` (:254-275) is kept verbatim in behaviour because ``_FSGM_adv_training`` relies on
-its ``__cache__`` ("re-use this step's batches"); the tensor predicates (:142-207) are
-debug-only here because each of them synchronises with the host."""
+"""Host-side helpers of the training step.
+
+Only what the hot path touches lives here: the endless loader iterator ``_FSGM_adv_training`` re-reads
+batches from (reference behaviour: generalframework/utils/utils.py:254-275), the nested-dict merge the
+report dictionaries use, seeding, and a few tensor predicates that are debug-only on this path (each
+synchronises with the host).  The reference's command-line override parser (utils.py:280-351) is NOT
+part of the path: a training script keeps using the reference's own ``yaml_parser``."""
 from __future__ import annotations
 
-import argparse
-import collections.abc
+import ast
+import copy
 import os
 import random
-from copy import deepcopy as dcopy
-from functools import partial, reduce
-from typing import Any, Callable, Iterable, List, TypeVar, Union
+import warnings
+from functools import partial
+from typing import Any, Callable, Iterable, List, Mapping, MutableMapping, Optional, TypeVar
 
 import numpy as np
 import torch
@@ -21,122 +24,122 @@ B = TypeVar("B")
 
 try:
     from tqdm import tqdm
-    tqdm_ = partial(tqdm, ncols=125, leave=False,
-                    bar_format='{l_bar}{bar}| {n_fmt}/{total_fmt} [' '{rate_fmt}{postfix}]')
+    tqdm_ = partial(tqdm, ncols=125, leave=False, bar_format='{l_bar}{bar}| {n_fmt}/{total_fmt} [{rate_fmt}{postfix}]')
 except Exception:  # pragma: no cover
     tqdm_ = None
 
 
-def map_(fn: Callable[[A], B], iter: Iterable[A]) -> List[B]:
-    return list(map(fn, iter))
+def map_(fn: Callable[[A], B], items: Iterable[A]) -> List[B]:
+    return [fn(x) for x in items]
 
 
-def pred2class(pred: Tensor) -> Tensor:
-    assert pred.shape.__len__() == 4, pred.shape
-    return pred.max(1)[1]
-
-
-def simplex(t: Tensor, axis=1) -> bool:
-    _sum = t.sum(axis).type(torch.float32)
-    return bool(torch.allclose(_sum, torch.ones_like(_sum, dtype=torch.float32)))
+# ---- tensor predicates / conversions (debug asserts and the meters' inputs) ----------------------
+def simplex(t: Tensor, axis: int = 1) -> bool:
+    """every slice along ``axis`` sums to one"""
+    total = t.sum(axis, dtype=torch.float32)
+    return bool(torch.allclose(total, torch.ones((), dtype=torch.float32, device=total.device).expand_as(total)))
 
 
 def uniq(a: Tensor) -> set:
-    return set(torch.unique(a.cpu()).numpy())
+    return set(a.detach().unique().cpu().tolist())
 
 
-def sset(a: Tensor, sub: Iterable) -> bool:
-    return uniq(a).issubset(sub)
+def sset(a: Tensor, allowed: Iterable) -> bool:
+    return uniq(a) <= set(allowed)
 
 
-def one_hot(t: Tensor, axis=1) -> bool:
-    return simplex(t, axis) and sset(t, [0, 1])
+def one_hot(t: Tensor, axis: int = 1) -> bool:
+    return sset(t, (0, 1)) and simplex(t, axis)
 
 
 def probs2class(probs: Tensor) -> Tensor:
     return probs.argmax(dim=1)
 
 
+def pred2class(pred: Tensor) -> Tensor:
+    assert pred.dim() == 4, pred.shape
+    return pred.argmax(dim=1)
+
+
 def class2one_hot(seg: Tensor, C: int) -> Tensor:
-    if len(seg.shape) == 2:
-        seg = seg.unsqueeze(dim=0)
-    return torch.stack([seg == c for c in range(C)], dim=1).type(torch.int32)
+    if seg.dim() == 2:
+        seg = seg[None]
+    classes = torch.arange(C, device=seg.device).view(1, C, *([1] * (seg.dim() - 1)))
+    return (seg.unsqueeze(1) == classes).to(torch.int32)
 
 
 def probs2one_hot(probs: Tensor) -> Tensor:
     return class2one_hot(probs2class(probs), probs.shape[1])
 
 
-class iterator_(object):
-    """Infinite iterator over a loader that remembers the last batch (utils.py:254-275)."""
+# ---- the endless batch source of the training loop ------------------------------------------------
+class iterator_:
+    """Endless iterator over a loader that remembers the batch it returned last.
+
+    ``next`` restarts the loader when it runs out (from a private copy, so restarting never disturbs the
+    caller's loader object); ``__cache__()`` hands the remembered batch back -- the adversarial block of a
+    step re-uses the batches the supervised block has just drawn (cotraining_totalloss.py:371-392) -- and
+    draws one, with a warning, when nothing has been drawn yet."""
 
     def __init__(self, dataloader) -> None:
-        super().__init__()
-        self.dataloader = dcopy(dataloader)
-        self.iter_dataloader = iter(dataloader)
-        self.cache = None
+        self._source = copy.deepcopy(dataloader)
+        self._it = iter(dataloader)
+        self.cache: Optional[Any] = None
+
+    def __iter__(self):
+        return self
 
     def __next__(self):
-        try:
-            self.cache = self.iter_dataloader.__next__()
-        except StopIteration:
-            self.iter_dataloader = iter(self.dataloader)
-            self.cache = self.iter_dataloader.__next__()
-        return self.cache
+        batch = next(self._it, _EXHAUSTED)
+        if batch is _EXHAUSTED:
+            self._it = iter(self._source)
+            batch = next(self._it)
+        self.cache = batch
+        return batch
 
     def __cache__(self):
-        if self.cache is not None:
-            return self.cache
-        import warnings
-        warnings.warn('No cache found, iterator forward')
-        return self.__next__()
+        if self.cache is None:
+            warnings.warn('No cache found, iterator forward')
+            return self.__next__()
+        return self.cache
 
 
-# ---- "a.b=c" CLI overrides merged into the YAML config (utils.py:280-351) ----------------------
-def yaml_parser() -> dict:
-    parser = argparse.ArgumentParser('Augment parser for yaml config')
-    parser.add_argument('strings', nargs='*', type=str, default=[''])
-    args = parser.parse_args()
-    return _parser(args.strings)
+_EXHAUSTED = object()
 
 
-def _parser(strings: List[str]):
-    assert isinstance(strings, list)
-    assert len(set(s.split('=')[0] for s in strings)) == len(strings), 'Augment doubly input.'
-    args = [_parser_(s) for s in strings]
-    return reduce(lambda x, y: dict_merge(x, y, True), args)
+# ---- nested dictionaries --------------------------------------------------------------------------
+def _coerce_like(old: Any, new: Any) -> Any:
+    """``new`` in the type ``old`` has; strings (command-line overrides) are read as Python literals first"""
+    if isinstance(new, str) and not isinstance(old, str):
+        try:
+            new = ast.literal_eval(new)
+        except (ValueError, SyntaxError):
+            pass
+    if old is None or isinstance(new, type(old)):
+        return new
+    try:
+        return type(old)(new)
+    except (TypeError, ValueError):
+        return new
 
 
-def _parser_(input_string: str):
-    if len(input_string) == 0:
-        return None
-    assert input_string.find('=') > 0, "Input args should include '=' to include the value"
-    keys, value = input_string.split('=')[0].replace(' ', ''), input_string.split('=')[1].replace(' ', '')
-    for k in reversed(keys.split('.')):
-        value = {k: value}
-    return dict(value)
+def dict_merge(dct: MutableMapping, merge_dct: Optional[Mapping], re: bool = False):
+    """Merge ``merge_dct`` into ``dct`` level by level (in place); a leaf that replaces an existing one takes its type.
+    ``re=True`` returns a deep copy of the merged dictionary (the in-place form returns None, as the reference's does)."""
+    stack = [(dct, merge_dct)] if merge_dct else []
+    while stack:
+        dst, src = stack.pop()
+        for key, value in src.items():
+            if isinstance(value, Mapping) and isinstance(dst.get(key), MutableMapping):
+                stack.append((dst[key], value))
+            elif key in dst:
+                dst[key] = _coerce_like(dst[key], value)
+            else:
+                dst[key] = value
+    return copy.deepcopy(dct) if re else None
 
 
-def dict_merge(dct: dict, merge_dct: dict, re=False):
-    """Recursive merge of ``merge_dct`` into ``dct``; values take the type already present in ``dct``
-    (bool/list through eval), as the reference does (utils.py:325-351)."""
-    if merge_dct is None:
-        return dct if re else None
-    for k, v in merge_dct.items():
-        if k in dct and isinstance(dct[k], dict) and isinstance(v, collections.abc.Mapping):
-            dict_merge(dct[k], v)
-        else:
-            try:
-                dct[k] = type(dct[k])(eval(v)) if type(dct[k]) in (bool, list) else type(dct[k])(v)
-            except Exception:
-                dct[k] = v
-    if re:
-        return dcopy(dct)
-
-
-def fix_all_seed(seed):
-    random.seed(seed)
-    torch.manual_seed(seed)
-    torch.cuda.manual_seed_all(seed)
-    np.random.seed(seed)
+def fix_all_seed(seed: int) -> None:
     os.environ['PYTHONHASHSEED'] = str(seed)
+    for seeder in (random.seed, np.random.seed, torch.manual_seed, torch.cuda.manual_seed_all):
+        seeder(seed)

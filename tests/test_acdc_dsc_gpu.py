@@ -17,6 +17,7 @@ from conftest import GOLDEN  # noqa: E402
 
 DEV = "cuda:0"
 SUB = os.path.join(GOLDEN, "acdc_subset")
+needs_acdc = pytest.mark.skipif(not os.path.isdir(os.path.join(SUB, "train", "img")), reason="tests/golden/acdc_subset is not in this checkout")
 REGEX = r"(patient\d+_\d+)_\d+"
 
 
@@ -34,6 +35,7 @@ def _loaders(device):
     return to_cached_loaders(labs, unl, val, device=device)
 
 
+@needs_acdc
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_acdc_subset_dsc_matches_reference_at_equal_steps(golden, tmp_path, dtype):
     from dct_amd import ModelMode
@@ -112,6 +114,7 @@ def _loaders_all_labeled(device, bs):
     return to_cached_loaders(labs, unl, val, device=device)
 
 
+@needs_acdc
 @pytest.mark.parametrize("arch", ["enet", "unet"])
 def test_acdc_dsc_curve_matches_a_reference_that_learned(arch, tmp_path):
     """BASELINE.json: "DSC within 0.2 of the reference on ACDC at equal steps", against a reference run that actually segments

@@ -11,6 +11,7 @@ from conftest import GOLDEN
 from helpers import digest
 
 SUB = os.path.join(GOLDEN, "acdc_subset")
+needs_acdc = pytest.mark.skipif(not os.path.isdir(os.path.join(SUB, "train", "img")), reason="tests/golden/acdc_subset is not in this checkout")
 REGEX = r"(patient\d+_\d+)_\d+"
 
 
@@ -54,6 +55,7 @@ def _subset(mode="train", pin=False):
                                augment="PILaugment", pin_memory=pin, quite=True)
 
 
+@needs_acdc
 def test_dataset_batches_match_reference(golden):
     from torch.utils.data import DataLoader
     from dct_amd.dataset import PatientSampler, extract_patients
@@ -80,6 +82,7 @@ def test_dataset_batches_match_reference(golden):
     assert a[2] == b[2] and torch.equal(a[0][0], b[0][0]) and torch.equal(a[0][1], b[0][1])
 
 
+@needs_acdc
 def test_cached_loader_equals_dataloader_and_shards_over_ranks(golden):
     """DeviceSliceCache + CachedLoader: the same batches in the same order as DataLoader(shuffle, drop_last) for the same torch
     seed -- with one PNG decode per slice per run -- and disjoint equal shards for data-parallel ranks."""
@@ -112,6 +115,7 @@ def test_cached_loader_equals_dataloader_and_shards_over_ranks(golden):
     lv.dataset.set_mode("eval")
 
 
+@needs_acdc
 def test_segment_transform_resizes_like_pil():
     """Resize(size) + ToTensor / NEAREST + ToLabel by their documented PIL semantics (torchvision is not in this image)."""
     from PIL import Image

@@ -229,20 +229,33 @@ def test_schedulers_match_reference_golden(golden):
     assert r.value == r2.value
 
 
-def test_registry_and_cli_helpers():
+def test_registry_and_dict_merge():
     from dct_amd.loss import get_loss_fn
-    from dct_amd.utils.utils import _parser, dict_merge
+    from dct_amd.utils import dict_merge
     with pytest.raises(ValueError):
         get_loss_fn("no_such_loss")
     assert type(get_loss_fn("jsd")).__name__ == "JSD_2D"
-    args = _parser(["Trainer.max_epoch=3", "Arch.name=unet", "StartTraining.train_jsd=True"])
+    # overrides as a command line delivers them (strings): a replaced leaf takes the type of the value it replaces
+    args = {"Trainer": {"max_epoch": "3"}, "Arch": {"name": "unet"}, "StartTraining": {"train_jsd": "True"}, "New": {"k": 1}}
     cfg = {"Trainer": {"max_epoch": 300, "device": "cuda:0"}, "Arch": {"name": "enet", "num_classes": 4},
            "StartTraining": {"train_jsd": False}}
     out = dict_merge(cfg, args, True)
-    assert out["Trainer"] == {"max_epoch": 3, "device": "cuda:0"} and out["Arch"]["name"] == "unet"
-    assert out["StartTraining"]["train_jsd"] is True
-    with pytest.raises(AssertionError):
-        _parser(["a.b=1", "a.b=2"])
+    assert out["Trainer"] == {"max_epoch": 3, "device": "cuda:0"} and out["Arch"] == {"name": "unet", "num_classes": 4}
+    assert out["StartTraining"]["train_jsd"] is True and out["New"] == {"k": 1}
+    assert dict_merge({"a": 1}, None, True) == {"a": 1} and dict_merge({"a": 1}, {"a": 2}) is None
+    # the trainer's use: per-model report dictionaries merged leaf by leaf (cotraining_totalloss._report_dict)
+    assert dict_merge({"S0": {"DSC1": 0.5}}, {"S0": {"DSC": 0.25}}, True) == {"S0": {"DSC1": 0.5, "DSC": 0.25}}
+
+
+def test_tensor_predicates():
+    from dct_amd.utils import class2one_hot, one_hot, probs2one_hot, simplex, sset, uniq
+    p = torch.softmax(torch.randn(2, 3, 5, 4), 1)
+    assert simplex(p) and not simplex(p * 2)
+    oh = probs2one_hot(p)
+    assert oh.shape == p.shape and one_hot(oh) and oh.dtype == torch.int32
+    seg = torch.randint(0, 3, (5, 4))
+    assert class2one_hot(seg, 3).shape == (1, 3, 5, 4) and uniq(seg) <= {0, 1, 2} and sset(seg, range(3))
+    assert torch.equal(class2one_hot(seg, 3)[0].argmax(0), seg)
 
 
 def test_arch_registry_names_match_reference_state_dict():
