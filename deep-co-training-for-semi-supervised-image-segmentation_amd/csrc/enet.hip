@@ -21,14 +21,11 @@ int g_enet_reduce_ppt = 8;           // pixels per thread of a per-channel reduc
 int g_enet_fold_threads = 1024;      // threads of the one-block finalize kernels (DCT_TUNE_ENET_FOLD_THREADS: 256 | 512 | 1024)
 int g_enet_mfma = 3;                 // bf16 / f16 mode: bit 0 = MFMA form of the convolutions with >= 16 input channels, bit 1 = of the
                                      // weight gradients (0: the fp32 VALU kernels)
-int g_enet_apply_vec = 0;            // BatchNorm backward apply on 8 channels per thread (vector loads / stores, an eighth of the threads):
-                                     // SLOWER in the step (cfg4 16.6 vs 15.9 ms, cfg5 38.9 vs 36.8) -- off, kept for A/B
 int g_enet_mwgrad_waves = 2048;      // MFMA weight gradient: waves a launch aims for (pixel slices x tiles) ...
 int g_enet_mwgrad_min_steps = 4;     // ... with at least this many 16-pixel MFMA steps per slice (multiple of 4)
-int g_enet_bn_owner = 0;             // small tensors: one-launch channel-owner BatchNorm statistics / backward (0: split reduction).
-                                     // Measured SLOWER (8 x 25 x 25 x 32 backward: 60 us against 14 us for the three split launches --
-                                     // C / 8 blocks cannot pull the tensor through 4-16 CUs fast enough): kept for A/B only
-int g_enet_reduce_vec = 1;           // 8-channel vector loads in the per-channel reductions (0: scalar kernel everywhere)
+// (measured and removed, DESIGN.md 4.2: a one-launch channel-owner BatchNorm for small tensors -- 8 x 25 x 25 x 32 backward 60 us against
+//  14 us for the three split launches: C / 8 blocks cannot pull the tensor through 4-16 CUs fast enough; a BatchNorm-backward apply
+//  kernel on 8 channels per thread -- cfg4 16.6 vs 15.9 ms, cfg5 38.9 vs 36.8)
 int g_enet_wgrad_slices = 1;          // 0: one pixel slice per round whatever the tile count
 int g_enet_wgrad_max_blocks = 1024;   // dct_tune_set(DCT_TUNE_ENET_WGRAD_BLOCKS, n); <= WG_MAX_BLOCKS
 
@@ -982,220 +979,7 @@ template <typename T> struct ReduceVecK {
 }
 };
 
-// The same for whole 8-channel groups (every BatchNorm of stages 1-3): a thread owns 8 consecutive channels of one pixel -- one or
-// two 16-byte loads per operand and one 16-byte store instead of eight scalar round trips, an eighth of the threads.
 struct ApplyP { RedP p; const float* c1; const float* c2; View out; };
-template <typename T> struct BnApplyVecK {
-  using Args = ApplyP;
-  static constexpr int THREADS = 256;
-  static __device__ __forceinline__ void run(const Args& a) {
-    const RedP& p = a.p;
-    const float* c1 = a.c1; const float* c2 = a.c2;
-    const View& out = a.out;
-
-  const int C = p.x.c, CV = C >> 3;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = (long long)p.x.n * p.x.h * p.x.w * CV;
-  if (idx >= total) return;
-  const int cv = (int)(idx % CV);
-  int n, y, x;
-  pix3(idx / CV, p.x.h, p.x.w, n, y, x);
-  const int c0 = cv * 8;
-  float v[8], g[8];
-  ld8<T>(p.x, voff(p.x, n, y, x) + c0, p.fm & 1, v);
-  ld8<T>(p.g, voff(p.g, n, y, x) + c0, p.fm & 2, g);
-  if (p.has_mask) {
-    float m[8];
-    ld8<T>(p.m, voff(p.m, n, y, x) + c0, p.fm & 4, m);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) if (!(m[i] > 0.f)) g[i] = 0.f;
-  }
-  float r[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = c0 + i;
-    r[i] = bn_bwd_draw(v[i], g[i], p.scale[c], p.shift[c], p.act == 2 ? p.slope[c] : 0.f, p.mean[c], p.invstd[c], c1[c], c2[c], p.act);
-  }
-  const long long oo = voff(out, n, y, x) + c0;
-  if ((p.fm & 8) || sizeof(T) == 4) {
-    float* o = reinterpret_cast<float*>(out.ptr) + oo;
-    *reinterpret_cast<f32x4*>(o) = f32x4{r[0], r[1], r[2], r[3]};
-    *reinterpret_cast<f32x4*>(o + 4) = f32x4{r[4], r[5], r[6], r[7]};
-  } else {
-    typedef typename vec8_of<T>::type V8;
-    V8 q;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = from_f32<T>(r[i]);
-    *reinterpret_cast<V8*>(reinterpret_cast<T*>(out.ptr) + oo) = q;
-  }
-}
-};
-
-// ---- channel-owner BatchNorm kernels for small tensors -----------------------------------------------
-// Stage-2/3 tensors (8 x 25 x 25 x 32...128, 8 x 50 x 50 x 16...64) hold 0.3 - 2.5 MB: the split reduction above is three
-// dependent launches of ~6-9 us each for a few microseconds of memory traffic, and those launches sit on the step's critical
-// chain (tools/probe_step_program.py).  Here one block OWNS 8 channels for all pixels, so nothing crosses blocks: sums, the
-// per-channel finalize and (backward) the apply pass over the same pixels -- L2-resident by then -- are ONE launch of C / 8
-// blocks x 1024 threads.  Per thread <= 32 pixels in fp32, then doubles through a fixed shuffle tree and a fixed-order fold
-// of the 16 waves.
-constexpr int OWN_T = 1024;
-constexpr long long OWN_MAX_PIXELS = 32768;
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-// s[k][i]: sum k of owned channel i, valid in every thread after the call
-template <int NS>
-__device__ __forceinline__ void own_fold(const float (&a)[3][8], double (&s)[3][8], double* red /* [16][NS][8] */) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k < NS; ++k)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const double w = wave_sum((double)a[k][i]);
-      if (lane == 0) red[(wave * NS + k) * 8 + i] = w;
-    }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NS; ++k)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      double t = 0.0;
-      for (int w = 0; w < OWN_T / 64; ++w) t += red[(w * NS + k) * 8 + i];
-      s[k][i] = t;
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(OWN_T) void enet_bn_fwd_owner_kernel(RedP p, double count, const float* gamma, const float* beta, float eps,
-                                                                  float momentum, float* running_mean, float* running_var,
-                                                                  float* scale, float* shift, float* save_mean, float* save_invstd,
-                                                                  float* save_var) {
-  __shared__ double red[(OWN_T / 64) * 2 * 8];
-  const int c0 = blockIdx.x * 8;
-  const long long P = (long long)p.x.n * p.x.h * p.x.w;
-  float a[3][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a[0][i] = a[1][i] = a[2][i] = 0.f;
-  for (long long pix = threadIdx.x; pix < P; pix += OWN_T) {
-    int n, y, x;
-    pix3(pix, p.x.h, p.x.w, n, y, x);
-    float v[8];
-    ld8<T>(p.x, voff(p.x, n, y, x) + c0, p.fm & 1, v);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { a[0][i] += v[i]; a[1][i] = fmaf(v[i], v[i], a[1][i]); }
-  }
-  double s[3][8];
-  own_fold<2>(a, s, red);
-  if (threadIdx.x < 8) {
-    const int i = threadIdx.x, c = c0 + i;
-    // (select by constant index: s[][] lives in registers)
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) if (j == i) { s0 = s[0][j]; s1 = s[1][j]; }
-    const double m = s0 / count;
-    double v = s1 / count - m * m;
-    if (v < 0.0) v = 0.0;
-    const float mean = (float)m, var = (float)v;
-    const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
-    if (running_mean) {
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-    }
-    if (save_var) save_var[c] = (float)unbiased;
-    const float invstd = 1.0f / sqrtf(var + eps);
-    const float sc = gamma[c] * invstd;
-    scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
-    if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(OWN_T) void enet_bn_bwd_owner_kernel(RedP p, double count, int training, float* dgamma, float* dbeta,
-                                                                  float* dslope, float* c1c2, View out) {
-  __shared__ double red[(OWN_T / 64) * 3 * 8];
-  __shared__ float cc[2][8];
-  const int c0 = blockIdx.x * 8, C = p.x.c;
-  const long long P = (long long)p.x.n * p.x.h * p.x.w;
-  float sc[8], sh[8], sl[8], mu[8], is[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = c0 + i;
-    sc[i] = p.scale[c]; sh[i] = p.shift[c]; mu[i] = p.mean[c]; is[i] = p.invstd[c]; sl[i] = p.act == 2 ? p.slope[c] : 0.f;
-  }
-  float a[3][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a[0][i] = a[1][i] = a[2][i] = 0.f;
-  for (long long pix = threadIdx.x; pix < P; pix += OWN_T) {
-    int n, y, x;
-    pix3(pix, p.x.h, p.x.w, n, y, x);
-    float v[8], g[8];
-    ld8<T>(p.x, voff(p.x, n, y, x) + c0, p.fm & 1, v);
-    ld8<T>(p.g, voff(p.g, n, y, x) + c0, p.fm & 2, g);
-    if (p.has_mask) {
-      float m[8];
-      ld8<T>(p.m, voff(p.m, n, y, x) + c0, p.fm & 4, m);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) if (!(m[i] > 0.f)) g[i] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float z = fmaf(sc[i], v[i], sh[i]);
-      float dz = g[i];
-      if (p.act == 2) { if (!(z > 0.f)) { dz = g[i] * sl[i]; a[2][i] = fmaf(g[i], z, a[2][i]); } }
-      else if (p.act == 3) { if (!(z > 0.f)) dz = 0.f; }
-      const float xh = (v[i] - mu[i]) * is[i];
-      a[0][i] += dz; a[1][i] = fmaf(dz, xh, a[1][i]);
-    }
-  }
-  double s[3][8];
-  own_fold<3>(a, s, red);
-  if (threadIdx.x < 8) {
-    const int i = threadIdx.x, c = c0 + i;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) if (j == i) { s0 = s[0][j]; s1 = s[1][j]; s2 = s[2][j]; }
-    if (dbeta) dbeta[c] += (float)s0;
-    if (dgamma) dgamma[c] += (float)s1;
-    if (dslope) dslope[c] += (float)s2;
-    const float k1 = training ? (float)(s0 / count) : 0.f, k2 = training ? (float)(s1 / count) : 0.f;
-    cc[0][i] = k1; cc[1][i] = k2;
-    c1c2[c] = k1; c1c2[C + c] = k2;
-  }
-  __syncthreads();
-  float k1[8], k2[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { k1[i] = cc[0][i]; k2[i] = cc[1][i]; }
-  // apply: draw = scale * (dz - c1 - xhat * c2), same arithmetic as enet_bn_bwd_apply_kernel
-  for (long long pix = threadIdx.x; pix < P; pix += OWN_T) {
-    int n, y, x;
-    pix3(pix, p.x.h, p.x.w, n, y, x);
-    float v[8], g[8];
-    ld8<T>(p.x, voff(p.x, n, y, x) + c0, p.fm & 1, v);
-    ld8<T>(p.g, voff(p.g, n, y, x) + c0, p.fm & 2, g);
-    if (p.has_mask) {
-      float m[8];
-      ld8<T>(p.m, voff(p.m, n, y, x) + c0, p.fm & 4, m);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) if (!(m[i] > 0.f)) g[i] = 0.f;
-    }
-    const long long oo = voff(out, n, y, x) + c0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float z = fmaf(sc[i], v[i], sh[i]);
-      float dz = g[i];
-      if (p.act == 2) { if (!(z > 0.f)) dz = g[i] * sl[i]; }
-      else if (p.act == 3) { if (!(z > 0.f)) dz = 0.f; }
-      const float xh = (v[i] - mu[i]) * is[i];
-      stv<T>(out, oo + i, p.fm & 8, sc[i] * (dz - k1[i] - xh * k2[i]));
-    }
-  }
-}
-
 // draw = scale * (dz - c1 - xhat * c2)
 template <typename T> struct BnApplyK {
   using Args = ApplyP;
@@ -1840,20 +1624,6 @@ extern "C" size_t dct_enet_reduce_workspace_bytes(int channels) {
   return (size_t)256 * (channels > 0 ? channels : 1) * 3 * sizeof(double);
 }
 
-// channel-owner form: whole 8-channel groups, vector-loadable views, few enough pixels for one block per group
-static bool enet_owner_ok(const RedP& p, int dtype, const View* out) {
-  if (!g_enet_bn_owner || (g_grp.active && !g_grp.leaves_only)) return false;      // (the owner kernels have no grouped form)
-  const long long P = (long long)p.x.n * p.x.h * p.x.w;
-  if (P > OWN_MAX_PIXELS || p.x.c % 8 != 0 || p.x.c < 8) return false;
-  auto v8 = [&](const View& v, int f32) {
-    const int esz = (f32 || dtype == DCT_F32) ? 4 : 2;
-    return v.c % 8 == 0 && v.sw % 8 == 0 && v.sh % 8 == 0 && v.sn % 8 == 0 && ((uintptr_t)v.ptr % (8 * esz)) == 0;
-  };
-  if (!v8(p.x, p.fm & 1)) return false;
-  if (p.kind == 1 && (!v8(p.g, p.fm & 2) || (p.has_mask && !v8(p.m, p.fm & 4)))) return false;
-  (void)out;
-  return true;
-}
 
 // fin (nullable; mode + everything but partial / blocks / C / count filled in): the finalize of these sums rides in the launch's last
 // block where a ticket can be had -> *fused = true; otherwise the caller launches the finalize kernel as before
@@ -1883,7 +1653,7 @@ static int enet_reduce_launch(const RedP& p0, int dtype, void* workspace, size_t
     return v.c % 8 == 0 && v.sw % 8 == 0 && v.sh % 8 == 0 && v.sn % 8 == 0 && ((uintptr_t)v.ptr % (8 * esz)) == 0;
   };
   const int C = p.x.c;
-  bool vec = g_enet_reduce_vec && C >= 16 && C <= 128 && (C & (C - 1)) == 0 && v8(p.x, p.fm & 1);
+  bool vec = C >= 16 && C <= 128 && (C & (C - 1)) == 0 && v8(p.x, p.fm & 1);
   if (vec && p.kind == 1) vec = v8(p.g, p.fm & 2) && (!p.has_mask || v8(p.m, p.fm & 4));
   if (vec) {
     const size_t lds = (size_t)(256 / (C / 8)) * C * 3 * sizeof(double);      // 48 KiB
@@ -1921,12 +1691,6 @@ extern "C" int dct_enet_bn_fwd_stats_rows(const dct_view* raw, const float* gamm
     RedP p; p.x = to_view(raw); p.g = p.x; p.m = p.x;
     p.scale = p.shift = p.slope = p.mean = p.invstd = nullptr;
     p.act = 0; p.has_mask = 0; p.kind = 0; p.ppb = 0; p.fm = f32_mask & 1; p.partial = nullptr;
-    if (enet_owner_ok(p, dtype, nullptr)) {
-      const double cnt = (double)raw->n * raw->h * raw->w;
-      ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_fwd_owner_kernel<T>, dim3(raw->c / 8), dim3(OWN_T), 0, st, p, cnt, gamma, beta, eps,
-                               momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, save_var));
-      return dct_check_launch();
-    }
     FinU u;
     u.mode = 1; u.ticket = nullptr;
     u.f = FinP{nullptr, 0, 0, 0.0, gamma, beta, eps, momentum, running_mean, running_var, 1, scale, shift, save_mean, save_invstd, save_var};
@@ -1971,17 +1735,6 @@ static int enet_bn_bwd_impl(const dct_view* raw, const dct_view* g, const dct_vi
   p.act = act; p.kind = 1; p.ppb = 0; p.fm = f32_mask; p.partial = nullptr;
   hipStream_t st = (hipStream_t)stream;
   int blocks = 0;
-  if (do_sums && do_apply) {
-    const View vo0 = to_view(draw);
-    const int oesz = ((f32_mask & 8) || dtype == DCT_F32) ? 4 : 2;
-    if (partial_rows == 0 && enet_owner_ok(p, dtype, &vo0) && vo0.c == p.x.c && vo0.n == p.x.n && vo0.h == p.x.h && vo0.w == p.x.w &&
-        ((uintptr_t)vo0.ptr % oesz) == 0) {
-      const double cnt = (double)raw->n * raw->h * raw->w;
-      ENET_T(dtype, DCT_LAUNCH(DCT_PROF_OTHER, enet_bn_bwd_owner_kernel<T>, dim3(raw->c / 8), dim3(OWN_T), 0, st, p, cnt, training ? 1 : 0,
-                               dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, vo0));
-      return dct_check_launch();
-    }
-  }
   bool finalized = partial_rows < 0;    // < 0: dct_enet_conv_bnbwd_stats_fin has finalized already (c1c2 and the parameter gradients are set)
   const double count = (double)raw->n * raw->h * raw->w;
   if (partial_rows > 0) {         // the data-gradient convolution that produced g wrote the partial rows (dct_enet_conv_bnbwd_stats)
@@ -2002,17 +1755,6 @@ static int enet_bn_bwd_impl(const dct_view* raw, const dct_view* g, const dct_vi
   }
   if (!do_apply) return dct_check_launch();
   const ApplyP ap = {p, (const float*)c1c2, (const float*)(c1c2 + raw->c), vo};
-  {
-    auto v8 = [&](const View& v, int f32) {
-      const int esz = (f32 || dtype == DCT_F32) ? 4 : 2;
-      return v.c % 8 == 0 && v.sw % 8 == 0 && v.sh % 8 == 0 && v.sn % 8 == 0 && ((uintptr_t)v.ptr % (8 * esz)) == 0;
-    };
-    if (g_enet_apply_vec && v8(p.x, p.fm & 1) && v8(p.g, p.fm & 2) && (!p.has_mask || v8(p.m, p.fm & 4)) && v8(vo, p.fm & 8) &&
-        vo.c == p.x.c) {
-      ENET_T(dtype, enet_launch<BnApplyVecK<T>>(DCT_PROF_OTHER, dim3(div_up(total / 8, 256)), dim3(256), 0, st, ap));
-      return dct_check_launch();
-    }
-  }
   ENET_T(dtype, enet_launch<BnApplyK<T>>(DCT_PROF_OTHER, dim3(div_up(total, 256)), dim3(256), 0, st, ap));
   return dct_check_launch();
 }

@@ -231,10 +231,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 // 128-B zero page instead of branching around the DMA; rows past M are clamped to the last pixel
 // (their results are never stored).
 
-#ifdef DCT_STAMPS
-#define DCT_STAMP_WAVES 65536
-__device__ unsigned long long* g_stamp_buf = nullptr;   // diagnostic build only (make EXTRA=-DDCT_STAMPS): per-phase cycle sums
-#endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool BOUNDS>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmParams p) {
@@ -251,18 +247,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WAVES_M, wm = wave % WAVES_M;
-  // XCD-aware tile order (knob DCT_TUNE_IGEMM_XCD2): workgroups go round-robin over the 8 XCDs, each with its own 4 MiB L2.
-  // The plain (M tile fastest) grid hands every XCD every eighth pixel tile of EVERY channel tile, so each XCD streams the
-  // whole weight matrix (cen_b: 18.9 MB, deep levels: the dominant operand) through its L2.  Here XCD x gets a contiguous
-  // range of the (split, channel tile, pixel tile) order: few channel tiles per XCD, whose weight slices stay L2-resident.
-  int bxi, byi, bzi;
-  if (p.xcd_tiles > 0) {
-    const int slot = blockIdx.x >> 3;
-    int t = (blockIdx.x & 7) * p.xcd_tiles + slot;
-    if (slot >= p.xcd_tiles || t >= p.xcd_total) return;
-    bxi = t % p.xcd_gm; t /= p.xcd_gm;
-    byi = t % p.xcd_gn; bzi = t / p.xcd_gn;
-  } else { bxi = blockIdx.x; byi = blockIdx.y; bzi = blockIdx.z; }
+  // (an XCD-aware 1-D tile order -- each XCD a contiguous range of (split, channel tile, pixel tile) -- measured level on the step: removed)
+  const int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
   const int m0 = bxi * BM, n0 = byi * BN;
   const int srow = wave * 8 + (lane >> 3);                 // staging row within a pass
   const int schunk = (lane & 7) ^ ((srow >> 1) & 7);       // source chunk for this lane's LDS slot
@@ -534,15 +520,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
 // here a block owns an 8 x 16 patch of output pixels of one image and stages the 10 x 18 input halo of a 64-channel
 // slice ONCE for all nine taps (22.5 KiB per nine K-steps instead of 16 KiB per step); only the weight tile of
 // the tap (BN rows x 128 B) streams every step: (BN * 128 + 2.5 KiB) per step = 113 FLOP/B at BN = 128.
-// A tap's pixel fragment is the same LDS image read at rows (py + r) * 18 + px + s.  Lane l of a 32-pixel
-// fragment holds patch pixel (2 * wm + G(l), I(l)) with (G, I) chosen so that each 16-lane group of a ds_read_b128
-// reads 16 consecutive LDS rows (conflict-free under the row-pair XOR swizzle shared with v2).
+// A tap's pixel fragment is the same LDS image read at rows (py + r) * 18 + px + s.  On v_mfma_f32_16x16x32_bf16 (MI355X holds a
+// higher clock on this shape under load than on 32x32x16: MI355X_MICROARCH.md, DVFS item 7; the 32x32x16 form of this kernel was
+// 8 % behind in isolation, level on the step, and is gone) a fragment's 16 lanes are 16 consecutive pixels of one patch row.
 // K order: channel slice outermost, taps inside; weights [cout][tap][cin] as for v2; LDS-staged epilogue as v2,
 // plus read-modify-write for accumulate.
 // ABUFS: halo stages -- 1 when Cin == 64 (a single channel slice: nothing to prefetch), which lets four
 // BN = 64 blocks (or two BN = 128 blocks) share a CU's LDS.
+// Variants of this tile that were measured and removed: a four-slot ring of 32-channel weight half-stages with
+// counted vmcnt and raw barriers (-15 %: twice the barriers for the same MFMAs), four waves of 64 x 64 instead of eight of
+// 32 x 64 (-8 %), three unrolled taps per loop trip (-13 %), an XCD-aware tile order (level), amdgpu_waves_per_eu(4) (-1 %).
 template <int BN, int NWM, int NWN, int ABUFS>
-__global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, int tiles_x, int tiles_y) {
   constexpr int NW = NWM * NWN;
   constexpr int TH = 8, TW = 16, BM = TH * TW, HW = TW + 2, HROWS = (TH + 2) * HW;   // 180 halo rows of 128 B
   constexpr int APIECES = (HROWS + 7) / 8, A_BYTES = APIECES * 8 * 128;              // 23 pieces, 23552 B
@@ -550,236 +539,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3_kernel(IgemmParams p, i
   constexpr int NPA = (APIECES + NW - 1) / NW, NPB = BPIECES / NW;
   constexpr int WTN = BN / NWN, TN = WTN / 32;
   static_assert(NWM == 4 && BPIECES % NW == 0 && TN >= 1, "tile/wave mismatch");
-  extern __shared__ __attribute__((aligned(128))) char smem[];
-  char* Abuf = smem;                       // halo stage(s)
-  char* Bbuf = smem + ABUFS * A_BYTES;     // two weight stages
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave / NWM, wm = wave % NWM;
-  int bx = blockIdx.x;
-  const int tx = bx % tiles_x; bx /= tiles_x;
-  const int ty = bx % tiles_y; const int img = bx / tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * BN;
-  const long long Ktot = 9ll * p.Cin;
-  const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
-  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
-
-  // halo staging: wave w issues pieces w, w + NW, ...; lane -> (row = piece * 8 + lane / 8, its swizzled source chunk)
-  long long aoff[NPA];
-#pragma unroll
-  for (int i = 0; i < NPA; ++i) {
-    const int piece = wave + i * NW;
-    const int row = piece * 8 + (lane >> 3);
-    aoff[i] = -1;
-    if (piece < APIECES && row < HROWS) {
-      const int hy = row / HW, hx = row - hy * HW;
-      const int iy = y0 - p.pad_h + hy, ix = x0 - p.pad_w + hx;
-      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-        aoff[i] = img * p.xsN + iy * p.xsH + ix * p.xsW + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
-    }
-  }
-  auto stageA = [&](char* buf, int c0) {
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-      const int piece = wave + i * NW;
-      if (piece < APIECES) {
-        const char* src = aoff[i] >= 0 ? reinterpret_cast<const char*>(xb + aoff[i] + c0) : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + piece * 1024), 16, 0, 0);
-      }
-    }
-  };
-  // weight staging: piece = 8 cout rows.  The source is (wave-uniform base of the step's tap / channel slice) + (a lane's constant
-  // 32-bit byte offset): the global_load_lds takes the SGPR-base form and a step's staging costs no vector ALU work
-  // (the loop is bound by the SIMD's vector ISSUE -- MFMA issue slots plus VALU -- not by the matrix pipe: see DESIGN 4.1)
-  unsigned woffL[NPB];
-#pragma unroll
-  for (int i = 0; i < NPB; ++i) {
-    const int row = (wave + i * NW) * 8 + (lane >> 3);
-    woffL[i] = (unsigned)(((long long)row * Ktot + (((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2);
-  }
-  const char* wtile = p.w + (long long)n0 * Ktot * 2;
-  auto stageB = [&](char* buf, int tap, int c0) {
-    const char* wstep = wtile + ((long long)tap * p.Cin + c0) * 2;          // scalar
-#pragma unroll
-    for (int i = 0; i < NPB; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wstep + woffL[i]), (lptr_t)(buf + (wave + i * NW) * 1024), 16, 0, 0);
-  };
-
-  f32x16 acc[TN];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-  const int half = lane >> 5, l31 = lane & 31;
-  // fragment lane -> patch pixel: ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} each get one patch row
-  const int q4 = l31 >> 2;                                     // 0..7
-  const int grp = (q4 == 1 || q4 == 2 || q4 == 4 || q4 == 7) ? 1 : 0;
-  const int idx = grp ? (q4 == 1 ? l31 - 4 : q4 == 2 ? l31 - 4 : q4 == 4 ? l31 - 8 : l31 - 16)
-                      : (q4 == 0 ? l31 : q4 == 3 ? l31 - 8 : l31 - 12);
-  const int prow = 2 * wm + grp, pcol = idx;                   // pixel within the 8 x 16 patch
-  const int rho0 = prow * HW + pcol;
-  const int aswz = (l31 >> 1) & 7;
-
-  const int nch = p.Cin / 64;
-  const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
-#ifdef DCT_STAMPS
-  unsigned long long st_issue = 0, st_comp = 0, st_vm = 0, st_bar = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_pro;
-  const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz reference: shader clock = d(memtime) / d(memrealtime) x 100 MHz
-#endif
-  stageA(Abuf, 0);
-  stageB(Bbuf, 0, 0);
-  float* biasL = reinterpret_cast<float*>(smem + ABUFS * A_BYTES + 2 * B_BYTES);   // bias -> LDS now: no memory round trip in the epilogue
-  if (tid < BN) biasL[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
-  __syncthreads();
-#ifdef DCT_STAMPS
-  st_pro = __builtin_amdgcn_s_memtime() - st_t0;
-#endif
-  int ab = 0, bb = 0;
-  for (int c = 0; c < nch; ++c) {
-#pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-#ifdef DCT_STAMPS
-      const unsigned long long s0 = __builtin_amdgcn_s_memtime();
-#endif
-      if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
-      else if (c + 1 < nch) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
-      if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
-#ifdef DCT_STAMPS
-      const unsigned long long s1 = __builtin_amdgcn_s_memtime();
-#endif
-      const int r = t / 3, s = t - 3 * r;
-      const int rho = rho0 + r * HW + s;
-      const int pswz = (rho >> 1) & 7;
-      // Fragment reads are inline asm with counted waits: the reads of sub-step kk + 1 are issued first, then the
-      // wave waits only for the (older) reads of sub-step kk.  Left to the compiler the loads sink between the MFMAs
-      // behind an lgkmcnt(0) and every sub-step exposes a full LDS round trip.
-      const unsigned Wl = smem_l + ABUFS * A_BYTES + bb * B_BYTES + (wn * WTN + l31) * 128 + ((half ^ aswz) * 16);
-      const unsigned Xl = smem_l + ab * A_BYTES + rho * 128 + ((half ^ pswz) * 16);
-      bf16x8 a[2][TN], b[2];
-      auto issue = [&](int set, int kk) {
-#pragma unroll
-        for (int i = 0; i < TN; ++i) rd128((Wl + i * 32 * 128) ^ (kk * 32), a[set][i]);
-        rd128(Xl ^ (kk * 32), b[set]);
-      };
-      issue(0, 0);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int set = kk & 1;
-        if (kk + 1 < 4) { issue(set ^ 1, kk + 1); lgkm_wait3<TN + 1>(); } else { lgkm_wait3<0>(); }
-#pragma unroll
-        for (int i = 0; i < TN; ++i) touch8(a[set][i]);
-        touch8(b[set]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][i], b[set], acc[i], 0, 0, 0);
-      }
-#ifdef DCT_STAMPS
-      const unsigned long long s2 = __builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned long long s3 = __builtin_amdgcn_s_memtime();
-      __syncthreads();
-      const unsigned long long s4 = __builtin_amdgcn_s_memtime();
-      st_issue += s1 - s0; st_comp += s2 - s1; st_vm += s3 - s2; st_bar += s4 - s3;
-#else
-      __syncthreads();
-#endif
-      bb ^= 1;
-    }
-    ab ^= 1;
-  }
-
-#ifdef DCT_STAMPS
-  const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
-#endif
-  // ---- epilogue (staged through LDS as in v2): tile row = patch pixel py * 16 + px
-  constexpr int CPR = BN / 8;
-  static_assert(BM * BN * 2 <= ABUFS * A_BYTES + (BN * 128 * 2 - BM * 8), "epilogue tile does not fit");
-  char* tile = smem;                                   // BM * BN * 2 bytes: the halo stage(s) and, if needed, the head of the weight stages
-  int* rowY = reinterpret_cast<int*>(smem + ABUFS * A_BYTES + 2 * B_BYTES - BM * 8);   // tail of the weight stages
-  int* rowM = rowY + BM;
-  if (tid < BM) {
-    const int oy = y0 + (tid >> 4), ox = x0 + (tid & 15);
-    int oy_ = -1, om_ = -1;
-    if (oy < p.Ho && ox < p.Wo) {
-      oy_ = (int)(img * p.ysN + oy * p.ysH + ox * p.ysW);
-      om_ = (int)(img * p.msN + oy * p.msH + ox * p.msW);
-    }
-    rowY[tid] = oy_; rowM[tid] = om_;
-  }
-#ifdef DCT_STAMPS
-  const unsigned long long e0 = __builtin_amdgcn_s_memtime();
-#endif
-  {
-    const int row = prow * TW + pcol;
-    // bias vectors from the LDS copy made in the prologue
-    f32x4 bv[TN][4];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const f32x4*>(biasL + wn * WTN + i * 32 + 8 * q + 4 * half);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int cl = wn * WTN + i * 32 + 8 * q + 4 * half;
-        float v[4] = {acc[i][4 * q + 0] + bv[i][q][0], acc[i][4 * q + 1] + bv[i][q][1], acc[i][4 * q + 2] + bv[i][q][2],
-                      acc[i][4 * q + 3] + bv[i][q][3]};
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-        const int chunk = (cl >> 3) ^ (row & (CPR - 1));
-        *reinterpret_cast<bf16x4*>(tile + row * (BN * 2) + chunk * 16 + (cl & 4) * 2) = o;
-      }
-    }
-  }
-#ifdef DCT_STAMPS
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const unsigned long long e1 = __builtin_amdgcn_s_memtime();
-#endif
-  __syncthreads();
-#ifdef DCT_STAMPS
-  const unsigned long long e2 = __builtin_amdgcn_s_memtime();
-#endif
-  staged_rows_out<BM, BN, NW>(p, tile, rowY, rowM, n0, tid);
-#ifdef DCT_STAMPS
-  if (lane == 0 && g_stamp_buf) {
-    const unsigned long long st_end = __builtin_amdgcn_s_memtime();
-    // one 16-counter record per wave (no atomics: a same-address atomic storm stalls the very loads being timed)
-    const unsigned long long wid = ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave;
-    unsigned long long* o = g_stamp_buf + (wid % DCT_STAMP_WAVES) * 16;
-    o[0] += 1ull; o[1] += st_pro; o[2] += st_issue; o[3] += st_comp; o[4] += st_vm; o[5] += st_bar;
-    o[6] += st_end - st_loop_end; o[7] += st_end - st_t0; o[8] += (unsigned long long)(nch * 9);
-    o[9] += e0 - st_loop_end; o[10] += e1 - e0; o[11] += e2 - e1; o[12] += st_end - e2;
-    o[13] += __builtin_amdgcn_s_memrealtime() - st_r0;
-  }
-#endif
-}
-
-// igemm3_kernel on v_mfma_f32_16x16x32_bf16 (same FLOPs per cycle, same LDS traffic, 32-deep sub-steps): MI355X holds a
-// higher clock on this shape under load (MI355X_MICROARCH.md, DVFS item 7).  dct_tune_set(DCT_TUNE_IGEMM_MFMA16, 0/1).
-#ifndef DCT_V3M_WPE
-#define DCT_V3M_WPE 0          /* forcing four waves per SIMD through the attribute measured 1 % behind the compiler's own 100 registers */
-#endif
-#if DCT_V3M_WPE
-#define V3M_ATTR __attribute__((amdgpu_waves_per_eu(4, 8)))
-#else
-#define V3M_ATTR
-#endif
-template <int BN, int NWM, int NWN, int ABUFS>
-__global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmParams p, int tiles_x, int tiles_y) {
-  constexpr int NW = NWM * NWN;
-  constexpr int TH = 8, TW = 16, BM = TH * TW, HW = TW + 2, HROWS = (TH + 2) * HW;   // 180 halo rows of 128 B
-  constexpr int APIECES = (HROWS + 7) / 8, A_BYTES = APIECES * 8 * 128;              // 23 pieces, 23552 B
-  constexpr int B_BYTES = BN * 128, BPIECES = BN / 8;
-  constexpr int NPA = (APIECES + NW - 1) / NW, NPB = BPIECES / NW;
-  constexpr int WTN = BN / NWN, TN = WTN / 32;
-  static_assert((NWM == 4 || NWM == 2) && BPIECES % NW == 0 && TN >= 1, "tile/wave mismatch");
-  constexpr int PXB = 8 / NWM;             // 16-pixel column blocks (patch rows) per wave: 2 with eight waves, 4 with four
+  constexpr int PXB = 8 / NWM;             // 16-pixel column blocks (patch rows) per wave: 2
   extern __shared__ __attribute__((aligned(128))) char smem[];
   char* Abuf = smem;                       // halo stage(s)
   char* Bbuf = smem + ABUFS * A_BYTES;     // two weight stages
@@ -787,18 +547,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmP
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: LDS-DMA destinations and piece bookkeeping stay in SGPRs
   const int wn = wave / NWM, wm = wave % NWM;
-  // XCD-aware tile order (knob DCT_TUNE_IGEMM_XCD): workgroups go round-robin over the 8 XCDs, each with its own L2.
-  // Tile t of a 1-D grid is given to XCD t % 8's (t / 8)-th slot, and an XCD's slots cover a CONTIGUOUS range of
-  // (patch, channel tile) pairs with the channel tile fastest: the N tiles of one patch and neighbouring patches
-  // (shared halo rows) read their input through the same L2.
-  int bx, ntile;
-  if (p.xcd_tiles > 0) {
-    const int per_xcd = p.xcd_tiles;                          // ceil(total tiles / 8)
-    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int nt = p.N / BN;
-    if ((blockIdx.x >> 3) >= per_xcd || t >= p.xcd_total) return;
-    bx = t / nt; ntile = t - bx * nt;
-  } else { bx = blockIdx.x; ntile = blockIdx.y; }
+  int bx = blockIdx.x;
+  const int ntile = blockIdx.y;
   const int tx = bx % tiles_x; bx /= tiles_x;
   const int ty = bx % tiles_y; const int img = bx / tiles_y;
   const int y0 = ty * TH, x0 = tx * TW, n0 = ntile * BN;
@@ -873,16 +623,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmP
   int ab = 0, bb = 0;
   for (int c = 0; c < nch; ++c) {
     const unsigned Xs = smem_l + ab * A_BYTES;                // scalar
-#ifndef DCT_V3M_UNROLL
-#define DCT_V3M_UNROLL 1      /* measured (tools/gpu/r3f.sh): three unrolled taps per trip 13 % slower than one */
-#endif
 #pragma unroll 1
-    for (int r = 0; r < (DCT_V3M_UNROLL == 3 ? 3 : 9); ++r) {
-#pragma unroll
-    for (int sx0 = 0; sx0 < (DCT_V3M_UNROLL == 3 ? 3 : 1); ++sx0) {
-      const int t = DCT_V3M_UNROLL == 3 ? 3 * r + sx0 : r;
-      const int sx = DCT_V3M_UNROLL == 3 ? sx0 : r % 3;
-      const int rr = DCT_V3M_UNROLL == 3 ? r : r / 3;
+    for (int t = 0; t < 9; ++t) {
+      const int sx = t % 3, rr = t / 3;
       if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
       else if (c + 1 < nch) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
       if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
@@ -916,7 +659,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmP
       __syncthreads();
       bb ^= 1;
     }
-    }
     ab ^= 1;
   }
 
@@ -943,213 +685,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) V3M_ATTR void igemm3m_kernel(IgemmP
 #pragma unroll
     for (int j = 0; j < PXB; ++j) {
       const int row = (PXB * wm + j) * TW + l15;
-#pragma unroll
-      for (int i = 0; i < TR; ++i) {
-        const int cl = wn * WTN + i * 16 + 4 * kq;
-        float v[4] = {acc[i][j][0] + bv[i][0], acc[i][j][1] + bv[i][1], acc[i][j][2] + bv[i][2], acc[i][j][3] + bv[i][3]};
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-        const int chunk = (cl >> 3) ^ (row & (CPR - 1));
-        *reinterpret_cast<bf16x4*>(tile + row * (BN * 2) + chunk * 16 + (cl & 4) * 2) = o;
-      }
-    }
-  }
-  __syncthreads();
-  staged_rows_out<BM, BN, NW>(p, tile, rowY, rowM, n0, tid);
-}
-
-// igemm3m_kernel with a RING of four 32-channel weight half-stages filled three half-steps ahead (counted vmcnt waits, raw
-// s_barrier) instead of two 64-channel stages drained with vmcnt(0) at every barrier.  Same tile, same LDS bytes, same
-// fragment maps and the same order of accumulation (slice, tap, 32-channel half), so the results are bit-identical to
-// igemm3m_kernel.  dct_tune_set(DCT_TUNE_IGEMM_RING, 0/1).
-__device__ __forceinline__ void wait_vm(int n) {       // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the count is an immediate)
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-}
-template <int BN, int NWM, int NWN, int ABUFS>
-__global__ __launch_bounds__(NWM * NWN * 64) void igemm3r_kernel(IgemmParams p, int tiles_x, int tiles_y) {
-  constexpr int NW = NWM * NWN;
-  constexpr int TH = 8, TW = 16, BM = TH * TW, HW = TW + 2, HROWS = (TH + 2) * HW;   // 180 halo rows of 128 B
-  constexpr int APIECES = (HROWS + 7) / 8, A_BYTES = APIECES * 8 * 128;              // 23 pieces, 23552 B
-  constexpr int B_BYTES = BN * 64, BPIECES = BN / 16, NB = 4, PF = 3;              // weight stage: BN rows x 32 channels; ring of NB, PF half-steps ahead
-  constexpr int NPA = (APIECES + NW - 1) / NW;
-  static_assert(BPIECES == NW, "one weight piece per wave and half-step");
-  constexpr int WTN = BN / NWN, TN = WTN / 32;
-  static_assert(NWM == 4 && TN >= 1, "tile/wave mismatch");
-  extern __shared__ __attribute__((aligned(128))) char smem[];
-  char* Abuf = smem;                       // halo stage(s)
-  char* Bbuf = smem + ABUFS * A_BYTES;     // ring of four weight half-stages
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: LDS-DMA destinations and piece bookkeeping stay in SGPRs
-  const int wn = wave / NWM, wm = wave % NWM;
-  // XCD-aware tile order (knob DCT_TUNE_IGEMM_XCD): workgroups go round-robin over the 8 XCDs, each with its own L2.
-  // Tile t of a 1-D grid is given to XCD t % 8's (t / 8)-th slot, and an XCD's slots cover a CONTIGUOUS range of
-  // (patch, channel tile) pairs with the channel tile fastest: the N tiles of one patch and neighbouring patches
-  // (shared halo rows) read their input through the same L2.
-  int bx, ntile;
-  if (p.xcd_tiles > 0) {
-    const int per_xcd = p.xcd_tiles;                          // ceil(total tiles / 8)
-    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int nt = p.N / BN;
-    if ((blockIdx.x >> 3) >= per_xcd || t >= p.xcd_total) return;
-    bx = t / nt; ntile = t - bx * nt;
-  } else { bx = blockIdx.x; ntile = blockIdx.y; }
-  const int tx = bx % tiles_x; bx /= tiles_x;
-  const int ty = bx % tiles_y; const int img = bx / tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW, n0 = ntile * BN;
-  const long long Ktot = 9ll * p.Cin;
-  const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
-  const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
-
-  // halo staging: wave w issues pieces w, w + NW, ...; lane -> (row = piece * 8 + lane / 8, its swizzled source chunk)
-  int aoff[NPA];                      // element offsets (the host admits this kernel only when x spans < 2^31 elements)
-#pragma unroll
-  for (int i = 0; i < NPA; ++i) {
-    const int piece = wave + i * NW;
-    const int row = piece * 8 + (lane >> 3);
-    aoff[i] = -1;
-    if (piece < APIECES && row < HROWS) {
-      const int hy = row / HW, hx = row - hy * HW;
-      const int iy = y0 - p.pad_h + hy, ix = x0 - p.pad_w + hx;
-      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-        aoff[i] = (int)(img * p.xsN + iy * p.xsH + ix * p.xsW + (((lane & 7) ^ ((row >> 1) & 7)) * 8));
-    }
-  }
-  auto stageA = [&](char* buf, int c0) {
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-      const int piece = wave + i * NW;
-      if (piece < APIECES) {
-        const char* src = aoff[i] >= 0 ? reinterpret_cast<const char*>(xb + aoff[i] + c0) : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + piece * 1024), 16, 0, 0);
-      }
-    }
-  };
-  // weight staging: ONE piece per wave and half-step = 16 cout rows x 64 bytes (32 input channels of one tap).  16-byte chunk c of
-  // row r sits at chunk c ^ (((r >> 2) & 1) << 1): with 64-byte rows that makes the ds_read_b128 lane groups (16 consecutive rows at
-  // one logical chunk, or two runs of them) hit 16 distinct 16-byte slots of the 256-byte bank row.
-  unsigned woffL;
-  {
-    const int row = wave * 16 + (lane >> 2);
-    woffL = (unsigned)(((long long)row * Ktot + (((lane & 3) ^ (((row >> 2) & 1) << 1)) * 8)) * 2);
-  }
-  const char* wtile = p.w + (long long)n0 * Ktot * 2;
-  // half-step q of the tile (0 .. 18 * nch - 1): channel slice q / 18, tap (q % 18) / 2, 32-channel half q % 2
-  auto stageBq = [&](int q) {
-    const int c = q / 18, rem = q - 18 * c, tap = rem >> 1, hh = rem & 1;
-    const char* wstep = wtile + ((long long)tap * p.Cin + c * 64 + hh * 32) * 2;          // scalar
-    __builtin_amdgcn_global_load_lds((gptr_t)(wstep + woffL), (lptr_t)(Bbuf + (q & (NB - 1)) * B_BYTES + wave * 1024), 16, 0, 0);
-  };
-
-  constexpr int TR = WTN / 16;                 // 16-channel row blocks per wave
-  f32x4 acc[TR][2];
-#pragma unroll
-  for (int i = 0; i < TR; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // v_mfma_f32_16x16x32_bf16 fragments: lane l holds row / column l % 16 and the 16-byte K chunk l / 16 of a 32-deep
-  // sub-step.  Column block j of the wave's 32 pixels is patch row 2 * wm + j, columns 0..15 in lane order.
-  const int l15 = lane & 15, kq = lane >> 4;
-  const int rho0 = (2 * wm) * HW + l15;
-  const int aswz = (l15 >> 1) & 7;
-
-  const int nch = p.Cin / 64, nq = 18 * nch;
-  const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
-  // this wave's halo pieces per slice (pieces wave, wave + NW, ... below APIECES): the LDS-DMA bookkeeping below counts them
-  int nA = 0;
-#pragma unroll
-  for (int i = 0; i < NPA; ++i) nA += (wave + i * NW < APIECES) ? 1 : 0;
-  stageA(Abuf, 0);
-#pragma unroll
-  for (int q = 0; q < PF; ++q) stageBq(q);                  // (nq >= 18 > PF)
-  float* biasL = reinterpret_cast<float*>(smem + ABUFS * A_BYTES + NB * B_BYTES);   // bias -> LDS now: no memory round trip in the epilogue
-  if (tid < BN) biasL[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
-  // Fragment addresses (see igemm3m_kernel).  Weights: 64-byte rows, a lane's address is a constant + the ring slot.
-  const unsigned Wb = smem_l + ABUFS * A_BYTES + (wn * WTN + l15) * 64 + ((kq ^ ((l15 >> 1) & 2)) * 16);
-  // The weight ring runs PF half-steps ahead of the MFMAs; a wave waits (counted vmcnt: LDS-DMA pieces retire in issue order)
-  // only for the pieces of the half-step it is about to read, then the block meets at a raw s_barrier -- never a vmcnt(0) in the
-  // loop (PMC on the two-stage kernel: its waves sat parked at "vmcnt(0) + barrier" for 43 % of every K-step, the DMA of step
-  // t + 1 being issued only one step -- 0.6 us -- before it is needed).
-  int h1 = 1, h2 = 1;                                        // pieces this wave issued in the previous half-step and the one before
-  int ab = 0;
-  for (int c = 0; c < nch; ++c) {
-    const unsigned Xs = smem_l + ab * A_BYTES;                // scalar
-#pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-      unsigned rho_t = rho0;
-      asm volatile("" : "+v"(rho_t));                        // the tap's addresses are recomputed here (6 VALU), not kept hoisted in registers
-      const unsigned pi0 = rho_t + (t / 3) * HW + (t % 3), pi1 = pi0 + HW;
-      const unsigned x00 = (Xs + (pi0 << 7)) | (((kq ^ (pi0 >> 1)) & 7) << 4);
-      const unsigned x10 = (Xs + (pi0 << 7)) | (((kq ^ (pi1 >> 1)) & 7) << 4);     // (+ HW * 128 through the read's offset)
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int q = (c * 9 + t) * 2 + hh;
-        wait_vm(h1 + h2);                                    // the pieces of half-step q (and, at a slice's first step, its halo) have landed
-        __builtin_amdgcn_s_barrier();                        // ... for every wave; and every wave is done reading half-step q - 1
-        int issued = 0;
-        if (ABUFS == 2 && t == 0 && hh == 0 && c + 1 < nch) { stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64); issued += nA; }
-        if (q + PF < nq) { stageBq(q + PF); issued += 1; }
-        h2 = h1; h1 = issued;
-        const unsigned wa = Wb + (q & (NB - 1)) * B_BYTES;
-        bf16x8 a[TR], b[2];
-        RdRows<0, TR, 16 * 64>::run(wa, a);
-        rd128o<0>(hh ? (x00 ^ 64u) : x00, b[0]);
-        rd128o<HW * 128>(hh ? (x10 ^ 64u) : x10, b[1]);
-        lgkm_wait3<0>();
-#pragma unroll
-        for (int i = 0; i < TR; ++i) touch8(a[i]);
-        touch8(b[0]); touch8(b[1]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TR; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    ab ^= 1;
-  }
-  __syncthreads();                                           // every wave is done with the stages: the epilogue reuses them
-
-  // ---- epilogue (staged through LDS as in v2): tile row = patch pixel py * 16 + px
-  constexpr int CPR = BN / 8;
-  static_assert(BM * BN * 2 <= ABUFS * A_BYTES + (NB * B_BYTES - BM * 8), "epilogue tile does not fit");
-  char* tile = smem;                                   // BM * BN * 2 bytes: the halo stage(s) and, if needed, the head of the weight stages
-  int* rowY = reinterpret_cast<int*>(smem + ABUFS * A_BYTES + NB * B_BYTES - BM * 8);   // tail of the weight stages
-  int* rowM = rowY + BM;
-  if (tid < BM) {
-    const int oy = y0 + (tid >> 4), ox = x0 + (tid & 15);
-    int oy_ = -1, om_ = -1;
-    if (oy < p.Ho && ox < p.Wo) {
-      oy_ = (int)(img * p.ysN + oy * p.ysH + ox * p.ysW);
-      om_ = (int)(img * p.msN + oy * p.msH + ox * p.msW);
-    }
-    rowY[tid] = oy_; rowM[tid] = om_;
-  }
-  {
-    // accumulator (i, j): channels wn * WTN + 16 * i + 4 * kq + {0..3} of pixel (patch row 2 * wm + j, column l15)
-    f32x4 bv[TR];
-#pragma unroll
-    for (int i = 0; i < TR; ++i) bv[i] = *reinterpret_cast<const f32x4*>(biasL + wn * WTN + i * 16 + 4 * kq);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = (2 * wm + j) * TW + l15;
 #pragma unroll
       for (int i = 0; i < TR; ++i) {
         const int cl = wn * WTN + i * 16 + 4 * kq;
@@ -1404,27 +939,20 @@ struct Plan {
   long long tiles;
 };
 
-int g_tune_igemm_v2 = 1;        // dct_tune_set(DCT_TUNE_IGEMM_V2, 0) forces the register-staged kernel
+// Planner settings (dct_tune_set).  The per-tap tile always runs on eight waves (32 pixels x 64 channels each: an LDS-DMA piece
+// costs ~100 issue cycles, so halving the pieces per wave shortened every K-step by 4-15 %) with the LDS-staged epilogue where
+// the alignment allows it (scattered 8-byte stores kept the last waves in the store queue for a quarter of a block's life).
 int g_tune_igemm_split_target = 450;   // block target of a split layer (tiles < 200)
 int g_tune_igemm_split = -1;    // >= 1 forces the split-K factor
-int g_tune_igemm_waves8 = 1;    // 8 waves per tile (32 pixels x 64 channels each) instead of 4: an LDS-DMA piece costs ~100 issue
-                                // cycles, so halving the pieces per wave shortens every K-step (+4..15 % in-process A/B)
-int g_tune_igemm_staged = 1;    // 0: scattered 8-byte epilogue stores instead of the LDS-staged epilogue
-int g_tune_igemm_xcd = 0;       // XCD-aware tile order of the shared-halo kernel
-int g_tune_igemm_xcd2 = 0;      // XCD-aware tile order of the per-tap kernel (weight slices stay in one XCD's L2)
-int g_tune_igemm_mfma16 = 1;    // shared-halo kernel on 16x16x32 MFMAs (igemm3m_kernel)
 int g_tune_igemm_halo_cover = 75;      // percent of the image the 8 x 16 patches must cover
 int g_tune_igemm_halo_min_blocks = 400;
-int g_tune_igemm_ring = 0;      // 1: shared-halo kernel with a four-slot ring of 32-channel weight half-stages, counted vmcnt (igemm3r_kernel):
-                                // bit-identical, measured 15 % SLOWER than two 64-channel stages (twice the barriers for the same MFMAs)
-int g_tune_igemm_waves4h = 0;   // 1: the 128-channel shared-halo tile on four waves of 64 x 64 instead of eight of 32 x 64
-int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3_kernel); 0: always v2
+int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3m_kernel); 0: always the per-tap kernel
 
 static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int M, int N, Plan& pl) {
   const int bk0 = dtype == DCT_BF16 ? 32 : 16;
   if (x->c % bk0 != 0) return false;
   if (N % 64 != 0) return false;
-  pl.v2 = (dtype == DCT_BF16 && x->c % 64 == 0 && g_tune_igemm_v2) ? 1 : 0;
+  pl.v2 = (dtype == DCT_BF16 && x->c % 64 == 0) ? 1 : 0;
   if (pl.v2) {
     pl.bk = 64;
     if (N % 128 == 0) { pl.bn = 128; pl.bm = 128; } else { pl.bn = 64; pl.bm = 256; }
@@ -1473,14 +1001,6 @@ static void launch_v2(const IgemmParams& p, dim3 grid, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  if (g_tune_igemm_xcd2 && (long long)grid.x * grid.y * grid.z >= 16) {
-    IgemmParams q = p;
-    q.xcd_gm = (int)grid.x; q.xcd_gn = (int)grid.y;
-    q.xcd_total = (int)(grid.x * grid.y * grid.z);
-    q.xcd_tiles = (q.xcd_total + 7) / 8;
-    DCT_LAUNCH(DCT_PROF_IGEMM, (igemm2_kernel<BM, BN, WM, WN, BOUNDS>), dim3((unsigned)(q.xcd_tiles * 8)), dim3(WM * WN * 64), lds, st, q);
-    return;
-  }
   DCT_LAUNCH(DCT_PROF_IGEMM, (igemm2_kernel<BM, BN, WM, WN, BOUNDS>), grid, dim3(WM * WN * 64), lds, st, p);
 }
 
@@ -1489,51 +1009,12 @@ static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images
   constexpr size_t lds = ABUFS * (size_t)(23 * 1024) + 2 * (size_t)BN * 128 + (size_t)BN * 4;   // halo stage(s), two weight stages, bias
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3_kernel<BN, 4, NWN, ABUFS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3m_kernel<BN, 4, NWN, ABUFS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const dim3 grid((unsigned)(images * tiles_y * tiles_x), p.N / BN, 1);
-  if (g_tune_igemm_mfma16) {
-    IgemmParams q = p;
-    dim3 g1 = grid;
-    if (g_tune_igemm_xcd) {
-      q.xcd_total = (int)(grid.x * grid.y);
-      q.xcd_tiles = (q.xcd_total + 7) / 8;
-      g1 = dim3((unsigned)(q.xcd_tiles * 8), 1, 1);
-    }
-    static bool attr16 = false;
-    if (!attr16) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3m_kernel<BN, 4, NWN, ABUFS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr16 = true;
-    }
-    if (g_tune_igemm_ring) {
-      static bool attrr = false;
-      if (!attrr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3r_kernel<BN, 4, NWN, ABUFS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attrr = true;
-      }
-      DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3r_kernel<BN, 4, NWN, ABUFS>), g1, dim3(4 * NWN * 64), lds, st, q, tiles_x, tiles_y);
-      return;
-    }
-    if constexpr (BN == 128) {
-      if (g_tune_igemm_waves4h) {       // the same tile on FOUR waves of 64 pixels x 64 channels (two blocks per CU = two waves per SIMD)
-        static bool attr4 = false;
-        if (!attr4) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3m_kernel<BN, 2, NWN, ABUFS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-          attr4 = true;
-        }
-        DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 2, NWN, ABUFS>), g1, dim3(2 * NWN * 64), lds, st, q, tiles_x, tiles_y);
-        return;
-      }
-    }
-    DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 4, NWN, ABUFS>), g1, dim3(4 * NWN * 64), lds, st, q, tiles_x, tiles_y);
-    return;
-  }
-  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3_kernel<BN, 4, NWN, ABUFS>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
+  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 4, NWN, ABUFS>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
 }
 
 // Packed-rows shared-halo kernel (igemm3p_kernel) for small images: geometry and split over channel slices.
@@ -1594,13 +1075,9 @@ static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
   dim3 grid(div_up(p.M, pl.bm), p.N / pl.bn, pl.splits);
   if (pl.v2) {
     if (pl.bn == 128) {
-      if (g_tune_igemm_waves8) {
-        if (pl.bounds) launch_v2<128, 128, 4, 2, true>(p, grid, st); else launch_v2<128, 128, 4, 2, false>(p, grid, st);
-      } else if (pl.bounds) launch_v2<128, 128, 2, 2, true>(p, grid, st); else launch_v2<128, 128, 2, 2, false>(p, grid, st);
+      if (pl.bounds) launch_v2<128, 128, 4, 2, true>(p, grid, st); else launch_v2<128, 128, 4, 2, false>(p, grid, st);
     } else {
-      if (g_tune_igemm_waves8) {
-        if (pl.bounds) launch_v2<256, 64, 8, 1, true>(p, grid, st); else launch_v2<256, 64, 8, 1, false>(p, grid, st);
-      } else if (pl.bounds) launch_v2<256, 64, 4, 1, true>(p, grid, st); else launch_v2<256, 64, 4, 1, false>(p, grid, st);
+      if (pl.bounds) launch_v2<256, 64, 8, 1, true>(p, grid, st); else launch_v2<256, 64, 8, 1, false>(p, grid, st);
     }
   } else if (pl.bn == 128) {
     DCT_LAUNCH(DCT_PROF_IGEMM, (igemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, p);
@@ -1707,8 +1184,8 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   p.cin_iters = x->c / pl.bk;
   p.partial = nullptr;
   p.staged = 0;
-  p.xcd_tiles = 0; p.xcd_total = 0; p.xcd_gm = 0; p.xcd_gn = 0; p.stamps = nullptr;
-  if (pl.v2 && pl.splits == 1 && !d->accumulate && g_tune_igemm_staged) {
+  p.stamps = nullptr;
+  if (pl.v2 && pl.splits == 1 && !d->accumulate) {
     const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
                      (long long)y->n * y->sn < (1ll << 31);
     const bool m16 = !mask || (!((uintptr_t)mask->ptr & 15) && mask->sw % 8 == 0 && mask->sh % 8 == 0 && mask->sn % 8 == 0 &&
@@ -1721,7 +1198,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     if (!workspace || workspace_bytes < need) return DCT_ERR_WORKSPACE;
     p.partial = (float*)workspace;
   }
-  if (pl.v2 && g_tune_igemm_halo && g_tune_igemm_staged && (!bias || !((uintptr_t)bias & 15)) && d->R == 3 && d->S == 3 && d->stride == 1 &&
+  if (pl.v2 && g_tune_igemm_halo && (!bias || !((uintptr_t)bias & 15)) && d->R == 3 && d->S == 3 && d->stride == 1 &&
       d->dil == 1 && !p.scatter) {
     // one-block-per-CU ping-pong tile (igemm4.hip): 256 pixels x 128 channels, eight waves of 64 x 64
     const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
@@ -1745,7 +1222,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
       }
     }
   }
-  if (pl.v2 && pl.splits == 1 && g_tune_igemm_halo && g_tune_igemm_staged && (!bias || !((uintptr_t)bias & 15)) && d->R == 3 && d->S == 3 && d->stride == 1 &&
+  if (pl.v2 && pl.splits == 1 && g_tune_igemm_halo && (!bias || !((uintptr_t)bias & 15)) && d->R == 3 && d->S == 3 && d->stride == 1 &&
       d->dil == 1 && !p.scatter) {
     // shared-halo kernel: 8 x 16 output patches; worth it when the patches cover the image well and fill the device
     const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
@@ -1766,7 +1243,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
       return dct_check_launch();
     }
   }
-  if (pl.v2 && g_tune_igemm_staged && (!bias || !((uintptr_t)bias & 15))) {
+  if (pl.v2 && (!bias || !((uintptr_t)bias & 15))) {
     const PlanP pp = make_plan_p(x, y, d, dtype, p.N);
     if (pp.use) {
       const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
@@ -1788,64 +1265,28 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   return rc == DCT_OK ? dct_check_launch() : rc;
 }
 
-#ifdef DCT_STAMPS
-// diagnostic build only: read (summed over the per-wave records) / zero the 16 per-phase counters of igemm3_kernel
-extern "C" int dct_debug_stamps(unsigned long long* out16, int reset) {
-  static unsigned long long* dev = nullptr;
-  const size_t bytes = (size_t)DCT_STAMP_WAVES * 16 * sizeof(unsigned long long);
-  if (!dev) {
-    if (hipMalloc(&dev, bytes) != hipSuccess) return DCT_ERR_LAUNCH;
-    (void)hipMemset(dev, 0, bytes);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dev, sizeof(dev));
-  }
-  (void)hipDeviceSynchronize();
-  if (out16) {
-    unsigned long long* host = (unsigned long long*)malloc(bytes);
-    (void)hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
-    for (int k = 0; k < 16; ++k) out16[k] = 0;
-    for (size_t w = 0; w < DCT_STAMP_WAVES; ++w)
-      for (int k = 0; k < 16; ++k) out16[k] += host[w * 16 + k];
-    free(host);
-  }
-  if (reset) (void)hipMemset(dev, 0, bytes);
-  return DCT_OK;
-}
-#endif
 
 int dct_tune_set_wgrad(int knob, int value);  // wgrad.hip
 extern int g_enet_wgrad_max_blocks;           // enet.hip
 extern int g_enet_reduce_ppt;                 // enet.hip
-extern int g_enet_reduce_vec;                 // enet.hip
 extern int g_enet_fold_threads;               // enet.hip
 extern int g_enet_mfma;                       // enet.hip
-extern int g_enet_bn_owner;                   // enet.hip
-extern int g_enet_mwgrad_waves, g_enet_mwgrad_min_steps, g_enet_apply_vec, g_enet_fuse_finalize;
+extern int g_enet_mwgrad_waves, g_enet_mwgrad_min_steps, g_enet_fuse_finalize;
 
 extern "C" int dct_tune_set(int knob, int value) {
   switch (knob) {
-    case DCT_TUNE_IGEMM_V2: g_tune_igemm_v2 = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT: g_tune_igemm_split = value; return DCT_OK;
-    case DCT_TUNE_IGEMM_STAGED: g_tune_igemm_staged = value; return DCT_OK;
-    case DCT_TUNE_IGEMM_WAVES8: g_tune_igemm_waves8 = value; return DCT_OK;
     case DCT_TUNE_IGEMM_HALO: g_tune_igemm_halo = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED: g_tune_igemm_packed = value; return DCT_OK;
-    case DCT_TUNE_IGEMM_MFMA16: g_tune_igemm_mfma16 = value; return DCT_OK;
-    case DCT_TUNE_IGEMM_XCD: g_tune_igemm_xcd = value; return DCT_OK;
     case DCT_TUNE_IGEMM_HALO_MIN_BLOCKS: g_tune_igemm_halo_min_blocks = value; return DCT_OK;
     case DCT_TUNE_IGEMM_HALO_COVER: g_tune_igemm_halo_cover = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT_TARGET: if (value < 64) return DCT_ERR_BAD_ARG; g_tune_igemm_split_target = value; return DCT_OK;
     case DCT_TUNE_ENET_REDUCE_PPT: if (value < 1 || value > 4096) return DCT_ERR_BAD_ARG; g_enet_reduce_ppt = value; return DCT_OK;
     case DCT_TUNE_ENET_MWGRAD_WAVES: if (value < 64) return DCT_ERR_BAD_ARG; g_enet_mwgrad_waves = value; return DCT_OK;
     case DCT_TUNE_ENET_MWGRAD_MIN_STEPS: if (value < 4 || value % 4) return DCT_ERR_BAD_ARG; g_enet_mwgrad_min_steps = value; return DCT_OK;
-    case DCT_TUNE_ENET_APPLY_VEC: g_enet_apply_vec = value ? 1 : 0; return DCT_OK;
-    case DCT_TUNE_ENET_BN_OWNER: g_enet_bn_owner = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_MFMA: if (value < 0 || value > 3) return DCT_ERR_BAD_ARG; g_enet_mfma = value; return DCT_OK;
-    case DCT_TUNE_IGEMM_XCD2: g_tune_igemm_xcd2 = value ? 1 : 0; return DCT_OK;
-    case DCT_TUNE_IGEMM_RING: g_tune_igemm_ring = value ? 1 : 0; return DCT_OK;
-    case DCT_TUNE_IGEMM_HALO_WAVES4: g_tune_igemm_waves4h = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_SPLIT: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
-    case DCT_TUNE_ENET_REDUCE_VEC: g_enet_reduce_vec = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_ENET_FOLD_THREADS: if (value != 256 && value != 512 && value != 1024) return DCT_ERR_BAD_ARG; g_enet_fold_threads = value; return DCT_OK;
     case DCT_TUNE_ENET_FUSE_FINALIZE: g_enet_fuse_finalize = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM4: g_tune_igemm4 = value ? 1 : 0; return DCT_OK;

@@ -21,8 +21,6 @@ struct IgemmParams {
   int kiters, kiters_per_split, cin_iters;
   int cout;  // real Cout (N/4 in scatter mode)
   int staged;  // v2: LDS-staged epilogue with 16-byte row stores (host-checked alignment / 32-bit offsets)
-  int xcd_tiles, xcd_total;  // v3m / v2: XCD-aware 1-D tile order (0: plain grid)
-  int xcd_gm, xcd_gn;        // v2: tiles along M and N of the plain grid (decode of the 1-D order)
   unsigned long long* stamps;   // igemm4 diagnostic builds: per-wave cycle sums
 };
 

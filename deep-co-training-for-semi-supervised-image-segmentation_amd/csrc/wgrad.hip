@@ -811,10 +811,8 @@ struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct, slabs; int v
 int g_tune_wgrad_target = 384;     // block target of the per-tap kernel (slab bytes = blocks x 64 KiB).  In isolation ~1150 blocks is
                                    // fastest; on the whole step (tools/ab_step.py --knob 14) 256-768 are level and 1.5 % ahead of 1150
 int g_tune_wgrad3_target = 768;    // same for the filter-row kernel, in 4-wave units
-int g_tune_wgrad_groups = 2;       // wave groups per wgrad3 block (1 | 2)
 int g_tune_wgrad_rows_fill = 70;   // percent: minimum fill of the 64-row K-steps for the filter-row kernel
 int g_tune_wgrad_rows = 1;     // 3x3 stride-1 layers on wide images: three taps of a filter row per block (wgrad3_kernel)
-int g_tune_wgrad_v2 = 1;       // dct_tune_set(DCT_TUNE_WGRAD_V2, 0): register-staged kernel
 int g_tune_wgrad_chunks = -1;  // >= 1 forces the number of pixel chunks
 
 static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc* d, int dtype, WPlan& pl) {
@@ -824,7 +822,7 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
   pl.bq = (q->c % 128 == 0) ? 128 : 64;
   pl.ptiles = p->c / pl.bp; pl.qtiles = q->c / pl.bq;
   const bool fits32 = (long long)p->n * p->sn < (1ll << 30) && (long long)q->n * q->sn < (1ll << 30);   // 32-bit element offsets
-  pl.v2 = (dtype == DCT_BF16 && g_tune_wgrad_v2 && M < (1 << 24) && fits32) ? 1 : 0;
+  pl.v2 = (dtype == DCT_BF16 && M < (1 << 24) && fits32) ? 1 : 0;
   const int bkp = pl.v2 ? 64 : (dtype == DCT_BF16 ? 32 : 16);
   const long long tiles = (long long)pl.ptiles * pl.qtiles * d->R * d->S;
   long long chunks;
@@ -872,7 +870,7 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
       pl.bp = 64; pl.ptiles = p->c / 64; pl.bq = 64; pl.qtiles = q->c / 64;
       const int tiles3 = pl.ptiles * pl.qtiles * 3;
       const int target = g_tune_wgrad3_target;     // 4-wave units; swept 384 / 512 / 640 / 768 / 1024 on the UNet layers: 768 is 10-25 % ahead of the rest
-      pl.groups = g_tune_wgrad_groups == 2 ? 2 : 1;     // four groups (one 16-wave block per CU) measured 0.7 % behind two     // two wave groups per block: half the slabs at the same waves per CU
+      pl.groups = 2;     // four groups (one 16-wave block per CU) measured 0.7 % behind two     // two wave groups per block: half the slabs at the same waves per CU
       long long ch = (target / pl.groups + tiles3 / 2) / tiles3;
       if (ch > 256) ch = 256;
       if (ch > nseg / (4 * pl.groups)) ch = nseg / (4 * pl.groups);
@@ -905,7 +903,6 @@ static void launch_w(const WgradParams& wp, const WPlan& pl, hipStream_t st) {
   else DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad_kernel<T, 64, 64>), dim3(grid), dim3(256), 0, st, wp);
 }
 
-int g_tune_wgrad_waves8 = 1;    // 8 waves on the 128 x 128 tile (half the LDS-DMA pieces and decode work per wave)
 template <int BP, int BQ, int NW>
 static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
   constexpr size_t lds = 2 * 64 * (size_t)(BP + BQ) * 2;
@@ -928,22 +925,17 @@ static void launch_w3_q(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
   }
   DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT>), dim3(grid), dim3(G * NW * 64), lds, st, pr);
 }
-int g_tune_wgrad3_shift = 1;       // filter-row kernel: the three taps' x fragments from one 12-pixel window per lane (5 reads per sub-step, not 8)
-template <int BP, int BQ, int NW, bool NARROW, int G>
-static void launch_w3_t(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
-  if (g_tune_wgrad3_shift) launch_w3_q<BP, BQ, NW, NARROW, G, true>(pr, grid, st); else launch_w3_q<BP, BQ, NW, NARROW, G, false>(pr, grid, st);
-}
 static void launch_w3(const Wgrad3Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, 3);
-  // the planner only picks 64 x 64 tiles for this kernel
-  if (pl.groups == 2) {
-    if (pr.pitch > 0) launch_w3_t<64, 64, 4, true, 2>(pr, grid, st); else launch_w3_t<64, 64, 4, false, 2>(pr, grid, st);
-  } else if (pr.pitch > 0) launch_w3_t<64, 64, 4, true, 1>(pr, grid, st); else launch_w3_t<64, 64, 4, false, 1>(pr, grid, st);
+  // the planner only picks 64 x 64 tiles for this kernel; always two wave groups per block (half the fp32 slabs at the same waves
+  // per CU: +4 % on the step; one group and four groups measured behind) and the three taps' x fragments from ONE 12-pixel window
+  // per lane (QSHIFT: 5 transposing reads per sub-step instead of 8, +5-6.5 % on the twelve layers that take this kernel)
+  if (pr.pitch > 0) launch_w3_q<64, 64, 4, true, 2, true>(pr, grid, st); else launch_w3_q<64, 64, 4, false, 2, true>(pr, grid, st);
 }
 static void launch_w2(const Wgrad2Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, pr.w.R * pr.w.S);
   if (pl.bp == 128 && pl.bq == 128) {
-    if (g_tune_wgrad_waves8) launch_w2_t<128, 128, 8>(pr, grid, st); else launch_w2_t<128, 128, 4>(pr, grid, st);
+    launch_w2_t<128, 128, 8>(pr, grid, st);      // eight waves: half the LDS-DMA pieces and decode work per wave
   } else if (pl.bp == 128) launch_w2_t<128, 64, 4>(pr, grid, st);
   else if (pl.bq == 128) launch_w2_t<64, 128, 4>(pr, grid, st);
   else launch_w2_t<64, 64, 4>(pr, grid, st);
@@ -1019,14 +1011,10 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float
 }
 
 int dct_tune_set_wgrad(int knob, int value) {
-  if (knob == DCT_TUNE_WGRAD_V2) { g_tune_wgrad_v2 = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_CHUNKS) { g_tune_wgrad_chunks = value; return DCT_OK; }
-  if (knob == DCT_TUNE_WGRAD_WAVES8) { g_tune_wgrad_waves8 = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_ROWS) { g_tune_wgrad_rows = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_ROWS_FILL) { g_tune_wgrad_rows_fill = value; return DCT_OK; }
-  if (knob == DCT_TUNE_WGRAD_GROUPS) { g_tune_wgrad_groups = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD3_TARGET) { if (value < 64) return DCT_ERR_BAD_ARG; g_tune_wgrad3_target = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_TARGET) { if (value < 64) return DCT_ERR_BAD_ARG; g_tune_wgrad_target = value; return DCT_OK; }
-  if (knob == DCT_TUNE_WGRAD3_SHIFT) { g_tune_wgrad3_shift = value ? 1 : 0; return DCT_OK; }
   return DCT_ERR_BAD_ARG;
 }

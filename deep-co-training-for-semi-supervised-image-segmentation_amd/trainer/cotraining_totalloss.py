@@ -18,6 +18,8 @@ all optimizers step.  The numpy RNG is consumed once per step when ``train_adv``
 """
 from __future__ import annotations
 
+import dataclasses
+
 import contextlib
 import os
 from operator import itemgetter
@@ -80,6 +82,33 @@ def _make_writer(save_dir):
         return SummaryWriter(str(save_dir))
     except Exception:
         return _NullWriter()
+
+
+@dataclasses.dataclass
+class ExecutionPlan:
+    """Layout switches of the fused step (none changes a result bit; each is an A/B handle whose default is the measured optimum --
+    DESIGN.md 4.3).  ``CoTrainer.<name>`` reads and writes the field of the same name (``tr.model_streams = False`` still works)."""
+    batch_lab_unlab: bool = True        # one B_l+B_u pass per batch-independent net (see _run_step_fused)
+    model_streams: bool = True          # one HIP stream per model in the fused step (see _streams)
+    spread_streams: bool = True         # deal the model / pass streams over different hardware queues (stream_sched.queue_groups)
+    pass_streams: bool = True           # nets that support it (Enet): the backward passes of one model run on separate streams
+    group_one: bool = True              # labeled and unlabeled passes in ONE group where the batch shapes agree (False: two groups, two queues)
+    leaf_offload: bool = True           # ... with the adversarial backward pass's weight gradients on the queue that leaves idle
+    group_passes: bool = True           # ... and issue the 2S co-training passes as grouped launches where the networks can (Enet)
+    wide_forward: bool = True           # networks with deferred running statistics: lay the step out on four hardware queues (_run_step_wide)
+    adv_chain_layout: bool = True       # two batch-independent networks (UNet) with FGSM: see _run_step_adv_chain
+    early_backward: bool = True         # start the labeled / unlabeled backward passes right after the JSD, beside the adversarial block
+    grad_overwrite: bool = True         # nets that support it: first backward pass of a step writes the gradients (no zero fill)
+    segmented_graphs: Optional[bool] = None   # capture the step as one graph per stream segment (different hardware queues) instead of one
+                                        # graph with forked streams inside (one queue).  None = by network: those made of many short launches
+                                        # ask for it (Enet: 39 -> 22 ms per cfg4 step), those whose kernels fill the chip do not (UNet)
+    use_hip_graph: bool = True          # replay the fused step from a captured HIP graph (trainer/step_graph.py)
+    ddp_segmented_graph: bool = True    # data parallelism: replay the step as graph segments around the eager all-reduces
+    force_loss_scale: Optional[float] = None  # tests: a power of two applied to every loss gradient and divided out by the optimizers
+
+
+def _plan_property(name):
+    return property(lambda self: getattr(self.plan, name), lambda self, value: setattr(self.plan, name, value))
 
 
 class CoTrainer(Trainer):
@@ -146,40 +175,19 @@ class CoTrainer(Trainer):
         self.grad_sync = grad_sync          # dct_amd.ddp.FlatGradSync or None (single process)
         if grad_sync is not None and hasattr(grad_sync, "prepare"):
             grad_sync.prepare()             # small models' gradient buffers -> one arena, one collective per step
-        self.batch_lab_unlab = True         # one B_l+B_u pass per batch-independent net (see _run_step_fused)
-        self.model_streams = True           # one HIP stream per model in the fused step (see _streams)
+        self.plan = ExecutionPlan()         # how the fused step is laid out on streams / queues / graphs (every switch in one place)
         self._stream_pool = None
         self._sched = EagerSchedule()       # stream operations of the fused step: eager, or recorded (trainer/stream_sched.py)
-        self.spread_streams = True          # deal the model / pass streams over different hardware queues (stream_sched.queue_groups)
         self._dealer = None
-        self.pass_streams = True            # nets that support it (Enet): the backward passes of one model run on separate streams
         self._pass_pool = None
         self._pass_bufs = {}
-        self.group_one = True               # labeled and unlabeled passes in ONE group where the batch shapes agree (False: two groups, two queues)
-        self.leaf_offload = True            # ... with the adversarial backward pass's weight gradients on the queue that leaves idle
-        self.group_passes = True            # ... and issue the 2S co-training passes as grouped launches where the networks can (Enet)
-        self.wide_forward = True            # networks with deferred running statistics: lay the step out on four hardware queues
-                                            # (see _run_step_wide)
         self._qstreams = None
-        self.adv_chain_layout = True        # two batch-independent networks (UNet) with FGSM: see _run_step_adv_chain
         self._step_hint_adv_chain = False
-        self.early_backward = True          # start the labeled / unlabeled backward passes right after the JSD, beside the
-                                            # adversarial block (pass-stream nets; see _run_step_fused)
-        self.grad_overwrite = True          # nets that support it: first backward pass of a step writes the gradients (no zero fill)
         self._overwrite_models = set()
         self._pass_early = {}
-        self.segmented_graphs = None        # capture the step as one graph per stream segment (they then run on different hardware
-                                            # queues) instead of one graph with forked streams inside (one queue): stream_sched.py.
-                                            # None = by network: those made of many short launches ask for it (Enet: ~780 launches of
-                                            # ~8 us per pass; 39 -> 22 ms per cfg4 step), those whose kernels fill the chip do not
-                                            # (UNet: 6.24 against 6.06 ms per cfg2 step)
-        self.use_hip_graph = True           # replay the fused step from a captured HIP graph (trainer/step_graph.py)
         self._step_graphs = None
         self.last_step = None
-        self.force_loss_scale = None        # tests: a power of two applied to every loss gradient and divided out by the optimizers
         self._defer_optimizer = False       # segmented capture: _finish_step stops after the backward passes (see _optimizer_phase)
-        self.ddp_segmented_graph = True     # data parallelism: replay the step as graph segments around the eager all-reduces (UNet:
-                                            # one per gradient bucket, issued from inside the backward pass; Enet: one per model)
 
     def to(self, device: torch.device):
         [segmentator.to(device) for segmentator in self.segmentators]
@@ -1183,3 +1191,8 @@ class CoTrainer(Trainer):
             self.segmentator = self.segmentators[i]
             super().checkpoint(score, epoch, filename=f'best_{i}.pth')
             self.best_scores[i] = self.best_score
+
+
+for _f in dataclasses.fields(ExecutionPlan):
+    setattr(CoTrainer, _f.name, _plan_property(_f.name))
+del _f

@@ -411,52 +411,38 @@ enum { DCT_PROF_IGEMM = 0, DCT_PROF_WGRAD = 1, DCT_PROF_POINTWISE = 2, DCT_PROF_
 int dct_prof_enable(int on);
 /* Process-wide tuning / A-B knobs for benchmarking (never needed for correctness; defaults are the
  * shipped configuration). */
-enum { DCT_TUNE_IGEMM_V2 = 0,      /* 1 (default): LDS-DMA staged bf16 kernel; 0: register-staged kernel */
-       DCT_TUNE_IGEMM_SPLIT = 1,   /* >= 1: force the split-K factor; -1 (default): planner's choice */
-       DCT_TUNE_WGRAD_V2 = 2,      /* 1 (default): LDS-DMA staged bf16 wgrad kernel; 0: register-staged */
+enum { DCT_TUNE_IGEMM_SPLIT = 1,   /* >= 1: force the split-K factor; -1 (default): planner's choice */
        DCT_TUNE_WGRAD_CHUNKS = 3,  /* >= 1: force the number of pixel chunks (split-K) of wgrad */
-       DCT_TUNE_IGEMM_STAGED = 4,  /* 1 (default): LDS-staged epilogue with 16-byte row stores; 0: scattered 8-byte stores */
-       DCT_TUNE_IGEMM_WAVES8 = 5,  /* 1 (default): 8 waves per tile; 0: 4 waves */
-       DCT_TUNE_WGRAD_WAVES8 = 6,  /* 1 (default): 8 waves on the 128x128 weight-gradient tile; 0: 4 waves */
-       DCT_TUNE_IGEMM_HALO = 7,    /* 1 (default): shared-halo kernel for 3x3 stride-1 layers on large images; 0: v2 everywhere */
-       DCT_TUNE_WGRAD_ROWS = 8,    /* 1 (default): filter-row weight-gradient kernel (three taps share the x strip); 0: v2 */
+       DCT_TUNE_IGEMM_HALO = 7,    /* 1 (default): shared-halo kernel for 3x3 stride-1 layers on large images; 0: per-tap kernel everywhere
+                                      (the reference path of the bit-level cross-checks in tests/test_kernels_gpu.py) */
+       DCT_TUNE_WGRAD_ROWS = 8,    /* 1 (default): filter-row weight-gradient kernel (three taps share the x strip); 0: per-tap kernel */
        DCT_TUNE_WGRAD_ROWS_FILL = 9,   /* percent (default 70): minimum fill of the filter-row kernel's 64-pixel K-steps */
        DCT_TUNE_IGEMM_PACKED = 10,     /* 1 (default): packed-rows shared-halo kernel for 3x3 stride-1 layers on small images; 0: per-tap kernel */
-       DCT_TUNE_IGEMM_MFMA16 = 11,     /* 1 (default): shared-halo kernel on v_mfma_f32_16x16x32_bf16; 0: 32x32x16 */
        DCT_TUNE_ENET_WGRAD_BLOCKS = 12,/* 1..1024 (default 1024): cap on the pixel chunks (blocks) of dct_enet_wgrad */
-       DCT_TUNE_WGRAD_GROUPS = 13,     /* 1 | 2 (default 2): wave groups per block of the filter-row weight-gradient kernel */
        DCT_TUNE_WGRAD_TARGET = 14,     /* >= 64 (default: see wgrad.hip): block target of the per-tap weight-gradient kernel */
        DCT_TUNE_WGRAD3_TARGET = 15,    /* >= 64: block target (4-wave units) of the filter-row weight-gradient kernel */
        DCT_TUNE_IGEMM_SPLIT_TARGET = 16, /* >= 64 (default 450): block target of a split-K conv layer */
-       DCT_TUNE_IGEMM_XCD = 17,        /* 1: XCD-aware tile order in the shared-halo kernel (default 0: level on the step) */
        DCT_TUNE_ENET_REDUCE_PPT = 18,  /* pixels per thread of an Enet per-channel reduction (default: see enet.hip) */
        DCT_TUNE_IGEMM_HALO_MIN_BLOCKS = 19,  /* default 400: fewest blocks for which the shared-halo patch kernel is taken */
        DCT_TUNE_IGEMM_HALO_COVER = 20,       /* percent (default 75): least image cover of its 8 x 16 patches */
-       DCT_TUNE_ENET_REDUCE_VEC = 21,        /* 1 (default): 8-channel vector loads in the Enet per-channel reductions; 0: scalar kernel */
-       DCT_TUNE_ENET_FOLD_THREADS = 22,      /* 256 | 512 | 1024 (default): threads of the one-block fold kernels behind those reductions */
+       DCT_TUNE_ENET_FOLD_THREADS = 22,      /* 256 | 512 | 1024 (default): threads of the one-block fold kernels behind the Enet reductions */
        DCT_TUNE_IGEMM_PACKED_SPLIT = 23,     /* default 100: packed-rows kernel splits layers with fewer blocks over channel slices */
        DCT_TUNE_IGEMM_PACKED_FILL = 24,      /* percent (default 76): least fill of the packed-rows kernel's 128-pixel tiles */
-       DCT_TUNE_IGEMM_XCD2 = 25,             /* 1: XCD-aware tile order in the per-tap kernel (default 0: level on the step) */
        DCT_TUNE_ENET_MFMA = 26,              /* bf16 / f16 Enet: bit 0 = MFMA form of the convolutions with >= 16 input channels,
                                                 bit 1 = of the weight gradients; 3 (default), 0 = the fp32 VALU kernels */
-       DCT_TUNE_ENET_BN_OWNER = 27,          /* 1: one-launch channel-owner BatchNorm statistics / backward for tensors of <= 32768 pixels
-                                                with whole 8-channel groups (measured slower); 0 (default): split reduction + fold [+ apply] */
        DCT_TUNE_ENET_MWGRAD_WAVES = 28,      /* >= 64 (default 2048): waves an MFMA weight-gradient launch aims for */
        DCT_TUNE_ENET_MWGRAD_MIN_STEPS = 29,  /* multiple of 4 (default 4): least 16-pixel MFMA steps per pixel slice */
-       DCT_TUNE_ENET_APPLY_VEC = 30,         /* 1: BatchNorm-backward apply kernel on 8 channels per thread (measured slower in the step);
-                                                0 (default): one element per thread */
-       DCT_TUNE_IGEMM_RING = 31,             /* 1: shared-halo conv kernel with a four-slot ring of 32-channel weight half-stages filled three half-steps
-                                                ahead (counted vmcnt, raw barrier) -- bit-identical, measured 15 % slower; 0 (default): two 64-channel stages */
-       DCT_TUNE_IGEMM_HALO_WAVES4 = 32,      /* 1: the 128-channel shared-halo tile on four waves of 64 pixels x 64 channels; 0: eight of 32 x 64 */
-       DCT_TUNE_WGRAD3_SHIFT = 33,           /* 1 (default): filter-row weight gradient builds a row's three x fragments from one 12-pixel window per lane
-                                                (register shifts) instead of three LDS reads; 0: one read per tap */
-       DCT_TUNE_ENET_FUSE_FINALIZE = 34,
+       DCT_TUNE_ENET_FUSE_FINALIZE = 34,     /* 1: Enet BatchNorm / bias-sum finalizes ride in the producing launch's last block (measured slower:
+                                                csrc/enet.hip g_enet_fuse_finalize); 0 (default): one-block launches of their own */
        DCT_TUNE_IGEMM4 = 35,                 /* 1: 3x3 stride-1 bf16 layers on the persistent one-block-per-CU ping-pong tile (csrc/igemm4.hip); 0 (default): igemm.hip tiles -- level on the step */
        DCT_TUNE_IGEMM4_FILL = 36,            /* percent (default 70): least fill of its 256-pixel tiles */
        DCT_TUNE_IGEMM4_MIN_BLOCKS = 37,      /* default 96: fewest blocks for which it is taken */
        DCT_TUNE_IGEMM4_SPLIT_BELOW = 38,     /* default 200: layers with fewer blocks are split over channel slices (fp32 slabs) */
-       DCT_TUNE_IGEMM4_BLOCKS = 39 };        /* persistent blocks per launch of that kernel; 0 (default): one per compute unit */   /* 1: Enet BatchNorm / bias-sum finalizes ride in the producing launch's last block (measured slower:
-                                                csrc/enet.hip g_enet_fuse_finalize); 0 (default): one-block launches of their own */
+       DCT_TUNE_IGEMM4_BLOCKS = 39 };        /* persistent blocks per launch of that kernel; 0 (default): one per compute unit */
+/* (Knob numbers are stable across rounds; the gaps are A/B switches of variants that were measured slower and removed with their
+ *  kernels -- DESIGN.md 4.1 / 4.2: register-staged bf16 kernels, 4-wave tiles, scattered epilogue stores, the 32x32x16 shared-halo
+ *  form, XCD-aware tile orders, the weight-ring and four-fat-wave shared-halo tiles, one / four wave groups and per-tap reads in the
+ *  filter-row weight gradient, the scalar Enet reductions, the channel-owner BatchNorm, the vector BatchNorm-backward apply.) */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 

@@ -165,19 +165,11 @@ def test_enet_convT(K, dt, cin, cout, k, pad, opad, in_f32):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("C,act", [(16, 2), (64, 3), (13, 2), (3, 3), (64, 0)])
 @pytest.mark.parametrize("training", [True, False])
-@pytest.mark.parametrize("owner,shape", [(1, (2, 9, 11)), (1, (3, 41, 37)), (0, (3, 41, 37)), (3, (3, 41, 37))])
-def test_enet_bn_fwd_bwd(K, dt, C, act, training, owner, shape):
-    """owner = 1: the one-launch channel-owner kernels where they apply (whole 8-channel groups; the 13- and 3-channel cases
-    take the split reduction either way); owner = 0 (the default): split reduction + one-block fold + apply; owner = 3: the same
-    with the 8-channels-per-thread apply kernel."""
-    from dct_amd import _lib
-    _lib.check(_lib.load().dct_tune_set(27, 1 if owner == 1 else 0), "dct_tune_set(ENET_BN_OWNER)")
-    _lib.check(_lib.load().dct_tune_set(30, 1 if owner == 3 else 0), "dct_tune_set(ENET_APPLY_VEC)")      # 3: 8-channel apply kernel
-    try:
-        _bn_fwd_bwd(K, dt, C, act, training, shape)
-    finally:
-        _lib.check(_lib.load().dct_tune_set(27, 0), "dct_tune_set(ENET_BN_OWNER)")
-        _lib.check(_lib.load().dct_tune_set(30, 0), "dct_tune_set(ENET_APPLY_VEC)")
+@pytest.mark.parametrize("shape", [(2, 9, 11), (3, 41, 37)])
+def test_enet_bn_fwd_bwd(K, dt, C, act, training, shape):
+    """BatchNorm statistics / apply / backward: split reduction + one-block fold + apply (whole 8-channel groups take the vector
+    reduction kernel, the 13- and 3-channel cases the scalar one)."""
+    _bn_fwd_bwd(K, dt, C, act, training, shape)
 
 
 def _bn_fwd_bwd(K, dt, C, act, training, shape):

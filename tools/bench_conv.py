@@ -112,7 +112,6 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--only", default="", help="comma-separated layer names")
-    ap.add_argument("--ab-mfma16", action="store_true", help="A/B the MFMA shape of the shared-halo kernel (knob 11)")
     ap.add_argument("--ab-packed", action="store_true", help="A/B the packed-rows shared-halo kernel (knob 10) on the deep levels")
     ap.add_argument("--ab-wgrad", action="store_true", help="A/B the filter-row weight-gradient kernel (knob 8) against the per-tap kernel")
     ap.add_argument("--ab", action="store_true", help="A/B the shared-halo 3x3 kernel against the per-tap kernel, interleaved in one process")
@@ -140,12 +139,6 @@ def main():
                 assert lib.dct_tune_set(int(knob), v) == 0, (knob, v)
                 run(args.batch, args.reps, what, f"round {rnd}: knob {knob} = {v}", only)
         lib.dct_tune_set(int(knob), vals[0])
-    if args.ab_mfma16:
-        for rnd in range(2):
-            lib.dct_tune_set(11, 0)
-            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: shared-halo kernel on 32x32x16 MFMAs", only)
-            lib.dct_tune_set(11, 1)
-            run(args.batch, args.reps, [w for w in what if w != "wgrad"], f"round {rnd}: shared-halo kernel on 16x16x32 MFMAs", only)
     if args.ab_packed:
         for rnd in range(2):
             lib.dct_tune_set(10, 0)

@@ -22,8 +22,8 @@ timeout 600 python tools/bench_conv.py --batch 16 > $O/bench_conv_per_layer.txt 
 timeout 600 python bench.py --steps 30 --warmup 10 --no-cpu-baseline > $O/cfg2_bench.json 2> $O/bench.err
 timeout 600 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --train-steps 300 > $O/cfg2_after_300_steps.json 2>> $O/bench.err
 timeout 600 python bench.py --config cfg3 --steps 30 --warmup 10 --no-cpu-baseline > $O/cfg3_bench.json 2>> $O/bench.err
-# (the in-kernel clock, profiles/r03_in_kernel_clock.txt, needs the diagnostic build: make EXTRA=-DDCT_STAMPS OUT=../libdct_hip_stamps.so, then
-#  DCT_LIB_PATH=.../libdct_hip_stamps.so python tools/stamps_igemm3.py --layer dec2b --zeros 0|0.5|0.9)
+# (the in-kernel clock of profiles/r03_in_kernel_clock.txt came from a stamped build of the 32x32x16 shared-halo kernel, removed in round 4;
+#  round 4's stamps: tools/gpu/i4_stamps.py on the -DDCT_I4_ABLATE build)
 # Enet configurations: kernel statistics of the default command, bench lines, the step program's timeline
 run kd_cfg4 --kernel-trace --stats -d $O/kd_cfg4 -o k --output-format csv -- python3 bench.py --config cfg4 --steps 20 --warmup 5 $B
 python3 tools/rocprof_summary.py $(find $O/kd_cfg4 -name "*kernel_trace.csv" | head -1) > $O/cfg4_default_command_kernel_stats.txt

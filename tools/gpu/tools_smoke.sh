@@ -10,7 +10,6 @@ t bench_meters       python tools/bench_meters.py
 t bench_pointwise    python tools/bench_pointwise.py
 t debug_conv_case    python tools/debug_conv_case.py
 t debug_enet_blocks  python tools/debug_enet_blocks.py
-t debug_enet_margin  python tools/debug_enet_margin.py
 t debug_fuse_bn      python tools/debug_fuse_bn.py
 t debug_unet_layers  python tools/debug_unet_layers.py
 t host_time          python tools/host_time.py
