@@ -17,12 +17,12 @@
 #include <vector>
 #include "dct_common.h"
 
-int g_enet_reduce_ppt = 8;           // pixels per thread of a per-channel reduction (sets the number of partial rows)
-int g_enet_fold_threads = 1024;      // threads of the one-block finalize kernels (DCT_TUNE_ENET_FOLD_THREADS: 256 | 512 | 1024)
+static const int g_enet_reduce_ppt = 8;           // pixels per thread of a per-channel reduction (sets the number of partial rows)
+static const int g_enet_fold_threads = 1024;      // threads of the one-block finalize kernels (256 / 512 swept in round 3: level or slower)
 int g_enet_mfma = 3;                 // bf16 / f16 mode: bit 0 = MFMA form of the convolutions with >= 16 input channels, bit 1 = of the
                                      // weight gradients (0: the fp32 VALU kernels)
 int g_enet_mwgrad_waves = 2048;      // MFMA weight gradient: waves a launch aims for (pixel slices x tiles) ...
-int g_enet_mwgrad_min_steps = 4;     // ... with at least this many 16-pixel MFMA steps per slice (multiple of 4)
+static const int g_enet_mwgrad_min_steps = 4;     // ... with at least this many 16-pixel MFMA steps per slice (multiple of 4)
 // (measured and removed, DESIGN.md 4.2: a one-launch channel-owner BatchNorm for small tensors -- 8 x 25 x 25 x 32 backward 60 us against
 //  14 us for the three split launches: C / 8 blocks cannot pull the tensor through 4-16 CUs fast enough; a BatchNorm-backward apply
 //  kernel on 8 channels per thread -- cfg4 16.6 vs 15.9 ms, cfg5 38.9 vs 36.8)

@@ -1096,7 +1096,7 @@ static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
 // igemm4.hip
 size_t dct_igemm4_workspace(int images, int Ho, int Wo, int Cin, int N);
 int dct_igemm4_launch(const void* params, int images, void* workspace, size_t workspace_bytes, hipStream_t st);
-extern int g_tune_igemm4, g_tune_igemm4_fill, g_tune_igemm4_min_blocks, g_tune_igemm4_split_below, g_tune_igemm4_ablate, g_tune_igemm4_blocks;
+extern int g_tune_igemm4, g_tune_igemm4_min_blocks, g_tune_igemm4_ablate;
 
 void dct_relu_bits_launch(const void* y_bf16, unsigned char* bits, long long chunks, hipStream_t st) {
   DCT_LAUNCH(DCT_PROF_POINTWISE, relu_bits_kernel, dim3(div_up(chunks, 256)), dim3(256), 0, st, (const bf16_t*)y_bf16, bits, chunks);
@@ -1268,10 +1268,8 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
 
 int dct_tune_set_wgrad(int knob, int value);  // wgrad.hip
 extern int g_enet_wgrad_max_blocks;           // enet.hip
-extern int g_enet_reduce_ppt;                 // enet.hip
-extern int g_enet_fold_threads;               // enet.hip
 extern int g_enet_mfma;                       // enet.hip
-extern int g_enet_mwgrad_waves, g_enet_mwgrad_min_steps, g_enet_fuse_finalize;
+extern int g_enet_mwgrad_waves, g_enet_fuse_finalize;
 
 extern "C" int dct_tune_set(int knob, int value) {
   switch (knob) {
@@ -1281,20 +1279,14 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_HALO_MIN_BLOCKS: g_tune_igemm_halo_min_blocks = value; return DCT_OK;
     case DCT_TUNE_IGEMM_HALO_COVER: g_tune_igemm_halo_cover = value; return DCT_OK;
     case DCT_TUNE_IGEMM_SPLIT_TARGET: if (value < 64) return DCT_ERR_BAD_ARG; g_tune_igemm_split_target = value; return DCT_OK;
-    case DCT_TUNE_ENET_REDUCE_PPT: if (value < 1 || value > 4096) return DCT_ERR_BAD_ARG; g_enet_reduce_ppt = value; return DCT_OK;
     case DCT_TUNE_ENET_MWGRAD_WAVES: if (value < 64) return DCT_ERR_BAD_ARG; g_enet_mwgrad_waves = value; return DCT_OK;
-    case DCT_TUNE_ENET_MWGRAD_MIN_STEPS: if (value < 4 || value % 4) return DCT_ERR_BAD_ARG; g_enet_mwgrad_min_steps = value; return DCT_OK;
     case DCT_TUNE_ENET_MFMA: if (value < 0 || value > 3) return DCT_ERR_BAD_ARG; g_enet_mfma = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_SPLIT: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
-    case DCT_TUNE_ENET_FOLD_THREADS: if (value != 256 && value != 512 && value != 1024) return DCT_ERR_BAD_ARG; g_enet_fold_threads = value; return DCT_OK;
     case DCT_TUNE_ENET_FUSE_FINALIZE: g_enet_fuse_finalize = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM4: g_tune_igemm4 = value ? 1 : 0; return DCT_OK;
-    case DCT_TUNE_IGEMM4_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm4_fill = value; return DCT_OK;
     case DCT_TUNE_IGEMM4_MIN_BLOCKS: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm4_min_blocks = value; return DCT_OK;
-    case DCT_TUNE_IGEMM4_SPLIT_BELOW: if (value < 0) return DCT_ERR_BAD_ARG; g_tune_igemm4_split_below = value; return DCT_OK;
     case 1000: g_tune_igemm4_ablate = value; return DCT_OK;      // diagnostic builds only
-    case DCT_TUNE_IGEMM4_BLOCKS: if (value < 0) return DCT_ERR_BAD_ARG; g_tune_igemm4_blocks = value; return DCT_OK;
     case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }

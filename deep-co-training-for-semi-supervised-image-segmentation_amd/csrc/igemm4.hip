@@ -503,13 +503,13 @@ static bool i4_geometry(int Ho, int Wo, I4Geom& g, double& fill) {
 }  // namespace
 
 int g_tune_igemm4 = 0;             // dct_tune_set(DCT_TUNE_IGEMM4, 0): 3x3 stride-1 layers stay on the igemm.hip tiles
-int g_tune_igemm4_fill = 70;       // percent: least fill of the 256-pixel tiles
+static const int g_tune_igemm4_fill = 70;       // percent: least fill of the 256-pixel tiles
 int g_tune_igemm4_min_blocks = 96; // fewest blocks (before a split over channel slices) for which the kernel is taken
-int g_tune_igemm4_blocks = 0;      // persistent blocks per launch (0: one per CU)
+static const int g_tune_igemm4_blocks = 0;      // persistent blocks per launch (0: one per CU)
 unsigned long long* g_igemm4_stamps = nullptr;   // diagnostic builds: per-wave cycle sums (dct_debug_i4_stamps)
 extern "C" int dct_debug_i4_stamps(void* buf) { g_igemm4_stamps = (unsigned long long*)buf; return 0; }
 int g_tune_igemm4_ablate = 0;      // diagnostic builds (-DDCT_I4_ABLATE): ablation variant, see igemm4_kernel
-int g_tune_igemm4_split_below = 200;  // layers with fewer blocks than this are split over channel slices (fp32 slabs)
+static const int g_tune_igemm4_split_below = 200;  // layers with fewer blocks than this are split over channel slices (fp32 slabs)
 
 // Plan of the ping-pong kernel for one layer (shared with dct_conv2d_workspace_bytes): use = 0 when the layer stays on igemm.hip.
 struct I4Plan { int use; I4Geom g; int splits; };

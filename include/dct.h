@@ -422,27 +422,22 @@ enum { DCT_TUNE_IGEMM_SPLIT = 1,   /* >= 1: force the split-K factor; -1 (defaul
        DCT_TUNE_WGRAD_TARGET = 14,     /* >= 64 (default: see wgrad.hip): block target of the per-tap weight-gradient kernel */
        DCT_TUNE_WGRAD3_TARGET = 15,    /* >= 64: block target (4-wave units) of the filter-row weight-gradient kernel */
        DCT_TUNE_IGEMM_SPLIT_TARGET = 16, /* >= 64 (default 450): block target of a split-K conv layer */
-       DCT_TUNE_ENET_REDUCE_PPT = 18,  /* pixels per thread of an Enet per-channel reduction (default: see enet.hip) */
        DCT_TUNE_IGEMM_HALO_MIN_BLOCKS = 19,  /* default 400: fewest blocks for which the shared-halo patch kernel is taken */
        DCT_TUNE_IGEMM_HALO_COVER = 20,       /* percent (default 75): least image cover of its 8 x 16 patches */
-       DCT_TUNE_ENET_FOLD_THREADS = 22,      /* 256 | 512 | 1024 (default): threads of the one-block fold kernels behind the Enet reductions */
        DCT_TUNE_IGEMM_PACKED_SPLIT = 23,     /* default 100: packed-rows kernel splits layers with fewer blocks over channel slices */
        DCT_TUNE_IGEMM_PACKED_FILL = 24,      /* percent (default 76): least fill of the packed-rows kernel's 128-pixel tiles */
        DCT_TUNE_ENET_MFMA = 26,              /* bf16 / f16 Enet: bit 0 = MFMA form of the convolutions with >= 16 input channels,
                                                 bit 1 = of the weight gradients; 3 (default), 0 = the fp32 VALU kernels */
        DCT_TUNE_ENET_MWGRAD_WAVES = 28,      /* >= 64 (default 2048): waves an MFMA weight-gradient launch aims for */
-       DCT_TUNE_ENET_MWGRAD_MIN_STEPS = 29,  /* multiple of 4 (default 4): least 16-pixel MFMA steps per pixel slice */
        DCT_TUNE_ENET_FUSE_FINALIZE = 34,     /* 1: Enet BatchNorm / bias-sum finalizes ride in the producing launch's last block (measured slower:
                                                 csrc/enet.hip g_enet_fuse_finalize); 0 (default): one-block launches of their own */
        DCT_TUNE_IGEMM4 = 35,                 /* 1: 3x3 stride-1 bf16 layers on the persistent one-block-per-CU ping-pong tile (csrc/igemm4.hip); 0 (default): igemm.hip tiles -- level on the step */
-       DCT_TUNE_IGEMM4_FILL = 36,            /* percent (default 70): least fill of its 256-pixel tiles */
-       DCT_TUNE_IGEMM4_MIN_BLOCKS = 37,      /* default 96: fewest blocks for which it is taken */
-       DCT_TUNE_IGEMM4_SPLIT_BELOW = 38,     /* default 200: layers with fewer blocks are split over channel slices (fp32 slabs) */
-       DCT_TUNE_IGEMM4_BLOCKS = 39 };        /* persistent blocks per launch of that kernel; 0 (default): one per compute unit */
+       DCT_TUNE_IGEMM4_MIN_BLOCKS = 37 };    /* default 96: fewest blocks for which it is taken (1: whatever the layer, the tests' setting) */
 /* (Knob numbers are stable across rounds; the gaps are A/B switches of variants that were measured slower and removed with their
  *  kernels -- DESIGN.md 4.1 / 4.2: register-staged bf16 kernels, 4-wave tiles, scattered epilogue stores, the 32x32x16 shared-halo
  *  form, XCD-aware tile orders, the weight-ring and four-fat-wave shared-halo tiles, one / four wave groups and per-tap reads in the
- *  filter-row weight gradient, the scalar Enet reductions, the channel-owner BatchNorm, the vector BatchNorm-backward apply.) */
+ *  filter-row weight gradient, the scalar Enet reductions, the channel-owner BatchNorm, the vector BatchNorm-backward apply -- and planner constants whose
+ *  sweeps are on file: profiles/r03_knob_sweeps.txt.) */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
 
