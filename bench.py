@@ -98,7 +98,7 @@ def pmc_mfma_busy(config):
     (profiles/r03_<config>_pmc_mfma_busy.txt, profiles/r03_in_kernel_clock.txt); None when absent."""
     out = {}
     try:
-        with open(os.path.join(ROOT, "profiles", f"r03_{config}_pmc_mfma_busy.txt")) as f:
+        with open(os.path.join(ROOT, "profiles", f"r04_{config}_pmc_mfma_busy.txt")) as f:
             for line in f:
                 t = line.split()
                 if len(t) >= 4 and t[2].endswith("%"):
@@ -109,7 +109,7 @@ def pmc_mfma_busy(config):
                 if "in-kernel shader clock" in line and "zeros 0%" in line:
                     clocks.append(float(line.split("clock:")[1].split("GHz")[0]))
         return {"mfma_pipe_busy_share_of_simd_cycles": out, "in_kernel_clock_ghz_dense_inputs": clocks,
-                "source": f"profiles/r03_{config}_pmc_mfma_busy.txt, profiles/r03_in_kernel_clock.txt (rocprofv3 --pmc passes of this command, round 3)"}
+                "source": f"profiles/r04_{config}_pmc_mfma_busy.txt, profiles/r03_in_kernel_clock.txt (rocprofv3 --pmc passes of this command, round 3)"}
     except Exception:
         return None
 

@@ -7,6 +7,7 @@ and tensors that are not on a HIP device are rejected (no CPU fallback exists).
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import os
 
 import torch
@@ -206,12 +207,16 @@ def ptr(t) -> int:
 
 # While a pass group is open (hip_ops.PassGroup) only the entry points that RECORD their launches may be called: anything
 # else would launch at once, ahead of the recorded launches it depends on.
-GROUP_OPEN = False
+_group_tls = threading.local()     # per thread, as the library's own recording state (csrc/enet.hip: thread_local g_grp)
 _RECORDING = None
 
 
+def set_group_open(flag: bool) -> None:
+    _group_tls.open = bool(flag)
+
+
 def call(name: str, *args) -> None:
-    if GROUP_OPEN and not name.startswith(("dct_enet_", "dct_group_", "dct_leaves_")):
+    if getattr(_group_tls, "open", False) and not name.startswith(("dct_enet_", "dct_group_", "dct_leaves_")):
         raise RuntimeError(f"dct_amd: {name} inside an open pass group (only the Enet entry points record their launches)")
     check(getattr(load(), name)(*args), name)
 

@@ -61,8 +61,10 @@ struct GroupState {
   int member = 0;
   std::vector<std::vector<GroupRec>> recs;
 };
-GroupState g_grp;
-bool g_leaf_scope = false;    // set by the entry points whose launches are leaves (dct_enet_wgrad, dct_enet_channel_sum)
+// The recording state belongs to the thread that opened the group: a dct_enet_* call from another thread (a second trainer, a
+// background evaluation) launches normally instead of being captured into -- or refused by -- somebody else's open group.
+thread_local GroupState g_grp;
+thread_local bool g_leaf_scope = false;    // set by the entry points whose launches are leaves (dct_enet_wgrad, dct_enet_channel_sum)
 struct LeafScope { bool was; LeafScope() : was(g_leaf_scope) { g_leaf_scope = true; } ~LeafScope() { g_leaf_scope = was; } };
 
 template <typename F>

@@ -505,7 +505,7 @@ static bool i4_geometry(int Ho, int Wo, I4Geom& g, double& fill) {
 int g_tune_igemm4 = 0;             // dct_tune_set(DCT_TUNE_IGEMM4, 0): 3x3 stride-1 layers stay on the igemm.hip tiles
 static const int g_tune_igemm4_fill = 70;       // percent: least fill of the 256-pixel tiles
 int g_tune_igemm4_min_blocks = 96; // fewest blocks (before a split over channel slices) for which the kernel is taken
-static const int g_tune_igemm4_blocks = 0;      // persistent blocks per launch (0: one per CU)
+int g_tune_igemm4_blocks = 0;      // persistent blocks per launch (0: one per CU); diagnostic knob 1001
 unsigned long long* g_igemm4_stamps = nullptr;   // diagnostic builds: per-wave cycle sums (dct_debug_i4_stamps)
 extern "C" int dct_debug_i4_stamps(void* buf) { g_igemm4_stamps = (unsigned long long*)buf; return 0; }
 int g_tune_igemm4_ablate = 0;      // diagnostic builds (-DDCT_I4_ABLATE): ablation variant, see igemm4_kernel

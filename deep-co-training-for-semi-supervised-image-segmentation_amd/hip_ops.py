@@ -4,12 +4,21 @@ torch tensors that only provide device memory and the stream.  Used by the netwo
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import List, Optional, Sequence
 
 import torch
 
 from . import _lib
 from ._lib import BF16, DTYPE_OF, F32, EnetTf, call, conv_desc, ptr, stream, view
+
+
+# The open pass group / leaf side of THIS thread (the library keeps its recording state per thread too: csrc/enet.hip g_grp)
+_tls = threading.local()
+
+
+def _group():
+    return getattr(_tls, "group", None)
 
 
 _WS_CACHE = {}      # (device index, stream handle) -> uint8 workspace, grown geometrically
@@ -21,7 +30,7 @@ def _ws(nbytes: int, device) -> Optional[torch.Tensor]:
     capture the buffer comes from the graph's private pool as before: a cached buffer baked into a graph could be
     replaced (and freed) by a later, larger request while the graph still replays."""
     nbytes = max(int(nbytes), 16)
-    if _GROUP is not None:        # recorded launches of different members run at the same time: scratch of their own, kept until then
+    if _group() is not None:        # recorded launches of different members run at the same time: scratch of their own, kept until then
         return keep(torch.empty(nbytes, dtype=torch.uint8, device=device))
     if torch.cuda.is_current_stream_capturing():
         return torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -54,20 +63,18 @@ class PassGroup(object):
         self.grouped = self.single = 0
 
     def __enter__(self):
-        global _GROUP
-        assert _GROUP is None, "pass groups do not nest"
+        assert _group() is None, "pass groups do not nest"
         call("dct_group_begin", self.n)
-        _GROUP = self
-        _lib.GROUP_OPEN = True
+        _tls.group = self
+        _lib.set_group_open(True)
         return self
 
     def member(self, m: int) -> None:
         call("dct_group_member", int(m))
 
     def __exit__(self, et, ev, tb):
-        global _GROUP
-        _GROUP = None
-        _lib.GROUP_OPEN = False
+        _tls.group = None
+        _lib.set_group_open(False)
         if et is not None:
             _lib.load().dct_group_abort()
             self.kept.clear()
@@ -94,10 +101,9 @@ class LeafSide(object):
         self.launches = 0
 
     def __enter__(self):
-        global _GROUP
-        assert _GROUP is None, "pass groups / leaf sides do not nest"
+        assert _group() is None, "pass groups / leaf sides do not nest"
         call("dct_leaves_begin")
-        _GROUP = self
+        _tls.group = self
         return self
 
     def flush(self) -> None:
@@ -106,8 +112,7 @@ class LeafSide(object):
         self.launches += n.value
 
     def __exit__(self, et, ev, tb):
-        global _GROUP
-        _GROUP = None
+        _tls.group = None
         if et is not None:
             _lib.load().dct_group_abort()
             return False
@@ -117,13 +122,11 @@ class LeafSide(object):
         return False
 
 
-_GROUP = None
-
 
 def keep(t):
     """Tensor ``t`` (allocated by a pass that may be recording into a PassGroup) -> t, referenced until the group launches."""
-    if _GROUP is not None:
-        _GROUP.kept.append(t)
+    if _group() is not None:
+        _group().kept.append(t)
     return t
 
 
@@ -535,7 +538,7 @@ _red_ws = {}
 def _enet_ws(device, nbytes):
     """Reduction scratch, cached per (device, stream): kernels of two models queued on different streams must not
     share it.  While a HIP graph is being captured the buffer comes from the graph's own pool instead."""
-    if _GROUP is not None:        # members of a pass group run at the same time: scratch of their own, kept until the launches
+    if _group() is not None:        # members of a pass group run at the same time: scratch of their own, kept until the launches
         return keep(torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device))
     if torch.cuda.is_current_stream_capturing():
         return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
