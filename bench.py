@@ -94,11 +94,13 @@ def pmc_traffic(config):
 
 
 def pmc_mfma_busy(config):
-    """MFMA-pipe busy share per kernel class and the in-kernel shader clock from the committed round-3 counter passes
-    (profiles/r03_<config>_pmc_mfma_busy.txt, profiles/r03_in_kernel_clock.txt); None when absent."""
+    """MFMA-pipe busy share per kernel class (newest committed profiles/r*_<config>_pmc_mfma_busy.txt) and the in-kernel shader clock
+    (profiles/r03_in_kernel_clock.txt): counter evidence of EARLIER rocprofv3 --pmc passes of this command; None when absent."""
+    import glob
     out = {}
     try:
-        with open(os.path.join(ROOT, "profiles", f"r04_{config}_pmc_mfma_busy.txt")) as f:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config}_pmc_mfma_busy.txt")), reverse=True)[0]
+        with open(path) as f:
             for line in f:
                 t = line.split()
                 if len(t) >= 4 and t[2].endswith("%"):
@@ -109,7 +111,7 @@ def pmc_mfma_busy(config):
                 if "in-kernel shader clock" in line and "zeros 0%" in line:
                     clocks.append(float(line.split("clock:")[1].split("GHz")[0]))
         return {"mfma_pipe_busy_share_of_simd_cycles": out, "in_kernel_clock_ghz_dense_inputs": clocks,
-                "source": f"profiles/r04_{config}_pmc_mfma_busy.txt, profiles/r03_in_kernel_clock.txt (rocprofv3 --pmc passes of this command, round 3)"}
+                "source": f"{os.path.relpath(path, ROOT)}, profiles/r03_in_kernel_clock.txt (committed rocprofv3 --pmc passes of this command)"}
     except Exception:
         return None
 
