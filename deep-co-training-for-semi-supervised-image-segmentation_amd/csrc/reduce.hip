@@ -10,6 +10,11 @@
 #include <algorithm>
 #include "dct_common.h"
 
+// blocks of stem_wgrad_mfma_kernel: one 16-wave block per CU.  Swept on 16 x 254 x 254 x 64 (whole call, fold included): 64 / 128 / 192 / 256 /
+// 384 / 512 / 768 blocks -> 107 / 58 / 44 / 36 / 47 / 42 / 47 us (the VALU kernel: 78 us); four-wave blocks: 512-4096 blocks 50-104 us (the
+// fold walks one partial row per block)
+static const int g_stem_mfma_blocks = 256;
+
 namespace {
 
 template <typename T> struct Vec;
@@ -225,6 +230,101 @@ __global__ __launch_bounds__(256) void stem_wgrad_fast_kernel(View x, View dy, f
   }
 }
 
+// MFMA form of the bf16 stem weight gradient (3x3, stride 1, Cout = 64, x fp32 [N,H,W,1]).  The VALU kernel above is bound by its ten
+// FMAs per dy element (66 us for 16 x 252 x 252 x 64, 1.4 TB/s); here the reduction over pixels runs on the matrix pipe and the kernel
+// is a stream over dy:  D[64 channels][16 columns] = sum_p dy[p][c] * win[p][j],  columns j = 0..8 the nine window values x[p + (r, s)],
+// j = 9 the constant one (the bias gradient), the rest zero.  v_mfma_f32_32x32x16_bf16: K = 16 pixels of a row per step ("unit"),
+//   A = dy^T (rows = channels): dy sits [pixel][channel] in memory, the reduction index is the SLOW one, so the unit's 2 KiB tile goes
+//       through LDS as it is and comes back through the transposing read ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group);
+//   B = win (columns = taps): lane (j, half) loads its eight consecutive x values itself (L2-resident 4-byte loads) and splits each into
+//       bf16 high + bf16 low parts -- two MFMAs per channel half keep x to 16 mantissa bits (the products with the bf16 dy are then
+//       exact to ~2^-17, as good as the fp32 FMAs of the VALU kernel for a sum that is rounded to fp32 anyway).
+// A wave owns a unit at a time (no block barrier in the loop: it reads back only what it wrote), the next unit's loads are in flight
+// while the current one is multiplied.  partial[blk][co][10] as the VALU kernel writes it.
+typedef __attribute__((address_space(3))) bf16x4* stem_lds_bf16x4_ptr;
+constexpr int STEM_NW = 16;          // waves per block: few blocks (= few partial rows for the fold), many waves in flight per CU
+__global__ __launch_bounds__(STEM_NW * 64) void stem_wgrad_mfma_kernel(View x, View dy, float* partial, StemG g, int upr, long long nunits) {
+  constexpr int NT = 10, C = 64, NWV = STEM_NW;
+  __shared__ __attribute__((aligned(16))) char tile[NWV][16 * 128];
+  __shared__ float red[NWV][C * NT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, kh = lane >> 5;                 // B column (tap) / K half of this lane
+  const int tr = j / 3, ts = j - 3 * tr;                   // tap (r, s) for j < 9
+  const float* xp = reinterpret_cast<const float*>(x.ptr);
+  const bf16_t* dyp = reinterpret_cast<const bf16_t*>(dy.ptr);
+  char* my = tile[wave];
+  f32x16 acc[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[h][e] = 0.f;
+  // transposing-read addresses: 16-lane group G = lane / 16 reads pixels 8 * (G / 2) + 4 * q .. + 3, channels 32 * hc + 16 * (G & 1) .. + 15;
+  // lane 4 q' + p' of the group supplies row q', columns 4 p' .. 4 p' + 3 and receives column (lane % 16) of the four rows
+  const int li = lane & 15;
+  const unsigned tr_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)my +
+                           (unsigned)((8 * kh + (li >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2);
+  // staging: lane -> (pixel row of the unit, 16-byte chunk of its 128 bytes), two loads per lane
+  const int srow = lane >> 3, schunk = lane & 7;
+
+  const long long u0 = (long long)blockIdx.x * NWV + wave, ustep = (long long)gridDim.x * NWV;
+  uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
+  float xv[8];
+  auto fetch = [&](long long u) {
+    const unsigned rowid = (unsigned)(u / upr), ub = (unsigned)(u - (long long)rowid * upr);
+    const int n = (int)(rowid / (unsigned)dy.h), oy = (int)(rowid - (unsigned)n * (unsigned)dy.h), ox0 = (int)ub * 16;
+    const bf16_t* row = dyp + n * dy.sn + oy * dy.sh + schunk * 8;
+    d0 = (ox0 + srow < dy.w) ? *reinterpret_cast<const uint4*>(row + (ox0 + srow) * dy.sw) : make_uint4(0, 0, 0, 0);
+    d1 = (ox0 + srow + 8 < dy.w) ? *reinterpret_cast<const uint4*>(row + (ox0 + srow + 8) * dy.sw) : make_uint4(0, 0, 0, 0);
+    const int iy = oy + tr - g.pad_h, ix0 = ox0 + 8 * kh + ts - g.pad_w;
+    const bool rok = j < 9 && (unsigned)iy < (unsigned)x.h;
+    const float* xr = xp + n * x.sn + iy * x.sh;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xv[e] = (rok && (unsigned)(ix0 + e) < (unsigned)x.w) ? xr[(ix0 + e) * x.sw] : 0.f;
+  };
+  if (u0 < nunits) fetch(u0);
+  for (long long u = u0; u < nunits; u += ustep) {
+    // this unit's operands are in registers: dy tile -> LDS, x window -> bf16 high / low fragments
+    *reinterpret_cast<uint4*>(my + srow * 128 + schunk * 16) = d0;
+    *reinterpret_cast<uint4*>(my + (srow + 8) * 128 + schunk * 16) = d1;
+    bf16x8 whi, wlo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = j == 9 ? 1.f : xv[e];
+      const bf16_t hi = (bf16_t)v;
+      whi[e] = hi;
+      wlo[e] = (bf16_t)(v - (float)hi);
+    }
+    if (u + ustep < nunits) fetch(u + ustep);              // next unit's loads fly while this one is multiplied
+#pragma unroll
+    for (int hc = 0; hc < 2; ++hc) {
+      const unsigned a0 = tr_base + hc * 64;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((stem_lds_bf16x4_ptr)(size_t)(a0));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((stem_lds_bf16x4_ptr)(size_t)(a0 + 4 * 128));
+      bf16x8 a;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = lo[e]; a[4 + e] = hi[e]; }
+      acc[hc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, whi, acc[hc], 0, 0, 0);
+      acc[hc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wlo, acc[hc], 0, 0, 0);
+    }
+  }
+  // accumulator (hc, register 4 q + e) of lane (j, kh): channel 32 hc + 8 q + 4 kh + e, column j
+  if (j < NT) {
+#pragma unroll
+    for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][(32 * hc + 8 * q + 4 * kh + e) * NT + j] = acc[hc][4 * q + e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * NT; i += NWV * 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) t += red[w][i];          // fixed order: deterministic
+    partial[(long long)blockIdx.x * (C * NT) + i] = t;
+  }
+}
+
 // out: dw[co][inner], db[co] from partial[blk][co][inner+1]
 __global__ __launch_bounds__(256) void split_dw_db_kernel(const float* partial, float* dw, float* db, int cout, int inner, int blocks, int accumulate) {
   __shared__ float red[256];
@@ -357,7 +457,7 @@ extern "C" int dct_bias_grad(const dct_view* dy, float* db, int accumulate, int 
 
 extern "C" size_t dct_conv_cin1_wgrad_workspace_bytes(const dct_view* dy, const dct_conv_desc* d) {
   if (!dy || !d) return 0;
-  return (size_t)1024 * dy->c * (d->R * d->S + 1) * sizeof(float);
+  return (size_t)4096 * dy->c * (d->R * d->S + 1) * sizeof(float);
 }
 
 extern "C" int dct_conv_cin1_wgrad(const dct_view* x, const dct_view* dy, float* dw, float* db,
@@ -385,6 +485,17 @@ extern "C" int dct_conv_cin1_wgrad(const dct_view* x, const dct_view* dy, float*
   if (!workspace || workspace_bytes < (size_t)blocks * dy->c * (taps + 1) * sizeof(float)) return DCT_ERR_WORKSPACE;
   StemG g; g.R = d->R; g.S = d->S; g.stride = d->stride; g.dil = d->dil; g.pad_h = d->pad_h; g.pad_w = d->pad_w;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == DCT_BF16 && quad && dy->c == 64 && dy->sw % 8 == 0 && (long long)dy->n * dy->sn < (1ll << 31) && (long long)x->n * x->sn < (1ll << 31)) {
+    // MFMA form: units of 16 pixels of a row, one per wave at a time; 1024 blocks of four waves at most
+    const int upr = (dy->w + 15) / 16;
+    const long long nunits = (long long)dy->n * dy->h * upr;
+    const int mblocks = (int)std::min<long long>(g_stem_mfma_blocks, (nunits + STEM_NW - 1) / STEM_NW);
+    if (workspace_bytes < (size_t)mblocks * dy->c * (taps + 1) * sizeof(float)) return DCT_ERR_WORKSPACE;
+    DCT_LAUNCH(DCT_PROF_POINTWISE, stem_wgrad_mfma_kernel, dim3(mblocks), dim3(STEM_NW * 64), 0, st, to_view(x), to_view(dy), (float*)workspace, g, upr, nunits);
+    DCT_LAUNCH(DCT_PROF_POINTWISE, split_dw_db_kernel, dim3(div_up(dy->c * (taps + 1), 16)), dim3(256), 0, st,
+               (const float*)workspace, dw, db, dy->c, taps, mblocks, accumulate);
+    return dct_check_launch();
+  }
   if (dtype == DCT_BF16) {
     if (quad) DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_wgrad_fast_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);
     else DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_wgrad_fast_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, st, to_view(x), to_view(dy), (float*)workspace, g, ppb);

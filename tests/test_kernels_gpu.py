@@ -516,6 +516,32 @@ def test_stem_cin1(ops, dtype):
     close(db.cpu(), rb, torch.float32, "stem bgrad")
 
 
+@pytest.mark.parametrize("B,H,W,pad", [(3, 37, 30, 0), (2, 50, 67, 1), (16, 66, 130, 0), (1, 19, 16, 2)])
+def test_stem_wgrad_mfma_form(ops, B, H, W, pad):
+    """bf16 stem weight gradient on the matrix pipe (csrc/reduce.hip stem_wgrad_mfma_kernel): units of 16 pixels of a row through the
+    transposing LDS read, x split into bf16 high + low parts -- held to the fp32 tolerance of the VALU kernel it replaces, on ragged
+    widths (the last unit of a row is partly empty), padded windows and many blocks, with and without accumulation."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(81)
+    Cout = 64
+    x = torch.rand(B, 1, H, W, generator=g)
+    w = torch.zeros(Cout, 1, 3, 3, requires_grad=True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = F.conv2d(x, w, b, padding=pad)
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    rw, rb = torch.autograd.grad(y, [w, b], dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dw = torch.full((Cout, 9), 0.5, device=DEV)
+    db = torch.full((Cout,), -2.0, device=DEV)
+    ops.conv_cin1_wgrad(xd, to_dev(dy, dtype), dw, db, pad_h=pad, pad_w=pad, accumulate=True)
+    close(dw.cpu() - 0.5, rw.reshape(Cout, 9), torch.float32, "stem wgrad (MFMA), accumulated", rtol32=3e-4)
+    close(db.cpu() + 2.0, rb, torch.float32, "stem bgrad (MFMA), accumulated", rtol32=3e-4)
+    dw2, db2 = torch.full_like(dw, float("nan")), torch.full_like(db, float("nan"))
+    ops.conv_cin1_wgrad(xd, to_dev(dy, dtype), dw2, db2, pad_h=pad, pad_w=pad, accumulate=False)
+    close(dw2.cpu(), rw.reshape(Cout, 9), torch.float32, "stem wgrad (MFMA)")
+    close(db2.cpu(), rb, torch.float32, "stem bgrad (MFMA)")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C", [2, 4])
 def test_head(ops, dtype, C):
