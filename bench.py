@@ -281,6 +281,7 @@ def main():
     ap.add_argument("--global-batch", default="", metavar="L+U",
                     help="fixed GLOBAL batch (labeled+unlabeled, e.g. 64+64 for cfg4: BASELINE.json configs[3]) split evenly over the "
                          "ranks; the line then says \"scaling\": \"strong\".  Default: the configuration's per-GPU batch on every rank (weak)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of K steps each; the median is reported (default 3)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="exercise the N-rank launch path on CPU (gloo, oracle-injected networks); prints one JSON line, measures nothing")
     args = ap.parse_args()
@@ -366,20 +367,33 @@ def main():
         tr.grad_sync.exchanged_bytes = 0
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = one_step(args.warmup + i)
-    torch.cuda.synchronize()
-    if ddp_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # The timed region: EXACTLY K steps between barrier + synchronize on both sides -- taken `--repeats` times back to back (default 3)
+    # and the MEDIAN region reported: a region is 0.1-0.3 s, and run-to-run noise on one box is of the size of a round's gains.
+    regions = []
+    for rep in range(max(1, args.repeats)):
+        if ddp_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = one_step(args.warmup + rep * args.steps + i)
+        torch.cuda.synchronize()
+        if ddp_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_rep = time.perf_counter() - t0
+        if ddp_on:                      # MAX over ranks, per region
+            tt = torch.tensor([t_rep], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_rep = float(tt.item())
+        regions.append(t_rep)
+    elapsed = sorted(regions)[len(regions) // 2]
     exchange = None
     if ddp_on:
-        ex = torch.tensor([tr.grad_sync.exposed_ms(reset=True) / args.steps], dtype=torch.float64, device=device)
+        ex = torch.tensor([tr.grad_sync.exposed_ms(reset=True) / (args.steps * len(regions))], dtype=torch.float64, device=device)
         dist.all_reduce(ex, op=dist.ReduceOp.MAX)
         exchange = {"exposed_allreduce_ms_per_step_max_over_ranks": float(ex.item()),
-                    "bytes_per_step_per_rank": tr.grad_sync.exchanged_bytes / args.steps,
+                    "bytes_per_step_per_rank": tr.grad_sync.exchanged_bytes / (args.steps * len(regions)),
                     "wire_dtype": "bf16" if args.grad_compress == "bf16" else "f32",
                     "mode": "captured graph segments around the eager all-reduces" if tr._step_graphs is not None and tr._step_graphs.captures
                     else "eager launches, bucketed all-reduce from inside the backward pass"}
@@ -395,9 +409,9 @@ def main():
         torch.cuda.synchronize()
         tm = time.perf_counter()
         for i in range(nm):
-            o = one_step(args.warmup + args.steps + i)
-            lb_gt = [lab[m][(args.warmup + args.steps + i) % nb][0][1] for m in range(S)]
-            ub_gt = unl[(args.warmup + args.steps + i) % nb][0][1]
+            o = one_step(args.warmup + args.steps * max(1, args.repeats) + i)
+            lb_gt = [lab[m][(args.warmup + args.steps * max(1, args.repeats) + i) % nb][0][1] for m in range(S)]
+            ub_gt = unl[(args.warmup + args.steps * max(1, args.repeats) + i) % nb][0][1]
             for m in range(S):
                 dm[m].add(o["preds"][m], lb_gt[m])
                 dm[S + m].add(o["unlab_probs"][m], ub_gt)
@@ -429,16 +443,12 @@ def main():
         _lib.prof_read(reset=True)
         _lib.prof_enable(True)
         for i in range(args.steps):
-            one_step(args.warmup + args.steps + i)
+            one_step(args.warmup + args.steps * max(1, args.repeats) + i)
         torch.cuda.synchronize()
         _lib.prof_enable(False)
         prof = _lib.prof_read(reset=True)
     if ddp_on:
         dist.barrier()
-    if ddp_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     losses = dict(sup=[float(s) for s in out["sup"]], jsd=float(out["jsd"]))
     assert all(v == v for v in losses["sup"]) and losses["jsd"] == losses["jsd"], "NaN loss in the timed region"
 
@@ -452,6 +462,8 @@ def main():
         "value": value, "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
+        "timed_regions": {"count": len(regions), "steps_each": args.steps, "ms_per_step_each": [round(1e3 * r / args.steps, 4) for r in regions],
+                          "reported": "median"},
         "config": {"workload": f"{args.config}: {cfg['desc']}", "imgs_per_step_per_gpu": imgs_per_step,
                    "global_batch": f"{cfg['B_l'] * world}+{cfg['B_u'] * world}", "parallelism": f"dp{world}",
                    "weights": "random init (xavier_normal), reference architecture; trained for the setup + warm-up steps on "
