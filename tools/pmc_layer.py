@@ -24,7 +24,12 @@ def main():
     ap.add_argument("--what", default="fwd", choices=["fwd", "dgrad", "wgrad"])
     ap.add_argument("--n", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="dct_tune_set before the launches")
     a = ap.parse_args()
+    from dct_amd import _lib
+    for kv in a.tune:
+        k, v = kv.split("=")
+        assert _lib.load().dct_tune_set(int(k), int(v)) == 0, kv
     cin, hin, cout = LAYERS[a.layer]
     dev, dt, B, ho = "cuda:0", torch.bfloat16, a.batch, hin - 2
     g = torch.Generator(device=dev).manual_seed(0)
