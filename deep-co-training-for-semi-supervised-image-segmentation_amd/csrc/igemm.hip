@@ -1097,9 +1097,6 @@ static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
 size_t dct_igemm4_workspace(int images, int Ho, int Wo, int Cin, int N);
 int dct_igemm4_launch(const void* params, int images, void* workspace, size_t workspace_bytes, hipStream_t st);
 extern int g_tune_igemm4, g_tune_igemm4_min_blocks, g_tune_igemm4_ablate, g_tune_igemm4_blocks;
-// igemm5.hip
-int dct_igemm5_launch(const void* params, int images, hipStream_t st);
-extern int g_tune_igemm5, g_tune_igemm5_min_patches;
 
 void dct_relu_bits_launch(const void* y_bf16, unsigned char* bits, long long chunks, hipStream_t st) {
   DCT_LAUNCH(DCT_PROF_POINTWISE, relu_bits_kernel, dim3(div_up(chunks, 256)), dim3(256), 0, st, (const bf16_t*)y_bf16, bits, chunks);
@@ -1212,7 +1209,6 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     if (y16 && m16 && x32) {
       IgemmParams q = p;
       q.partial = nullptr;
-      if (dct_igemm5_launch(&q, y->n, st)) return dct_check_launch();      // role-split kernel (igemm5.hip), large images
       const int took = dct_igemm4_launch(&q, y->n, workspace, workspace_bytes, st);
       if (took == 1) return dct_check_launch();
       if (took == 2) {
@@ -1290,8 +1286,6 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_ENET_FUSE_FINALIZE: g_enet_fuse_finalize = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM4: g_tune_igemm4 = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM4_MIN_BLOCKS: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm4_min_blocks = value; return DCT_OK;
-    case DCT_TUNE_IGEMM5: g_tune_igemm5 = value ? 1 : 0; return DCT_OK;
-    case DCT_TUNE_IGEMM5_MIN_PATCHES: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm5_min_patches = value; return DCT_OK;
     case 1000: g_tune_igemm4_ablate = value; return DCT_OK;      // diagnostic builds only
     case 1001: if (value < 0) return DCT_ERR_BAD_ARG; g_tune_igemm4_blocks = value; return DCT_OK;      // diagnostic: persistent blocks per launch
     case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;
