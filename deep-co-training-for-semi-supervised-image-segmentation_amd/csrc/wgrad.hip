@@ -16,6 +16,7 @@
 // tiles go to a workspace and are summed in fixed order by a second kernel: deterministic,
 // and "+=" into an existing gradient is folded into that pass.
 #include "dct_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -40,6 +41,16 @@ typedef __attribute__((address_space(3))) char* lds_char_ptr;
 __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(lds_char_ptr)(p); }
 __device__ __forceinline__ void tr_issue(unsigned addr, bf16x4& dst) {
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <int OFF> __device__ __forceinline__ void tr_issue_o(unsigned addr, bf16x4& dst) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// one LDS-DMA piece through a buffer descriptor: 16 bytes per lane to lds + lane * 16, from base + voff + soff; a lane whose
+// voff + soff falls outside the descriptor's range writes zeros.  (A __device__ helper: called straight from the kernel template,
+// hipcc's host pass fails to instantiate the kernel's stub -- silently, the .so then lacks the symbol.)
+__device__ __forceinline__ void buf_lds16(__amdgpu_buffer_rsrc_t r, char* lds, int voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, (int)soff, 0, 0);
 }
 template <int N> __device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void touch(bf16x4& r) { asm volatile("" : "+v"(r)); }
@@ -495,6 +506,7 @@ struct Wgrad3Params {
   int direct, accumulate, with_bias;
   float* bias;
   long long slab_stride;
+  long long p_bytes, q_bytes;         // LEAN: bytes from P / Q to the end of the views (buffer descriptor ranges, < 2^31)
 };
 
 template <int RB> __device__ __forceinline__ int swz3(int k) {       // in 16-B chunks
@@ -507,7 +519,7 @@ template <int RB> __device__ __forceinline__ int swz3(int k) {       // in 16-B 
 // QSHIFT: the x fragments of a row's three taps come from ONE 12-pixel window per lane (three transposing reads) -- tap 2 is the
 // window moved by one dword, tap 1 four v_alignbit_b32 -- instead of three separate 8-pixel reads: 5 instead of 8 fragment reads per
 // sub-step (0.83 KiB of LDS per MFMA instead of 1.33; the kernel is LDS-bandwidth bound).  Same MFMA operands bit for bit.
-template <int BP, int BQ, int NW, bool NARROW, int G, bool QSHIFT>
+template <int BP, int BQ, int NW, bool NARROW, int G, bool QSHIFT, bool LEAN>
 __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   const WgradParams& p = pr.w;
   constexpr int RBP = BP * 2, RBQ = BQ * 2;
@@ -518,6 +530,7 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   constexpr int WPR = BP / (NW / 2), TP = WPR / 32, TQ = BQ / 64;
   constexpr int STAGE = 64 * RBP + QROWS * RBQ;
   static_assert(TP >= 1 && TQ >= 1, "tile/wave mismatch");
+  static_assert(!LEAN || NPCP % NW == 0, "LEAN: piece i of every wave must be of one kind");
   extern __shared__ __attribute__((aligned(128))) char smem_all[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -550,6 +563,14 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   // per-lane staging constants: piece (wave + i * NW) is a dy piece (8 or 4 pixel rows) or an x piece.  LDS row k of a
   // tile is pixel (rho, col) of the step: (0, k) for wide images (one run of a row per step), (k / pitch, k % pitch)
   // for narrow ones (nr image rows per step, each followed by two gap rows so that tap s is still "row k + s").
+  //
+  // LEAN (pad 0, views under 2 GiB; round 4): the loop was bound by instruction issue, not by the matrix pipe -- 144 vector +
+  // 111 scalar instructions per 12 MFMAs (tools/isa_loop_mix.py), two thirds of them the staging's per-piece pointer selects
+  // and 64-bit step bases.  Here a piece is ONE buffer_load_dwordx4 ... lds: the tensor is a buffer descriptor, the lane's
+  // offset inside a step is a constant (a lane that must stage zeros -- gap rows, rows past the tile -- holds an offset the
+  // descriptor's range check rejects: such a lane writes zeros to LDS, tools/probe_buffer_lds), the step's base is a 32-bit
+  // scalar offset advanced by adds, and only a step that is not full (row tail, last rows of an image) compares the lane's
+  // row with the step's limit.  Fragment reads take their sub-step / row-group offsets as immediates.
   int rho[NPW], col[NPW], loff[NPW], ldst[NPW];
   bool isP[NPW], live[NPW];
 #pragma unroll
@@ -567,6 +588,11 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
       loff[i] = (rho[i] * (int)p.qsH + col[i] * qsW) * 2 + (((lane % CPRQ) ^ swz3<RBQ>(k)) * 16);
       ldst[i] = 64 * RBP + (piece - NPCP) * 1024;
     }
+    if constexpr (LEAN) {
+      // static part of "this lane stages a pixel": dy gap columns / rows past the last packed row, x rows past the strip
+      const bool ok = NARROW ? (rho[i] < pr.nr && (!isP[i] || col[i] < p.Wp)) : (isP[i] || k < 66);
+      if (!ok) loff[i] = (int)0x80000000u;
+    }
   }
   // (image, first dy row, first dy column) of the next step to stage: one decode here, then increments
   int s_n, s_y, s_x;
@@ -576,7 +602,70 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
     if (NARROW) { s_y = u * pr.nr; s_x = 0; }
     else { s_y = u / pr.segs_per_row; s_x = (u - s_y * pr.segs_per_row) * 64; }
   }
+  // LEAN: byte offsets of the step's first dy / x pixel from the descriptors' bases, as 32-bit scalars
+  unsigned offP = 0, offQ = 0;
+  __amdgpu_buffer_rsrc_t rsP, rsQ;
+  if constexpr (LEAN) {
+    offP = (unsigned)((s_n * (int)p.psN + s_y * (int)p.psH + s_x * psW) * 2);
+    offQ = (unsigned)((s_n * (int)p.qsN + (s_y + tr) * (int)p.qsH + s_x * qsW) * 2);
+    rsP = __builtin_amdgcn_make_buffer_rsrc((void*)Pb, 0, (int)(pr.p_bytes - (long long)p0 * 2), 0x00020000);
+    rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qb, 0, (int)(pr.q_bytes - (long long)q0 * 2), 0x00020000);
+  }
+  const int lrowP = lane / CPRP, lrowQ = lane / CPRQ;
   auto stage = [&](char* buf) {
+    if constexpr (LEAN) {
+      const unsigned cP = offP, cQ = offQ;
+      int lim;                    // LDS rows of this step that hold pixels (dy; the x strip has two more on wide images)
+      bool full;
+      if (NARROW) {
+        const int nrows = min(pr.nr, p.Hp - s_y);
+        lim = nrows * pr.pitch; full = nrows == pr.nr;
+        s_y += pr.nr;
+        offP += (unsigned)(pr.nr * (int)p.psH * 2); offQ += (unsigned)(pr.nr * (int)p.qsH * 2);
+        if (s_y >= p.Hp) {
+          s_y = 0;
+          offP += (unsigned)(((int)p.psN - pr.units_per_image * pr.nr * (int)p.psH) * 2);
+          offQ += (unsigned)(((int)p.qsN - pr.units_per_image * pr.nr * (int)p.qsH) * 2);
+        }
+      } else {
+        lim = min(64, p.Wp - s_x); full = lim == 64;
+        s_x += 64;
+        offP += (unsigned)(128 * psW); offQ += (unsigned)(128 * qsW);
+        if (s_x >= p.Wp) {
+          s_x = 0;
+          offP += (unsigned)(((int)p.psH - pr.segs_per_row * 64 * psW) * 2);
+          offQ += (unsigned)(((int)p.qsH - pr.segs_per_row * 64 * qsW) * 2);
+          if (++s_y == p.Hp) {
+            s_y = 0;
+            offP += (unsigned)(((int)p.psN - p.Hp * (int)p.psH) * 2);
+            offQ += (unsigned)(((int)p.qsN - p.Hp * (int)p.qsH) * 2);
+          }
+        }
+      }
+      if (full) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+          if (!live[i]) continue;
+          if (i < NPCP / NW) buf_lds16(rsP, buf + ldst[i], loff[i], cP);
+          else buf_lds16(rsQ, buf + ldst[i], loff[i], cQ);
+        }
+      } else {
+        const int limQ = NARROW ? lim : lim + 2;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+          if (!live[i]) continue;
+          const int piece = wave + i * NW;
+          if (i < NPCP / NW) {
+            const int v = lrowP < lim - piece * RPIP ? loff[i] : (int)0x80000000u;
+            buf_lds16(rsP, buf + ldst[i], v, cP);
+          } else {
+            const int v = lrowQ < limQ - (piece - NPCP) * RPIQ ? loff[i] : (int)0x80000000u;
+            buf_lds16(rsQ, buf + ldst[i], v, cQ);
+          }
+        }
+      }
+      return;
+    }
     const int n = s_n, ybase = s_y, x0 = s_x;
     int len, nrows;
     if (NARROW) {
@@ -644,31 +733,16 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
 #pragma unroll
   for (int i = 0; i < TP; ++i) accb[i] = 0.f;
 
+  constexpr int QF = QSHIFT ? 1 : 3, QR = QSHIFT ? 3 : 2;     // fragment groups per column block and transposing reads per group
   for (int it = 0; it < per_group; ++it) {
     const int gi = gbeg + it;
     if (gi + 1 < gend) stage(smem + (cur ^ 1) * STAGE);
     if (gi < gend) {                    // wave-uniform: a group with one step fewer only keeps the barrier     // all pieces up front: spreading them between the MFMA groups lands the stage later and was 8 % slower
     const unsigned Pl = smem_off + cur * STAGE;
-    constexpr int QF = QSHIFT ? 1 : 3, QR = QSHIFT ? 3 : 2;     // fragment groups per column block and transposing reads per group
     bf16x4 fa[2][TP][2], fb[2][QF][TQ][QR];
-    auto issue = [&](int set, int kk) {
-#pragma unroll
-      for (int i = 0; i < TP; ++i) {
-        tr_issue(Pl + pbase[i] + kk * P_KK, fa[set][i][0]);
-        tr_issue(Pl + pbase[i] + kk * P_KK + P_HI, fa[set][i][1]);
-      }
-#pragma unroll
-      for (int s = 0; s < QF; ++s)
-#pragma unroll
-        for (int j = 0; j < TQ; ++j)
-#pragma unroll
-          for (int r = 0; r < QR; ++r) tr_issue(Pl + qbase[s][j] + kk * Q_KK + r * Q_HI, fb[set][s][j][r]);     // rows +0..3, +4..7 [, +8..11]
-    };
-    issue(0, 0);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int set = kk & 1;
-      if (kk + 1 < 4) { issue(set ^ 1, kk + 1); lgkm_wait<NRD>(); } else { lgkm_wait<0>(); }
+    // the MFMAs (and the bias sums) of one 16-pixel sub-step on fragment set `set`
+    auto compute = [&](auto setc) {
+      constexpr int set = decltype(setc)::value;
 #pragma unroll
       for (int i = 0; i < TP; ++i) { touch(fa[set][i][0]); touch(fa[set][i][1]); }
 #pragma unroll
@@ -711,6 +785,56 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) accb[i] += (float)a[i][e];
       }
+    };
+    constexpr std::integral_constant<int, 0> set0{};
+    constexpr std::integral_constant<int, 1> set1{};
+    if constexpr (LEAN) {
+      // one address register per fragment column block; sub-step (kk) and row-group offsets ride in the reads' immediates
+      unsigned pa[TP], qa[QF][TQ];
+#pragma unroll
+      for (int i = 0; i < TP; ++i) pa[i] = Pl + pbase[i];
+#pragma unroll
+      for (int s = 0; s < QF; ++s)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) qa[s][j] = Pl + qbase[s][j];
+#define DCT_W3_ISSUE(set, KK)                                                                                       \
+      {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < TP; ++i) {                                                            \
+          tr_issue_o<(KK) * P_KK>(pa[i], fa[set][i][0]);                                                            \
+          tr_issue_o<(KK) * P_KK + P_HI>(pa[i], fa[set][i][1]);                                                     \
+        }                                                                                                           \
+        _Pragma("unroll") for (int s = 0; s < QF; ++s)                                                              \
+          _Pragma("unroll") for (int j = 0; j < TQ; ++j) {                                                          \
+            tr_issue_o<(KK) * Q_KK>(qa[s][j], fb[set][s][j][0]);                                                    \
+            tr_issue_o<(KK) * Q_KK + Q_HI>(qa[s][j], fb[set][s][j][1]);                                             \
+            if constexpr (QR == 3) tr_issue_o<(KK) * Q_KK + 2 * Q_HI>(qa[s][j], fb[set][s][j][QR - 1]);             \
+          }                                                                                                         \
+      }
+      DCT_W3_ISSUE(0, 0)
+      DCT_W3_ISSUE(1, 1) lgkm_wait<NRD>(); compute(set0);
+      DCT_W3_ISSUE(0, 2) lgkm_wait<NRD>(); compute(set1);
+      DCT_W3_ISSUE(1, 3) lgkm_wait<NRD>(); compute(set0);
+      lgkm_wait<0>(); compute(set1);
+#undef DCT_W3_ISSUE
+    } else {
+    auto issue = [&](int set, int kk) {
+#pragma unroll
+      for (int i = 0; i < TP; ++i) {
+        tr_issue(Pl + pbase[i] + kk * P_KK, fa[set][i][0]);
+        tr_issue(Pl + pbase[i] + kk * P_KK + P_HI, fa[set][i][1]);
+      }
+#pragma unroll
+      for (int s = 0; s < QF; ++s)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+          for (int r = 0; r < QR; ++r) tr_issue(Pl + qbase[s][j] + kk * Q_KK + r * Q_HI, fb[set][s][j][r]);     // rows +0..3, +4..7 [, +8..11]
+    };
+    issue(0, 0);
+    issue(1, 1); lgkm_wait<NRD>(); compute(set0);
+    issue(0, 2); lgkm_wait<NRD>(); compute(set1);
+    issue(1, 3); lgkm_wait<NRD>(); compute(set0);
+    lgkm_wait<0>(); compute(set1);
     }
     }
     __syncthreads();
@@ -814,6 +938,7 @@ int g_tune_wgrad3_target = 768;    // same for the filter-row kernel, in 4-wave 
 int g_tune_wgrad_rows_fill = 70;   // percent: minimum fill of the 64-row K-steps for the filter-row kernel
 int g_tune_wgrad_rows = 1;     // 3x3 stride-1 layers on wide images: three taps of a filter row per block (wgrad3_kernel)
 int g_tune_wgrad_chunks = -1;  // >= 1 forces the number of pixel chunks
+int g_tune_lean = 1;           // bit 0: filter-row kernel with the lean staging (buffer loads, constant lane offsets, immediate read offsets)
 
 static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc* d, int dtype, WPlan& pl) {
   if (p->c % 64 || q->c % 64) return false;
@@ -914,23 +1039,29 @@ static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
   }
   DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ, NW>), dim3(grid), dim3(NW * 64), lds, st, pr);
 }
-template <int BP, int BQ, int NW, bool NARROW, int G, bool QSHIFT>
+template <int BP, int BQ, int NW, bool NARROW, int G, bool QSHIFT, bool LEAN>
 static void launch_w3_q(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
   constexpr size_t lds = G * 2 * (64 * (size_t)BP * 2 + 72 * (size_t)BQ * 2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT, LEAN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT>), dim3(grid), dim3(G * NW * 64), lds, st, pr);
+  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT, LEAN>), dim3(grid), dim3(G * NW * 64), lds, st, pr);
 }
 static void launch_w3(const Wgrad3Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, 3);
   // the planner only picks 64 x 64 tiles for this kernel; always two wave groups per block (half the fp32 slabs at the same waves
   // per CU: +4 % on the step; one group and four groups measured behind) and the three taps' x fragments from ONE 12-pixel window
   // per lane (QSHIFT: 5 transposing reads per sub-step instead of 8, +5-6.5 % on the twelve layers that take this kernel)
-  if (pr.pitch > 0) launch_w3_q<64, 64, 4, true, 2, true>(pr, grid, st); else launch_w3_q<64, 64, 4, false, 2, true>(pr, grid, st);
+  // LEAN (the staging as buffer loads with constant lane offsets; bit-identical): layers without padding whose views stay under 2 GiB
+  const bool lean = (g_tune_lean & 1) && pr.w.pad_h == 0 && pr.w.pad_w == 0 && pr.p_bytes < (1ll << 31) && pr.q_bytes < (1ll << 31);
+  if (pr.pitch > 0) {
+    if (lean) launch_w3_q<64, 64, 4, true, 2, true, true>(pr, grid, st); else launch_w3_q<64, 64, 4, true, 2, true, false>(pr, grid, st);
+  } else {
+    if (lean) launch_w3_q<64, 64, 4, false, 2, true, true>(pr, grid, st); else launch_w3_q<64, 64, 4, false, 2, true, false>(pr, grid, st);
+  }
 }
 static void launch_w2(const Wgrad2Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, pr.w.R * pr.w.S);
@@ -991,6 +1122,8 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float
     pr.pitch = pl.pitch; pr.nr = pl.nr; pr.units_per_image = pl.units;
     pr.direct = pl.direct; pr.accumulate = d->accumulate;
     pr.bias = db; pr.with_bias = db ? 1 : 0; pr.slab_stride = slab_stride;
+    pr.p_bytes = ((long long)(p->n - 1) * p->sn + (long long)(p->h - 1) * p->sh + (long long)(p->w - 1) * p->sw + p->c) * 2;
+    pr.q_bytes = ((long long)(q->n - 1) * q->sn + (long long)(q->h - 1) * q->sh + (long long)(q->w - 1) * q->sw + q->c) * 2;
     launch_w3(pr, pl, st);
   } else if (pl.v2) {
     Wgrad2Params pr;
@@ -1015,6 +1148,7 @@ int dct_tune_set_wgrad(int knob, int value) {
   if (knob == DCT_TUNE_WGRAD_ROWS) { g_tune_wgrad_rows = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_ROWS_FILL) { g_tune_wgrad_rows_fill = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD3_TARGET) { if (value < 64) return DCT_ERR_BAD_ARG; g_tune_wgrad3_target = value; return DCT_OK; }
+  if (knob == DCT_TUNE_LEAN) { g_tune_lean = value; return DCT_OK; }
   if (knob == DCT_TUNE_WGRAD_TARGET) { if (value < 64) return DCT_ERR_BAD_ARG; g_tune_wgrad_target = value; return DCT_OK; }
   return DCT_ERR_BAD_ARG;
 }
