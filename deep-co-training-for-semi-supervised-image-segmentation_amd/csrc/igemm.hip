@@ -19,6 +19,8 @@
 #include <algorithm>
 #include "igemm_common.h"
 
+extern int g_tune_lean;           // wgrad.hip: bit mask of the instruction-lean loop forms (bit 1: this file's packed-rows kernel)
+
 namespace {
 
 
@@ -711,7 +713,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
 // r * pitch + s), so the halo of a 64-channel slice is (PR + 2) * (Wo + 2) <= 192 rows, staged once for nine taps.
 // These layers have few tiles (16 images x 1-7 tiles x Cout / 128), so the channel slices are split over blockIdx.z
 // and the fp32 partial tiles go to slabs folded by splitk_epilogue_kernel (fixed order, as v2's split-K).
-template <int BN, int NWM, int NWN>
+// LEAN (round 4): the same loop with a third fewer instructions per K-step (tools/isa_loop_mix.py: 8 MFMAs carried 20-29 vector and
+// 30-33 scalar instructions; at one block per CU -- the deep levels -- a wave's own instruction stream, not the matrix pipe, set
+// the step).  Halo and weight pieces are buffer loads to LDS with constant lane offsets (out-of-image halo lanes hold an offset the
+// descriptor rejects and stage zeros), the step's offsets are 32-bit scalars advanced by adds, tap offsets advance without a
+// division.  Same LDS image, same reads, same MFMA order: bit-identical.
+template <int BN, int NWM, int NWN, bool LEAN>
 __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, int PR, int tiles_per_img, int chunks_per_split) {
   constexpr int NW = NWM * NWN;
   constexpr int BM = 128, APIECES = 24, A_BYTES = APIECES * 1024;                  // <= 192 halo rows of 128 B
@@ -732,8 +739,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
   const long long Ktot = 9ll * p.Cin;
   const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
   const char* zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 7) * 16;
+  const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
 
   long long aoff[NPA];
+  int aoffb[NPA];                                                // LEAN: the same as a byte offset, or the rejected offset
 #pragma unroll
   for (int i = 0; i < NPA; ++i) {
     const int row = (wave + i * NW) * 8 + (lane >> 3);
@@ -744,6 +753,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
       if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
         aoff[i] = img * p.xsN + iy * p.xsH + ix * p.xsW + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
     }
+    aoffb[i] = aoff[i] >= 0 ? (int)(aoff[i] * 2) : DCT_BUF_INVALID;
+  }
+  __amdgpu_buffer_rsrc_t rsX, rsW;
+  if constexpr (LEAN) {
+    rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)n0 * Ktot * 2), 0, (int)(p.w_bytes - (long long)n0 * Ktot * 2), 0x00020000);
   }
   auto stageA = [&](char* buf, int c0) {
 #pragma unroll
@@ -753,10 +768,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
     }
   };
   const bf16_t* wsrc[NPB];
+  int woffb[NPB];                                                // LEAN: byte offset of the lane's chunk from the tile's first weight row
 #pragma unroll
   for (int i = 0; i < NPB; ++i) {
     const int row = (wave + i * NW) * 8 + (lane >> 3);
     wsrc[i] = reinterpret_cast<const bf16_t*>(p.w) + (long long)(n0 + row) * Ktot + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+    woffb[i] = (int)(((long long)row * Ktot + (((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2);
   }
   auto stageB = [&](char* buf, int tap, int c0) {
     const long long woff = (long long)tap * p.Cin + c0;
@@ -782,7 +799,70 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
 
   const int nch = p.Cin / 64;
   const int cbeg = blockIdx.z * chunks_per_split, cend = min(nch, cbeg + chunks_per_split);
-  const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
+  if constexpr (LEAN) {
+    // LDS byte addresses of this wave's first halo / weight piece in stage 0 (pieces of one kind are NW KiB apart)
+    const unsigned ldsA = smem_l + wave * 1024, ldsB = smem_l + 2 * A_BYTES + wave * 1024;
+    auto stA = [&](int ab_, unsigned soff) {
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) buf_lds16(rsX, ldsA + ab_ * A_BYTES + i * NW * 1024, aoffb[i], soff);
+    };
+    auto stB = [&](int bb_, unsigned soff) {
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) buf_lds16(rsW, ldsB + bb_ * B_BYTES + i * NW * 1024, woffb[i], soff);
+    };
+    const unsigned cin2 = (unsigned)p.Cin * 2;
+    unsigned xo = (unsigned)cbeg * 128;                         // byte offset of the current channel slice in a pixel
+    unsigned wo = xo;                                           // (tap * Cin + c * 64) * 2 of the NEXT weight stage to fetch
+    stA(0, xo);
+    stB(0, wo);
+    __syncthreads();
+    // lane constants of the fragment reads: weight rows at a fixed place, pixel rows move with the tap (rho = rho0 + r * pitch + s)
+    const unsigned Wl0 = smem_l + 2 * A_BYTES + (wn * WTN + l31) * 128 + ((half ^ aswz) * 16);
+    int ab = 0, bb = 0;
+    const int nsteps = 9 * (cend - cbeg);
+    int t = 0, tapoff = 0, scol = 0;                            // tap index, r * pitch + s, s
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k) {
+      // next weight stage: the following tap of this slice, or tap 0 of the next slice
+      if (k + 1 < nsteps) {
+        if (t < 8) wo += cin2; else wo += 128u - 8u * cin2;
+        stB(bb ^ 1, wo);
+      }
+      if (t == 0 && k + 9 < nsteps) stA(ab ^ 1, xo + 128u);
+      const int rho = rho0 + tapoff;
+      const unsigned Wl = Wl0 + bb * B_BYTES;
+      const unsigned Xl = smem_l + ab * A_BYTES + rho * 128 + ((half ^ ((rho >> 1) & 7)) * 16);
+      bf16x8 a[2][TN], b[2];
+      auto issue = [&](int set, int kk) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) rd128((Wl + i * 32 * 128) ^ (kk * 32), a[set][i]);
+        rd128(Xl ^ (kk * 32), b[set]);
+      };
+      issue(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int set = kk & 1;
+        if (kk + 1 < 4) { issue(set ^ 1, kk + 1); lgkm_wait3<TN + 1>(); } else { lgkm_wait3<0>(); }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) touch8(a[set][i]);
+        touch8(b[set]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][i], b[set], acc[i], 0, 0, 0);
+      }
+      __syncthreads();
+      bb ^= 1;
+      // next tap without branches: s wraps every third step (one halo row down, two columns back), the slice every ninth
+      ++t; ++scol;
+      const bool w3 = scol == 3, w9 = t == 9;
+      tapoff += w3 ? pitch - 2 : 1;
+      scol = w3 ? 0 : scol;
+      tapoff = w9 ? 0 : tapoff;
+      t = w9 ? 0 : t;
+      ab ^= w9 ? 1 : 0;
+      xo += w9 ? 128u : 0u;
+    }
+  } else {
   stageA(Abuf, cbeg * 64);
   stageB(Bbuf, 0, cbeg * 64);
   __syncthreads();
@@ -820,6 +900,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
       bb ^= 1;
     }
     ab ^= 1;
+  }
   }
 
   // ---- epilogue: tile row m = pixel slot; row tables behind the tile
@@ -1054,16 +1135,22 @@ static PlanP make_plan_p(const dct_view* x, const dct_view* y, const dct_conv_de
   pp.use = 1; pp.PR = PR; pp.tiles_per_img = tiles;
   return pp;
 }
-static void launch_v3p(const IgemmParams& p, const PlanP& pp, int images, hipStream_t st) {
+template <bool LEAN>
+static void launch_v3p_k(const IgemmParams& p, const PlanP& pp, dim3 grid, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(24 * 1024) + 2 * (size_t)128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3p_kernel<128, 4, 2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3p_kernel<128, 4, 2, LEAN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3p_kernel<128, 4, 2, LEAN>), grid, dim3(512), lds, st, p, pp.PR, pp.tiles_per_img, pp.cps);
+}
+static void launch_v3p(const IgemmParams& p, const PlanP& pp, int images, hipStream_t st) {
   const dim3 grid((unsigned)(images * pp.tiles_per_img), p.N / 128, pp.splits);
-  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3p_kernel<128, 4, 2>), grid, dim3(512), lds, st, p, pp.PR, pp.tiles_per_img, pp.cps);
+  // lean loop: buffer descriptors need the activations and the packed weights under 2 GiB each
+  if ((g_tune_lean & 2) && p.x_bytes < (1ll << 31) && p.w_bytes < (1ll << 31)) launch_v3p_k<true>(p, pp, grid, st);
+  else launch_v3p_k<false>(p, pp, grid, st);
   if (pp.splits > 1) {
     const long long work = (long long)p.M * (p.N / 4);
     DCT_LAUNCH(DCT_PROF_IGEMM, (splitk_epilogue_kernel<bf16_t>), dim3(div_up(work, 256)), dim3(256), 0, st, p, pp.splits);
@@ -1185,6 +1272,8 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   p.partial = nullptr;
   p.staged = 0;
   p.stamps = nullptr;
+  p.x_bytes = ((long long)(x->n - 1) * x->sn + (long long)(x->h - 1) * x->sh + (long long)(x->w - 1) * x->sw + x->c) * esz;
+  p.w_bytes = (long long)p.N * d->R * d->S * x->c * esz;
   if (pl.v2 && pl.splits == 1 && !d->accumulate) {
     const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
                      (long long)y->n * y->sn < (1ll << 31);

@@ -22,6 +22,7 @@ struct IgemmParams {
   int cout;  // real Cout (N/4 in scatter mode)
   int staged;  // v2: LDS-staged epilogue with 16-byte row stores (host-checked alignment / 32-bit offsets)
   unsigned long long* stamps;   // igemm4 diagnostic builds: per-wave cycle sums
+  long long x_bytes, w_bytes;   // lean loops: bytes from x / w to the end of the view / packed weights (buffer descriptor ranges)
 };
 
 // ReLU-gate bits of eight bf16 values (bit e: element e > 0) -- the one-bit-per-element image of an activation that the data
@@ -100,6 +101,13 @@ template <int J, int N, int STRIDE> struct RdCols {      // dst[j] <- 16 bytes a
     if constexpr (J + 1 < N) RdCols<J + 1, N, STRIDE>::run(addr, flip, dst);
   }
 };
+// one LDS-DMA piece through a buffer descriptor: 16 bytes per lane to lds + lane * 16, from base + voff + soff; a lane whose
+// voff + soff lies outside the descriptor's range writes ZEROS (tools/probe_buffer_lds).  Kept in a __device__ helper: called
+// straight from a kernel template, hipcc's host pass silently fails to instantiate the kernel's stub.
+__device__ __forceinline__ void buf_lds16(__amdgpu_buffer_rsrc_t r, unsigned lds, int voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)(size_t)lds, 16, voff, (int)soff, 0, 0);
+}
+#define DCT_BUF_INVALID ((int)0x80000000u)      /* a lane offset every descriptor (< 2 GiB) rejects */
 template <int N> __device__ __forceinline__ void lgkm_wait3() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void touch8(bf16x8& r) { asm volatile("" : "+v"(r)); }
 

@@ -18,6 +18,10 @@
 #include "dct_common.h"
 #include <type_traits>
 
+// bit mask of the instruction-lean loop forms (dct_tune_set(DCT_TUNE_LEAN, ...); all bit-identical to the forms they replace):
+// bit 0 = filter-row weight gradient (this file), bit 1 = packed-rows conv kernel (igemm.hip)
+int g_tune_lean = 3;
+
 namespace {
 
 struct WgradParams {
@@ -938,7 +942,6 @@ int g_tune_wgrad3_target = 768;    // same for the filter-row kernel, in 4-wave 
 int g_tune_wgrad_rows_fill = 70;   // percent: minimum fill of the 64-row K-steps for the filter-row kernel
 int g_tune_wgrad_rows = 1;     // 3x3 stride-1 layers on wide images: three taps of a filter row per block (wgrad3_kernel)
 int g_tune_wgrad_chunks = -1;  // >= 1 forces the number of pixel chunks
-int g_tune_lean = 1;           // bit 0: filter-row kernel with the lean staging (buffer loads, constant lane offsets, immediate read offsets)
 
 static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc* d, int dtype, WPlan& pl) {
   if (p->c % 64 || q->c % 64) return false;
