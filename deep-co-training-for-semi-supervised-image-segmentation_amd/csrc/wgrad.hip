@@ -19,8 +19,8 @@
 #include <type_traits>
 
 // bit mask of the instruction-lean loop forms (dct_tune_set(DCT_TUNE_LEAN, ...); all bit-identical to the forms they replace):
-// bit 0 = filter-row weight gradient (this file), bit 1 = packed-rows conv kernel (igemm.hip)
-int g_tune_lean = 3;
+// bit 0 = filter-row weight gradient, bit 2 = per-tap weight gradient (this file), bit 1 = packed-rows conv kernel (igemm.hip)
+int g_tune_lean = 7;
 
 namespace {
 
@@ -278,6 +278,7 @@ struct Wgrad2Params {
   float* bias;     // bias gradient (column sums of P): direct -> db itself, else unused (slab tail holds it)
   int with_bias;
   long long slab_stride;   // floats per slab: Cp*taps*Cq (+ Cp with the bias tail)
+  long long p_bytes, q_bytes;   // LEAN: bytes from P / Q to the end of the views (buffer descriptor ranges, < 2^31)
 };
 
 // Tile rows are RB bytes (128 or 256); the NW waves of a block each issue NI wave-instructions (RPI rows apiece) per
@@ -300,7 +301,11 @@ template <int RB, int NW> struct TileGeo {
   }
 };
 
-template <int BP, int BQ, int NW>
+// LEAN (round 4; views under 2 GiB): the loop carried 107 vector instructions per 8 MFMAs (tools/isa_loop_mix.py) and was bound by
+// their issue.  A piece is one buffer_load_dwordx4 ... lds whose lane offset is the decoded pixel's byte offset + the lane's chunk
+// (a pixel that contributes zero decodes to an offset the descriptor rejects: that lane stages zeros), so the per-piece 64-bit
+// pointer arithmetic and selects go; the fragment reads carry their sub-step / row-group offsets as immediates.  Bit-identical.
+template <int BP, int BQ, int NW, bool LEAN>
 __global__ __launch_bounds__(NW * 64) void wgrad2_kernel(Wgrad2Params pr) {
   const WgradParams& p = pr.w;
   constexpr int BKP = 64;
@@ -314,7 +319,8 @@ __global__ __launch_bounds__(NW * 64) void wgrad2_kernel(Wgrad2Params pr) {
   constexpr int STAGE = BKP * (RBP + RBQ);
   extern __shared__ __attribute__((aligned(128))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = LEAN ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;     // LEAN: piece bookkeeping and the bias branch stay scalar
   const int wp = wave >> 1, wq = wave & 1;
 
   int chunk, tile;
@@ -351,6 +357,42 @@ __global__ __launch_bounds__(NW * 64) void wgrad2_kernel(Wgrad2Params pr) {
   const int psN = (int)p.psN, psH = (int)p.psH, psW = (int)p.psW;
   const int qsN = (int)p.qsN, qsH = (int)p.qsH, qsW = (int)p.qsW;
 
+  __amdgpu_buffer_rsrc_t rsP, rsQ;
+  if constexpr (LEAN) {
+    rsP = __builtin_amdgcn_make_buffer_rsrc((void*)Pb, 0, (int)(pr.p_bytes - (long long)p0 * 2), 0x00020000);
+    rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qb, 0, (int)(pr.q_bytes - (long long)q0 * 2), 0x00020000);
+  }
+  // LEAN: ONE wave per K-step decodes all 64 pixels of the step two ahead (a lane per pixel) into an LDS table of byte offsets
+  // (0x80000000 = contributes zero: rejected by the descriptors); the waves take turns, and every wave picks the offsets of the
+  // pixels it stages from the table one step later.  The 50 vector instructions of the decode then run once per block and step
+  // instead of once per wave.  table[slot][pixel] = {dy offset, x offset}; slot = step & 1.
+  int* const tab = reinterpret_cast<int*>(smem + 2 * STAGE);
+  auto decode = [&](int slot, int mit) {
+    const int m = mit + lane;
+    int bP = (int)0x80000000u, bQ = (int)0x80000000u;
+    int rem, x;
+    const int n = fdiv(min(m, p.M - 1), pr.dhw, rem);
+    const int y = fdiv(rem, pr.dw_, x);
+    const int iy = y * p.stride + tyo, ix = x * p.stride + txo;
+    if (m < mend) {
+      bP = (n * psN + y * psH + x * psW) * 2;
+      if ((unsigned)iy < (unsigned)p.Hq && (unsigned)ix < (unsigned)p.Wq) bQ = (n * qsN + iy * qsH + ix * qsW) * 2;
+    }
+    int2 v; v.x = bP; v.y = bQ;
+    *reinterpret_cast<int2*>(tab + (slot * 64 + lane) * 2) = v;
+  };
+  auto stage_l = [&](char* buf, int slot) {
+    const int* t = tab + slot * 128 + PPW * wave * 2;
+    int vP[GP::NI], vQ[GQ::NI];
+#pragma unroll
+    for (int i = 0; i < GP::NI; ++i) vP[i] = t[(GP::NI * cP + i) * 2] + chP[i];
+#pragma unroll
+    for (int i = 0; i < GQ::NI; ++i) vQ[i] = t[(GQ::NI * cQ + i) * 2 + 1] + chQ[i];
+#pragma unroll
+    for (int i = 0; i < GP::NI; ++i) buf_lds16(rsP, buf + (GP::RS * i + wave * GP::RPI) * RBP, vP[i], 0u);
+#pragma unroll
+    for (int i = 0; i < GQ::NI; ++i) buf_lds16(rsQ, buf + BKP * RBP + (GQ::RS * i + wave * GQ::RPI) * RBQ, vQ[i], 0u);
+  };
   auto stage = [&](char* buf, int mit) {
     const int m = mit + PPW * wave + (lane % PPW);
     int offP = -1, offQ = -1;
@@ -386,7 +428,13 @@ __global__ __launch_bounds__(NW * 64) void wgrad2_kernel(Wgrad2Params pr) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (mbeg < mend) stage(smem, mbeg);
+  if constexpr (LEAN) {
+    if (wave == 0) { decode(0, mbeg); decode(1, mbeg + BKP); }
+    __syncthreads();
+    if (mbeg < mend) stage_l(smem, 0);
+  } else {
+    if (mbeg < mend) stage(smem, mbeg);
+  }
   __syncthreads();
   int cur = 0;
   // per-lane fragment bases: everything lane-dependent hoisted; kk and the +4 partner are constants
@@ -420,27 +468,23 @@ __global__ __launch_bounds__(NW * 64) void wgrad2_kernel(Wgrad2Params pr) {
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+  constexpr std::integral_constant<int, 0> set0{};
+  constexpr std::integral_constant<int, 1> set1{};
+  static_assert(BKP / 16 == 4, "four sub-steps per K-step");
+  int turn = 0;                                  // LEAN: the wave that decodes in this step
   for (int mit = mbeg; mit < mend; mit += BKP) {
-    if (mit + BKP < mend) stage(smem + (cur ^ 1) * STAGE, mit + BKP);
+    if constexpr (LEAN) {
+      // the table slot of step k (= cur) was read at the top of step k - 1: free since that step's barrier
+      if (wave == turn && mit + 2 * BKP < mend) decode(cur, mit + 2 * BKP);
+      turn = turn + 1 == NW ? 0 : turn + 1;
+      if (mit + BKP < mend) stage_l(smem + (cur ^ 1) * STAGE, cur ^ 1);
+    } else {
+      if (mit + BKP < mend) stage(smem + (cur ^ 1) * STAGE, mit + BKP);
+    }
     const unsigned Pl = smem_off + cur * STAGE;
     bf16x4 fa[2][TP][2], fb[2][TQ][2];           // [set][tile][lo/hi], sets alternate per sub-step
-    auto issue = [&](int set, int kk) {
-#pragma unroll
-      for (int i = 0; i < TP; ++i) {
-        tr_issue(Pl + pbase[i] + kk * P_KK, fa[set][i][0]);
-        tr_issue(Pl + pbase[i] + kk * P_KK + P_HI, fa[set][i][1]);
-      }
-#pragma unroll
-      for (int j = 0; j < TQ; ++j) {
-        tr_issue(Pl + qbase[j] + kk * Q_KK, fb[set][j][0]);
-        tr_issue(Pl + qbase[j] + kk * Q_KK + Q_HI, fb[set][j][1]);
-      }
-    };
-    issue(0, 0);
-#pragma unroll
-    for (int kk = 0; kk < BKP / 16; ++kk) {
-      const int set = kk & 1;
-      if (kk + 1 < BKP / 16) { issue(set ^ 1, kk + 1); lgkm_wait<NRD>(); } else { lgkm_wait<0>(); }
+    auto compute = [&](auto setc) {
+      constexpr int set = decltype(setc)::value;
 #pragma unroll
       for (int i = 0; i < TP; ++i) { touch(fa[set][i][0]); touch(fa[set][i][1]); }
 #pragma unroll
@@ -460,6 +504,48 @@ __global__ __launch_bounds__(NW * 64) void wgrad2_kernel(Wgrad2Params pr) {
 #pragma unroll
         for (int i = 0; i < TP; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, accb[i], 0, 0, 0);
       }
+    };
+    if constexpr (LEAN) {
+      unsigned pa[TP], qa[TQ];
+#pragma unroll
+      for (int i = 0; i < TP; ++i) pa[i] = Pl + pbase[i];
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) qa[j] = Pl + qbase[j];
+#define DCT_W2_ISSUE(set, KK)                                                                  \
+      {                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < TP; ++i) {                                       \
+          tr_issue_o<(KK) * P_KK>(pa[i], fa[set][i][0]);                                       \
+          tr_issue_o<(KK) * P_KK + P_HI>(pa[i], fa[set][i][1]);                                \
+        }                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < TQ; ++j) {                                       \
+          tr_issue_o<(KK) * Q_KK>(qa[j], fb[set][j][0]);                                       \
+          tr_issue_o<(KK) * Q_KK + Q_HI>(qa[j], fb[set][j][1]);                                \
+        }                                                                                      \
+      }
+      DCT_W2_ISSUE(0, 0)
+      DCT_W2_ISSUE(1, 1) lgkm_wait<NRD>(); compute(set0);
+      DCT_W2_ISSUE(0, 2) lgkm_wait<NRD>(); compute(set1);
+      DCT_W2_ISSUE(1, 3) lgkm_wait<NRD>(); compute(set0);
+      lgkm_wait<0>(); compute(set1);
+#undef DCT_W2_ISSUE
+    } else {
+    auto issue = [&](int set, int kk) {
+#pragma unroll
+      for (int i = 0; i < TP; ++i) {
+        tr_issue(Pl + pbase[i] + kk * P_KK, fa[set][i][0]);
+        tr_issue(Pl + pbase[i] + kk * P_KK + P_HI, fa[set][i][1]);
+      }
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) {
+        tr_issue(Pl + qbase[j] + kk * Q_KK, fb[set][j][0]);
+        tr_issue(Pl + qbase[j] + kk * Q_KK + Q_HI, fb[set][j][1]);
+      }
+    };
+    issue(0, 0);
+    issue(1, 1); lgkm_wait<NRD>(); compute(set0);
+    issue(0, 2); lgkm_wait<NRD>(); compute(set1);
+    issue(1, 3); lgkm_wait<NRD>(); compute(set0);
+    lgkm_wait<0>(); compute(set1);
     }
     __syncthreads();
     cur ^= 1;
@@ -1031,16 +1117,21 @@ static void launch_w(const WgradParams& wp, const WPlan& pl, hipStream_t st) {
   else DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad_kernel<T, 64, 64>), dim3(grid), dim3(256), 0, st, wp);
 }
 
-template <int BP, int BQ, int NW>
-static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
-  constexpr size_t lds = 2 * 64 * (size_t)(BP + BQ) * 2;
+template <int BP, int BQ, int NW, bool LEAN>
+static void launch_w2_k(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
+  constexpr size_t lds = 2 * 64 * (size_t)(BP + BQ) * 2 + (LEAN ? 1024 : 0);      // two stages [+ the offset table of the lean form]
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<BP, BQ, NW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<BP, BQ, NW, LEAN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ, NW>), dim3(grid), dim3(NW * 64), lds, st, pr);
+  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ, NW, LEAN>), dim3(grid), dim3(NW * 64), lds, st, pr);
+}
+template <int BP, int BQ, int NW>
+static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
+  if ((g_tune_lean & 4) && pr.p_bytes < (1ll << 31) && pr.q_bytes < (1ll << 31)) launch_w2_k<BP, BQ, NW, true>(pr, grid, st);
+  else launch_w2_k<BP, BQ, NW, false>(pr, grid, st);
 }
 template <int BP, int BQ, int NW, bool NARROW, int G, bool QSHIFT, bool LEAN>
 static void launch_w3_q(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
@@ -1135,6 +1226,8 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float
     pr.dw_.d = p->w; pr.dw_.rcp = 1.0f / (float)pr.dw_.d;
     pr.direct = pl.direct; pr.accumulate = d->accumulate;
     pr.bias = db; pr.with_bias = db ? 1 : 0; pr.slab_stride = slab_stride;
+    pr.p_bytes = ((long long)(p->n - 1) * p->sn + (long long)(p->h - 1) * p->sh + (long long)(p->w - 1) * p->sw + p->c) * 2;
+    pr.q_bytes = ((long long)(q->n - 1) * q->sn + (long long)(q->h - 1) * q->sh + (long long)(q->w - 1) * q->sw + q->c) * 2;
     launch_w2(pr, pl, st);
   } else if (dtype == DCT_BF16) launch_w<bf16_t>(wp, pl, st);
   else launch_w<float>(wp, pl, st);
