@@ -234,7 +234,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 // (their results are never stored).
 
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BOUNDS>
+// LEAN (round 4): pieces as buffer loads to LDS -- a weight piece's lane offset is a constant and its step offset the scalar
+// it * 128 (K runs [tap][cin] in the packed weights), a pixel piece's lane offset is its row's constant plus the tap's scalar offset,
+// and a tap outside the image (BOUNDS) is one bit of a per-row mask built once (such a lane holds the offset the descriptor rejects
+// and stages zeros).  28-58 vector and 41-79 scalar instructions per 8 MFMAs before (tools/isa_loop_mix.py).  Bit-identical.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BOUNDS, bool LEAN>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int ROWB = 128;                 // bytes per LDS row = 64 bf16 of K
@@ -247,7 +251,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
   static_assert(BN % RPP == 0 && BM % RPP == 0 && TM >= 1 && TN >= 1, "tile/wave mismatch");
   extern __shared__ __attribute__((aligned(128))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = LEAN ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
   const int wn = wave / WAVES_M, wm = wave % WAVES_M;
   // (an XCD-aware 1-D tile order -- each XCD a contiguous range of (split, channel tile, pixel tile) -- measured level on the step: removed)
   const int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
@@ -258,6 +263,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
 
   long long rowoff[PB];
   int biy0[PB], bix0[PB];
+  unsigned tapmask[PB];                       // LEAN + BOUNDS: bit t = tap t of this row lies inside the image (R * S <= 32)
 #pragma unroll
   for (int pp = 0; pp < PB; ++pp) {
     int m = m0 + srow + RPP * pp;
@@ -268,6 +274,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
     const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
     rowoff[pp] = n * p.xsN + iy0 * p.xsH + ix0 * p.xsW + schunk * 8;
     biy0[pp] = iy0; bix0[pp] = ix0;
+    tapmask[pp] = 0;
+    if constexpr (LEAN && BOUNDS) {
+      for (int rr = 0; rr < p.R; ++rr)
+        for (int ss = 0; ss < p.S; ++ss)
+          if ((unsigned)(iy0 + rr * p.dil) < (unsigned)p.Hi && (unsigned)(ix0 + ss * p.dil) < (unsigned)p.Wi) tapmask[pp] |= 1u << (rr * p.S + ss);
+    }
   }
   const bf16_t* wrow = reinterpret_cast<const bf16_t*>(p.w) + (long long)(n0 + srow) * Ktot + schunk * 8;
   const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
@@ -279,7 +291,39 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
   int cit = kbeg - tap * p.cin_iters;
   int r = tap / p.S, s = tap - r * p.S;
 
+  __amdgpu_buffer_rsrc_t rsX, rsW;
+  int wvo[PA], xvo[PB];                       // LEAN: constant lane offsets (bytes) of the weight / pixel pieces
+  if constexpr (LEAN) {
+    rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)n0 * Ktot * 2), 0, (int)(p.w_bytes - (long long)n0 * Ktot * 2), 0x00020000);
+#pragma unroll
+    for (int pp = 0; pp < PA; ++pp) wvo[pp] = (int)(((long long)(srow + pp * RPP) * Ktot + schunk * 8) * 2);
+#pragma unroll
+    for (int pp = 0; pp < PB; ++pp) xvo[pp] = (int)(rowoff[pp] * 2);
+  }
+  const unsigned smem_l2 = (unsigned)(size_t)(lptr_c)(smem);
+  int itn = kbeg;                             // LEAN: K-step the next stage() call fetches
   auto stage = [&](char* buf) {
+    if constexpr (LEAN) {
+      const unsigned la = smem_l2 + (unsigned)(buf - smem) + wave * 8 * ROWB;
+#pragma unroll
+      for (int pp = 0; pp < PA; ++pp) buf_lds16(rsW, la + pp * RPP * ROWB, wvo[pp], (unsigned)itn * 128u);
+      const unsigned lb = la + BN * ROWB;
+      const int toffb = ((r * p.dil) * (int)p.xsH + (s * p.dil) * (int)p.xsW + cit * BK) * 2;
+      if (BOUNDS) {
+        // the tap's offset rides in the lane offset (a row's own offset is negative above / left of the image)
+        const int tapi = r * p.S + s;
+#pragma unroll
+        for (int pp = 0; pp < PB; ++pp)
+          buf_lds16(rsX, lb + pp * RPP * ROWB, ((tapmask[pp] >> tapi) & 1u) ? xvo[pp] + toffb : DCT_BUF_INVALID, 0u);
+      } else {
+#pragma unroll
+        for (int pp = 0; pp < PB; ++pp) buf_lds16(rsX, lb + pp * RPP * ROWB, xvo[pp], (unsigned)toffb);
+      }
+      ++itn;
+      if (++cit == p.cin_iters) { cit = 0; if (++s == p.S) { s = 0; ++r; } }
+      return;
+    }
     const int c0 = cit * BK;
     const long long woff = (long long)(r * p.S + s) * p.Cin + c0;
     char* la = buf + wave * 8 * ROWB;
@@ -1072,17 +1116,24 @@ static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc*
   return true;
 }
 
-template <int BM, int BN, int WM, int WN, bool BOUNDS>
-static void launch_v2(const IgemmParams& p, dim3 grid, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, bool BOUNDS, bool LEAN>
+static void launch_v2_k(const IgemmParams& p, dim3 grid, hipStream_t st) {
   constexpr size_t stages = 2 * (size_t)(BM + BN) * 128;
   constexpr size_t lds = stages + (stages + BN * 4 <= 80 * 1024 ? (size_t)BN * 4 : 0);     // two stages [+ the tile's bias vector]
   static bool attr_set = false;   // idempotent one-time opt-in to > 64 KiB dynamic LDS
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, BOUNDS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, BOUNDS, LEAN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm2_kernel<BM, BN, WM, WN, BOUNDS>), grid, dim3(WM * WN * 64), lds, st, p);
+  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm2_kernel<BM, BN, WM, WN, BOUNDS, LEAN>), grid, dim3(WM * WN * 64), lds, st, p);
+}
+template <int BM, int BN, int WM, int WN, bool BOUNDS>
+static void launch_v2(const IgemmParams& p, dim3 grid, hipStream_t st) {
+  // lean loop: activations and packed weights under 2 GiB (buffer descriptors), at most 32 taps (one mask word per row)
+  if ((g_tune_lean & 8) && p.x_bytes < (1ll << 31) && p.w_bytes < (1ll << 31) && p.R * p.S <= 32)
+    launch_v2_k<BM, BN, WM, WN, BOUNDS, true>(p, grid, st);
+  else launch_v2_k<BM, BN, WM, WN, BOUNDS, false>(p, grid, st);
 }
 
 template <int BN, int NWN, int ABUFS>

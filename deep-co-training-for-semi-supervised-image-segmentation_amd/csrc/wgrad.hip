@@ -19,8 +19,8 @@
 #include <type_traits>
 
 // bit mask of the instruction-lean loop forms (dct_tune_set(DCT_TUNE_LEAN, ...); all bit-identical to the forms they replace):
-// bit 0 = filter-row weight gradient, bit 2 = per-tap weight gradient (this file), bit 1 = packed-rows conv kernel (igemm.hip)
-int g_tune_lean = 7;
+// bit 0 = filter-row weight gradient, bit 2 = per-tap weight gradient (this file), bit 1 = packed-rows conv kernel, bit 3 = per-tap conv kernel (igemm.hip)
+int g_tune_lean = 15;
 
 namespace {
 
