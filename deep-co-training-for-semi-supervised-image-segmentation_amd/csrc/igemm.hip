@@ -496,13 +496,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
       const int id = t * (NW * 64) + tid;
       const int row = id / CPR, cc = id % CPR;
       bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
-      if (p.mask_bits) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ((mb[t] >> e) & 1u) ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-      } else if (use_mask[t]) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-      }
+      if (p.mask_bits) chunk_gate_bits(v, mb[t], p.mask_scale);
+      else if (use_mask[t]) chunk_gate_act(v, mk[t], p.mask_scale);
       *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yoff[t]) = v;
       if (p.bits_out) p.bits_out[(unsigned long long)yoff[t] >> 3] = (unsigned char)relu_bits8(v);
     }

@@ -77,16 +77,11 @@ __device__ __forceinline__ void i4_rows_out(const IgemmParams& p, const char* ti
     if (yo[t] < 0) continue;
     bf16x8 v = *reinterpret_cast<const bf16x8*>((row < ROWS0 ? tile0 : tile1) + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
     const int co = n0 + cc * 8;
-    if (p.mask_bits) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = ((mb[t] >> e) & 1u) ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-    } else if (p.mask && co < p.mask_channels) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-    }
+    if (p.mask_bits) chunk_gate_bits(v, mb[t], p.mask_scale);
+    else if (p.mask && co < p.mask_channels) chunk_gate_act(v, mk[t], p.mask_scale);
     if (p.accumulate) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
+      asm volatile("" ::: "memory");
+      chunk_add(v, old[t]);
     }
     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
     if (p.bits_out) p.bits_out[(unsigned)(yo[t] + co) >> 3] = (unsigned char)relu_bits8(v);

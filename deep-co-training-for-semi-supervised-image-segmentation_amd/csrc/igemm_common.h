@@ -25,13 +25,71 @@ struct IgemmParams {
   long long x_bytes, w_bytes;   // lean loops: bytes from x / w to the end of the view / packed weights (buffer descriptor ranges)
 };
 
+// ---- the per-chunk part of the staged epilogues (eight bf16 of one pixel = one 16-byte chunk) on PACKED 16-bit integer arithmetic.
+// Round 4: the epilogues, not the K loops, carried most of the vector instructions of the conv kernels (rocprofv3 SQ_INSTS_VALU:
+// 1040 per wave against 144 MFMAs in the 64-channel patch kernel; ~100 of them per chunk here -- every element unpacked to fp32,
+// compared, multiplied, re-rounded, re-packed, and the accumulate path computed whether asked for or not).  A bf16 is positive exactly
+// when its bits, read as int16, are > 0 (+0 / -0 / negatives are not; a NaN with a clear sign bit would count as positive -- the gate
+// producers are ReLU / max-pool / dropout outputs, which never hold one), so gates and masks are two packed min / max per dword,
+// and "keep or zero" with a unit scale is one AND.
+union Chunk8 { bf16x8 v; unsigned d[4]; };
+// per 16-bit half: 1 where the half, as a signed integer, is > 0 (a positive bf16), else 0.  Inline asm: from the vector-extension
+// form (__builtin_elementwise_min / max on short2) hipcc builds compares + selects + a byte permute, five instructions per dword.
+__device__ __forceinline__ unsigned pk_positive01(unsigned d) {
+  unsigned r;
+  asm("v_pk_min_i16 %0, %1, %2\n\tv_pk_max_i16 %0, %0, %3" : "=&v"(r) : "v"(d), "v"(0x00010001u), "v"(0u));
+  return r;
+}
+// per 16-bit half: 0xFFFF where pk_positive01 says 1
+__device__ __forceinline__ unsigned pk_positive_mask(unsigned d) {
+  unsigned r;
+  asm("v_pk_min_i16 %0, %1, %2\n\tv_pk_max_i16 %0, %0, %3\n\tv_pk_sub_i16 %0, %3, %0" : "=&v"(r) : "v"(d), "v"(0x00010001u), "v"(0u));
+  return r;
+}
+
 // ReLU-gate bits of eight bf16 values (bit e: element e > 0) -- the one-bit-per-element image of an activation that the data
-// gradient of the layer it feeds needs (1/16 of the bytes of the activation itself).
+// gradient of the layer it feeds needs (1/16 of the bytes of the activation itself).  Bits above 7 of the result are junk: callers
+// store the low byte.
 __device__ __forceinline__ unsigned relu_bits8(const bf16x8& v) {
-  unsigned b = 0;
+  Chunk8 c; c.v = v;
+  // dword k holds elements 2k (low half) and 2k + 1: gates at bit 0 and bit 16; the shifted sum puts element 2k at bit 2k and
+  // element 2k + 1 at bit 16 + 2k
+  const unsigned r = pk_positive01(c.d[0]) + (pk_positive01(c.d[1]) << 2) + (pk_positive01(c.d[2]) << 4) + (pk_positive01(c.d[3]) << 6);
+  return r | (r >> 15);
+}
+// v = gate bit ? v * scale : 0 (the ReLU / dropout backward of the producer), gates as one byte
+__device__ __forceinline__ void chunk_gate_bits(bf16x8& v, unsigned bits, float scale) {
+  if (scale == 1.0f) {
+    Chunk8 c; c.v = v;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) b |= ((float)v[e] > 0.f ? 1u : 0u) << e;
-  return b;
+    for (int k = 0; k < 4; ++k) {
+      // 0 / -1 from each element's bit (v_bfe_i32), merged into one AND mask per dword (v_bfi_b32)
+      const int lo = __builtin_amdgcn_sbfe((int)bits, 2 * k, 1), hi = __builtin_amdgcn_sbfe((int)bits, 2 * k + 1, 1);
+      unsigned m;
+      asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(m) : "v"(0xFFFFu), "v"(lo), "v"(hi));
+      c.d[k] &= m;
+    }
+    v = c.v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ((bits >> e) & 1u) ? (bf16_t)((float)v[e] * scale) : (bf16_t)0.f;
+  }
+}
+// the same with the gates read off the activation itself (mk > 0)
+__device__ __forceinline__ void chunk_gate_act(bf16x8& v, const bf16x8& mk, float scale) {
+  if (scale == 1.0f) {
+    Chunk8 c, m; c.v = v; m.v = mk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c.d[k] &= pk_positive_mask(m.d[k]);
+    v = c.v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? (bf16_t)((float)v[e] * scale) : (bf16_t)0.f;
+  }
+}
+__device__ __forceinline__ void chunk_add(bf16x8& v, const bf16x8& old) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
 }
 
 // Second half of the LDS-staged epilogue of the shared-halo kernels: the block streams the [pixel][channel] image of its tile
@@ -63,16 +121,11 @@ __device__ __forceinline__ void staged_rows_out(const IgemmParams& p, const char
     if (yo[t] < 0) continue;
     bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
     const int co = n0 + cc * 8;
-    if (p.mask_bits) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = ((mb[t] >> e) & 1u) ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-    } else if (p.mask && co < p.mask_channels) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (float)mk[t][e] > 0.f ? (bf16_t)((float)v[e] * p.mask_scale) : (bf16_t)0.f;
-    }
-    if (p.accumulate) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[t][e]);
+    if (p.mask_bits) chunk_gate_bits(v, mb[t], p.mask_scale);
+    else if (p.mask && co < p.mask_channels) chunk_gate_act(v, mk[t], p.mask_scale);
+    if (p.accumulate) {                                   // a real (scalar) branch: the compiler used to compute the sum for every chunk and select
+      asm volatile("" ::: "memory");
+      chunk_add(v, old[t]);
     }
     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
     if (p.bits_out) p.bits_out[(unsigned)(yo[t] + co) >> 3] = (unsigned char)relu_bits8(v);
