@@ -870,10 +870,22 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
           for (int i = 0; i < TP; ++i) acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[s][i][j], 0, 0, 0);
         }
       if (do_bias) {
+        if constexpr (LEAN) {
+          // v_dot2c_f32_bf16 against (1, 1): two pixels per instruction instead of an unpack + add each (16 -> 4 per fragment)
+          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+          const bf16x2_t ones2 = {(bf16_t)1.0f, (bf16_t)1.0f};
 #pragma unroll
-        for (int i = 0; i < TP; ++i)
+          for (int i = 0; i < TP; ++i) {
+            union { bf16x8 v; bf16x2_t h[4]; } u; u.v = a[i];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) accb[i] += (float)a[i][e];
+            for (int e = 0; e < 4; ++e) accb[i] = __builtin_amdgcn_fdot2_f32_bf16(u.h[e], ones2, accb[i], false);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) accb[i] += (float)a[i][e];
+        }
       }
     };
     constexpr std::integral_constant<int, 0> set0{};

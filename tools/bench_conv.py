@@ -41,6 +41,10 @@ def timeit(fn, reps):
     return a.elapsed_time(b) / reps * 1e-3
 
 
+TRAINER_FORM = True      # the launches as the trainer makes them: forward leaves ReLU-gate bits, the data gradient masks by such bits
+                         # (1/16 of the bytes of the activation), the weight gradient carries the bias gradient (--plain: none of these)
+
+
 def run(B, reps, what, label, only=None, use_mask=True):
     dt = torch.bfloat16
     rows = []
@@ -60,14 +64,17 @@ def run(B, reps, what, label, only=None, use_mask=True):
         dw = torch.zeros(cout * 9 * cin, device=DEV)
         fl = 2.0 * B * ho * ho * 9 * cin * cout
         r = {"name": name, "flops": fl}
+        ybits = K.relu_bits_like(y) if TRAINER_FORM else None
+        xbits = K.relu_bits_like(x) if TRAINER_FORM and use_mask else None
+        db = torch.zeros(cout, device=DEV) if TRAINER_FORM else None
         if "fwd" in what:
-            t = timeit(lambda: K.conv2d(x, w, bias, y, relu=True), reps)
+            t = timeit(lambda: K.conv2d(x, w, bias, y, relu=True, relu_bits_out=ybits), reps)
             r["fwd"] = t; tot["fwd"][0] += fl; tot["fwd"][1] += t
         if "dgrad" in what:
-            t = timeit(lambda: K.conv2d(dy, wd, None, dx, pad_h=2, pad_w=2, mask=x if use_mask else None), reps)
+            t = timeit(lambda: K.conv2d(dy, wd, None, dx, pad_h=2, pad_w=2, mask=x if use_mask else None, mask_bits=xbits), reps)
             r["dgrad"] = t; tot["dgrad"][0] += fl; tot["dgrad"][1] += t
         if "wgrad" in what:
-            t = timeit(lambda: K.conv2d_wgrad(dy, x, dw, accumulate=True), reps)
+            t = timeit(lambda: K.conv2d_wgrad(dy, x, dw, accumulate=True, db=db), reps)
             r["wgrad"] = t; tot["wgrad"][0] += fl; tot["wgrad"][1] += t
         rows.append(r)
     for name, cin, hin, cout in CONVT:
@@ -118,11 +125,14 @@ def main():
     ap.add_argument("--ab-knob", action="append", default=[], metavar="KNOB=V0,V1[,...]",
                     help="A/B any dct_tune_set knob: interleaved rounds of the listed values in one process (repeatable)")
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--plain", action="store_true", help="no gate bits / bias gradient riding along (the launches of rounds 1-3 of this table)")
     ap.add_argument("--no-mask", action="store_true", help="data gradients without the ReLU mask re-read (timing study only)")
     args = ap.parse_args()
     what = args.what.split(",")
     lib = _lib.load()
     only = set(args.only.split(",")) if args.only else None
+    global TRAINER_FORM
+    TRAINER_FORM = not args.plain
     if args.no_mask:
         for rnd in range(args.rounds):
             run(args.batch, args.reps, ["dgrad"], f"round {rnd}: data gradient with the ReLU mask (re-reads the layer input)", only)
