@@ -58,7 +58,7 @@ __device__ __forceinline__ void epilogue_store4(const IgemmParams& p, int n, int
   }
   if (p.relu) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
   }
   if (p.mask && co < p.mask_channels) {
     const T* mp = reinterpret_cast<const T*>(p.mask) + (n * p.msN + oy * p.msH + ox * p.msW + co);
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
                         acc[i][j][4 * q + 2] + bv[i][q][2], acc[i][j][4 * q + 3] + bv[i][q][3]};
           if (p.relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
           }
           bf16x4 o;
 #pragma unroll
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
         float v[4] = {acc[i][j][0] + bv[i][0], acc[i][j][1] + bv[i][1], acc[i][j][2] + bv[i][2], acc[i][j][3] + bv[i][3]};
         if (p.relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
         }
         bf16x4 o;
 #pragma unroll
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
                       acc[i][4 * q + 3] + bv[i][q][3]};
         if (p.relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
         }
         bf16x4 o;
 #pragma unroll

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(512) void igemm4_kernel(IgemmParams p, I4Geom g) {
           float v[4] = {acc[i][j][0] + bv[i][0], acc[i][j][1] + bv[i][1], acc[i][j][2] + bv[i][2], acc[i][j][3] + bv[i][3]};
           if (p.relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
           }
           bf16x4 o;
 #pragma unroll

@@ -132,6 +132,14 @@ __device__ __forceinline__ void staged_rows_out(const IgemmParams& p, const char
   }
 }
 
+// max(v, 0) as ONE instruction: from fmaxf() hipcc emits a canonicalising v_max_f32 v, v, v in front of the real one (signalling-NaN
+// quieting); the values here are sums of MFMA results and biases, which are never signalling
+__device__ __forceinline__ float relu1(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
 // 128 B of zeros: the LDS-DMA source of taps / halo pixels that fall outside the image (no branch around the DMA)
 __device__ __attribute__((aligned(128))) const uint4 g_zero_page[8] = {};
 
