@@ -147,6 +147,7 @@ def test_conv2d_3x3_shared_halo_is_reproducible(ops, B, Cin, H, W, Cout, pad):
 
 
 _PACKED_DEFAULT = 1
+_LEAN_DEFAULT = 15   # DCT_TUNE_LEAN default (csrc/wgrad.hip g_tune_lean)
 
 
 def _shared_halo_case(ops, B, Cin, H, W, Cout, pad):
@@ -183,6 +184,121 @@ def _shared_halo_case(ops, B, Cin, H, W, Cout, pad):
     ops.conv2d(xd, wd, None, yd[..., :Cout], pad_h=pad, pad_w=pad, mask=to_dev(maskt, dtype), mask_channels=64,
                mask_scale=2.0, accumulate=True)
     close(to_cpu(yd), ref, dtype, "halo conv mask/accumulate/views")
+
+
+# Lean loop forms (DCT_TUNE_LEAN, knob 38): the same kernels with a shorter instruction stream -- staging by buffer_load ... lds with
+# constant lane offsets (lanes that must stage zeros hold an offset the descriptor rejects), scalar step offsets, immediate read
+# offsets.  Every form must reproduce the plain form bit for bit.  (Two further forms of the packed-rows loop were built on top of the
+# lean one, verified the same way -- 150 repeat launches each -- and removed because they lost: a ring of three weight stages behind
+# counted vmcnt waits and raw barriers, and all twelve fragment reads of a K-step issued up front: DESIGN.md 10.)
+@pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [
+    (8, 512, 27, 27, 128, 0),       # 5 rows of 25 per tile, two-way split over channel slices (fp32 slabs)
+    (16, 256, 18, 16, 256, 2),      # data-gradient form (pad 2: halo lanes outside the image stage zeros), ragged last tile
+    (16, 1024, 13, 13, 128, 0),     # one 11 x 11 tile per image, four-way split: 36 K-steps per block
+    (16, 512, 16, 16, 512, 0),      # 14 x 14 outputs, two tiles per image, unsplit: 72 K-steps, eight channel slices
+    (3, 64, 20, 30, 128, 0),        # a single channel slice: nine K-steps, the ring never wraps a slice
+])
+def test_conv2d_packed_rows_lean_form_is_bit_identical(ops, B, Cin, H, W, Cout, pad):
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(21)
+    x = to_dev(q(torch.randn(B, Cin, H, W, generator=g), dtype), dtype)
+    w = kmajor(q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9), dtype), dtype)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    lib = _lib.load()
+    lib.dct_tune_set(10, 1)
+    lib.dct_tune_set(24, 30)         # every case on the packed-rows kernel, whatever its tile fill
+    outs = {}
+    try:
+        for form in (0, 2):          # plain, lean
+            assert lib.dct_tune_set(38, form) == 0
+            y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=dtype, device=DEV)
+            ops.conv2d(x, w, b, y, pad_h=pad, pad_w=pad, relu=True)
+            outs[form] = y
+        first = outs[2]
+        for _ in range(20):          # repeat launches reproduce the first (LDS-DMA stages behind barriers)
+            y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=dtype, device=DEV)
+            ops.conv2d(x, w, b, y, pad_h=pad, pad_w=pad, relu=True)
+            assert torch.equal(y.view(torch.int16), first.view(torch.int16))
+    finally:
+        lib.dct_tune_set(38, _LEAN_DEFAULT)
+        lib.dct_tune_set(24, 76)
+        lib.dct_tune_set(10, _PACKED_DEFAULT)
+    assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16)), "lean form differs from the plain form"
+    assert not torch.isnan(first.float()).any()
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [
+    (4, 64, 130, 132, 64, 0),       # filter-row kernel, wide images: runs of 64 pixels, ragged row tail (130 = 2 x 64 + 2)
+    (8, 256, 27, 27, 128, 0),       # filter-row kernel, narrow images: packed rows at pitch 27, last step of an image partial
+    (16, 1024, 11, 11, 128, 0),     # per-tap kernel (step fill under the filter-row threshold): one wave per K-step decodes the pixels
+    (3, 128, 70, 101, 128, 1),      # padding: the filter-row kernel keeps its plain form, the per-tap kernel's bounds go through the table
+])
+def test_conv2d_wgrad_lean_forms_are_bit_identical(ops, B, Cin, H, W, Cout, pad):
+    """Weight gradients with DCT_TUNE_LEAN = 0 (plain loops) and 15 (lean loops): dW bit for bit; the bias gradient to fp32 rounding
+    (the lean filter-row kernel sums it with v_dot2c_f32_bf16, two pixels per instruction)."""
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(23)
+    x = to_dev(q(torch.randn(B, Cin, H, W, generator=g), dtype), dtype)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    dy = to_dev(q(torch.randn(B, Cout, Ho, Wo, generator=g), dtype), dtype)
+    lib = _lib.load()
+    outs = {}
+    try:
+        for form in (0, 15, 15):
+            assert lib.dct_tune_set(38, form) == 0
+            dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=DEV)
+            db = torch.full((Cout,), float("nan"), device=DEV)
+            ops.conv2d_wgrad(dy, x, dw, pad_h=pad, pad_w=pad, accumulate=False, db=db)
+            torch.cuda.synchronize()
+            outs.setdefault(form, []).append((dw, db))
+    finally:
+        lib.dct_tune_set(38, _LEAN_DEFAULT)
+    (dw0, db0), (dw1, db1), (dw2, db2) = outs[0][0], outs[15][0], outs[15][1]
+    assert torch.equal(dw0, dw1), "lean weight gradient differs from the plain form"
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2), "lean form does not reproduce itself"
+    assert (db0 - db1).abs().max().item() <= 2e-6 * max(1.0, db0.abs().max().item()) * math.sqrt(B * Ho * Wo)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,pad,stride,scatter", [
+    (16, 1024, 11, 11, 256, 3, 0, 1, False),    # per-tap kernel, taps inside the image
+    (16, 256, 11, 11, 256, 3, 2, 1, False),     # data-gradient form: taps outside the image through the per-row tap mask
+    (4, 128, 40, 44, 64, 3, 1, 1, False),       # 256 x 64 tile (Cout = 64), bounds
+    (16, 512, 9, 9, 256, 1, 0, 1, True),        # transposed 2x2 s2 convolution forward (scatter epilogue)
+])
+def test_conv2d_per_tap_lean_form_is_bit_identical(ops, B, Cin, H, W, Cout, k, pad, stride, scatter):
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(29)
+    x = to_dev(q(torch.randn(B, Cin, H, W, generator=g), dtype), dtype)
+    lib = _lib.load()
+    lib.dct_tune_set(7, 0)           # per-tap kernel everywhere
+    outs = []
+    try:
+        if scatter:
+            w = q(torch.randn(4 * Cout, Cin, generator=g) / math.sqrt(Cin), dtype).to(DEV).to(dtype).contiguous()
+            b = torch.randn(Cout, generator=g).to(DEV)
+            for form in (0, 15):
+                lib.dct_tune_set(38, form)
+                y = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), dtype=dtype, device=DEV)
+                ops.conv2d(x, w, b, y, R=1, S=1, relu=True, scatter2x2=True)
+                outs.append(y)
+        else:
+            w = kmajor(q(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype), dtype)
+            b = torch.randn(Cout, generator=g).to(DEV)
+            Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+            for form in (0, 15):
+                lib.dct_tune_set(38, form)
+                y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=dtype, device=DEV)
+                ops.conv2d(x, w, b, y, R=k, S=k, stride=stride, pad_h=pad, pad_w=pad, relu=True)
+                outs.append(y)
+    finally:
+        lib.dct_tune_set(38, _LEAN_DEFAULT)
+        lib.dct_tune_set(7, 1)
+    assert not torch.isnan(outs[0].float()).any()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "lean per-tap kernel differs from the plain form"
 
 
 _I4_DEFAULT = 0      # the kernel is an alternative tile family (level with igemm.hip on the cfg2 step): off unless asked for
