@@ -13,7 +13,7 @@ for c in cfg2; do
   run m_$c  --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/m_$c -o m --output-format csv -- python3 bench.py --config $c --steps 5 --warmup 3 $B --single-stream --no-graph
   python3 tools/rocprof_summary.py $(find $O/k_$c -name "*kernel_trace.csv" | head -1) > $O/${c}_single_stream_kernel_stats.txt
   python3 tools/rocprof_summary.py $(find $O/kd_$c -name "*kernel_trace.csv" | head -1) > $O/${c}_default_command_kernel_stats.txt
-  python3 tools/pmc_traffic.py "$(find $O/f_$c -name "*counter_collection.csv" | head -1)" "$(find $O/w_$c -name "*counter_collection.csv" | head -1)" $c 16 > $O/${c}_pmc_traffic.json
+  python3 tools/pmc_traffic.py "$(find $O/f_$c -name "*counter_collection.csv" | head -1)" "$(find $O/w_$c -name "*counter_collection.csv" | head -1)" $c 24 > $O/${c}_pmc_traffic.json
   python3 tools/pmc_mfma.py "$(find $O/m_$c -name "*counter_collection.csv" | head -1)" "$(find $O/m_$c -name "*kernel_trace.csv" | head -1)" > $O/${c}_pmc_mfma_busy.txt
 done
 timeout 600 python tools/bench_conv.py --batch 16 > $O/bench_conv_per_layer.txt 2>&1
