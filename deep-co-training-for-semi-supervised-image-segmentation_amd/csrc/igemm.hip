@@ -1150,7 +1150,10 @@ int g_tune_igemm_packed = 1;     // packed-rows shared-halo kernel for the deep 
                                  // level on the step because every layer under 400 blocks was split over channel slices (fp32 slabs);
                                  // with the split only under 100 blocks -- the two model streams supply the parallelism -- it is
                                  // +0.9 / +2.1 / +1.3 % on the cfg2 step (three in-process A/B rounds, tools/ab_step.py --pre 23=100 --knob 10)
-int g_tune_igemm_packed_split = 100;   // packed kernel: layers with fewer blocks than this are split over channel slices (fp32 slabs)
+int g_tune_igemm_packed_split = 160;   // packed kernel: layers with fewer blocks than this are split over channel slices (fp32 slabs).  Round 3: 100
+                                       // (+0.9 / +2.1 / +1.3 % on the step against 400); round 4, after the instruction diet: 160-200 are 1.7 % ahead of
+                                       // 100 on the step (5.52 -> 5.43 ms, three alternating graph-mode runs each; 260: 5.45) -- cen_a, enc4a and enc4b
+                                       // (128 blocks each) now run as 256
 int g_tune_igemm_packed_fill = 76;     // percent: least fill of the packed 128-pixel tiles
 static PlanP make_plan_p(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int N) {
   PlanP pp = {0, 0, 0, 1, 0};
