@@ -433,8 +433,9 @@ enum { DCT_TUNE_IGEMM_SPLIT = 1,   /* >= 1: force the split-K factor; -1 (defaul
                                                 csrc/enet.hip g_enet_fuse_finalize); 0 (default): one-block launches of their own */
        DCT_TUNE_IGEMM4 = 35,                 /* 1: 3x3 stride-1 bf16 layers on the persistent one-block-per-CU ping-pong tile (csrc/igemm4.hip); 0 (default): igemm.hip tiles -- level on the step */
        DCT_TUNE_IGEMM4_MIN_BLOCKS = 37,      /* default 96: fewest blocks for which it is taken (1: whatever the layer, the tests' setting) */
-       DCT_TUNE_LEAN = 38 };                 /* bit mask (default: all set) of the instruction-lean loop forms, bit-identical to the forms they replace:
-                                                bit 0 = filter-row weight gradient (staging by buffer loads with constant lane offsets) */
+       DCT_TUNE_LEAN = 38 };                 /* bit mask (default 15: all set) of the instruction-lean loop forms, each bit-identical to
+                                                the plain form it replaces (0 = the plain forms, the tests' reference): bit 0 = filter-row weight gradient,
+                                                bit 1 = packed-rows conv kernel, bit 2 = per-tap weight gradient, bit 3 = per-tap conv kernel */
 /* (Knob numbers are stable across rounds; the gaps are A/B switches of variants that were measured slower and removed with their
  *  kernels -- DESIGN.md 4.1 / 4.2: register-staged bf16 kernels, 4-wave tiles, scattered epilogue stores, the 32x32x16 shared-halo
  *  form, XCD-aware tile orders, the weight-ring and four-fat-wave shared-halo tiles, one / four wave groups and per-tap reads in the
