@@ -871,6 +871,8 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
         }
       if (do_bias) {
         if constexpr (LEAN) {
+          // a real (scalar) branch: without the barrier hipcc computes the four dot products in EVERY wave and selects
+          asm volatile("" ::: "memory");
           // v_dot2c_f32_bf16 against (1, 1): two pixels per instruction instead of an unpack + add each (16 -> 4 per fragment)
           typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
           const bf16x2_t ones2 = {(bf16_t)1.0f, (bf16_t)1.0f};
