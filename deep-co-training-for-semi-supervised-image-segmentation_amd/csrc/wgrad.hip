@@ -597,7 +597,18 @@ struct Wgrad3Params {
   float* bias;
   long long slab_stride;
   long long p_bytes, q_bytes;         // LEAN: bytes from P / Q to the end of the views (buffer descriptor ranges, < 2^31)
+  unsigned long long* stamps;         // diagnostic build (-DDCT_W3_STAMPS, tools/gpu/w3_stamps.py): per-wave cycle sums of the K-step's segments
 };
+#ifdef DCT_W3_STAMPS
+// s_memtime with its own lgkmcnt(0) (cdna_hip_programming.md, In-kernel stamps): placed only where no counted LDS wait is pending
+__device__ __forceinline__ unsigned long long w3_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#endif
 
 template <int RB> __device__ __forceinline__ int swz3(int k) {       // in 16-B chunks
   return RB == 256 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2);
@@ -824,9 +835,16 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   for (int i = 0; i < TP; ++i) accb[i] = 0.f;
 
   constexpr int QF = QSHIFT ? 1 : 3, QR = QSHIFT ? 3 : 2;     // fragment groups per column block and transposing reads per group
+#ifdef DCT_W3_STAMPS
+  unsigned long long st_dma = 0, st_comp = 0, st_bar = 0, st_t0 = w3_stamp();
+  const unsigned long long st_begin = st_t0;
+#endif
   for (int it = 0; it < per_group; ++it) {
     const int gi = gbeg + it;
     if (gi + 1 < gend) stage(smem + (cur ^ 1) * STAGE);
+#ifdef DCT_W3_STAMPS
+    { const unsigned long long t = w3_stamp(); st_dma += t - st_t0; st_t0 = t; }
+#endif
     if (gi < gend) {                    // wave-uniform: a group with one step fewer only keeps the barrier     // all pieces up front: spreading them between the MFMA groups lands the stage later and was 8 % slower
     const unsigned Pl = smem_off + cur * STAGE;
     bf16x4 fa[2][TP][2], fb[2][QF][TQ][QR];
@@ -941,9 +959,21 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
     lgkm_wait<0>(); compute(set1);
     }
     }
+#ifdef DCT_W3_STAMPS
+    { const unsigned long long t = w3_stamp(); st_comp += t - st_t0; st_t0 = t; }
+#endif
     __syncthreads();
+#ifdef DCT_W3_STAMPS
+    { const unsigned long long t = w3_stamp(); st_bar += t - st_t0; st_t0 = t; }
+#endif
     cur ^= 1;
   }
+#ifdef DCT_W3_STAMPS
+  if (pr.stamps && lane == 0 && blockIdx.x < 4096) {
+    unsigned long long* o = pr.stamps + ((size_t)blockIdx.x * (G * NW) + wave_all) * 8;
+    o[0] = st_dma; o[1] = st_comp; o[2] = st_bar; o[3] = st_t0 - st_begin; o[4] = (unsigned long long)per_group; o[5] = st_begin;
+  }
+#endif
   if constexpr (G > 1) {
     // fold the groups: group g > 0 parks its accumulators in LDS (lane-linear), group 0 adds them in order
     float* fold = reinterpret_cast<float*>(smem_all);
@@ -1182,6 +1212,9 @@ static void launch_w2(const Wgrad2Params& pr, const WPlan& pl, hipStream_t st) {
 
 }  // namespace
 
+unsigned long long* g_w3_stamps = nullptr;    // diagnostic builds only
+extern "C" int dct_debug_w3_stamps(void* buf) { g_w3_stamps = (unsigned long long*)buf; return 0; }
+
 extern "C" size_t dct_conv2d_wgrad_workspace_bytes(const dct_view* p, const dct_view* q, const dct_conv_desc* d, int dtype) {
   if (!p || !q || !d) return 0;
   WPlan pl;
@@ -1232,6 +1265,7 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float
     pr.bias = db; pr.with_bias = db ? 1 : 0; pr.slab_stride = slab_stride;
     pr.p_bytes = ((long long)(p->n - 1) * p->sn + (long long)(p->h - 1) * p->sh + (long long)(p->w - 1) * p->sw + p->c) * 2;
     pr.q_bytes = ((long long)(q->n - 1) * q->sn + (long long)(q->h - 1) * q->sh + (long long)(q->w - 1) * q->sw + q->c) * 2;
+    pr.stamps = g_w3_stamps;
     launch_w3(pr, pl, st);
   } else if (pl.v2) {
     Wgrad2Params pr;
