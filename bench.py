@@ -331,7 +331,7 @@ def main():
     for kv in args.attr:
         k, v = kv.split("=")
         assert hasattr(tr, k), k
-        setattr(tr, k, bool(int(v)))
+        setattr(tr, k, bool(int(v)) if isinstance(getattr(tr, k), bool) or getattr(tr, k) is None else int(v))
     for kv in args.net_attr:
         k, v = kv.split("=")
         for seg in tr.segmentators:
