@@ -262,6 +262,33 @@ def test_conv2d_wgrad_lean_forms_are_bit_identical(ops, B, Cin, H, W, Cout, pad)
     assert (db0 - db1).abs().max().item() <= 2e-6 * max(1.0, db0.abs().max().item()) * math.sqrt(B * Ho * Wo)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [
+    (16, 1024, 11, 11, 128, 0),     # per-tap kernel: the rotating decoder wave and its two-slot offset table, 31 K-steps per block
+    (6, 128, 9, 9, 128, 0),         # per-tap kernel, ONE to two K-steps per chunk: the table's prologue and tail
+    (8, 256, 27, 27, 128, 0),       # filter-row kernel, narrow images
+    (4, 64, 130, 132, 64, 0),       # filter-row kernel, wide images with a ragged row tail
+])
+def test_conv2d_wgrad_lean_forms_race_screen(ops, B, Cin, H, W, Cout, pad):
+    """The lean weight-gradient kernels stage through buffer loads behind the same barriers as before, and the per-tap one adds a new
+    hand-off: one wave per K-step writes the step-after-next's pixel offsets into an LDS table slot that every wave read one step
+    earlier.  A missed wait there shows as a launch that differs: 200 launches must reproduce the first bit for bit."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(31)
+    x = to_dev(q(torch.randn(B, Cin, H, W, generator=g), dtype), dtype)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    dy = to_dev(q(torch.randn(B, Cout, Ho, Wo, generator=g), dtype), dtype)
+    first = None
+    for it in range(200):
+        dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=DEV)
+        db = torch.full((Cout,), float("nan"), device=DEV)
+        ops.conv2d_wgrad(dy, x, dw, pad_h=pad, pad_w=pad, accumulate=False, db=db)
+        if first is None:
+            first = (dw, db)
+            assert not torch.isnan(dw).any() and not torch.isnan(db).any()
+        else:
+            assert torch.equal(dw, first[0]) and torch.equal(db, first[1]), f"launch {it} differs from the first"
+
+
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,pad,stride,scatter", [
     (16, 1024, 11, 11, 256, 3, 0, 1, False),    # per-tap kernel, taps inside the image
     (16, 256, 11, 11, 256, 3, 2, 1, False),     # data-gradient form: taps outside the image through the per-row tap mask
