@@ -1064,6 +1064,8 @@ struct Plan {
 // the alignment allows it (scattered 8-byte stores kept the last waves in the store queue for a quarter of a block's life).
 int g_tune_igemm_split_target = 450;   // block target of a split layer (tiles < 200)
 int g_tune_igemm_split = -1;    // >= 1 forces the split-K factor
+int g_tune_igemm_split_max_tiles = 96;   // layers with at least this many tiles run unsplit
+int g_tune_igemm_split_min_kiters = 4;    // ... and so do layers with fewer K-steps than this
 int g_tune_igemm_halo_cover = 75;      // percent of the image the 8 x 16 patches must cover
 int g_tune_igemm_halo_min_blocks = 400;
 int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3m_kernel); 0: always the per-tap kernel
@@ -1094,7 +1096,7 @@ static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc*
     // measured on the UNet layer set (tools/bench_conv.py --ab): a layer with >= 200 tiles runs fastest unsplit
     // (two resident blocks per CU interleave); below that ~450 blocks in total is the sweet spot, and each
     // split must keep >= 4 K-steps to amortise its prologue and its fp32 slab
-    if (pl.tiles < 200) {
+    if (pl.tiles < g_tune_igemm_split_max_tiles && pl.kiters >= g_tune_igemm_split_min_kiters) {
       splits = (int)((g_tune_igemm_split_target + pl.tiles / 2) / pl.tiles);
       if (splits > 8) splits = 8;
       while (splits > 1 && pl.kiters / splits < 4) --splits;
@@ -1425,6 +1427,8 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM4: g_tune_igemm4 = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM4_MIN_BLOCKS: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm4_min_blocks = value; return DCT_OK;
     case 1000: g_tune_igemm4_ablate = value; return DCT_OK;      // diagnostic builds only
+    case 1002: g_tune_igemm_split_max_tiles = value; return DCT_OK;     // planner studies (tools/bench_conv.py --ab-knob)
+    case 1003: g_tune_igemm_split_min_kiters = value; return DCT_OK;
     case 1001: if (value < 0) return DCT_ERR_BAD_ARG; g_tune_igemm4_blocks = value; return DCT_OK;      // diagnostic: persistent blocks per launch
     case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
