@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels of libdct_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <stdint.h>
 #include "../../include/dct.h"
 
@@ -71,6 +72,9 @@ __device__ __forceinline__ float block_sum_256(float v, float* smem4) {
 void dct_prof_begin(int cls, hipStream_t s);
 void dct_prof_end(int cls, hipStream_t s);
 extern int g_dct_prof_on;
+
+extern thread_local char g_dct_last_plan[200];
+#define DCT_PLAN_NOTE(...) snprintf(g_dct_last_plan, sizeof(g_dct_last_plan), __VA_ARGS__)
 
 #define DCT_LAUNCH(cls, kernel, grid, block, shmem, stream, ...)                       \
   do {                                                                                 \

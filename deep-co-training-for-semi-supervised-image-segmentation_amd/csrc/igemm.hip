@@ -1350,6 +1350,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
       IgemmParams q = p;
       q.partial = nullptr;
       const int took = dct_igemm4_launch(&q, y->n, workspace, workspace_bytes, st);
+      if (took) DCT_PLAN_NOTE("igemm4 (one block per CU, 256 px x 128 ch)%s", took == 2 ? " split" : "");
       if (took == 1) return dct_check_launch();
       if (took == 2) {
         q.partial = (float*)workspace;
@@ -1380,6 +1381,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
       if (bn == 128) {
         if (x->c == 64) launch_v3<128, 2, 1>(p, tiles_x, tiles_y, y->n, st); else launch_v3<128, 2, 2>(p, tiles_x, tiles_y, y->n, st);
       } else launch_v3<64, 1, 1>(p, tiles_x, tiles_y, y->n, st);
+      DCT_PLAN_NOTE("igemm3m shared-halo 8x16 patches x %d ch: %lld blocks, cover %.0f %%, %d K-steps", bn, blocks, cover * 100, 9 * x->c / 64);
       return dct_check_launch();
     }
   }
@@ -1395,12 +1397,16 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
         IgemmParams q = p;
         q.partial = pp.splits > 1 ? (float*)workspace : nullptr;
         launch_v3p(q, pp, y->n, st);
+        DCT_PLAN_NOTE("igemm3p packed rows (%d rows of %d px per 128-px tile): %d x %d blocks x %d channel-slice splits", pp.PR, p.Wo,
+                      y->n * pp.tiles_per_img, p.N / 128, pp.splits);
         if (pp.splits > 1) bits_after();
         return dct_check_launch();
       }
     }
   }
   const int rc = dtype == DCT_BF16 ? launch<bf16_t>(p, pl, st) : launch<float>(p, pl, st);
+  DCT_PLAN_NOTE("%s per-tap %d x %d tile%s: %lld tiles x %d splits, %d K-steps each%s", pl.v2 ? "igemm2" : "igemm", pl.bm, pl.bn,
+                pl.bounds ? " (bounds)" : "", pl.tiles, pl.splits, pl.kiters_per_split, p.staged ? ", staged epilogue" : "");
   if (rc == DCT_OK && !p.staged) bits_after();
   return rc == DCT_OK ? dct_check_launch() : rc;
 }

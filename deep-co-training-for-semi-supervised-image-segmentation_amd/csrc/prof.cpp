@@ -7,6 +7,11 @@
 
 int g_dct_prof_on = 0;
 
+// Diagnostic: which kernel / grid the planner chose for the last dct_conv2d / dct_conv2d_wgrad call of this thread
+// (tools/bench_conv.py --plan prints it per layer).  Not part of the ABI contract.
+thread_local char g_dct_last_plan[200] = "";
+extern "C" const char* dct_debug_last_plan() { return g_dct_last_plan; }
+
 namespace {
 struct Rec { int cls; hipEvent_t a, b; };
 std::mutex g_mu;

@@ -1279,6 +1279,9 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float
     launch_w2(pr, pl, st);
   } else if (dtype == DCT_BF16) launch_w<bf16_t>(wp, pl, st);
   else launch_w<float>(wp, pl, st);
+  DCT_PLAN_NOTE("%s %d x %d tile: %d x %d x %d taps, %d pixel chunks%s%s", pl.v3 ? "wgrad3 filter-row" : pl.v2 ? "wgrad2 per-tap" : "wgrad",
+                pl.bp, pl.bq, pl.ptiles, pl.qtiles, d->R * d->S, pl.chunks, pl.v3 ? (pl.pitch ? " (narrow rows)" : " (wide rows)") : "",
+                pl.direct ? ", direct" : "");
   if (!pl.direct) {
     const long long n4b = db ? p->c / 4 : 0;
     DCT_LAUNCH(DCT_PROF_WGRAD, wgrad_reduce_kernel, dim3(div_up(E / 4 + n4b, 256)), dim3(256), 0, st,

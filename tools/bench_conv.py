@@ -41,6 +41,16 @@ def timeit(fn, reps):
     return a.elapsed_time(b) / reps * 1e-3
 
 
+PLAN = False             # --plan: the planner's choice per launch (dct_debug_last_plan)
+
+
+def plan_note():
+    import ctypes
+    f = _lib.load().dct_debug_last_plan
+    f.restype = ctypes.c_char_p
+    return f().decode()
+
+
 TRAINER_FORM = True      # the launches as the trainer makes them: forward leaves ReLU-gate bits, the data gradient masks by such bits
                          # (1/16 of the bytes of the activation), the weight gradient carries the bias gradient (--plain: none of these)
 
@@ -69,13 +79,13 @@ def run(B, reps, what, label, only=None, use_mask=True):
         db = torch.zeros(cout, device=DEV) if TRAINER_FORM else None
         if "fwd" in what:
             t = timeit(lambda: K.conv2d(x, w, bias, y, relu=True, relu_bits_out=ybits), reps)
-            r["fwd"] = t; tot["fwd"][0] += fl; tot["fwd"][1] += t
+            r["fwd"] = t; tot["fwd"][0] += fl; tot["fwd"][1] += t; r["fwd_plan"] = plan_note()
         if "dgrad" in what:
             t = timeit(lambda: K.conv2d(dy, wd, None, dx, pad_h=2, pad_w=2, mask=x if use_mask else None, mask_bits=xbits), reps)
-            r["dgrad"] = t; tot["dgrad"][0] += fl; tot["dgrad"][1] += t
+            r["dgrad"] = t; tot["dgrad"][0] += fl; tot["dgrad"][1] += t; r["dgrad_plan"] = plan_note()
         if "wgrad" in what:
             t = timeit(lambda: K.conv2d_wgrad(dy, x, dw, accumulate=True, db=db), reps)
-            r["wgrad"] = t; tot["wgrad"][0] += fl; tot["wgrad"][1] += t
+            r["wgrad"] = t; tot["wgrad"][0] += fl; tot["wgrad"][1] += t; r["wgrad_plan"] = plan_note()
         rows.append(r)
     for name, cin, hin, cout in CONVT:
         if only and name not in only:
@@ -92,13 +102,13 @@ def run(B, reps, what, label, only=None, use_mask=True):
         r = {"name": name, "flops": fl}
         if "fwd" in what:
             t = timeit(lambda: K.conv2d(x, wf, bias, y, R=1, S=1, relu=True, scatter2x2=True), reps)
-            r["fwd"] = t; tot["fwd"][0] += fl; tot["fwd"][1] += t
+            r["fwd"] = t; tot["fwd"][0] += fl; tot["fwd"][1] += t; r["fwd_plan"] = plan_note()
         if "dgrad" in what:
             t = timeit(lambda: K.conv2d(dy, wd, None, dx, R=2, S=2, stride=2, mask=x if use_mask else None), reps)
-            r["dgrad"] = t; tot["dgrad"][0] += fl; tot["dgrad"][1] += t
+            r["dgrad"] = t; tot["dgrad"][0] += fl; tot["dgrad"][1] += t; r["dgrad_plan"] = plan_note()
         if "wgrad" in what:
             t = timeit(lambda: K.conv2d_wgrad(x, dy, dw, R=2, S=2, stride=2, accumulate=True), reps)
-            r["wgrad"] = t; tot["wgrad"][0] += fl; tot["wgrad"][1] += t
+            r["wgrad"] = t; tot["wgrad"][0] += fl; tot["wgrad"][1] += t; r["wgrad_plan"] = plan_note()
         rows.append(r)
     print(f"--- {label}  (B={B}; us / TFLOP/s)")
     for r in rows:
@@ -110,6 +120,12 @@ def run(B, reps, what, label, only=None, use_mask=True):
     for k, (f, t) in tot.items():
         if t > 0:
             print(f"TOTAL {k}: {t * 1e3:.3f} ms, {f / t / 1e12:.1f} TFLOP/s")
+    if PLAN:
+        print("--- planner's choice per launch")
+        for r in rows:
+            for k in ("fwd", "dgrad", "wgrad"):
+                if k in r:
+                    print(f"{r['name']:7s} {k:5s} {r[k] * 1e6:7.1f} us {r['flops'] / r[k] / 1e12:6.1f} TF  {r[k + '_plan']}")
     return rows
 
 
@@ -126,13 +142,15 @@ def main():
                     help="A/B any dct_tune_set knob: interleaved rounds of the listed values in one process (repeatable)")
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--plain", action="store_true", help="no gate bits / bias gradient riding along (the launches of rounds 1-3 of this table)")
+    ap.add_argument("--plan", action="store_true", help="also print which kernel / grid the planner chose for every launch")
     ap.add_argument("--no-mask", action="store_true", help="data gradients without the ReLU mask re-read (timing study only)")
     args = ap.parse_args()
     what = args.what.split(",")
     lib = _lib.load()
     only = set(args.only.split(",")) if args.only else None
-    global TRAINER_FORM
+    global TRAINER_FORM, PLAN
     TRAINER_FORM = not args.plain
+    PLAN = args.plan
     if args.no_mask:
         for rnd in range(args.rounds):
             run(args.batch, args.reps, ["dgrad"], f"round {rnd}: data gradient with the ReLU mask (re-reads the layer input)", only)
