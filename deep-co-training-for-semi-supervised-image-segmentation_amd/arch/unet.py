@@ -191,6 +191,7 @@ class UNet(nn.Module):
         self.relu_bits = True                # convolutions keep the ReLU-gate bits of activations whose consumer's data gradient masks by them
         self.pool_codes = True               # max-pool keeps its routing codes for the backward pass (which then does not re-read its input)
         self.wgrad_side_stream = False       # opt-in: weight gradients on a second HIP stream (see _run_backward)
+        self.fuse_pool = True                # an encoder block's max pooling rides in its second convolution's call (dct_conv_desc.pool_out)
         self._wgrad_stream = None
 
     # ------------------------------------------------------------------------------ weights
@@ -351,9 +352,10 @@ class UNet(nn.Module):
                 bits[id(t)] = b
             return b
 
-        def conv3(src, conv, dst, bn=None, name=None, gate=False):
+        def conv3(src, conv, dst, bn=None, name=None, gate=False, pool_out=None, pool_codes=None):
             """``gate``: dst feeds a convolution whose data gradient is masked by (dst > 0) -- keep the one-bit image of it."""
-            K.conv2d(src, P[id(conv)]["fwd"], conv.bias, dst, relu=bn is None, relu_bits_out=want_bits(dst, bn) if gate else None)
+            K.conv2d(src, P[id(conv)]["fwd"], conv.bias, dst, relu=bn is None, relu_bits_out=want_bits(dst, bn) if gate else None,
+                     pool_out=pool_out, pool_codes=pool_codes)
             return dst if bn is None else bn_relu(dst, bn, name)
 
         xs = x.detach().to(torch.float32).reshape(B, H, W, 1)
@@ -392,11 +394,16 @@ class UNet(nn.Module):
                     a = bn_relu(a, bna, "a1")
             else:
                 a = conv3(src, ca, a, bna, f"a{lvl}", gate=True)
-            d = conv3(a, cb, new(h - 4, w - 4, width))
+            hp, wp = (h - 4 + 1) // 2, (w - 4 + 1) // 2
+            codes = torch.empty(B, hp, wp, width, dtype=torch.uint8, device=dev) if (save and self.pool_codes) else None
+            # the pool reads the convolution's output as it is (no dropout in between: every level but a training pass's fourth)
+            fuse = self.fuse_pool and not (lvl == 4 and (training or self.external_dropout_masks is not None))
+            p = new(hp, wp, width)
+            d = conv3(a, cb, new(h - 4, w - 4, width), pool_out=p if fuse else None, pool_codes=codes if fuse else None)
             dd = dropout(d, 0) if lvl == 4 else d
-            h, w = (h - 4 + 1) // 2, (w - 4 + 1) // 2
-            codes = torch.empty(B, h, w, width, dtype=torch.uint8, device=dev) if (save and self.pool_codes) else None
-            p = K.maxpool_fwd(dd, new(h, w, width), codes=codes)
+            h, w = hp, wp
+            if not fuse:
+                K.maxpool_fwd(dd, p, codes=codes)
             A[f"a{lvl}"], A[f"d{lvl}"], A[f"p{lvl}"], A[f"pc{lvl}"] = a, dd, p, codes
             src = p
         # center

@@ -743,6 +743,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
     }
   }
   __syncthreads();
+  if (p.pool_y) {
+    asm volatile("" ::: "memory");       // a real branch (the forward launches of three encoder levels take it, nobody else)
+    staged_pool_out<BN, NW>(p, tile, img, y0, x0, n0, tid);
+  }
   staged_rows_out<BM, BN, NW>(p, tile, rowY, rowM, n0, tid);
 }
 
@@ -1068,6 +1072,7 @@ int g_tune_igemm_split_max_tiles = 96;   // layers with at least this many tiles
 int g_tune_igemm_split_min_kiters = 4;    // ... and so do layers with fewer K-steps than this
 int g_tune_igemm_halo_cover = 75;      // percent of the image the 8 x 16 patches must cover
 int g_tune_igemm_halo_min_blocks = 400;
+int g_tune_igemm_pool = 1;      // diagnostic (1005): 0 = a requested pooling always runs as its own launch behind the conv
 int g_tune_igemm_halo = 1;      // 3x3 stride-1 layers with large images: shared-halo kernel (igemm3m_kernel); 0: always the per-tap kernel
 
 static bool make_plan(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int M, int N, Plan& pl) {
@@ -1312,7 +1317,19 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     if (dtype != DCT_BF16 || !dense(y) || y->c % 8 || p.scatter || ((uintptr_t)y->ptr & 15)) return DCT_ERR_BAD_ARG;
     p.bits_out = d->relu_bits_out;
   }
+  p.pool_y = nullptr; p.pool_codes = nullptr; p.Hp = (y->h + 1) / 2; p.Wp = (y->w + 1) / 2;
+  if (d->pool_codes && !d->pool_out) return DCT_ERR_BAD_ARG;
+  if (d->pool_out) {
+    if (p.scatter || d->accumulate || ((uintptr_t)d->pool_out & 15) || ((uintptr_t)d->pool_codes & 7) || y->c % 8) return DCT_ERR_BAD_ARG;
+  }
   hipStream_t st = (hipStream_t)stream;
+  const auto pool_after = [&]() -> int {   // the launch just issued did not pool its tile: the pooling kernel behind it
+    if (!d->pool_out) return DCT_OK;
+    dct_view pv;
+    pv.ptr = d->pool_out; pv.n = y->n; pv.h = p.Hp; pv.w = p.Wp; pv.c = y->c;
+    pv.sw = y->c; pv.sh = (long long)p.Wp * y->c; pv.sn = (long long)p.Hp * p.Wp * y->c;
+    return d->pool_codes ? dct_maxpool2x2_fwd_codes(y, &pv, d->pool_codes, dtype, stream) : dct_maxpool2x2_fwd(y, &pv, dtype, stream);
+  };
   const auto bits_after = [&]() {      // the launch just issued did not write the bits in its epilogue
     if (!p.bits_out) return;
     dct_relu_bits_launch(y->ptr, p.bits_out, (long long)y->n * y->h * y->w * (y->c / 8), st);
@@ -1351,7 +1368,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
       q.partial = nullptr;
       const int took = dct_igemm4_launch(&q, y->n, workspace, workspace_bytes, st);
       if (took) DCT_PLAN_NOTE("igemm4 (one block per CU, 256 px x 128 ch)%s", took == 2 ? " split" : "");
-      if (took == 1) return dct_check_launch();
+      if (took == 1) { const int rp = pool_after(); return rp != DCT_OK ? rp : dct_check_launch(); }
       if (took == 2) {
         q.partial = (float*)workspace;
         const long long work = (long long)p.M * (p.N / 4);
@@ -1359,7 +1376,8 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
         DCT_LAUNCH(DCT_PROF_IGEMM, (splitk_epilogue_kernel<bf16_t>), dim3(div_up(work, 256)), dim3(256), 0, st, q,
                    (int)(dct_igemm4_workspace(y->n, p.Ho, p.Wo, p.Cin, p.N) / per));
         bits_after();
-        return dct_check_launch();
+        const int rp = pool_after();
+        return rp != DCT_OK ? rp : dct_check_launch();
       }
     }
   }
@@ -1378,10 +1396,13 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     // 32-bit addressing inside the kernel: x within 2^31 elements, a weight tile's rows within 2^32 bytes of its first
     const bool x32 = (long long)x->n * x->sn < (1ll << 31) && (long long)bn * 9 * x->c * 2 < (1ll << 32);
     if (y16 && m16 && x32 && cover >= g_tune_igemm_halo_cover * 0.01 && blocks >= g_tune_igemm_halo_min_blocks && (bn == 128 || x->c == 64)) {
+      if (d->pool_out && g_tune_igemm_pool) { p.pool_y = (char*)d->pool_out; p.pool_codes = d->pool_codes; }
       if (bn == 128) {
         if (x->c == 64) launch_v3<128, 2, 1>(p, tiles_x, tiles_y, y->n, st); else launch_v3<128, 2, 2>(p, tiles_x, tiles_y, y->n, st);
       } else launch_v3<64, 1, 1>(p, tiles_x, tiles_y, y->n, st);
-      DCT_PLAN_NOTE("igemm3m shared-halo 8x16 patches x %d ch: %lld blocks, cover %.0f %%, %d K-steps", bn, blocks, cover * 100, 9 * x->c / 64);
+      DCT_PLAN_NOTE("igemm3m shared-halo 8x16 patches x %d ch: %lld blocks, cover %.0f %%, %d K-steps%s", bn, blocks, cover * 100, 9 * x->c / 64,
+                    p.pool_y ? ", pooled in the epilogue" : "");
+      if (!p.pool_y) { const int rp = pool_after(); if (rp != DCT_OK) return rp; }
       return dct_check_launch();
     }
   }
@@ -1397,6 +1418,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
         IgemmParams q = p;
         q.partial = pp.splits > 1 ? (float*)workspace : nullptr;
         launch_v3p(q, pp, y->n, st);
+        { const int rp = pool_after(); if (rp != DCT_OK) return rp; }
         DCT_PLAN_NOTE("igemm3p packed rows (%d rows of %d px per 128-px tile): %d x %d blocks x %d channel-slice splits", pp.PR, p.Wo,
                       y->n * pp.tiles_per_img, p.N / 128, pp.splits);
         if (pp.splits > 1) bits_after();
@@ -1408,6 +1430,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   DCT_PLAN_NOTE("%s per-tap %d x %d tile%s: %lld tiles x %d splits, %d K-steps each%s", pl.v2 ? "igemm2" : "igemm", pl.bm, pl.bn,
                 pl.bounds ? " (bounds)" : "", pl.tiles, pl.splits, pl.kiters_per_split, p.staged ? ", staged epilogue" : "");
   if (rc == DCT_OK && !p.staged) bits_after();
+  if (rc == DCT_OK) { const int rp = pool_after(); if (rp != DCT_OK) return rp; }
   return rc == DCT_OK ? dct_check_launch() : rc;
 }
 
@@ -1433,6 +1456,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM4: g_tune_igemm4 = value ? 1 : 0; return DCT_OK;
     case DCT_TUNE_IGEMM4_MIN_BLOCKS: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm4_min_blocks = value; return DCT_OK;
     case 1000: g_tune_igemm4_ablate = value; return DCT_OK;      // diagnostic builds only
+    case 1005: g_tune_igemm_pool = value ? 1 : 0; return DCT_OK;
     case 1002: g_tune_igemm_split_max_tiles = value; return DCT_OK;     // planner studies (tools/bench_conv.py --ab-knob)
     case 1003: g_tune_igemm_split_min_kiters = value; return DCT_OK;
     case 1001: if (value < 0) return DCT_ERR_BAD_ARG; g_tune_igemm4_blocks = value; return DCT_OK;      // diagnostic: persistent blocks per launch

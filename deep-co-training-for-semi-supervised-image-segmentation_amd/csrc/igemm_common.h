@@ -23,6 +23,9 @@ struct IgemmParams {
   int staged;  // v2: LDS-staged epilogue with 16-byte row stores (host-checked alignment / 32-bit offsets)
   unsigned long long* stamps;   // igemm4 diagnostic builds: per-wave cycle sums
   long long x_bytes, w_bytes;   // lean loops: bytes from x / w to the end of the view / packed weights (buffer descriptor ranges)
+  char* pool_y;                 // optional (shared-halo kernel): dense [n][Hp][Wp][cout] 2x2 ceil-mode max pooling of y, from the staged tile
+  unsigned char* pool_codes;    // ... and its routing codes (dct_maxpool2x2_fwd_codes), nullable
+  int Hp, Wp;
 };
 
 // ---- the per-chunk part of the staged epilogues (eight bf16 of one pixel = one 16-byte chunk) on PACKED 16-bit integer arithmetic.
@@ -129,6 +132,48 @@ __device__ __forceinline__ void staged_rows_out(const IgemmParams& p, const char
     }
     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
     if (p.bits_out) p.bits_out[(unsigned)(yo[t] + co) >> 3] = (unsigned char)relu_bits8(v);
+  }
+}
+
+// 2x2 / stride 2 / ceil-mode max pooling of a staged 8 x 16-pixel patch (tile row = py * 16 + px, chunk-swizzled as staged_rows_out
+// reads it): the patch starts at even image coordinates, so it holds whole windows -- 4 x 8 pooled pixels x BN / 8 chunks, one
+// item per thread.  Same scan order, comparisons and codes as maxpool_fwd_codes_kernel (pointwise.hip), on the same bf16 values
+// that go to y: bit-identical to pooling y afterwards, without re-reading it (130 MB per network and step at the first UNet level).
+template <int BN, int NW>
+__device__ __forceinline__ void staged_pool_out(const IgemmParams& p, const char* tile, int img, int y0, int x0, int n0, int tid) {
+  constexpr int CPR = BN / 8;
+  for (int id = tid; id < 32 * CPR; id += NW * 64) {
+    const int cc = id % CPR, q = id / CPR;
+    const int qy = q >> 3, qx = q & 7;
+    const int oy = y0 + 2 * qy, ox = x0 + 2 * qx;
+    if (oy >= p.Ho || ox >= p.Wo) continue;
+    float m[8];
+    int arg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { m[i] = -INFINITY; arg[i] = 8; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (oy + (k >> 1) < p.Ho && ox + (k & 1) < p.Wo) {
+        const int row = (2 * qy + (k >> 1)) * 16 + 2 * qx + (k & 1);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float f = (float)v[i];
+          if (f > m[i]) { m[i] = f; arg[i] = k; }
+        }
+      }
+    }
+    const long long o = (((long long)img * p.Hp + (oy >> 1)) * p.Wp + (ox >> 1)) * p.cout + n0 + cc * 8;
+    bf16x8 out;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (bf16_t)m[i];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.pool_y) + o) = out;
+    if (p.pool_codes) {
+      union { unsigned char b[8]; uint2 w; } cd;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cd.b[i] = (unsigned char)(arg[i] | (m[i] > 0.f ? 4 : 0));
+      *reinterpret_cast<uint2*>(p.pool_codes + o) = cd.w;
+    }
   }
 }
 

@@ -85,6 +85,14 @@ typedef struct dct_conv_desc {
    * channels) at 1/16 of the bytes; the kernels whose epilogue can, read it instead of the activation. */
   const uint8_t* mask_bits;
   uint8_t* relu_bits_out;
+  /* 2x2 / stride 2 / ceil-mode max pooling of y in the same call (nn.MaxPool2d behind the conv + ReLU of a UNet encoder block,
+   * arch/network.py:120-130): pool_out (nullable) is a DENSE NHWC tensor [n][(h+1)/2][(w+1)/2][c] of y's type; pool_codes
+   * (nullable) the routing codes of dct_maxpool2x2_fwd_codes, one byte per pooled element.  The shared-halo kernel pools its
+   * staged output tile before the tile leaves LDS (y is still written in full: the skip connection reads it, but the pool no
+   * longer re-reads it from memory); every other path launches the pooling kernel behind the conv.  Results are those of
+   * dct_conv2d followed by dct_maxpool2x2_fwd[_codes], bit for bit.  Not with scatter2x2 / accumulate. */
+  void* pool_out;
+  uint8_t* pool_codes;
 } dct_conv_desc;
 
 size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype);

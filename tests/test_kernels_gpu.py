@@ -262,6 +262,59 @@ def test_conv2d_wgrad_lean_forms_are_bit_identical(ops, B, Cin, H, W, Cout, pad)
     assert (db0 - db1).abs().max().item() <= 2e-6 * max(1.0, db0.abs().max().item()) * math.sqrt(B * Ho * Wo)
 
 
+@pytest.mark.parametrize("dtype,B,Cin,H,W,Cout,halo_min_blocks", [
+    (torch.bfloat16, 4, 64, 100, 132, 64, 400),     # shared-halo kernel, 64-channel tile: pooled in the epilogue (even extents)
+    (torch.bfloat16, 4, 128, 83, 147, 128, 400),    # ... 128-channel tile, odd extents: ceil-mode windows of one row / one column / one pixel
+    (torch.bfloat16, 5, 128, 66, 98, 256, 400),     # ... two channel tiles
+    (torch.bfloat16, 1, 64, 29, 23, 64, 1),         # ... a single partial patch row / column per image
+    (torch.bfloat16, 8, 256, 27, 27, 128, 400),     # packed-rows kernel: the pooling kernel runs behind it
+    (torch.bfloat16, 2, 64, 20, 20, 64, 400),       # per-tap kernel: same
+    (torch.float32, 2, 32, 21, 18, 64, 400),        # fp32: same
+])
+def test_conv2d_with_pooling_is_bit_identical_to_conv_then_pool(ops, dtype, B, Cin, H, W, Cout, halo_min_blocks):
+    """dct_conv_desc.pool_out / pool_codes: the 2x2 ceil-mode max pooling (and its routing codes) of a convolution's output from the
+    same call -- out of the staged tile in the shared-halo kernel, as a launch behind the conv elsewhere -- against
+    dct_conv2d followed by dct_maxpool2x2_fwd_codes: y, pooled values, codes and ReLU-gate bits bit for bit."""
+    from dct_amd import _lib
+    g = torch.Generator().manual_seed(53)
+    x = to_dev(q(torch.randn(B, Cin, H, W, generator=g), dtype), dtype)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    wp = kmajor(q(w, dtype), dtype)
+    Ho, Wo = H - 2, W - 2
+    Hp, Wp = (Ho + 1) // 2, (Wo + 1) // 2
+    lib = _lib.load()
+    assert lib.dct_tune_set(19, halo_min_blocks) == 0
+    try:
+        outs = []
+        for fused in (False, True):
+            y = torch.full((B, Ho, Wo, Cout), float("nan"), device=DEV, dtype=dtype)
+            pooled = torch.full((B, Hp, Wp, Cout), float("nan"), device=DEV, dtype=dtype)
+            codes = torch.full((B, Hp, Wp, Cout), 255, device=DEV, dtype=torch.uint8)
+            bits = ops.relu_bits_like(y) if dtype == torch.bfloat16 else None
+            if fused:
+                ops.conv2d(x, wp, bias, y, relu=True, relu_bits_out=bits, pool_out=pooled, pool_codes=codes)
+            else:
+                ops.conv2d(x, wp, bias, y, relu=True, relu_bits_out=bits)
+                ops.maxpool_fwd(y, pooled, codes=codes)
+            torch.cuda.synchronize()
+            outs.append((y, pooled, codes, bits))
+        # without codes (an inference pass)
+        y2 = torch.empty_like(outs[0][0])
+        pooled2 = torch.full_like(outs[0][1], float("nan"))
+        ops.conv2d(x, wp, bias, y2, relu=True, pool_out=pooled2)
+        torch.cuda.synchronize()
+    finally:
+        lib.dct_tune_set(19, 400)
+    (y0, p0, c0, b0), (y1, p1, c1, b1) = outs
+    assert torch.isfinite(p0.float()).all() and (c0 < 16).all()
+    assert torch.equal(y0, y1) and torch.equal(p0, p1) and torch.equal(c0, c1)
+    assert b0 is None or torch.equal(b0, b1)
+    assert torch.equal(y0, y2) and torch.equal(p0, pooled2)
+    ref = torch.nn.functional.max_pool2d(y0.float().permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
+    assert torch.equal(p0.float(), ref)
+
+
 @pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [
     (16, 1024, 11, 11, 128, 0),     # per-tap kernel: the rotating decoder wave and its two-slot offset table, 31 K-steps per block
     (6, 128, 9, 9, 128, 0),         # per-tap kernel, ONE to two K-steps per chunk: the table's prologue and tail

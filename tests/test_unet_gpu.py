@@ -164,6 +164,32 @@ def test_unet_gate_bits_and_pool_codes_leave_every_gradient_bit_identical():
         assert torch.equal(a, b), k
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_unet_pooling_in_the_conv_call_leaves_everything_bit_identical(dtype):
+    """Each encoder block's max pooling taken from its second convolution's call (dct_conv_desc.pool_out: out of the staged tile in
+    the shared-halo kernel, a launch behind the conv elsewhere) against the separate pooling launch: logits, d/dx and every
+    gradient bit for bit -- train mode (the fourth level keeps its own launch behind the dropout) and eval mode."""
+    C = 4
+    onet = _oracle_net(C, 13, p=0.5)
+    x = torch.rand(2, 1, 200, 216, generator=torch.Generator().manual_seed(26)).to(DEV)
+    gl = torch.randn(2, C, 200, 216, generator=torch.Generator().manual_seed(27)).to(DEV)
+    for train in (True, False):
+        outs = []
+        for flag in (False, True):
+            net = _hip_net(onet, C, dtype, p=0.5)
+            net = net.train() if train else net.eval()
+            net.fuse_pool = flag
+            net.dropout_seed = 99
+            xd = x.clone().requires_grad_(True)
+            y = net(xd)
+            y.backward(gl)
+            outs.append([y.detach().clone(), xd.grad.clone()] + [p.grad.clone() for p in net.parameters()])
+        names = ["logits", "grad_x"] + [k for k, _ in net.named_parameters()]
+        for k, a, b in zip(names, *outs):
+            assert torch.isfinite(a).all(), (train, k)
+            assert torch.equal(a, b), (train, k)
+
+
 def test_unet_rejects_small_and_cpu_inputs():
     from dct_amd.arch import get_arch
     net = get_arch("unet", {"num_classes": 4}).to(DEV)
