@@ -192,6 +192,7 @@ class UNet(nn.Module):
         self.pool_codes = True               # max-pool keeps its routing codes for the backward pass (which then does not re-read its input)
         self.wgrad_side_stream = False       # opt-in: weight gradients on a second HIP stream (see _run_backward)
         self.fuse_pool = True                # an encoder block's max pooling rides in its second convolution's call (dct_conv_desc.pool_out)
+        self.pool_only = True                # ... whose full-resolution output is then not stored at all (nobody else reads it)
         self._wgrad_stream = None
 
     # ------------------------------------------------------------------------------ weights
@@ -352,10 +353,10 @@ class UNet(nn.Module):
                 bits[id(t)] = b
             return b
 
-        def conv3(src, conv, dst, bn=None, name=None, gate=False, pool_out=None, pool_codes=None):
+        def conv3(src, conv, dst, bn=None, name=None, gate=False, pool_out=None, pool_codes=None, pool_only=False):
             """``gate``: dst feeds a convolution whose data gradient is masked by (dst > 0) -- keep the one-bit image of it."""
             K.conv2d(src, P[id(conv)]["fwd"], conv.bias, dst, relu=bn is None, relu_bits_out=want_bits(dst, bn) if gate else None,
-                     pool_out=pool_out, pool_codes=pool_codes)
+                     pool_out=pool_out, pool_codes=pool_codes, pool_only=pool_only)
             return dst if bn is None else bn_relu(dst, bn, name)
 
         xs = x.detach().to(torch.float32).reshape(B, H, W, 1)
@@ -399,7 +400,9 @@ class UNet(nn.Module):
             # the pool reads the convolution's output as it is (no dropout in between: every level but a training pass's fourth)
             fuse = self.fuse_pool and not (lvl == 4 and (training or self.external_dropout_masks is not None))
             p = new(hp, wp, width)
-            d = conv3(a, cb, new(h - 4, w - 4, width), pool_out=p if fuse else None, pool_codes=codes if fuse else None)
+            # ... and alone: the backward pass routes by the codes and never reads the block's full-resolution output
+            only = fuse and self.pool_only and (codes is not None or not save) and self._debug is None
+            d = conv3(a, cb, new(h - 4, w - 4, width), pool_out=p if fuse else None, pool_codes=codes if fuse else None, pool_only=only)
             dd = dropout(d, 0) if lvl == 4 else d
             h, w = hp, wp
             if not fuse:

@@ -746,6 +746,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
   if (p.pool_y) {
     asm volatile("" ::: "memory");       // a real branch (the forward launches of three encoder levels take it, nobody else)
     staged_pool_out<BN, NW>(p, tile, img, y0, x0, n0, tid);
+    if (p.pool_only) return;
   }
   staged_rows_out<BM, BN, NW>(p, tile, rowY, rowM, n0, tid);
 }
@@ -1317,7 +1318,8 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     if (dtype != DCT_BF16 || !dense(y) || y->c % 8 || p.scatter || ((uintptr_t)y->ptr & 15)) return DCT_ERR_BAD_ARG;
     p.bits_out = d->relu_bits_out;
   }
-  p.pool_y = nullptr; p.pool_codes = nullptr; p.Hp = (y->h + 1) / 2; p.Wp = (y->w + 1) / 2;
+  p.pool_y = nullptr; p.pool_codes = nullptr; p.Hp = (y->h + 1) / 2; p.Wp = (y->w + 1) / 2; p.pool_only = 0;
+  if (d->pool_only && (!d->pool_out || d->relu_bits_out)) return DCT_ERR_BAD_ARG;
   if (d->pool_codes && !d->pool_out) return DCT_ERR_BAD_ARG;
   if (d->pool_out) {
     if (p.scatter || d->accumulate || ((uintptr_t)d->pool_out & 15) || ((uintptr_t)d->pool_codes & 7) || y->c % 8) return DCT_ERR_BAD_ARG;
@@ -1396,12 +1398,12 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     // 32-bit addressing inside the kernel: x within 2^31 elements, a weight tile's rows within 2^32 bytes of its first
     const bool x32 = (long long)x->n * x->sn < (1ll << 31) && (long long)bn * 9 * x->c * 2 < (1ll << 32);
     if (y16 && m16 && x32 && cover >= g_tune_igemm_halo_cover * 0.01 && blocks >= g_tune_igemm_halo_min_blocks && (bn == 128 || x->c == 64)) {
-      if (d->pool_out && g_tune_igemm_pool) { p.pool_y = (char*)d->pool_out; p.pool_codes = d->pool_codes; }
+      if (d->pool_out && g_tune_igemm_pool) { p.pool_y = (char*)d->pool_out; p.pool_codes = d->pool_codes; p.pool_only = d->pool_only ? 1 : 0; }
       if (bn == 128) {
         if (x->c == 64) launch_v3<128, 2, 1>(p, tiles_x, tiles_y, y->n, st); else launch_v3<128, 2, 2>(p, tiles_x, tiles_y, y->n, st);
       } else launch_v3<64, 1, 1>(p, tiles_x, tiles_y, y->n, st);
       DCT_PLAN_NOTE("igemm3m shared-halo 8x16 patches x %d ch: %lld blocks, cover %.0f %%, %d K-steps%s", bn, blocks, cover * 100, 9 * x->c / 64,
-                    p.pool_y ? ", pooled in the epilogue" : "");
+                    p.pool_y ? (p.pool_only ? ", pooled in the epilogue, y not stored" : ", pooled in the epilogue") : "");
       if (!p.pool_y) { const int rp = pool_after(); if (rp != DCT_OK) return rp; }
       return dct_check_launch();
     }

@@ -26,6 +26,7 @@ struct IgemmParams {
   char* pool_y;                 // optional (shared-halo kernel): dense [n][Hp][Wp][cout] 2x2 ceil-mode max pooling of y, from the staged tile
   unsigned char* pool_codes;    // ... and its routing codes (dct_maxpool2x2_fwd_codes), nullable
   int Hp, Wp;
+  int pool_only;                // with pool_y: y itself is not wanted (no row stores)
 };
 
 // ---- the per-chunk part of the staged epilogues (eight bf16 of one pixel = one 16-byte chunk) on PACKED 16-bit integer arithmetic.

@@ -93,6 +93,10 @@ typedef struct dct_conv_desc {
    * dct_conv2d followed by dct_maxpool2x2_fwd[_codes], bit for bit.  Not with scatter2x2 / accumulate. */
   void* pool_out;
   uint8_t* pool_codes;
+  /* pool_only != 0 (with pool_out): the caller consumes only the pooled tensor -- y must still be a valid buffer, but its contents
+   * after the call are unspecified: the shared-halo kernel then skips its row stores (a UNet encoder block's full-resolution output
+   * is read by the pooling alone once the backward pass routes by pool_codes: 130 MB less to write at the first level). */
+  int32_t pool_only;
 } dct_conv_desc;
 
 size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype);

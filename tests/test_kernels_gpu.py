@@ -303,6 +303,11 @@ def test_conv2d_with_pooling_is_bit_identical_to_conv_then_pool(ops, dtype, B, C
         y2 = torch.empty_like(outs[0][0])
         pooled2 = torch.full_like(outs[0][1], float("nan"))
         ops.conv2d(x, wp, bias, y2, relu=True, pool_out=pooled2)
+        # pool_only: y's contents are unspecified afterwards, the pooled tensor and the codes are the same
+        y3 = torch.empty_like(outs[0][0])
+        pooled3 = torch.full_like(outs[0][1], float("nan"))
+        codes3 = torch.full_like(outs[0][2], 255)
+        ops.conv2d(x, wp, bias, y3, relu=True, pool_out=pooled3, pool_codes=codes3, pool_only=True)
         torch.cuda.synchronize()
     finally:
         lib.dct_tune_set(19, 400)
@@ -311,6 +316,7 @@ def test_conv2d_with_pooling_is_bit_identical_to_conv_then_pool(ops, dtype, B, C
     assert torch.equal(y0, y1) and torch.equal(p0, p1) and torch.equal(c0, c1)
     assert b0 is None or torch.equal(b0, b1)
     assert torch.equal(y0, y2) and torch.equal(p0, pooled2)
+    assert torch.equal(p0, pooled3) and torch.equal(c0, codes3)
     ref = torch.nn.functional.max_pool2d(y0.float().permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
     assert torch.equal(p0.float(), ref)
 

@@ -178,7 +178,7 @@ def test_unet_pooling_in_the_conv_call_leaves_everything_bit_identical(dtype):
         for flag in (False, True):
             net = _hip_net(onet, C, dtype, p=0.5)
             net = net.train() if train else net.eval()
-            net.fuse_pool = flag
+            net.fuse_pool = flag                # (with it, pool_only: the encoder blocks' full-resolution outputs are not stored)
             net.dropout_seed = 99
             xd = x.clone().requires_grad_(True)
             y = net(xd)
