@@ -1440,6 +1440,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
 int dct_tune_set_wgrad(int knob, int value);  // wgrad.hip
 extern int g_enet_wgrad_max_blocks;           // enet.hip
 extern int g_enet_mfma;                       // enet.hip
+extern int g_stem_dgrad_mfma;                 // pointwise.hip
 extern int g_enet_mwgrad_waves, g_enet_fuse_finalize;
 
 extern "C" int dct_tune_set(int knob, int value) {
@@ -1459,6 +1460,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM4_MIN_BLOCKS: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm4_min_blocks = value; return DCT_OK;
     case 1000: g_tune_igemm4_ablate = value; return DCT_OK;      // diagnostic builds only
     case 1005: g_tune_igemm_pool = value ? 1 : 0; return DCT_OK;
+    case 1008: g_stem_dgrad_mfma = value ? 1 : 0; return DCT_OK;
     case 1002: g_tune_igemm_split_max_tiles = value; return DCT_OK;     // planner studies (tools/bench_conv.py --ab-knob)
     case 1003: g_tune_igemm_split_min_kiters = value; return DCT_OK;
     case 1001: if (value < 0) return DCT_ERR_BAD_ARG; g_tune_igemm4_blocks = value; return DCT_OK;      // diagnostic: persistent blocks per launch

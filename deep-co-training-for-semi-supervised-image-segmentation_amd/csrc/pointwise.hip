@@ -339,6 +339,74 @@ __global__ __launch_bounds__(256) void stem_dgrad_kernel(View dy, const float* w
   if (id.ok && id.cv == 0) reinterpret_cast<float*>(dx.ptr)[voff(dx, id.n, id.y, id.x)] = a;
 }
 
+// The same data gradient on the matrix pipe (bf16 dy, 64 channels, 3x3, stride 1, no padding: the UNet stem's FGSM pass).  The kernel above
+// is vector-ALU bound (72 FMAs + their conversions and address arithmetic per eight channels of one tap window: 136 us at 16 x 256 x 256).
+// Here G[q][t] = sum_c dy[q][c] * w[c][t] for every dy pixel q of a block's 18 x 18 halo is a GEMM (M = pixels, K = 64 channels, N = 9 taps
+// padded to 16) on v_mfma_f32_16x16x32_bf16 -- dy is bf16 already, each fp32 weight is split into three bf16 parts (hi + mid + lo = all 24
+// mantissa bits, so the products are exact and only the order of the fp32 additions differs from the FMA chain) -- and
+// dx[p] = sum_t G[p - t][t] is nine LDS reads per pixel.  A fragment: lane l = pixel l % 16 of the row block, 16-byte channel chunk l / 16,
+// loaded straight from global memory (one 16-byte load per lane and MFMA triple).
+__global__ __launch_bounds__(256) void stem_dgrad_mfma_kernel(View dy, const float* __restrict__ w, View dx, int tiles_x, int tiles_y) {
+  constexpr int HW = 18, HPIX = HW * HW, MB = (HPIX + 15) / 16, GS = 17;      // 324 halo pixels in 21 row blocks; G row stride (floats)
+  __shared__ float G[MB * 16 * GS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y; const int n = b / tiles_y;
+  const int Y0 = ty * 16, X0 = tx * 16;
+  // B fragments: column l15 = tap, channels kb * 32 + kq * 8 + {0..7}; three bf16 parts of every weight
+  bf16x8 wb[2][3];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = kb * 32 + kq * 8 + i;
+      const float v = l15 < 9 ? w[c * 9 + l15] : 0.f;
+      const bf16_t h = (bf16_t)v;
+      const float r1 = v - (float)h;
+      const bf16_t m = (bf16_t)r1;
+      const bf16_t lo = (bf16_t)(r1 - (float)m);
+      wb[kb][0][i] = h; wb[kb][1][i] = m; wb[kb][2][i] = lo;
+    }
+  const bf16_t* dyp = reinterpret_cast<const bf16_t*>(dy.ptr) + (long long)n * dy.sn;
+  for (int mb = wave; mb < MB; mb += 4) {
+    const int h = mb * 16 + l15;
+    const int hy = h / HW, hx = h - hy * HW;
+    const int qy = Y0 - 2 + hy, qx = X0 - 2 + hx;
+    const bool ok = h < HPIX && (unsigned)qy < (unsigned)dy.h && (unsigned)qx < (unsigned)dy.w;
+    bf16x8 a[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (ok) a[kb] = *reinterpret_cast<const bf16x8*>(dyp + (long long)qy * dy.sh + (long long)qx * dy.sw + kb * 32 + kq * 8);
+      else
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[kb][i] = (bf16_t)0.f;
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int part = 2; part >= 0; --part)          // smallest parts first
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb], wb[kb][part], acc, 0, 0, 0);
+    // D: column l15 (tap), rows 4 * kq + {0..3} (pixels of the row block)
+    if (l15 < 9) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) G[(mb * 16 + 4 * kq + e) * GS + l15] = acc[e];
+    }
+  }
+  __syncthreads();
+  const int i = tid >> 4, j = tid & 15;
+  const int y = Y0 + i, x = X0 + j;
+  if (y < dx.h && x < dx.w) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s += G[((i + 2 - r) * HW + (j + 2 - c)) * GS + r * 3 + c];
+    reinterpret_cast<float*>(dx.ptr)[voff(dx, n, y, x)] = s;
+  }
+}
+
 // ---- classifier head -----------------------------------------------------------------------
 // y[pix][co] = sum_ci x[pix][ci]*w[co][ci] + b[co];  thread per pixel, cout <= 8
 template <typename T, int VEC>
@@ -738,12 +806,20 @@ extern "C" int dct_conv_cin1_fwd(const dct_view* x, const float* w, const float*
   return dct_check_launch();
 }
 
+int g_stem_dgrad_mfma = 1;      // diagnostic (dct_tune_set 1008): 0 = the vector-ALU kernel for every shape
 extern "C" int dct_conv_cin1_dgrad(const dct_view* dy, const float* w, const dct_view* dx,
                                    const dct_conv_desc* d, int dtype, dct_stream stream) {
   if (!view_ok(dy) || !view_ok(dx) || !w || !d || dx->c != 1 || dx->n != dy->n) return DCT_ERR_BAD_ARG;
   const StemGeom g = stem_geom(d, dy->c);
   hipStream_t st = (hipStream_t)stream;
   const size_t sh = (size_t)(dy->c * d->R * d->S) * sizeof(float);
+  if (dtype == DCT_BF16 && dy->c == 64 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 0 && d->pad_w == 0 &&
+      dx->h == dy->h + 2 && dx->w == dy->w + 2 && vec_ok(dy, 8, 2) && g_stem_dgrad_mfma) {
+    const int tiles_x = (dx->w + 15) / 16, tiles_y = (dx->h + 15) / 16;
+    DCT_LAUNCH(DCT_PROF_POINTWISE, stem_dgrad_mfma_kernel, dim3((unsigned)(dx->n * tiles_y * tiles_x)), dim3(256), 0, st, to_view(dy), w, to_view(dx),
+               tiles_x, tiles_y);
+    return dct_check_launch();
+  }
   DISPATCH_T(dtype, {
     const int cv = dy->c / VEC;
     if (dy->c % VEC || cv > 64 || (cv & (cv - 1)) || !vec_ok(dy, VEC, sizeof(T))) return DCT_ERR_UNSUPPORTED;

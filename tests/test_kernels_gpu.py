@@ -718,6 +718,35 @@ def test_stem_cin1(ops, dtype):
     close(db.cpu(), rb, torch.float32, "stem bgrad")
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 37, 30), (2, 50, 67), (5, 130, 66), (1, 19, 16)])
+def test_stem_dgrad_mfma_form(ops, B, H, W):
+    """bf16 stem data gradient (the FGSM pass's d/dx) on the matrix pipe (csrc/pointwise.hip stem_dgrad_mfma_kernel: per-pixel tap products as a
+    GEMM with the fp32 weights split into three bf16 parts, nine LDS reads per pixel) against F.conv_transpose2d in fp64 and against the
+    vector-ALU kernel it replaces (knob 1008 = 0): ragged 16 x 16 tiles, image borders, several images."""
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(83)
+    Cout = 64
+    w = torch.randn(Cout, 1, 3, 3, generator=g) / 3
+    dy = q(torch.randn(B, Cout, H - 2, W - 2, generator=g), dtype)
+    ref = F.conv_transpose2d(dy.double(), w.double()).float()          # d/dx of a valid 3x3 convolution
+    wd = w.reshape(Cout, 9).contiguous().to(DEV)
+    lib = _lib.load()
+    outs = []
+    try:
+        for form in (1, 0):
+            assert lib.dct_tune_set(1008, form) == 0
+            dx = torch.full((B, H, W, 1), float("nan"), device=DEV)
+            ops.conv_cin1_dgrad(to_dev(dy, dtype), wd, dx, pad_h=0, pad_w=0)
+            torch.cuda.synchronize()
+            outs.append(to_cpu(dx))
+    finally:
+        lib.dct_tune_set(1008, 1)
+    scale = ref.abs().max().item()
+    assert (outs[0] - ref).abs().max().item() <= 3e-6 * scale, "matrix-pipe form vs fp64 reference"
+    assert (outs[1] - ref).abs().max().item() <= 3e-6 * scale, "vector-ALU form vs fp64 reference"
+
+
 @pytest.mark.parametrize("B,H,W,pad", [(3, 37, 30, 0), (2, 50, 67, 1), (16, 66, 130, 0), (1, 19, 16, 2)])
 def test_stem_wgrad_mfma_form(ops, B, H, W, pad):
     """bf16 stem weight gradient on the matrix pipe (csrc/reduce.hip stem_wgrad_mfma_kernel): units of 16 pixels of a row through the
