@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ("pad_h", C.c_int32), ("pad_w", C.c_int32), ("relu", C.c_int32), ("scatter2x2", C.c_int32),
                 ("accumulate", C.c_int32), ("mask_channels", C.c_int32), ("mask_scale", C.c_float),
                 ("mask_bits", C.c_void_p), ("relu_bits_out", C.c_void_p), ("pool_out", C.c_void_p), ("pool_codes", C.c_void_p),
-                ("pool_only", C.c_int32)]
+                ("pool_only", C.c_int32), ("stem_x", C.c_void_p), ("stem_dw", C.c_void_p), ("stem_db", C.c_void_p),
+                ("stem_accumulate", C.c_int32)]
 
 
 class EnetTf(C.Structure):
@@ -55,13 +56,17 @@ class EnetBwdIn(C.Structure):
 
 def conv_desc(R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=0, scatter2x2=0, accumulate=0,
               mask_channels=0, mask_scale=1.0, mask_bits=None, relu_bits_out=None, pool_out=None, pool_codes=None,
-              pool_only=False) -> ConvDesc:
+              pool_only=False, stem=None) -> ConvDesc:
+    """``stem``: (x fp32 dense [N,H+2,W+2,1], dw [64,9], db [64], accumulate) -- dct_conv_desc.stem_*"""
+    sx, sdw, sdb, sacc = stem if stem is not None else (None, None, None, False)
     return ConvDesc(R, S, stride, dil, pad_h, pad_w, int(relu), int(scatter2x2), int(accumulate),
                     int(mask_channels), float(mask_scale),
                     mask_bits.data_ptr() if mask_bits is not None else None,
                     relu_bits_out.data_ptr() if relu_bits_out is not None else None,
                     pool_out.data_ptr() if pool_out is not None else None,
-                    pool_codes.data_ptr() if pool_codes is not None else None, int(bool(pool_only)))
+                    pool_codes.data_ptr() if pool_codes is not None else None, int(bool(pool_only)),
+                    sx.data_ptr() if sx is not None else None, sdw.data_ptr() if sdw is not None else None,
+                    sdb.data_ptr() if sdb is not None else None, int(bool(sacc)))
 
 
 def view(t: torch.Tensor) -> View:
@@ -189,6 +194,9 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+ERR_UNSUPPORTED = -2      # DCT_ERR_UNSUPPORTED
 
 
 def check(status: int, what: str = "") -> None:

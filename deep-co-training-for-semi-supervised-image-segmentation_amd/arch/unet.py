@@ -193,6 +193,7 @@ class UNet(nn.Module):
         self.wgrad_side_stream = False       # opt-in: weight gradients on a second HIP stream (see _run_backward)
         self.fuse_pool = True                # an encoder block's max pooling rides in its second convolution's call (dct_conv_desc.pool_out)
         self.pool_only = True                # ... whose full-resolution output is then not stored at all (nobody else reads it)
+        self.fuse_stem_wgrad = True          # the stem's weight gradient from the epilogue of the data gradient that produces its dy (not stored then)
         self._wgrad_stream = None
 
     # ------------------------------------------------------------------------------ weights
@@ -476,8 +477,11 @@ class UNet(nn.Module):
             keep.extend(operands)
             return torch.cuda.stream(side)
 
-        def conv_bwd(conv, x_in, dy, dx_out, mask=None, mask_channels=0, mask_scale=1.0, accumulate=False):
-            """dy: grad wrt the conv's pre-activation output (already ReLU-masked)."""
+        stem_fused = [False]
+
+        def conv_bwd(conv, x_in, dy, dx_out, mask=None, mask_channels=0, mask_scale=1.0, accumulate=False, stem=None):
+            """dy: grad wrt the conv's pre-activation output (already ReLU-masked).  ``stem``: (x, dw, db, accumulate) -- try to take
+            the stem's weight gradient from this data gradient's output tile (dx_out is then not written; stem_fused[0] tells)."""
             if need_dw:
                 with on_side(dy, x_in):
                     if dt == torch.bfloat16:     # bias gradient rides along in the weight-gradient launch
@@ -486,9 +490,16 @@ class UNet(nn.Module):
                         K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=gacc)
                         K.bias_grad(dy, self._gb(conv), accumulate=gacc)
             if dx_out is not None:
+                mb = gate_bits.get(id(mask)) if mask is not None else None
+                if stem is not None and mb is not None:
+                    try:
+                        K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, pad_h=2, pad_w=2, mask=mask, mask_bits=mb, stem=stem)
+                        stem_fused[0] = True
+                        return dx_out
+                    except K.StemFusionUnsupported:
+                        pass
                 K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, pad_h=2, pad_w=2, mask=mask,
-                         mask_channels=mask_channels, mask_scale=mask_scale, accumulate=accumulate,
-                         mask_bits=gate_bits.get(id(mask)) if mask is not None else None)
+                         mask_channels=mask_channels, mask_scale=mask_scale, accumulate=accumulate, mask_bits=mb)
             return dx_out
 
         def convT_bwd(conv, x_in, dy, dx_out, mask, mask_scale=1.0):
@@ -555,12 +566,16 @@ class UNet(nn.Module):
             ca, _, cb, _ = self._roles[f"dec{lvl}"]
             a, d = A[f"a{lvl}"], A[f"d{lvl}"]
             dd = K.maxpool_bwd(d, dp[lvl], new_like(d), relu_mask=True, scale=ds if lvl == 4 else 1.0, codes=A.get(f"pc{lvl}"))
-            da = bn_back(f"a{lvl}", conv_bwd(cb, a, dd, new_like(a), mask=a))
+            stem = None
+            if (lvl == 1 and need_dw and not need_dx and self.fuse_stem_wgrad and dt == torch.bfloat16 and side is None and
+                    A["bn"].get("a1") is None and self._debug is None):
+                stem = (A["x"], self._gw(ca), self._gb(ca), gacc)       # the stem's dy has no other reader: see dct_conv_desc.stem_x
+            da = bn_back(f"a{lvl}", conv_bwd(cb, a, dd, new_like(a), mask=a, stem=stem))
             if lvl > 1:
                 conv_bwd(ca, A[f"p{lvl - 1}"], da, dp[lvl - 1], accumulate=True)
             else:
                 c0 = ca
-                if need_dw:
+                if need_dw and not stem_fused[0]:
                     with on_side(da):
                         K.conv_cin1_wgrad(A["x"], da, self._gw(c0), self._gb(c0), accumulate=gacc)
                 if need_dx:

@@ -707,6 +707,103 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
   constexpr int CPR = BN / 8;
   static_assert(BM * BN * 2 <= ABUFS * A_BYTES + (BN * 128 * 2 - BM * 8), "epilogue tile does not fit");
   char* tile = smem;                                   // BM * BN * 2 bytes: the halo stage(s) and, if needed, the head of the weight stages
+  if constexpr (BN == 64 && NWN == 1 && ABUFS == 1) {
+    if (p.stem_x) {
+      // The stem's weight gradient from this tile (include/dct.h dct_conv_desc.stem_x): this launch is the data gradient of the UNet's second
+      // convolution, its output -- masked by the ReLU gate of the stem's output, rounded to bf16 -- is the stem's dy, and nobody else
+      // reads it.  dW[c][t] = sum_px dy[px][c] * x[px + t] over the block's 128 pixels is a [16 taps x 128] x [128 x 64] product:
+      // v_mfma_f32_16x16x32_bf16 with A = the x windows (bf16 high + low parts, row 9 = ones for the bias gradient), B = the tile read
+      // back through the transposing LDS read (K = pixels), one 32-pixel K block per wave, the four waves' results added through LDS.
+      asm volatile("" ::: "memory");
+      constexpr int XS = 32 * 1024, RED = 16 * 1024;        // LDS: x patch parts behind the reduction buffer, both in dead stage space
+      unsigned short* xs = reinterpret_cast<unsigned short*>(smem + XS);     // [2][180]
+      // gate nibbles of the lane's accumulators first (global loads in flight while the x patch is split)
+      unsigned gates[PXB][TR];
+#pragma unroll
+      for (int j = 0; j < PXB; ++j) {
+        const int oy = y0 + PXB * wm + j, ox = x0 + l15;
+        const bool inside = oy < p.Ho && ox < p.Wo;
+        const long long om = (long long)img * p.msN + (long long)oy * p.msH + (long long)ox * p.msW;
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+          const int cl = i * 16 + 4 * kq;
+          gates[j][i] = inside ? (unsigned)p.mask_bits[(unsigned long long)(om + cl) >> 3] : 0u;
+        }
+      }
+      for (int h = tid; h < 180; h += NW * 64) {
+        const int hy = h / 18, hx = h - hy * 18;
+        const int iy = y0 + hy, ix = x0 + hx;
+        const float v = (iy < p.Ho + 2 && ix < p.Wo + 2) ? p.stem_x[((long long)img * (p.Ho + 2) + iy) * (p.Wo + 2) + ix] : 0.f;
+        const bf16_t vh = (bf16_t)v;
+        const bf16_t vl = (bf16_t)(v - (float)vh);
+        xs[h] = __builtin_bit_cast(unsigned short, vh);
+        xs[180 + h] = __builtin_bit_cast(unsigned short, vl);
+      }
+      // masked accumulators -> tile.  Accumulator (i, j): channels 16 i + 4 kq + {0..3} of pixel (patch row 2 wm + j, column l15).
+#pragma unroll
+      for (int j = 0; j < PXB; ++j) {
+        const int py = PXB * wm + j;
+        const int row = py * TW + l15;
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+          const int cl = i * 16 + 4 * kq;
+          const unsigned gate = (gates[j][i] >> (cl & 4)) & 15u;
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(((gate >> e) & 1u) ? acc[i][j][e] : 0.f);
+          const int chunk = (cl >> 3) ^ (row & (CPR - 1));
+          *reinterpret_cast<bf16x4*>(tile + row * (BN * 2) + chunk * 16 + (cl & 4) * 2) = o;
+        }
+      }
+      __syncthreads();
+      const int kb = wave;                                   // this wave's 32 tile rows (two patch rows)
+      // A: row l15 = tap (9: ones, 10..15: zero), K chunk kq = pixels 8 kq .. 8 kq + 7 of the block: patch row 2 kb + (kq >> 1), columns 8 (kq & 1) + j
+      union { bf16x8 v; unsigned short u[8]; } ah, al;
+      {
+        const int t = l15 < 9 ? l15 : 0;
+        const int idx0 = (2 * kb + (kq >> 1) + t / 3) * 18 + 8 * (kq & 1) + t % 3;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          ah.u[jj] = l15 < 9 ? xs[idx0 + jj] : (l15 == 9 ? (unsigned short)0x3f80 : (unsigned short)0);
+          al.u[jj] = l15 < 9 ? xs[180 + idx0 + jj] : (unsigned short)0;
+        }
+      }
+      // B: column l15 = channel 16 nb + l15, K chunk kq: two transposing reads of 4 rows x 16 columns each; lane 4 q + pp of a 16-lane
+      // group supplies the address of row q, columns 4 pp .. 4 pp + 3 (cdna_hip_programming.md T10)
+      const int tq = l15 >> 2, tp = l15 & 3;
+      f32x4 sacc[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        bf16x4 b0, b1;
+        const int r0 = 32 * kb + 8 * kq + tq, r1 = r0 + 4;
+        const int ch = 2 * nb + (tp >> 1);
+        const unsigned a0 = smem_l + r0 * (BN * 2) + ((ch ^ (r0 & (CPR - 1))) * 16) + (tp & 1) * 8;
+        const unsigned a1 = smem_l + r1 * (BN * 2) + ((ch ^ (r1 & (CPR - 1))) * 16) + (tp & 1) * 8;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1) : "v"(a1));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bf16x8 bb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bb[e] = b0[e]; bb[4 + e] = b1[e]; }
+        touch8(bb);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bb, z, 0, 0, 0);
+        sacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bb, z, 0, 0, 0);
+      }
+      // D (nb): rows 4 kq + e = taps, column l15 = channel 16 nb + l15.  Add the four waves through LDS.
+      float* red = reinterpret_cast<float*>(smem + RED);          // [wave][nb][lane][4]
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) *reinterpret_cast<f32x4*>(red + ((wave * 4 + nb) * 64 + lane) * 4) = sacc[nb];
+      __syncthreads();
+      float* slab = p.stem_slab + (long long)blockIdx.x * 640;     // [channel][10]: nine taps, then the bias gradient
+      for (int idx = tid; idx < 640; idx += NW * 64) {
+        const int ch = idx / 10, t = idx - ch * 10;
+        const int o = ((ch >> 4) * 64 + (t >> 2) * 16 + (ch & 15)) * 4 + (t & 3);
+        slab[idx] = (red[o] + red[o + 1024]) + (red[o + 2048] + red[o + 3072]);
+      }
+      return;
+    }
+  }
   int* rowY = reinterpret_cast<int*>(smem + ABUFS * A_BYTES + 2 * B_BYTES - BM * 8);   // tail of the weight stages
   int* rowM = rowY + BM;
   if (tid < BM) {
@@ -1237,6 +1334,8 @@ static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
 
 }  // namespace
 
+void dct_split_dw_db_launch(const float* partial, float* scratch, float* dw, float* db, int cout, int inner, int blocks, int accumulate, hipStream_t st);   // reduce.hip
+size_t dct_split_dw_db_scratch(int cout, int inner);
 // igemm4.hip
 size_t dct_igemm4_workspace(int images, int Ho, int Wo, int Cin, int N);
 int dct_igemm4_launch(const void* params, int images, void* workspace, size_t workspace_bytes, hipStream_t st);
@@ -1258,6 +1357,7 @@ extern "C" size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* 
   if (pp.use && pp.splits > 1) need = std::max(need, (size_t)pp.splits * M * N * sizeof(float));
   if (dtype == DCT_BF16 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil == 1 && !d->scatter2x2)
     need = std::max(need, dct_igemm4_workspace(y->n, Ho, Wo, x->c, N));
+  if (d->stem_x) need = std::max(need, (size_t)y->n * ((Ho + 7) / 8) * ((Wo + 15) / 16) * 640 * sizeof(float) + dct_split_dw_db_scratch(64, 9));
   return need;
 }
 
@@ -1318,6 +1418,13 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     if (dtype != DCT_BF16 || !dense(y) || y->c % 8 || p.scatter || ((uintptr_t)y->ptr & 15)) return DCT_ERR_BAD_ARG;
     p.bits_out = d->relu_bits_out;
   }
+  p.stem_x = nullptr; p.stem_slab = nullptr;
+  if (d->stem_x) {
+    if (!d->stem_dw || !d->stem_db || ((uintptr_t)d->stem_x & 3)) return DCT_ERR_BAD_ARG;
+    if (dtype != DCT_BF16 || y->c != 64 || x->c != 64 || d->R != 3 || d->S != 3 || d->stride != 1 || d->dil != 1 || p.scatter || d->accumulate ||
+        d->relu || bias || !d->mask_bits || d->mask_scale != 1.f || d->pool_out || d->relu_bits_out || !g_tune_igemm_halo)
+      return DCT_ERR_UNSUPPORTED;
+  }
   p.pool_y = nullptr; p.pool_codes = nullptr; p.Hp = (y->h + 1) / 2; p.Wp = (y->w + 1) / 2; p.pool_only = 0;
   if (d->pool_only && (!d->pool_out || d->relu_bits_out)) return DCT_ERR_BAD_ARG;
   if (d->pool_codes && !d->pool_out) return DCT_ERR_BAD_ARG;
@@ -1358,7 +1465,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     p.partial = (float*)workspace;
   }
   if (pl.v2 && g_tune_igemm_halo && (!bias || !((uintptr_t)bias & 15)) && d->R == 3 && d->S == 3 && d->stride == 1 &&
-      d->dil == 1 && !p.scatter) {
+      d->dil == 1 && !p.scatter && !d->stem_x) {
     // one-block-per-CU ping-pong tile (igemm4.hip): 256 pixels x 128 channels, eight waves of 64 x 64
     const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
                      (long long)y->n * y->sn < (1ll << 31);
@@ -1399,6 +1506,15 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     const bool x32 = (long long)x->n * x->sn < (1ll << 31) && (long long)bn * 9 * x->c * 2 < (1ll << 32);
     if (y16 && m16 && x32 && cover >= g_tune_igemm_halo_cover * 0.01 && blocks >= g_tune_igemm_halo_min_blocks && (bn == 128 || x->c == 64)) {
       if (d->pool_out && g_tune_igemm_pool) { p.pool_y = (char*)d->pool_out; p.pool_codes = d->pool_codes; p.pool_only = d->pool_only ? 1 : 0; }
+      if (d->stem_x) {
+        const size_t need = (size_t)blocks * 640 * sizeof(float) + dct_split_dw_db_scratch(64, 9);
+        if (!workspace || workspace_bytes < need) return DCT_ERR_WORKSPACE;
+        p.stem_x = d->stem_x; p.stem_slab = (float*)workspace;
+        launch_v3<64, 1, 1>(p, tiles_x, tiles_y, y->n, st);
+        dct_split_dw_db_launch((const float*)workspace, (float*)workspace + blocks * 640, d->stem_dw, d->stem_db, 64, 9, (int)blocks, d->stem_accumulate, st);
+        DCT_PLAN_NOTE("igemm3m shared-halo 8x16 patches x 64 ch: %lld blocks, stem weight gradient from the tile, y not stored", blocks);
+        return dct_check_launch();
+      }
       if (bn == 128) {
         if (x->c == 64) launch_v3<128, 2, 1>(p, tiles_x, tiles_y, y->n, st); else launch_v3<128, 2, 2>(p, tiles_x, tiles_y, y->n, st);
       } else launch_v3<64, 1, 1>(p, tiles_x, tiles_y, y->n, st);
@@ -1408,6 +1524,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
       return dct_check_launch();
     }
   }
+  if (d->stem_x) return DCT_ERR_UNSUPPORTED;      // only the shared-halo 64-channel tile can take the stem along
   if (pl.v2 && (!bias || !((uintptr_t)bias & 15))) {
     const PlanP pp = make_plan_p(x, y, d, dtype, p.N);
     if (pp.use) {

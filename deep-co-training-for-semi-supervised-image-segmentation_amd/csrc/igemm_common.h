@@ -27,6 +27,8 @@ struct IgemmParams {
   unsigned char* pool_codes;    // ... and its routing codes (dct_maxpool2x2_fwd_codes), nullable
   int Hp, Wp;
   int pool_only;                // with pool_y: y itself is not wanted (no row stores)
+  const float* stem_x;          // optional (64-channel shared-halo data gradient): the stem's input image, dense [n][Ho + 2][Wo + 2]; the block then
+  float* stem_slab;             // leaves its [64][10] partial of the stem's weight (taps 0..8) / bias (9) gradient here and does not store y
 };
 
 // ---- the per-chunk part of the staged epilogues (eight bf16 of one pixel = one 16-byte chunk) on PACKED 16-bit integer arithmetic.

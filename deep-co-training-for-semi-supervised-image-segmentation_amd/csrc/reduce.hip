@@ -426,6 +426,32 @@ static int resident_blocks(K kernel, int fallback) {
 
 }  // namespace
 
+// igemm.hip (stem weight gradient from the data gradient's epilogue): partial[blk][cout][inner + 1] -> dw, db.  Thousands of slabs
+// (one per conv block) are first folded to STEM_FOLD_ROWS by coalesced row sums (block b adds slabs b, b + rows, ...: a fixed order).
+constexpr int STEM_FOLD_ROWS = 128;
+__global__ __launch_bounds__(640) void slab_rows_fold_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, int blocks) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = blockIdx.x;
+  for (; b + 3 * STEM_FOLD_ROWS < blocks; b += 4 * STEM_FOLD_ROWS) {
+    s0 += partial[(long long)b * n + i]; s1 += partial[(long long)(b + STEM_FOLD_ROWS) * n + i];
+    s2 += partial[(long long)(b + 2 * STEM_FOLD_ROWS) * n + i]; s3 += partial[(long long)(b + 3 * STEM_FOLD_ROWS) * n + i];
+  }
+  for (; b < blocks; b += STEM_FOLD_ROWS) s0 += partial[(long long)b * n + i];
+  out[(long long)blockIdx.x * n + i] = (s0 + s1) + (s2 + s3);
+}
+size_t dct_split_dw_db_scratch(int cout, int inner) { return (size_t)STEM_FOLD_ROWS * cout * (inner + 1) * sizeof(float); }
+// scratch: dct_split_dw_db_scratch bytes behind the slabs when blocks > STEM_FOLD_ROWS
+void dct_split_dw_db_launch(const float* partial, float* scratch, float* dw, float* db, int cout, int inner, int blocks, int accumulate, hipStream_t st) {
+  const int n = cout * (inner + 1);
+  if (blocks > STEM_FOLD_ROWS && n <= 640) {
+    DCT_LAUNCH(DCT_PROF_POINTWISE, slab_rows_fold_kernel, dim3(STEM_FOLD_ROWS), dim3(640), 0, st, partial, scratch, n, blocks);
+    partial = scratch; blocks = STEM_FOLD_ROWS;
+  }
+  DCT_LAUNCH(DCT_PROF_POINTWISE, split_dw_db_kernel, dim3(div_up(n, 16)), dim3(256), 0, st, partial, dw, db, cout, inner, blocks, accumulate);
+}
+
 // =============================================================================== C ABI
 extern "C" size_t dct_bias_grad_workspace_bytes(const dct_view* dy) {
   if (!dy || dy->c < 1) return 0;

@@ -157,16 +157,22 @@ def _bits_ok(bits, of):
     return bits
 
 
+class StemFusionUnsupported(RuntimeError):
+    """conv2d(..., stem=...) on a layer whose kernel cannot take the stem's weight gradient along (the caller runs the two launches instead)."""
+
+
 def conv2d(x, w_packed, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=False, mask=None,
            mask_channels=0, mask_scale=1.0, accumulate=False, scatter2x2=False, mask_bits=None, relu_bits_out=None,
-           pool_out=None, pool_codes=None, pool_only=False):
+           pool_out=None, pool_codes=None, pool_only=False, stem=None):
     """y (NHWC view, written in place) = epilogue(conv(x, w_packed)); see include/dct.h dct_conv2d.
 
     ``relu_bits_out`` (uint8 [N,H,W,C/8], dense y): the launch also leaves the ReLU-gate bits of y there (`relu_bits_like`);
     ``mask_bits``: such bits of ``mask`` -- the data gradient then reads 1/16 of the bytes where its epilogue can.
     ``pool_out`` (dense [N,(H+1)//2,(W+1)//2,C], y's dtype) / ``pool_codes`` (uint8, same shape): the 2x2 ceil-mode max pooling of y
     (and its routing codes) in the same call -- `maxpool_fwd(y, pool_out, codes=pool_codes)` bit for bit; ``pool_only``: the caller
-    reads the pooled tensor alone -- y may be left unwritten."""
+    reads the pooled tensor alone -- y may be left unwritten.
+    ``stem`` = (x, dw, db, accumulate): the UNet stem's weight / bias gradient from this data gradient's output tile (dct_conv_desc.stem_*);
+    y is then NOT written.  Raises ``StemFusionUnsupported`` when the layer does not take the kernel that can."""
     if pool_out is not None:
         want = (y.shape[0], (y.shape[1] + 1) // 2, (y.shape[2] + 1) // 2, y.shape[3])
         assert tuple(pool_out.shape) == want and pool_out.is_contiguous() and pool_out.dtype == y.dtype, "pool_out: dense ceil-mode half of y"
@@ -175,13 +181,24 @@ def conv2d(x, w_packed, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0,
     else:
         assert pool_codes is None and not pool_only
     d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu, scatter2x2, accumulate, mask_channels, mask_scale,
-                  _bits_ok(mask_bits, mask), _bits_ok(relu_bits_out, y), pool_out, pool_codes, pool_only)
+                  _bits_ok(mask_bits, mask), _bits_ok(relu_bits_out, y), pool_out, pool_codes, pool_only, stem)
+    if stem is not None:
+        sx, sdw, sdb, _ = stem
+        assert sx.dtype == torch.float32 and sx.is_contiguous() and sx.numel() == y.shape[0] * (y.shape[1] + 2) * (y.shape[2] + 2)
+        assert sdw.dtype == torch.float32 and sdw.numel() == 64 * 9 and sdb.dtype == torch.float32 and sdb.numel() == 64
     vx, vy = view(x), view(y)
     lib = _lib.load()
     dt = _dt(x)
     need = lib.dct_conv2d_workspace_bytes(C.byref(vx), C.byref(vy), C.byref(d), dt)
     ws = _ws(need, x.device)
     vm = view(mask) if mask is not None else None
+    if stem is not None:
+        rc = getattr(lib, "dct_conv2d")(C.byref(vx), ptr(w_packed), ptr(bias), C.byref(vm) if vm is not None else None,
+                                        C.byref(vy), C.byref(d), dt, ptr(ws), ws.numel(), stream())
+        if rc == _lib.ERR_UNSUPPORTED:
+            raise StemFusionUnsupported()
+        _lib.check(rc, "dct_conv2d")
+        return y
     call("dct_conv2d", C.byref(vx), ptr(w_packed), ptr(bias), C.byref(vm) if vm is not None else None,
          C.byref(vy), C.byref(d), dt, ptr(ws), ws.numel(), stream())
     return y

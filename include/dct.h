@@ -97,6 +97,17 @@ typedef struct dct_conv_desc {
    * after the call are unspecified: the shared-halo kernel then skips its row stores (a UNet encoder block's full-resolution output
    * is read by the pooling alone once the backward pass routes by pool_codes: 130 MB less to write at the first level). */
   int32_t pool_only;
+  /* The UNet stem's weight gradient from the epilogue of the data gradient that produces its dy (network.py:159-161: Conv2d(1, 64, 3),
+   * ReLU, Conv2d(64, 64, 3)): with stem_x (nullable; dense fp32 [n][y->h + 2][y->w + 2], the single-channel input of the stem) a
+   * bf16 64 -> 64 channel 3x3 data gradient with mask_bits (mask_scale 1) also forms stem_dw[64][9] (+)= sum_px y[px][c] * x[px + tap] and
+   * stem_db[64] (+)= sum_px y[px][c] from its masked, bf16-rounded output tile while the tile is in LDS -- and then does NOT store y
+   * (132 MB written and read back per network and step, by nobody else when d/dx of the network is not asked for).  y must still be a valid
+   * view (shapes).  Needs dct_conv2d_workspace_bytes of workspace; DCT_ERR_UNSUPPORTED when the layer does not take the shared-halo
+   * 64-channel tile (the caller then runs dct_conv2d and dct_conv_cin1_wgrad as before). */
+  const float* stem_x;
+  float* stem_dw;
+  float* stem_db;
+  int32_t stem_accumulate;
 } dct_conv_desc;
 
 size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype);

@@ -321,6 +321,49 @@ def test_conv2d_with_pooling_is_bit_identical_to_conv_then_pool(ops, dtype, B, C
     assert torch.equal(p0.float(), ref)
 
 
+@pytest.mark.parametrize("B,Ha,Wa,acc", [(4, 100, 132, False), (5, 83, 147, True), (2, 120, 110, False)])
+def test_conv2d_dgrad_with_stem_weight_gradient(ops, B, Ha, Wa, acc):
+    """dct_conv_desc.stem_x: the UNet stem's weight / bias gradient taken from the output tile of the 64 -> 64 channel data gradient that
+    produces its dy (masked by ReLU-gate bits, rounded to bf16; x windows as bf16 high + low parts on the matrix pipe) against the two
+    launches it replaces (dct_conv2d writing dy, dct_conv_cin1_wgrad reading it back): same gradients to fp32 rounding, with and
+    without accumulation, ragged patches, a single-patch image."""
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(61)
+    C = 64
+    dd = to_dev(q(torch.randn(B, C, Ha - 2, Wa - 2, generator=g), dtype), dtype)            # gradient at the second conv's output
+    w = q(torch.randn(C, C, 3, 3, generator=g) / 24, dtype)                                  # second conv's weights [cout][cin][3][3]
+    wd = kmajor(w.flip(2, 3).permute(1, 0, 2, 3).contiguous(), dtype)                        # data-gradient pack: [cin][tap'][cout]
+    a1 = to_dev(q(torch.randn(B, C, Ha, Wa, generator=g), dtype), dtype)                     # the stem's output (its sign is the gate)
+    a1bits = _pack_bits(a1)
+    ximg = torch.rand(B, Ha + 2, Wa + 2, 1, generator=g).to(DEV)
+    seed_w, seed_b = torch.randn(C, 9, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    lib = _lib.load()
+    assert lib.dct_tune_set(19, 1) == 0
+    try:
+        da = torch.full((B, Ha, Wa, C), float("nan"), device=DEV, dtype=dtype)
+        ops.conv2d(dd, wd, None, da, pad_h=2, pad_w=2, mask=a1, mask_bits=a1bits)
+        dw0, db0 = seed_w.clone(), seed_b.clone()
+        ops.conv_cin1_wgrad(ximg, da, dw0, db0, accumulate=acc)
+        dw1, db1 = seed_w.clone(), seed_b.clone()
+        scratch = torch.empty_like(da)
+        ops.conv2d(dd, wd, None, scratch, pad_h=2, pad_w=2, mask=a1, mask_bits=a1bits, stem=(ximg, dw1, db1, acc))
+        torch.cuda.synchronize()
+    finally:
+        lib.dct_tune_set(19, 400)
+    # fp64 reference from the stored (masked, rounded) data gradient
+    daf = da.double().permute(0, 3, 1, 2).cpu()
+    xr = ximg.double().permute(0, 3, 1, 2).cpu()
+    cols = F.unfold(xr, 3).view(B, 9, Ha * Wa)
+    ref_w = torch.einsum("bcp,btp->ct", daf.reshape(B, C, Ha * Wa), cols) + (seed_w.double().cpu() if acc else 0)
+    ref_b = daf.sum((0, 2, 3)) + (seed_b.double().cpu() if acc else 0)
+    sw, sb = ref_w.abs().max().item(), ref_b.abs().max().item()
+    assert (dw1.double().cpu() - ref_w).abs().max().item() <= 1e-4 * sw, "fused stem dW vs fp64"
+    assert (db1.double().cpu() - ref_b).abs().max().item() <= 1e-4 * sb, "fused stem db vs fp64"
+    assert (dw0.double().cpu() - ref_w).abs().max().item() <= 1e-4 * sw, "two-launch stem dW vs fp64"
+    assert (dw1 - dw0).abs().max().item() <= 5e-5 * sw and (db1 - db0).abs().max().item() <= 5e-5 * sb
+
+
 @pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [
     (16, 1024, 11, 11, 128, 0),     # per-tap kernel: the rotating decoder wave and its two-slot offset table, 31 K-steps per block
     (6, 128, 9, 9, 128, 0),         # per-tap kernel, ONE to two K-steps per chunk: the table's prologue and tail

@@ -190,6 +190,33 @@ def test_unet_pooling_in_the_conv_call_leaves_everything_bit_identical(dtype):
             assert torch.equal(a, b), (train, k)
 
 
+def test_unet_stem_weight_gradient_from_the_data_gradient_tile():
+    """The stem's weight / bias gradient taken from the epilogue of the second convolution's data gradient (whose output is then not
+    stored) against the two separate launches: every other gradient bit for bit, the stem's two within fp32 rounding of each other."""
+    C = 4
+    onet = _oracle_net(C, 17, p=0.5).train()
+    x = torch.rand(4, 1, 256, 256, generator=torch.Generator().manual_seed(36)).to(DEV)
+    gl = torch.randn(4, C, 256, 256, generator=torch.Generator().manual_seed(37)).to(DEV)
+    outs = []
+    for flag in (False, True):
+        net = _hip_net(onet, C, torch.bfloat16, p=0.5).train()
+        net.fuse_stem_wgrad = flag
+        net.dropout_seed = 99
+        for _ in range(2):                      # the second pass accumulates
+            y = net(x)
+            y.backward(gl)
+        outs.append([p.grad.clone() for p in net.parameters()])
+    stem = 0
+    for (k, prm), a, b in zip(net.named_parameters(), *outs):
+        assert torch.isfinite(b).all(), k
+        if k.startswith("dec1.down.0."):
+            stem += 1
+            assert (a - b).abs().max().item() <= 1e-4 * a.abs().max().item(), k
+        else:
+            assert torch.equal(a, b), k
+    assert stem == 2, [k for k, _ in net.named_parameters()][:4]
+
+
 def test_unet_rejects_small_and_cpu_inputs():
     from dct_amd.arch import get_arch
     net = get_arch("unet", {"num_classes": 4}).to(DEV)
