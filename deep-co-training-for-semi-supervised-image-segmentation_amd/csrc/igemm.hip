@@ -650,6 +650,28 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
 
   const int nch = p.Cin / 64;
   const unsigned smem_l = (unsigned)(size_t)(lptr_c)(smem);
+  // stem weight gradient from the tile (epilogue): its gate bytes and its x-patch value are fetched here, behind the K loop
+  unsigned stem_gates[PXB] = {};
+  float stem_xv = 0.f;
+  if constexpr (BN == 64 && NWN == 1 && ABUFS == 1) {
+    if (p.stem_x) {
+#pragma unroll
+      for (int j = 0; j < PXB; ++j) {
+        const int oy = y0 + PXB * wm + j, ox = x0 + (lane & 15);
+        if (oy < p.Ho && ox < p.Wo) {
+          const long long om = (long long)img * p.msN + (long long)oy * p.msH + (long long)ox * p.msW;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            stem_gates[j] |= (unsigned)p.mask_bits[(unsigned long long)(om + i * 16 + 4 * (lane >> 4)) >> 3] << (8 * i);
+        }
+      }
+      if (tid < 180) {
+        const int hy = tid / 18, hx = tid - hy * 18;
+        const int iy = y0 + hy, ix = x0 + hx;
+        if (iy < p.Ho + 2 && ix < p.Wo + 2) stem_xv = p.stem_x[((long long)img * (p.Ho + 2) + iy) * (p.Wo + 2) + ix];
+      }
+    }
+  }
   stageA(Abuf, 0);
   stageB(Bbuf, 0, 0);
   float* biasL = reinterpret_cast<float*>(smem + ABUFS * A_BYTES + 2 * B_BYTES);   // bias -> LDS now: no memory round trip in the epilogue
@@ -717,27 +739,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
       asm volatile("" ::: "memory");
       constexpr int XS = 32 * 1024, RED = 16 * 1024;        // LDS: x patch parts behind the reduction buffer, both in dead stage space
       unsigned short* xs = reinterpret_cast<unsigned short*>(smem + XS);     // [2][180]
-      // gate nibbles of the lane's accumulators first (global loads in flight while the x patch is split)
-      unsigned gates[PXB][TR];
-#pragma unroll
-      for (int j = 0; j < PXB; ++j) {
-        const int oy = y0 + PXB * wm + j, ox = x0 + l15;
-        const bool inside = oy < p.Ho && ox < p.Wo;
-        const long long om = (long long)img * p.msN + (long long)oy * p.msH + (long long)ox * p.msW;
-#pragma unroll
-        for (int i = 0; i < TR; ++i) {
-          const int cl = i * 16 + 4 * kq;
-          gates[j][i] = inside ? (unsigned)p.mask_bits[(unsigned long long)(om + cl) >> 3] : 0u;
-        }
-      }
-      for (int h = tid; h < 180; h += NW * 64) {
-        const int hy = h / 18, hx = h - hy * 18;
-        const int iy = y0 + hy, ix = x0 + hx;
-        const float v = (iy < p.Ho + 2 && ix < p.Wo + 2) ? p.stem_x[((long long)img * (p.Ho + 2) + iy) * (p.Wo + 2) + ix] : 0.f;
-        const bf16_t vh = (bf16_t)v;
-        const bf16_t vl = (bf16_t)(v - (float)vh);
-        xs[h] = __builtin_bit_cast(unsigned short, vh);
-        xs[180 + h] = __builtin_bit_cast(unsigned short, vl);
+      if (tid < 180) {
+        const bf16_t vh = (bf16_t)stem_xv;
+        const bf16_t vl = (bf16_t)(stem_xv - (float)vh);
+        xs[tid] = __builtin_bit_cast(unsigned short, vh);
+        xs[180 + tid] = __builtin_bit_cast(unsigned short, vl);
       }
       // masked accumulators -> tile.  Accumulator (i, j): channels 16 i + 4 kq + {0..3} of pixel (patch row 2 wm + j, column l15).
 #pragma unroll
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
 #pragma unroll
         for (int i = 0; i < TR; ++i) {
           const int cl = i * 16 + 4 * kq;
-          const unsigned gate = (gates[j][i] >> (cl & 4)) & 15u;
+          const unsigned gate = (stem_gates[j] >> (8 * i + (cl & 4))) & 15u;
           bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(((gate >> e) & 1u) ? acc[i][j][e] : 0.f);
