@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
 
 struct WPlan { int bp, bq, chunks, ppc, ptiles, qtiles, v2, direct, slabs; int v3, segs_per_row, nseg, seg_per_chunk, pitch, nr, units, groups; };
 
-int g_tune_wgrad_target = 384;     // block target of the per-tap kernel (slab bytes = blocks x 64 KiB).  In isolation ~1150 blocks is
+int g_tune_wgrad_target = 256;     // block target of the per-tap kernel (slab bytes = blocks x 64 KiB; round 4, final sweep: 256 is 0.7 % ahead of 384 / 320 / 192 on the step).  In isolation ~1150 blocks is
                                    // fastest; on the whole step (tools/ab_step.py --knob 14) 256-768 are level and 1.5 % ahead of 1150
 int g_tune_wgrad3_target = 768;    // same for the filter-row kernel, in 4-wave units
 int g_tune_wgrad_rows_fill = 70;   // percent: minimum fill of the 64-row K-steps for the filter-row kernel
