@@ -364,6 +364,48 @@ def test_conv2d_dgrad_with_stem_weight_gradient(ops, B, Ha, Wa, acc):
     assert (dw1 - dw0).abs().max().item() <= 5e-5 * sw and (db1 - db0).abs().max().item() <= 5e-5 * sb
 
 
+@pytest.mark.parametrize("B,Ha,Wa", [(4, 100, 132), (5, 83, 147)])
+def test_conv2d_fused_epilogues_race_screen(ops, B, Ha, Wa):
+    """The two round-4 epilogue branches of the shared-halo kernel re-use LDS the K loop has just left (the pooled items read the staged
+    tile before the row stores; the stem branch writes the x-patch parts and the four waves' partial products into dead stage space,
+    reads the tile back through transposing reads, and adds behind two more barriers).  A missed barrier shows as a launch that
+    differs: 200 launches of each must reproduce the first bit for bit (pooled values, codes, stem dW / db)."""
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(71)
+    C = 64
+    x = to_dev(q(torch.randn(B, C, Ha + 2, Wa + 2, generator=g), dtype), dtype)
+    w = kmajor(q(torch.randn(C, C, 3, 3, generator=g) / 24, dtype), dtype)
+    bias = torch.randn(C, generator=g).to(DEV)
+    dd = to_dev(q(torch.randn(B, C, Ha - 2, Wa - 2, generator=g), dtype), dtype)
+    a1 = to_dev(q(torch.randn(B, C, Ha, Wa, generator=g), dtype), dtype)
+    a1bits = _pack_bits(a1)
+    ximg = torch.rand(B, Ha + 2, Wa + 2, 1, generator=g).to(DEV)
+    lib = _lib.load()
+    assert lib.dct_tune_set(19, 1) == 0
+    try:
+        first = None
+        for it in range(200):
+            y = torch.empty(B, Ha, Wa, C, device=DEV, dtype=dtype)
+            pooled = torch.full((B, (Ha + 1) // 2, (Wa + 1) // 2, C), float("nan"), device=DEV, dtype=dtype)
+            codes = torch.full(pooled.shape, 255, device=DEV, dtype=torch.uint8)
+            ops.conv2d(x, w, bias, y, relu=True, pool_out=pooled, pool_codes=codes, pool_only=True)
+            dw = torch.full((C, 9), float("nan"), device=DEV)
+            db = torch.full((C,), float("nan"), device=DEV)
+            scratch = torch.empty(B, Ha, Wa, C, device=DEV, dtype=dtype)
+            ops.conv2d(dd, w, None, scratch, pad_h=2, pad_w=2, mask=a1, mask_bits=a1bits, stem=(ximg, dw, db, False))
+            torch.cuda.synchronize()
+            cur = (pooled, codes, dw, db)
+            if first is None:
+                first = cur
+                assert torch.isfinite(pooled.float()).all() and torch.isfinite(dw).all() and torch.isfinite(db).all()
+            else:
+                for k, (a, b) in enumerate(zip(first, cur)):
+                    assert torch.equal(a, b), f"launch {it}: output {k} differs from the first launch"
+    finally:
+        lib.dct_tune_set(19, 400)
+
+
 @pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [
     (16, 1024, 11, 11, 128, 0),     # per-tap kernel: the rotating decoder wave and its two-slot offset table, 31 K-steps per block
     (6, 128, 9, 9, 128, 0),         # per-tap kernel, ONE to two K-steps per chunk: the table's prologue and tail
