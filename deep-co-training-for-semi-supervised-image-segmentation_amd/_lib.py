@@ -112,6 +112,7 @@ SIGNATURES = {
     "dct_maxpool2x2_bwd": (_i, [_VP, _VP, _VP, _i, _f, _i, _P]),
     "dct_maxpool2x2_fwd_codes": (_i, [_VP, _VP, _P, _i, _P]),
     "dct_maxpool2x2_bwd_codes": (_i, [_P, _VP, _VP, _i, _f, _i, _P]),
+    "dct_maxpool2x2_bwd_codes_skip": (_i, [_P, _VP, _VP, _VP, _i, _f, _i, _P]),
     "dct_bilinear_fwd": (_i, [_VP, _VP, _i, _i, _P]),
     "dct_bilinear_bwd": (_i, [_VP, _VP, _i, _i, _i, _P]),
     "dct_dropout_fwd": (_i, [_VP, _VP, _P, _f, _u64, _u64, _i, _P]),

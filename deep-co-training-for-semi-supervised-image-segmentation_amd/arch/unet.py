@@ -194,6 +194,7 @@ class UNet(nn.Module):
         self.fuse_pool = True                # an encoder block's max pooling rides in its second convolution's call (dct_conv_desc.pool_out)
         self.pool_only = True                # ... whose full-resolution output is then not stored at all (nobody else reads it)
         self.fuse_stem_wgrad = True          # the stem's weight gradient from the epilogue of the data gradient that produces its dy (not stored then)
+        self.fuse_skip_grad = True           # the skip connections' bilinear backward gathered by the un-pooling instead of summed in memory
         self._wgrad_stream = None
 
     # ------------------------------------------------------------------------------ weights
@@ -536,11 +537,16 @@ class UNet(nn.Module):
         cat = A["cat1"]
         dcat = conv_bwd(ca, cat, de1a, new_like(cat), mask=cat, mask_channels=64)
         dp: Dict[int, torch.Tensor] = {}
+        skip_g: Dict[int, torch.Tensor] = {}
+        skip_fused = bool(self.fuse_skip_grad and all(A.get(f"pc{k}") is not None for k in (1, 2, 3, 4)))
         for lvl, co in ((2, 64), (3, 128), (4, 256)):
             ca, _, cb, _, ct = self._roles[f"enc{lvl}"]
             ea, eb = A[f"e{lvl}a"], A[f"e{lvl}b"]
             p = A[f"p{lvl - 1}"]
-            dp[lvl - 1] = K.bilinear_bwd(dcat[..., co:], new_like(p))
+            if skip_fused:
+                skip_g[lvl - 1] = dcat[..., co:]          # gathered by level (lvl - 1)'s un-pooling (K.maxpool_bwd(..., skip=))
+            else:
+                dp[lvl - 1] = K.bilinear_bwd(dcat[..., co:], new_like(p))
             deb = bn_back(f"e{lvl}b", convT_bwd(ct, eb, dcat[..., :co], new_like(eb), mask=eb))
             dea = bn_back(f"e{lvl}a", conv_bwd(cb, ea, deb, new_like(ea), mask=ea))
             if self._debug is not None:
@@ -553,11 +559,15 @@ class UNet(nn.Module):
         # center (cat4: 512 convT channels + 512 skip channels)
         ca, _, cb, _, ct = self._roles["center"]
         p4 = A["p4"]
-        dp[4] = K.bilinear_bwd(dcat[..., 512:], new_like(p4))
+        if skip_fused:
+            skip_g[4] = dcat[..., 512:]
+            dp[4] = new_like(p4)
+        else:
+            dp[4] = K.bilinear_bwd(dcat[..., 512:], new_like(p4))
         c2d, c1 = A["c2"], A["c1"]
         dc2 = bn_back("c2", convT_bwd(ct, c2d, dcat[..., :512], new_like(c2d), mask=c2d, mask_scale=ds))
         dc1 = bn_back("c1", conv_bwd(cb, c1, dc2, new_like(c1), mask=c1))
-        conv_bwd(ca, p4, dc1, dp[4], accumulate=True)
+        conv_bwd(ca, p4, dc1, dp[4], accumulate=not skip_fused)
         if hook is not None and side is None:
             hook(1)                           # centre gradients are complete
         # encoder
@@ -565,14 +575,17 @@ class UNet(nn.Module):
         for lvl in (4, 3, 2, 1):
             ca, _, cb, _ = self._roles[f"dec{lvl}"]
             a, d = A[f"a{lvl}"], A[f"d{lvl}"]
-            dd = K.maxpool_bwd(d, dp[lvl], new_like(d), relu_mask=True, scale=ds if lvl == 4 else 1.0, codes=A.get(f"pc{lvl}"))
+            dd = K.maxpool_bwd(d, dp[lvl], new_like(d), relu_mask=True, scale=ds if lvl == 4 else 1.0, codes=A.get(f"pc{lvl}"),
+                               skip=skip_g.get(lvl))
             stem = None
             if (lvl == 1 and need_dw and not need_dx and self.fuse_stem_wgrad and dt == torch.bfloat16 and side is None and
                     A["bn"].get("a1") is None and self._debug is None):
                 stem = (A["x"], self._gw(ca), self._gb(ca), gacc)       # the stem's dy has no other reader: see dct_conv_desc.stem_x
             da = bn_back(f"a{lvl}", conv_bwd(cb, a, dd, new_like(a), mask=a, stem=stem))
             if lvl > 1:
-                conv_bwd(ca, A[f"p{lvl - 1}"], da, dp[lvl - 1], accumulate=True)
+                if skip_fused:
+                    dp[lvl - 1] = new_like(A[f"p{lvl - 1}"])
+                conv_bwd(ca, A[f"p{lvl - 1}"], da, dp[lvl - 1], accumulate=not skip_fused)
             else:
                 c0 = ca
                 if need_dw and not stem_fused[0]:

@@ -649,6 +649,68 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(View dy, View dx, flo
   VecIO<T, VEC>::store(op, acc);
 }
 
+// Un-pooling with the skip connection's gradient gathered on the way (dct_maxpool2x2_bwd_codes_skip): the pooled tensor p feeds the next
+// encoder block AND, bilinearly resized, the decoder's concatenation, so its gradient is dp = (data gradient of the next block) + (bilinear
+// backward of the concatenation's gradient).  The sum used to be formed in memory (the bilinear backward wrote dp, the data gradient
+// read it back and added); here the data gradient writes dp alone and this kernel adds the gather -- the loop of bilinear_bwd_kernel, same
+// index arithmetic -- to the value it routes: one write and one read of dp less per level, and the sum is not rounded to 16 bits on the way.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_bwd_codes_skip_kernel(const unsigned char* __restrict__ codes, View dy, View skip, View dx, int relu_mask,
+                                                                     float scale, float sh, float sw) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const PixIdx id = decode(t, dy.n, dy.h, dy.w, dy.c / VEC);
+  if (!id.ok) return;
+  float g[VEC];
+  VecIO<T, VEC>::load(reinterpret_cast<const T*>(dy.ptr) + voff(dy, id.n, id.y, id.x) + id.cv * VEC, g);
+  {
+    auto range = [](int i, float sc, int out_size, int& lo, int& hi) {
+      if (sc <= 0.f) { lo = 0; hi = out_size - 1; return; }
+      lo = max(0, (int)floorf((float)(i - 1) / sc) - 1);
+      hi = min(out_size - 1, (int)ceilf((float)(i + 1) / sc) + 1);
+    };
+    int jlo, jhi, klo, khi;
+    range(id.y, sh, skip.h, jlo, jhi);
+    range(id.x, sw, skip.w, klo, khi);
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    for (int j = jlo; j <= jhi; ++j) {
+      const Lerp ly = lerp_of(j, sh, dy.h);
+      if (ly.i0 != id.y && ly.i1 != id.y) continue;
+      const float wy = (ly.i0 == id.y ? ly.w0 : 0.f) + (ly.i1 == id.y ? ly.w1 : 0.f);
+      for (int k = klo; k <= khi; ++k) {
+        const Lerp lx = lerp_of(k, sw, dy.w);
+        if (lx.i0 != id.x && lx.i1 != id.x) continue;
+        const float wx = (lx.i0 == id.x ? lx.w0 : 0.f) + (lx.i1 == id.x ? lx.w1 : 0.f);
+        float s[VEC];
+        VecIO<T, VEC>::load(reinterpret_cast<const T*>(skip.ptr) + voff(skip, id.n, j, k) + id.cv * VEC, s);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(s[i], wy * wx, acc[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] += acc[i];
+  }
+  union { unsigned char b[VEC]; unsigned w[VEC / 4]; } cu;
+  const unsigned* cp = reinterpret_cast<const unsigned*>(codes + t * VEC);
+  if constexpr (VEC == 8) { const uint2 q = *reinterpret_cast<const uint2*>(cp); cu.w[0] = q.x; cu.w[1] = q.y; }
+  else cu.w[0] = cp[0];
+  const unsigned char* cd = cu.b;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    if (relu_mask) g[i] = (cd[i] & 4) ? g[i] * scale : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int iy = 2 * id.y + (k >> 1), ix = 2 * id.x + (k & 1);
+    if (iy >= dx.h || ix >= dx.w) continue;
+    float out[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = (cd[i] & 11) == k ? g[i] : 0.f;
+    VecIO<T, VEC>::store(reinterpret_cast<T*>(dx.ptr) + voff(dx, id.n, iy, ix) + id.cv * VEC, out);
+  }
+}
+
 // ---- dropout (Philox4x32-10) ---------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned long long ctr, unsigned out[4]) {
   unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
@@ -917,6 +979,22 @@ extern "C" int dct_maxpool2x2_bwd_codes(const uint8_t* codes, const dct_view* dy
 }
 
 static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+extern "C" int dct_maxpool2x2_bwd_codes_skip(const uint8_t* codes, const dct_view* dy, const dct_view* skip, const dct_view* dx, int relu_mask,
+                                             float scale, int dtype, dct_stream stream) {
+  if (!codes || !view_ok(dy) || !view_ok(skip) || !view_ok(dx) || dy->c != dx->c || dx->n != dy->n || skip->n != dy->n || skip->c != dy->c)
+    return DCT_ERR_BAD_ARG;
+  if (dy->h != (dx->h + 1) / 2 || dy->w != (dx->w + 1) / 2) return DCT_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const float sh = ac_scale(dy->h, skip->h), sw = ac_scale(dy->w, skip->w);
+  DISPATCH_T(dtype, {
+    if (!vec_ok(dy, VEC, sizeof(T)) || !vec_ok(dx, VEC, sizeof(T)) || !vec_ok(skip, VEC, sizeof(T)) || ((uintptr_t)codes % VEC)) return DCT_ERR_UNSUPPORTED;
+    const long long total = (long long)dy->n * dy->h * dy->w * (dy->c / VEC);
+    DCT_LAUNCH(DCT_PROF_POINTWISE, (maxpool_bwd_codes_skip_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), 0, st, codes, to_view(dy), to_view(skip),
+               to_view(dx), relu_mask, scale, sh, sw);
+  });
+  return dct_check_launch();
+}
 
 extern "C" int dct_bilinear_fwd(const dct_view* x, const dct_view* y, int dtype_in, int dtype_out, dct_stream stream) {
   if (!view_ok(x) || !view_ok(y) || x->n != y->n || x->c != y->c) return DCT_ERR_BAD_ARG;

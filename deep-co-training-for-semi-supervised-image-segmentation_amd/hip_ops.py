@@ -343,8 +343,15 @@ def maxpool_fwd(x, y, codes=None):
     return y
 
 
-def maxpool_bwd(x, dy, dx, relu_mask=False, scale=1.0, codes=None):
+def maxpool_bwd(x, dy, dx, relu_mask=False, scale=1.0, codes=None, skip=None):
+    """``skip`` (with codes): the gradient at a bilinearly resized copy of the pooled tensor; its bilinear backward is added to dy on the way."""
     vdy, vdx = view(dy), view(dx)
+    if codes is not None and skip is not None:
+        assert codes.dtype == torch.uint8 and codes.is_contiguous() and tuple(codes.shape) == tuple(dy.shape)
+        vs = view(skip)
+        call("dct_maxpool2x2_bwd_codes_skip", ptr(codes), C.byref(vdy), C.byref(vs), C.byref(vdx), int(relu_mask), float(scale), _dt(dy), stream())
+        return dx
+    assert skip is None
     if codes is not None:
         assert codes.dtype == torch.uint8 and codes.is_contiguous() and tuple(codes.shape) == tuple(dy.shape)
         call("dct_maxpool2x2_bwd_codes", ptr(codes), C.byref(vdy), C.byref(vdx), int(relu_mask), float(scale), _dt(dy), stream())

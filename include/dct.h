@@ -186,6 +186,12 @@ int dct_maxpool2x2_bwd(const dct_view* x, const dct_view* dy, const dct_view* dx
 int dct_maxpool2x2_fwd_codes(const dct_view* x, const dct_view* y, uint8_t* codes, int dtype, dct_stream stream);
 int dct_maxpool2x2_bwd_codes(const uint8_t* codes, const dct_view* dy, const dct_view* dx, int relu_mask,
                              float scale, int dtype, dct_stream stream);
+/* The same with the gradient of a second reader of the pooled tensor gathered on the way: `skip` is the gradient at a bilinearly resized
+ * (align_corners) copy of it -- the UNet's skip connection, network.py:205-239 `F.upsample(dec_k, size, mode='bilinear')` -- and
+ * dx = unpool(dy + bilinear_backward(skip)): what dct_bilinear_bwd into dy followed by dct_maxpool2x2_bwd_codes gives, with one write and
+ * one read of dy less and the sum kept in fp32 until it is routed. */
+int dct_maxpool2x2_bwd_codes_skip(const uint8_t* codes, const dct_view* dy, const dct_view* skip, const dct_view* dx, int relu_mask,
+                                  float scale, int dtype, dct_stream stream);
 
 /* ---- K5: bilinear resize, align_corners=True -------------------------------------------
  * Replaces F.upsample_bilinear (network.py:232-240).  Any in/out size.  y may be a channel

@@ -364,6 +364,31 @@ def test_conv2d_dgrad_with_stem_weight_gradient(ops, B, Ha, Wa, acc):
     assert (dw1 - dw0).abs().max().item() <= 5e-5 * sw and (db1 - db0).abs().max().item() <= 5e-5 * sb
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,C,H,W,Hs,Ws", [(2, 64, 37, 50, 28, 41), (1, 128, 12, 9, 20, 16), (3, 64, 21, 21, 11, 11)])
+def test_maxpool_bwd_with_skip_gather(ops, dtype, B, C, H, W, Hs, Ws):
+    """dct_maxpool2x2_bwd_codes_skip: un-pooling of (dy + bilinear backward of the gradient at a resized copy of the pooled tensor) against
+    dct_bilinear_bwd (accumulating into dy) followed by dct_maxpool2x2_bwd_codes -- down- and up-sampled skips, odd extents, the ReLU gate."""
+    g = torch.Generator().manual_seed(91)
+    x = to_dev(q(torch.randn(B, C, H, W, generator=g), dtype), dtype)
+    Hp, Wp = (H + 1) // 2, (W + 1) // 2
+    pooled = torch.empty(B, Hp, Wp, C, device=DEV, dtype=dtype)
+    codes = torch.empty(B, Hp, Wp, C, device=DEV, dtype=torch.uint8)
+    ops.maxpool_fwd(x, pooled, codes=codes)
+    dy = to_dev(q(torch.randn(B, C, Hp, Wp, generator=g), dtype), dtype)
+    skip = to_dev(q(torch.randn(B, C, Hs, Ws, generator=g), dtype), dtype)
+    want_dy = dy.clone()
+    ops.bilinear_bwd(skip, want_dy, accumulate=True)
+    want = torch.full((B, H, W, C), float("nan"), device=DEV, dtype=dtype)
+    ops.maxpool_bwd(x, want_dy, want, relu_mask=True, scale=2.0, codes=codes)
+    got = torch.full((B, H, W, C), float("nan"), device=DEV, dtype=dtype)
+    ops.maxpool_bwd(x, dy, got, relu_mask=True, scale=2.0, codes=codes, skip=skip)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got == 0, want == 0) or dtype == torch.bfloat16        # the routing is the same (bf16: a sum may round to zero in one form only)
+    close(to_cpu(got), to_cpu(want), dtype, "unpool with skip gather", rtol32=2e-6, rtol16=8e-3)
+
+
 @pytest.mark.parametrize("B,Ha,Wa", [(4, 100, 132), (5, 83, 147)])
 def test_conv2d_fused_epilogues_race_screen(ops, B, Ha, Wa):
     """The two round-4 epilogue branches of the shared-halo kernel re-use LDS the K loop has just left (the pooled items read the staged

@@ -154,6 +154,7 @@ def test_unet_gate_bits_and_pool_codes_leave_every_gradient_bit_identical():
     for flag in (False, True):
         net = _hip_net(onet, C, torch.bfloat16, p=0.5).train()
         net.relu_bits = net.pool_codes = flag
+        net.fuse_skip_grad = False      # (needs the codes; it changes the rounding of an intermediate: its own test below)
         net.dropout_seed = 99
         xd = x.clone().requires_grad_(True)
         y = net(xd)
@@ -215,6 +216,34 @@ def test_unet_stem_weight_gradient_from_the_data_gradient_tile():
         else:
             assert torch.equal(a, b), k
     assert stem == 2, [k for k, _ in net.named_parameters()][:4]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+def test_unet_skip_gradient_gathered_by_the_unpooling(dtype, tol):
+    """The skip connections' bilinear backward gathered inside the un-pooling launch (dct_maxpool2x2_bwd_codes_skip) against the sum
+    formed in memory (dct_bilinear_bwd into dp, the data gradient accumulating onto it): the same gradients up to the rounding of
+    that intermediate -- fp32: to the order of the additions; bf16: the 16-bit rounding of dp that the fused form no longer makes."""
+    C = 4
+    onet = _oracle_net(C, 19, p=0.5).train()
+    x = torch.rand(2, 1, 200, 216, generator=torch.Generator().manual_seed(46)).to(DEV)
+    gl = torch.randn(2, C, 200, 216, generator=torch.Generator().manual_seed(47)).to(DEV)
+    outs = []
+    for flag in (False, True):
+        net = _hip_net(onet, C, dtype, p=0.5).train()
+        net.fuse_skip_grad = flag
+        net.fuse_stem_wgrad = False
+        net.dropout_seed = 99
+        xd = x.clone().requires_grad_(True)
+        y = net(xd)
+        y.backward(gl)
+        outs.append([xd.grad.clone()] + [p.grad.clone() for p in net.parameters()])
+    names = ["grad_x"] + [k for k, _ in net.named_parameters()]
+    changed = 0
+    for k, a, b in zip(names, *outs):
+        assert torch.isfinite(b).all(), k
+        assert _rel2(b.cpu().numpy(), a.cpu().numpy()) <= tol, (k, _rel2(b.cpu().numpy(), a.cpu().numpy()))
+        changed += int(not torch.equal(a, b))
+    assert k and (dtype == torch.float32 or changed > 0)
 
 
 def test_unet_rejects_small_and_cpu_inputs():
