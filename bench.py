@@ -221,36 +221,172 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+class HipLegs:
+    """Device side of the measurement legs on the MI355X: synchronisation and the library's per-launch HIP-event profiler."""
+    kind = "hip"
+
+    def __init__(self, device):
+        from dct_amd import _lib
+        self.device, self._lib = device, _lib
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def scalar(self, v):
+        return torch.tensor([v], dtype=torch.float64, device=self.device)
+
+    def prof_begin(self, record: bool):
+        self._lib.prof_read(reset=True)
+        self._lib.prof_enable(bool(record))
+
+    def prof_end(self, record: bool):
+        self._lib.prof_enable(False)
+        return self._lib.prof_read(reset=True) if record else None
+
+
+class DryLegs:
+    """CPU stand-in for `--dry-launch`: the same control flow without a device (nothing to synchronise, no event profiler)."""
+    kind = "dry"
+    device = torch.device("cpu")
+
+    def sync(self):
+        pass
+
+    def scalar(self, v):
+        return torch.tensor([v], dtype=torch.float64)
+
+    def prof_begin(self, record: bool):
+        self._on = bool(record)
+
+    def prof_end(self, record: bool):
+        return {"igemm": {"ms": 0.0, "launches": 0}} if record else None
+
+
+def measure(args, tr, one_step, legs, rank, world, ddp_on, meters_leg=None, operand_leg=None, enter_event_leg=None):
+    """W warm-up steps, the timed regions, and every leg behind them.  ONE rule keeps `--gpus N` from hanging: a leg that runs
+    `one_step` (which issues the gradient all-reduces when N > 1) is executed by EVERY rank; what is rank-conditional is only
+    who records or prints.  (Round 4 ran the HIP-event leg on rank 0 alone while the other ranks went on to the barrier:
+    mismatched collectives on one communicator.)  `--dry-launch` drives this same function on CPU with a collective counter per
+    rank (tests/test_ddp_cpu.py::test_bench_launches_its_own_ranks)."""
+    import torch.distributed as dist
+    for i in range(args.warmup):
+        one_step(i)
+    legs.sync()
+    if ddp_on:
+        tr.grad_sync.exposed_ms(reset=True)
+        tr.grad_sync.exchanged_bytes = 0
+        dist.barrier()
+    legs.sync()
+    # The timed region: EXACTLY K steps between barrier + synchronize on both sides -- taken `--repeats` times back to back (default 3)
+    # and the MEDIAN region reported: a region is 0.1-0.3 s, and run-to-run noise on one box is of the size of a round's gains.
+    regions, out = [], None
+    reps = max(1, args.repeats)
+    for rep in range(reps):
+        if ddp_on:
+            dist.barrier()
+        legs.sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = one_step(args.warmup + rep * args.steps + i)
+        legs.sync()
+        if ddp_on:
+            dist.barrier()
+        legs.sync()
+        t_rep = time.perf_counter() - t0
+        if ddp_on:                      # MAX over ranks, per region
+            tt = legs.scalar(t_rep)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_rep = float(tt.item())
+        regions.append(t_rep)
+    res = {"regions": regions, "elapsed": sorted(regions)[len(regions) // 2], "out": out, "exchange": None, "meters_ms": None,
+           "operand_stats": None, "prof": None}
+    if ddp_on:
+        ex = legs.scalar(tr.grad_sync.exposed_ms(reset=True) / (args.steps * reps))
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        graphs = getattr(tr, "_step_graphs", None)
+        res["exchange"] = {"exposed_allreduce_ms_per_step_max_over_ranks": float(ex.item()),
+                           "bytes_per_step_per_rank": tr.grad_sync.exchanged_bytes / (args.steps * reps),
+                           "wire_dtype": "bf16" if args.grad_compress == "bf16" else "f32",
+                           "mode": "captured graph segments around the eager all-reduces" if graphs is not None and graphs.captures
+                           else "eager launches, bucketed all-reduce from inside the backward pass"}
+    base = args.warmup + args.steps * reps
+    # The step with the in-step meters on (SURVEY.md 8d asks for it separately).  `world == 1` is the same on every rank.
+    if meters_leg is not None and world == 1:
+        res["meters_ms"] = meters_leg(base)
+    # Operand statistics: one forward pass of model 0 on rank 0 -- no step, no collective.
+    if operand_leg is not None and rank == 0:
+        res["operand_stats"] = operand_leg()
+    # Roofline leg: the SAME K steps once more with every launch bracketed by HIP events on its stream (kept out of the timed
+    # region above: ~1200 event records per step would cost the step ~25 % and `value` must be the unperturbed rate).  Every rank
+    # runs the steps (their all-reduces must meet); rank 0 alone records.
+    if not args.no_kernel_events:
+        if enter_event_leg is not None:
+            enter_event_leg()
+        record = rank == 0
+        legs.prof_begin(record)
+        for i in range(args.steps):
+            one_step(base + i)
+        legs.sync()
+        res["prof"] = legs.prof_end(record)
+    if ddp_on:
+        dist.barrier()
+    return res
+
+
 def dry_launch(args, rank: int, world: int) -> None:
-    """`--dry-launch`: the N-rank plumbing of this script on CPU -- gloo process group, FlatGradSync, the barrier / max-over-ranks
-    timing and rank 0's JSON line -- around CoTrainer._run_step with oracle-injected networks (the product kernels are HIP-only;
-    tests/test_ddp_cpu.py builds the same trainer).  Not a measurement: it exists so that the launch path is testable without a GPU."""
+    """`--dry-launch`: the N-rank plumbing of this script on CPU -- gloo process group, FlatGradSync, and `measure()` itself (the
+    barrier / max-over-ranks timing and EVERY leg behind the timed region, with CPU stand-ins for the device calls) -- around
+    CoTrainer._run_step with oracle-injected networks (the product kernels are HIP-only; tests/test_ddp_cpu.py builds the same
+    trainer).  Every collective a rank issues is counted; the line reports whether all ranks issued the same sequence.  Not a
+    measurement: it exists so that the launch path is testable without a GPU."""
+    import datetime
     import torch.distributed as dist
     from dct_amd import ddp
     from test_ddp_cpu import _build, _step
     torch.set_num_threads(2)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:        # a short timeout: mismatched collectives must fail the run, not park it for gloo's default 30 minutes
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.dry_timeout))
     ddp.init_from_env("gloo")
+    issued = []
+    originals = {name: getattr(dist, name) for name in ("all_reduce", "barrier", "broadcast", "all_gather", "reduce_scatter")}
+
+    def counted(name):
+        fn = originals[name]
+
+        def call(*a, **k):
+            issued.append(name)
+            return fn(*a, **k)
+        return call
+    for name in originals:
+        setattr(dist, name, counted(name))
     tr, lab, unl = _build(tempfile.mkdtemp(prefix=f"dct_dry_r{rank}_"), 100 * rank)
-    tr.grad_sync = ddp.FlatGradSync(tr.segmentators)
-    for _ in range(args.warmup):
-        _step(tr, lab, unl)
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = _step(tr, lab, unl)
-    dist.barrier()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    ddp_on = world > 1
+    if ddp_on:
+        tr.grad_sync = ddp.FlatGradSync(tr.segmentators, measure=False)
+    if args.dry_break_rank0_leg:        # the round-4 defect, kept reachable so that the test can show it is caught
+        args.no_kernel_events = rank != 0
+    res = measure(args, tr, lambda i: _step(tr, lab, unl), DryLegs(), rank, world, ddp_on)
+    for name, fn in originals.items():
+        setattr(dist, name, fn)
+    elapsed, out = res["elapsed"], res["out"]
+    sequences = [issued]
+    if ddp_on:
+        sequences = [None] * world
+        dist.all_gather_object(sequences, issued)
     imgs = 3            # tests/test_ddp_cpu.py::_build: 2 models x 1 labeled + 1 unlabeled slice per rank
     line = {"metric": "co-train imgs/sec/node (lab+unlab), dry launch of the rank plumbing (CPU oracle networks over gloo)",
             "value": imgs * world / (elapsed / args.steps), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "config": {"workload": "dry launch: 2xUNet 176x176 C=2 on CPU, bs 1+1 per rank (not a measurement)",
                                             "global_batch": f"{world}+{world}", "parallelism": f"dp{world}"},
-            "losses_last_step": {"sup": [float(v) for v in out["sup"]], "jsd": float(out["jsd"])}}
-    dist.barrier()
-    dist.destroy_process_group()
+            "losses_last_step": {"sup": [float(v) for v in out["sup"]], "jsd": float(out["jsd"])},
+            "collectives": {"per_rank": [len(s) for s in sequences], "same_sequence_on_every_rank": all(s == sequences[0] for s in sequences),
+                            "behind_the_timed_region_legs": ["meters (world 1 only)", "operand stats (rank 0, no step)", "per-launch events"],
+                            "event_leg_ran": res["prof"] is not None or rank != 0}}
+    if ddp_on:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line), flush=True)
 
@@ -284,6 +420,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of K steps each; the median is reported (default 3)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="exercise the N-rank launch path on CPU (gloo, oracle-injected networks); prints one JSON line, measures nothing")
+    ap.add_argument("--dry-timeout", type=int, default=180, help="--dry-launch: seconds before a stuck gloo collective fails the run")
+    ap.add_argument("--dry-break-rank0-leg", action="store_true",
+                    help="--dry-launch self-test: run the per-launch event leg on rank 0 only (the round-4 defect); the run must FAIL")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -359,48 +498,10 @@ def main():
     for i in range(SETUP_STEPS + args.train_steps):
         one_step(i)
     torch.cuda.synchronize()
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    if ddp_on:
-        tr.grad_sync.exposed_ms(reset=True)
-        tr.grad_sync.exchanged_bytes = 0
-        dist.barrier()
-    torch.cuda.synchronize()
-    # The timed region: EXACTLY K steps between barrier + synchronize on both sides -- taken `--repeats` times back to back (default 3)
-    # and the MEDIAN region reported: a region is 0.1-0.3 s, and run-to-run noise on one box is of the size of a round's gains.
-    regions = []
-    for rep in range(max(1, args.repeats)):
-        if ddp_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = one_step(args.warmup + rep * args.steps + i)
-        torch.cuda.synchronize()
-        if ddp_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t_rep = time.perf_counter() - t0
-        if ddp_on:                      # MAX over ranks, per region
-            tt = torch.tensor([t_rep], dtype=torch.float64, device=device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_rep = float(tt.item())
-        regions.append(t_rep)
-    elapsed = sorted(regions)[len(regions) // 2]
-    exchange = None
-    if ddp_on:
-        ex = torch.tensor([tr.grad_sync.exposed_ms(reset=True) / (args.steps * len(regions))], dtype=torch.float64, device=device)
-        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
-        exchange = {"exposed_allreduce_ms_per_step_max_over_ranks": float(ex.item()),
-                    "bytes_per_step_per_rank": tr.grad_sync.exchanged_bytes / (args.steps * len(regions)),
-                    "wire_dtype": "bf16" if args.grad_compress == "bf16" else "f32",
-                    "mode": "captured graph segments around the eager all-reduces" if tr._step_graphs is not None and tr._step_graphs.captures
-                    else "eager launches, bucketed all-reduce from inside the backward pass"}
-    # The step with the in-step meters on (SURVEY.md 8d asks for it separately): what _train_loop adds around _run_step --
-    # DiceMeter.add on the labeled and unlabeled predictions, the loss meters, and the progress read-out every 10 steps.
-    meters_ms = None
-    if rank == 0 and world == 1:
+
+    def meters_leg(base):
+        # what _train_loop adds around _run_step: DiceMeter.add on the labeled and unlabeled predictions, the loss meters, and the
+        # progress read-out every 10 steps
         from dct_amd.metrics import AverageValueMeter, DiceMeter
         axes = list(range(1, cfg["C"]))
         dm = [DiceMeter(report_axises=axes, method='2d', C=cfg["C"]) for _ in range(2 * S)]
@@ -409,9 +510,9 @@ def main():
         torch.cuda.synchronize()
         tm = time.perf_counter()
         for i in range(nm):
-            o = one_step(args.warmup + args.steps * max(1, args.repeats) + i)
-            lb_gt = [lab[m][(args.warmup + args.steps * max(1, args.repeats) + i) % nb][0][1] for m in range(S)]
-            ub_gt = unl[(args.warmup + args.steps * max(1, args.repeats) + i) % nb][0][1]
+            o = one_step(base + i)
+            lb_gt = [lab[m][(base + i) % nb][0][1] for m in range(S)]
+            ub_gt = unl[(base + i) % nb][0][1]
             for m in range(S):
                 dm[m].add(o["preds"][m], lb_gt[m])
                 dm[S + m].add(o["unlab_probs"][m], ub_gt)
@@ -419,38 +520,33 @@ def main():
             if i % 10 == 0 or i == nm - 1:
                 [float(d.value()[0][0]) for d in dm[:S]]
         torch.cuda.synchronize()
-        meters_ms = 1e3 * (time.perf_counter() - tm) / nm
-    # Operand statistics of the timed network (MI355X_MICROARCH.md, DVFS give-back: zero / trivial operands clock higher):
-    # fraction of exactly-zero activations at every conv output of model 0 on the next batch.
-    operand_stats = None
-    if rank == 0 and cfg["arch"] == "unet":
+        return 1e3 * (time.perf_counter() - tm) / nm
+
+    def operand_leg():
+        # Operand statistics of the timed network (MI355X_MICROARCH.md, DVFS give-back: zero / trivial operands clock higher):
+        # fraction of exactly-zero activations at every conv output of model 0 on the next batch.
+        if cfg["arch"] != "unet":
+            return None
         net0 = tr.segmentators[0].torchnet
         keep_only, net0.pool_only = getattr(net0, "pool_only", False), False     # this pass wants every block's full-resolution output
         _, tape = net0.plan_forward(torch.cat((lab[0][0][0][0], unl[0][0][0]), dim=0), True)
         torch.cuda.synchronize()
         net0.pool_only = keep_only
         keys = ["a1", "d1", "a2", "d2", "a3", "d3", "a4", "d4", "c1", "c2", "e4a", "e4b", "e3a", "e3b", "e2a", "e2b", "e1a", "e1b"]
-        operand_stats = {"zero_fraction_of_bf16_activations": {k: round(float((tape[k] == 0).float().mean()), 4) for k in keys if k in tape},
-                         "note": "ReLU outputs (d4 / c2 include dropout p=0.5); ~0.5 is what a trained ReLU net carries"}
+        stats = {"zero_fraction_of_bf16_activations": {k: round(float((tape[k] == 0).float().mean()), 4) for k in keys if k in tape},
+                 "note": "ReLU outputs (d4 / c2 include dropout p=0.5); ~0.5 is what a trained ReLU net carries"}
         del tape
-    # Roofline leg: the SAME K steps once more with every launch bracketed by HIP events on its
-    # stream (kept out of the timed region above: ~1200 event records per step would cost the
-    # step ~25 % and `value` must be the unperturbed rate).
-    prof = None
-    use_events = not args.no_kernel_events and rank == 0
-    if use_events:
+        return stats
+
+    def enter_event_leg():
         set_side_streams(False)
         tr.use_hip_graph = False      # event records are host calls around each launch
         tr.model_streams = False      # per-kernel durations are taken with one kernel on the device at a time
-        _lib.prof_read(reset=True)
-        _lib.prof_enable(True)
-        for i in range(args.steps):
-            one_step(args.warmup + args.steps * max(1, args.repeats) + i)
-        torch.cuda.synchronize()
-        _lib.prof_enable(False)
-        prof = _lib.prof_read(reset=True)
-    if ddp_on:
-        dist.barrier()
+
+    m = measure(args, tr, one_step, HipLegs(device), rank, world, ddp_on, meters_leg=meters_leg,
+                operand_leg=operand_leg, enter_event_leg=enter_event_leg)
+    regions, elapsed, out = m["regions"], m["elapsed"], m["out"]
+    exchange, meters_ms, operand_stats, prof = m["exchange"], m["meters_ms"], m["operand_stats"], m["prof"]
     losses = dict(sup=[float(s) for s in out["sup"]], jsd=float(out["jsd"]))
     assert all(v == v for v in losses["sup"]) and losses["jsd"] == losses["jsd"], "NaN loss in the timed region"
 

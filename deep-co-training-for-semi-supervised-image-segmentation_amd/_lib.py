@@ -39,17 +39,6 @@ class EnetTf(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_void_p), ("mode", C.c_int32)]
 
 
-class EnetBnFin(C.Structure):
-    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float),
-                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("training", C.c_int32),
-                ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
-                ("save_var", C.c_void_p)]
-
-
-class EnetBnBwdFin(C.Structure):
-    _fields_ = [("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dslope", C.c_void_p), ("c1c2", C.c_void_p), ("training", C.c_int32)]
-
-
 class EnetBwdIn(C.Structure):
     _fields_ = [("g", C.POINTER(View)), ("g_mask", C.POINTER(View)), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("c1c2", C.c_void_p)]
 
@@ -147,8 +136,6 @@ SIGNATURES = {
     "dct_enet_bn_bwd": (_i, [_VP, _VP, _VP, _P, _P, _P, _i, _P, _P, _P, _P, _P, _P, _i, _VP, _i, _i, _P, _sz, _P]),
     "dct_enet_bn_bwd_rows": (_i, [_VP, _VP, _VP, _P, _P, _P, _i, _P, _P, _P, _P, _P, _P, _i, _VP, _i, _i, _P, _sz, _i, _P]),
     "dct_enet_conv_bnbwd_stats": (_i, [_VP, _P, _VP, _DP, _i, _i, _i, _i, _i, _i, _VP, _P, _P, _P, _i, _P, _P, _P, _i, _P, _P]),
-    "dct_enet_conv_stats_fin": (_i, [_VP, _P, _P, _TP, _VP, _DP, _i, _i, _i, _i, _i, _i, _P, _i, _P, _P, _P, _P]),
-    "dct_enet_conv_bnbwd_stats_fin": (_i, [_VP, _P, _VP, _DP, _i, _i, _i, _i, _i, _i, _VP, _P, _P, _P, _i, _P, _P, _P, _i, _P, _P, _P, _P]),
     "dct_enet_conv_bwd_in": (_i, [_VP, _P, _TP, _P, _VP, _DP, _i, _i, _i, _i, _VP, _VP, _i, _i, _VP, _P, _P, _P, _i, _P, _P, _P, _i, _P, _P]),
     "dct_enet_bn_bwd_sums": (_i, [_VP, _VP, _VP, _P, _P, _P, _i, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _sz, _i, _P]),
     "dct_enet_bn_bwd_apply": (_i, [_VP, _VP, _VP, _P, _P, _P, _i, _P, _P, _P, _VP, _i, _i, _i, _P]),

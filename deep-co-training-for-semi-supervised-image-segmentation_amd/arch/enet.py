@@ -365,15 +365,12 @@ class Enet(nn.Module):
                 self._bn_stats = _empty(5 * self._bn_total, dtype=torch.float32, device=dev)
             cp, base = (c + 3) // 4 * 4, 5 * self._bn_off[id(bn)]
             vec = self._bn_stats[base:base + 5 * cp].view(5, cp)[:, :c]
-            done = False
-            if fused:       # the BatchNorm's finalize rides in the convolution's last block where the library can (-> done)
-                rows, done = self._conv_fwd(src, src_tf, conv, raw, stats=stats,
-                                            fin=(self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, vec[0], vec[1], vec[2], vec[3], vec[4]))
+            if fused:       # the convolution's epilogue leaves the BatchNorm's partial sums where the library can (-> rows)
+                rows = self._conv_fwd(src, src_tf, conv, raw, stats=stats)
             else:
                 self._conv_fwd(src, src_tf, conv, raw)
-            if not done:
-                K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, None, None,
-                                    True, vec[0], vec[1], vec[2], vec[3], save_var=vec[4], partial=stats, partial_rows=rows)
+            K.enet_bn_fwd_stats(raw, self._w(bn.weight), self._w(bn.bias), bn.eps, bn.momentum, None, None,
+                                True, vec[0], vec[1], vec[2], vec[3], save_var=vec[4], partial=stats, partial_rows=rows)
         else:
             self._conv_fwd(src, src_tf, conv, raw)
             vec = _empty(4, c, dtype=torch.float32, device=dev)
@@ -388,7 +385,7 @@ class Enet(nn.Module):
         rec.mean, rec.invstd = vec[2], vec[3]
         return rec
 
-    def _conv_fwd(self, src, src_tf, conv, dst, stats=None, fin=None):
+    def _conv_fwd(self, src, src_tf, conv, dst, stats=None):
         """``stats`` (float64 scratch): the convolution's epilogue also writes the BatchNorm partial sums of ``dst`` where it can;
         -> number of partial rows (0: not written)."""
         w = self._w(conv.weight)
@@ -397,8 +394,8 @@ class Enet(nn.Module):
         if stats is not None:
             kw = dict(R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1], compute=self.compute_dtype)
             if conv.transposed:
-                return K.enet_conv_stats(src, w, b, src_tf, dst, stats, transposed=True, ws=(1, conv.cout, t * conv.cout), fin=fin, **kw)
-            return K.enet_conv_stats(src, w, b, src_tf, dst, stats, dil=conv.dil, ws=(t * conv.cin, conv.cin, 1), fin=fin, **kw)
+                return K.enet_conv_stats(src, w, b, src_tf, dst, stats, transposed=True, ws=(1, conv.cout, t * conv.cout), **kw)
+            return K.enet_conv_stats(src, w, b, src_tf, dst, stats, dil=conv.dil, ws=(t * conv.cin, conv.cin, 1), **kw)
         if conv.transposed:
             K.enet_conv(src, w, b, src_tf, dst, R=conv.kh, S=conv.kw, stride=conv.stride, pad_h=conv.pad[0], pad_w=conv.pad[1],
                         transposed=True, ws=(1, conv.cout, t * conv.cout), compute=self.compute_dtype)
@@ -412,7 +409,7 @@ class Enet(nn.Module):
 
         ``bn_of_dst`` (a _Rec): dst is the gradient wrt act(BN(rec.raw)); where the MFMA form runs (and fuse_bn_bwd_stats is on), its
         epilogue also writes that BatchNorm's backward partial sums -> (dst, (stats, scratch) | None, rows) for _bn_bwd (rows = 0: not
-        written, < 0: finalized as well)."""
+        written)."""
         w = self._w(conv.weight)
         t = conv.taps
         rg, rm = resid if resid is not None else (None, None)
@@ -442,12 +439,8 @@ class Enet(nn.Module):
                 return (dst, (stats, scratch) if stats is not None else None, rows) if bn_of_dst is not None else dst
         gt = self._tensor_of(g, leaf=False)
         if stats is not None:
-            # the BatchNorm-backward finalize (parameter gradients + the apply pass's two means) rides in the launch where it can
-            fin = (self._g(rec.bn.weight) if need_dw else None, self._g(rec.bn.bias) if need_dw else None,
-                   self._g(rec.act.weight) if (need_dw and isinstance(rec.act, _PReLU)) else None, scratch, self._tape_training)
-            kw2 = {k: v for k, v in kw.items()}
-            rows, done = K.enet_conv_bnbwd_stats(gt, w, dst, stats, rec.raw, rec.tf, rec.mean, rec.invstd, fin=fin, **kw2)
-            return dst, (stats, scratch), (-1 if (done and rows > 0) else rows)
+            rows = K.enet_conv_bnbwd_stats(gt, w, dst, stats, rec.raw, rec.tf, rec.mean, rec.invstd, **kw)
+            return dst, (stats, scratch), rows
         K.enet_conv(gt, w, None, None, dst, accumulate=accumulate, resid_grad=rg, resid_mask=rm, **kw)
         return (dst, None, 0) if bn_of_dst is not None else dst
 
@@ -553,7 +546,7 @@ class Enet(nn.Module):
         partial sums, already written by the data-gradient convolution that produced g (_conv_dgrad(bn_of_dst=rec))."""
         dev = rec.raw.device
         c = rec.raw.shape[3]
-        if partial is not None:          # (_conv_dgrad: the rows and the scratch its fused finalize may have filled already; rows < 0)
+        if partial is not None:          # (_conv_dgrad: the partial rows and the scratch for the two means)
             partial, scratch = partial
         else:
             scratch = _empty(2 * c, dtype=torch.float32, device=dev)

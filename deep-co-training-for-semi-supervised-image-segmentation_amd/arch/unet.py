@@ -45,6 +45,14 @@ class _Holder(nn.Module):
     pass
 
 
+class _ShapeOf:
+    """Stands in the tape for an activation that is no longer stored: the backward plan sizes its gradient by it."""
+    __slots__ = ("shape",)
+
+    def __init__(self, t: torch.Tensor):
+        self.shape = tuple(t.shape)
+
+
 class _ConvP(nn.Module):
     """Parameters of nn.Conv2d(cin, cout, k): logical [cout,cin,k,k], physical [cout][k][k][cin]."""
     transposed = False
@@ -406,6 +414,10 @@ class UNet(nn.Module):
             only = fuse and self.pool_only and (codes is not None or not save) and self._debug is None
             d = conv3(a, cb, new(h - 4, w - 4, width), pool_out=p if fuse else None, pool_codes=codes if fuse else None, pool_only=only)
             dd = dropout(d, 0) if lvl == 4 else d
+            if only:
+                # nobody reads the block's full-resolution output again (the backward pass routes by the codes and needs its SHAPE):
+                # the buffer goes back to the allocator now instead of riding in the tape until the backward pass (130 MB at level 1)
+                d = dd = _ShapeOf(d)
             h, w = hp, wp
             if not fuse:
                 K.maxpool_fwd(dd, p, codes=codes)

@@ -148,23 +148,6 @@ static inline Tf to_tf(const dct_enet_tf* t) {
 // instead of one thread walking all blocks.  Result valid for threads with part == 0.
 constexpr int FT = 1024;      // threads of the one-block finalize kernels: with 256 a 128-channel fold walked 128 partial rows per
                               // thread (11 us of dependent loads, 16 % of a cfg4 step's kernel time); 1024 threads walk 32
-// SC1: the rows were written by OTHER blocks of this same launch (the finalize rides in the producing kernel's last block, see
-// last_block_arrived): every load of them is an agent-scope (sc1) load, which bypasses this CU's L1.
-template <bool SC1> __device__ __forceinline__ double ld_partial(const double* p) {
-  if constexpr (SC1) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  } else {
-    return *p;
-  }
-}
-template <bool SC1> __device__ __forceinline__ void st_partial(double* p, double v) {
-  if constexpr (SC1) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    *p = v;
-  }
-}
-template <bool SC1>
 __device__ __forceinline__ void fold_partials(const double* partial, int blocks, int C, double* red, double s[3]) {
   int CP = 1;
   while (CP < C) CP <<= 1;
@@ -180,14 +163,14 @@ __device__ __forceinline__ void fold_partials(const double* partial, int blocks,
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const double* p = partial + ((long long)(b + u * NP) * C + c) * 3;
-        q[u][0] = ld_partial<SC1>(p); q[u][1] = ld_partial<SC1>(p + 1); q[u][2] = ld_partial<SC1>(p + 2);
+        q[u][0] = *(p); q[u][1] = *(p + 1); q[u][2] = *(p + 2);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) { a0 += q[u][0]; a1 += q[u][1]; a2 += q[u][2]; }
     }
     for (; b < blocks; b += NP) {
       const double* q = partial + ((long long)b * C + c) * 3;
-      a0 += ld_partial<SC1>(q); a1 += ld_partial<SC1>(q + 1); a2 += ld_partial<SC1>(q + 2);
+      a0 += *(q); a1 += *(q + 1); a2 += *(q + 2);
     }
   }
   if (threadIdx.x < NP * CP) { red[threadIdx.x * 3] = a0; red[threadIdx.x * 3 + 1] = a1; red[threadIdx.x * 3 + 2] = a2; }
@@ -205,9 +188,9 @@ struct FinP {
   float* scale; float* shift; float* save_mean; float* save_invstd; float* save_var;
 };
 // red: >= blockDim.x * 3 doubles of LDS
-template <bool SC1> __device__ __forceinline__ void bn_fin_body(const FinP& p, double* red) {
+__device__ __forceinline__ void bn_fin_body(const FinP& p, double* red) {
   double s[3];
-  fold_partials<SC1>(p.partial, p.training ? p.blocks : 0, p.C, red, s);
+  fold_partials(p.partial, p.training ? p.blocks : 0, p.C, red, s);
   const int c = threadIdx.x;
   int CP = 1;
   while (CP < p.C) CP <<= 1;
@@ -238,7 +221,7 @@ struct BnFinK {
   static constexpr int THREADS = FT;
   static __device__ __forceinline__ void run(const Args& p) {
     __shared__ double red[FT * 3];
-    bn_fin_body<false>(p, red);
+    bn_fin_body(p, red);
   }
 };
 
@@ -247,9 +230,9 @@ struct BFinP {
   const double* partial; int blocks, C; double count; int training;
   float* dgamma; float* dbeta; float* dslope; float* c1; float* c2;
 };
-template <bool SC1> __device__ __forceinline__ void bn_bwd_fin_body(const BFinP& p, double* red) {
+__device__ __forceinline__ void bn_bwd_fin_body(const BFinP& p, double* red) {
   double s[3];
-  fold_partials<SC1>(p.partial, p.blocks, p.C, red, s);
+  fold_partials(p.partial, p.blocks, p.C, red, s);
   const int c = threadIdx.x;
   int CP = 1;
   while (CP < p.C) CP <<= 1;
@@ -266,15 +249,15 @@ struct BnBwdFinK {
   static constexpr int THREADS = FT;
   static __device__ __forceinline__ void run(const Args& p) {
     __shared__ double red[FT * 3];
-    bn_bwd_fin_body<false>(p, red);
+    bn_bwd_fin_body(p, red);
   }
 };
 
 // plain per-channel sum finalize (bias gradient): out[c] += sum_b partial[b][c][0]
 struct SFinP { const double* partial; int blocks, C; float* out; };
-template <bool SC1> __device__ __forceinline__ void sum_fin_body(const SFinP& p, double* red) {
+__device__ __forceinline__ void sum_fin_body(const SFinP& p, double* red) {
   double s[3];
-  fold_partials<SC1>(p.partial, p.blocks, p.C, red, s);
+  fold_partials(p.partial, p.blocks, p.C, red, s);
   const int c = threadIdx.x;
   int CP = 1;
   while (CP < p.C) CP <<= 1;
@@ -286,52 +269,9 @@ struct SumFinK {
   static constexpr int THREADS = FT;
   static __device__ __forceinline__ void run(const Args& p) {
     __shared__ double red[FT * 3];
-    sum_fin_body<false>(p, red);
+    sum_fin_body(p, red);
   }
 };
-
-// A finalize riding in its producer: the block of a launch that arrives LAST (every other block has published its partial rows)
-// runs the fold + finalize in place of a one-block launch of its own -- one seam less per BatchNorm on the chain, and a chain of
-// these ~8 us launches is what an Enet step is made of.  Visibility follows MI355X_MICROARCH.md "inter-workgroup visibility",
-// first row of the hand-off table: every partial row is stored sc1 (st_partial<true>), every storing wave drains its stores
-// (s_waitcnt vmcnt(0)), a workgroup barrier, ONE lane adds to the launch's ticket (agent scope); the workgroup whose add returns
-// total - 1 is last, its other waves join behind a barrier, and every load of the rows is an sc1 load (fold_partials<true>).
-// The ticket resets itself, so a replayed graph finds it at zero.
-struct FinU {
-  int mode;                   // 0: none (the caller launches the finalize kernel), 1: BnFinK, 2: BnBwdFinK, 3: SumFinK
-  int* ticket;
-  union { FinP f; BFinP b; SFinP s; };
-};
-// The ticket is a two-level tree: block b adds to shard b % S (each shard on a 64-byte line of its own), the last arrival of a
-// shard adds to the root, the last arrival at the root is the launch's last block.  (One counter for a whole launch serialises
-// its 500-1200 agent-scope adds on one line: ~20 ns each, i.e. 10-25 us on every fused launch -- measured, cfg4 15.5 -> 18.5 ms.)
-constexpr int TICKET_SHARDS = 32;
-constexpr int TICKET_INTS = 16 * (TICKET_SHARDS + 1);
-__device__ __forceinline__ bool last_block_arrived(int* ticket, unsigned total, int* s_flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's sc1 partial stores have left
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int last = 0;
-    const unsigned S = total < (unsigned)TICKET_SHARDS ? total : (unsigned)TICKET_SHARDS, s = blockIdx.x % S;
-    const unsigned mine = (total - s + S - 1) / S;        // blocks that report to shard s
-    int* sub = ticket + 16 * (1 + s);
-    if (__hip_atomic_fetch_add(sub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)mine - 1) {
-      __hip_atomic_store(sub, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)S - 1) {
-        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = 1;
-      }
-    }
-    *s_flag = last;
-  }
-  __syncthreads();
-  return *s_flag != 0;
-}
-__device__ __forceinline__ void run_fused_finalize(const FinU& u, double* red) {
-  if (u.mode == 1) bn_fin_body<true>(u.f, red);
-  else if (u.mode == 2) bn_bwd_fin_body<true>(u.b, red);
-  else sum_fin_body<true>(u.s, red);
-}
 
 // BatchNorm backward, one element: draw = scale (dz - c1 - xhat c2), dz = g act'(z), z = scale raw + shift, xhat = (raw - mean) invstd.
 // ONE definition for the apply kernels and for the data-gradient convolution that applies it on load (ConvP::bwd_in): the two must
@@ -361,7 +301,6 @@ struct ConvP {
   // sums {sum dz, sum dz xhat, sum g z [z<0]} (enet_reduce kind 1) go to stats instead
   View braw; const float* bscale; const float* bshift; const float* bslope; const float* bmean; const float* binvstd; int bact; int bn_bwd;
   int ngroups;       // MFMA form: output-channel groups of 32 NT (blockIdx.x = pixel tile * ngroups + group)
-  FinU fin;          // MFMA form with stats: the consumer's finalize rides in the last block (mode != 0)
   // MFMA form, optional ("de-normalise on load"): the input IS the BatchNorm-backward result of a layer -- x = that layer's raw fp32
   // output, tf = its scale / shift / slope, ig = the gradient wrt its activation (im: ReLU mask of ig, optional) -- and a lane
   // computes draw = bn_bwd_draw(...) for its 8 channels where it would load them: the elementwise apply launch leaves the chain
@@ -762,8 +701,7 @@ __device__ __forceinline__ void mconv_store(const ConvP& p, const float* red, fl
             d2 += (double)srd[((w * NT + j) * 32 + r) * 3 + 2];
           }
           double* o = p.stats + (row * Cout + c) * 3;
-          if (p.fin.mode) { st_partial<true>(o, a); st_partial<true>(o + 1, b); st_partial<true>(o + 2, d2); }
-          else { o[0] = a; o[1] = b; o[2] = d2; }
+          o[0] = a; o[1] = b; o[2] = d2;
         }
       }
     }
@@ -776,7 +714,7 @@ template <typename T, int NT> struct MconvK {
   static __device__ __forceinline__ void run(const Args& p) {
     const int ngroups = p.ngroups;
   __shared__ __attribute__((aligned(16))) float tfs[7 * 128];      // scale, shift, slope [, mean, invstd, c1, c2: bwd_in]
-  __shared__ __attribute__((aligned(16))) float red[MC_W * NT * 16 * 64];      // >= 256 * 3 doubles: the fused finalize folds through it
+  __shared__ __attribute__((aligned(16))) float red[MC_W * NT * 16 * 64];
   __shared__ float srd[MC_W * NT * 32 * 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -821,10 +759,6 @@ template <typename T, int NT> struct MconvK {
   __syncthreads();
   if (p.fm & 2) mconv_store<T, NT, true>(p, red, srd, cbase, wbase, P, r, h, wave);
   else mconv_store<T, NT, false>(p, red, srd, cbase, wbase, P, r, h, wave);
-  if (p.fin.mode) {        // (block-uniform) the statistics' finalize, in the block that arrives last; `red` is free again
-    __shared__ int s_last;
-    if (last_block_arrived(p.fin.ticket, gridDim.x, &s_last)) run_fused_finalize(p.fin, reinterpret_cast<double*>(red));
-  }
 }
 };
 
@@ -838,7 +772,6 @@ struct RedP {
   int has_mask, kind, ppb;
   int fm;                        // f32 mask: bit0 x (raw), bit1 g, bit2 g mask, bit3 draw
   double* partial;               // reductions: [block][C][3] partial sums
-  FinU fin;                      // the finalize of these sums rides in the last block (mode != 0)
 };
 
 template <typename T>
@@ -890,12 +823,7 @@ template <typename T> struct ReduceK {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int r = 0; r < rows; ++r) { s0 += red[(r * CP + c) * 3]; s1 += red[(r * CP + c) * 3 + 1]; s2 += red[(r * CP + c) * 3 + 2]; }
     double* o = partial + ((long long)blockIdx.x * C + c) * 3;
-    if (p.fin.mode) { st_partial<true>(o, s0); st_partial<true>(o + 1, s1); st_partial<true>(o + 2, s2); }
-    else { o[0] = s0; o[1] = s1; o[2] = s2; }
-  }
-  if (p.fin.mode) {
-    __shared__ int s_last;
-    if (last_block_arrived(p.fin.ticket, gridDim.x, &s_last)) run_fused_finalize(p.fin, red);
+    o[0] = s0; o[1] = s1; o[2] = s2;
   }
 }
 };
@@ -971,12 +899,7 @@ template <typename T> struct ReduceVecK {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int r = 0; r < rows; ++r) { const double* q = redv + ((long long)r * C + c) * 3; s0 += q[0]; s1 += q[1]; s2 += q[2]; }
     double* o = partial + ((long long)blockIdx.x * C + c) * 3;
-    if (p.fin.mode) { st_partial<true>(o, s0); st_partial<true>(o + 1, s1); st_partial<true>(o + 2, s2); }
-    else { o[0] = s0; o[1] = s1; o[2] = s2; }
-  }
-  if (p.fin.mode) {        // redv ([rows][C][3] doubles = 48 KiB) is free again behind the barrier inside
-    __shared__ int s_last;
-    if (last_block_arrived(p.fin.ticket, gridDim.x, &s_last)) run_fused_finalize(p.fin, redv);
+    o[0] = s0; o[1] = s1; o[2] = s2;
   }
 }
 };
@@ -1409,33 +1332,6 @@ static inline int red_plan(long long P, int C, int& ppb) {
 
 }  // namespace
 
-// Tickets of the fused finalizes: zeroed device ints handed out round-robin; a launch's last block resets its ticket, so a
-// replayed graph (which keeps the address it was captured with) finds it at zero.  2^15 of them: two launches in flight
-// could only meet on one after 32768 fused launches in between (a cfg4 step has ~1600).
-int g_enet_fuse_finalize = 0;       // dct_tune_set(DCT_TUNE_ENET_FUSE_FINALIZE, 1): finalizes ride in their producers' last blocks.  OFF: measured
-                                    // SLOWER (cfg4 15.4 -> 17.9 ms, cfg5 36.3 -> 40.7): a third fewer launches on every chain, but each fused launch
-                                    // grows by ~8 us -- the sc1 stores' drain, the ticket round trips, and above all one block folding 0.2-0.5 MB of
-                                    // rows it must fetch from memory at the ~65 GB/s a single block gets.  An in-launch hand-off between blocks
-                                    // costs as much as the launch seam it replaces.
-static int* enet_next_ticket(hipStream_t st) {
-  static int* pool = nullptr;
-  static unsigned next = 0;
-  constexpr unsigned N = 1u << 15;           // tickets of TICKET_INTS ints each: 69 MB
-  if (!g_enet_fuse_finalize) return nullptr;
-  if (!pool) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-    int* p = nullptr;
-    const size_t bytes = (size_t)N * TICKET_INTS * sizeof(int);
-    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    pool = p;
-  }
-  return pool + (size_t)(next++ & (N - 1)) * TICKET_INTS;
-}
-
 #define ENET_T(dtype, ...) do { if ((dtype) == DCT_BF16) { using T = bf16_t; __VA_ARGS__; } else if ((dtype) == DCT_F16) { using T = f16_t; __VA_ARGS__; } \
                                else { using T = float; __VA_ARGS__; } } while (0)
 
@@ -1446,9 +1342,8 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
                           int f32_mask, int dtype, double* stats_partial, int stats_capacity_rows, int* stats_rows, dct_stream stream,
                           const dct_view* bn_raw = nullptr, const float* bn_scale = nullptr, const float* bn_shift = nullptr,
                           const float* bn_slope = nullptr, int bn_act = 0, const float* bn_mean = nullptr, const float* bn_invstd = nullptr,
-                          const FinU* fin = nullptr, int* finalized = nullptr, const dct_enet_bwd_in* bin = nullptr) {
+                          const dct_enet_bwd_in* bin = nullptr) {
   if (stats_rows) *stats_rows = 0;
-  if (finalized) *finalized = 0;
   if (!view_ok(x) || !view_ok(y) || !w || !d || !ok_dtype(dtype) || x->n != y->n) return DCT_ERR_BAD_ARG;
   if (d->R < 1 || d->S < 1 || d->stride < 1 || d->dil < 1) return DCT_ERR_BAD_ARG;
   if (y->c > 128 || x->c > 128) return DCT_ERR_UNSUPPORTED;
@@ -1459,7 +1354,7 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
   p.transposed = transposed ? 1 : 0; p.accumulate = d->accumulate ? 1 : 0;
   p.ws_out = ws_out; p.ws_tap = ws_tap; p.ws_in = ws_in;
   p.has_resid = 0; p.wvec = 0; p.stats = nullptr; p.bn_bwd = 0; p.bact = 0; p.braw = p.y;
-  p.fin.mode = 0; p.fin.ticket = nullptr; p.ngroups = 0;
+  p.ngroups = 0;
   p.bwd_in = 0; p.i_act = 0; p.i_has_mask = 0; p.ig = p.x; p.im = p.x;
   p.i_mean = p.i_invstd = p.i_c1 = p.i_c2 = nullptr;
   if (bin) {
@@ -1516,16 +1411,6 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
         }
       }
       if (ok) { p.stats = stats_partial; *stats_rows = (int)ptiles; }
-      if (ok && fin && finalized && fin->mode == (p.bn_bwd ? 2 : 1)) {
-        int* ticket = enet_next_ticket(st0);
-        if (ticket) {               // the consumer BatchNorm's finalize rides in this launch's last block
-          p.fin = *fin; p.fin.ticket = ticket;
-          const double count = (double)Pm;
-          if (p.fin.mode == 1) { p.fin.f.partial = stats_partial; p.fin.f.blocks = (int)ptiles; p.fin.f.C = y->c; p.fin.f.count = count; }
-          else { p.fin.b.partial = stats_partial; p.fin.b.blocks = (int)ptiles; p.fin.b.C = y->c; p.fin.b.count = count; }
-          *finalized = 1;
-        }
-      }
     }
     int nt = 1;
     if (ntiles >= 4 && ptiles >= 2048) nt = 4;
@@ -1578,37 +1463,6 @@ extern "C" int dct_enet_conv_stats(const dct_view* x, const float* w, const floa
                         stats_capacity_rows, stats_rows, stream);
 }
 
-extern "C" int dct_enet_conv_stats_fin(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
-                                       const dct_view* y, const dct_conv_desc* d, int transposed,
-                                       int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
-                                       double* stats_partial, int stats_capacity_rows, int* stats_rows,
-                                       const dct_enet_bn_fin* fin, int* finalized, dct_stream stream) {
-  if (!stats_partial || !stats_rows || stats_capacity_rows < 1 || !fin || !finalized) return DCT_ERR_BAD_ARG;
-  if (!fin->gamma || !fin->beta || !fin->scale || !fin->shift || !fin->training) return DCT_ERR_BAD_ARG;
-  FinU u;
-  u.mode = 1; u.ticket = nullptr;
-  u.f = FinP{nullptr, 0, 0, 0.0, fin->gamma, fin->beta, fin->eps, fin->momentum, fin->running_mean, fin->running_var, 1,
-             fin->scale, fin->shift, fin->save_mean, fin->save_invstd, fin->save_var};
-  return enet_conv_impl(x, w, bias, tf, y, d, transposed, ws_out, ws_tap, ws_in, nullptr, nullptr, f32_mask, dtype, stats_partial,
-                        stats_capacity_rows, stats_rows, stream, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, &u, finalized);
-}
-
-extern "C" int dct_enet_conv_bnbwd_stats_fin(const dct_view* x, const float* w, const dct_view* y, const dct_conv_desc* d, int transposed,
-                                             int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
-                                             const dct_view* bn_raw, const float* bn_scale, const float* bn_shift, const float* bn_slope,
-                                             int bn_act, const float* bn_mean, const float* bn_invstd,
-                                             double* stats_partial, int stats_capacity_rows, int* stats_rows,
-                                             const dct_enet_bn_bwd_fin* fin, int* finalized, dct_stream stream) {
-  if (!stats_partial || !stats_rows || stats_capacity_rows < 1 || !bn_raw || !fin || !finalized || !fin->c1c2) return DCT_ERR_BAD_ARG;
-  FinU u;
-  u.mode = 2; u.ticket = nullptr;
-  u.b = BFinP{nullptr, 0, 0, 0.0, fin->training ? 1 : 0, fin->dgamma, fin->dbeta, bn_act == 2 ? fin->dslope : nullptr, fin->c1c2,
-              fin->c1c2 + y->c};
-  return enet_conv_impl(x, w, nullptr, nullptr, y, d, transposed, ws_out, ws_tap, ws_in, nullptr, nullptr, f32_mask, dtype, stats_partial,
-                        stats_capacity_rows, stats_rows, stream, bn_raw, bn_scale, bn_shift, bn_slope, bn_act, bn_mean, bn_invstd, &u,
-                        finalized);
-}
-
 extern "C" int dct_enet_conv_bwd_in(const dct_view* raw, const float* w, const dct_enet_tf* tf, const dct_enet_bwd_in* bin,
                                     const dct_view* y, const dct_conv_desc* d, int transposed, int ws_out, int ws_tap, int ws_in,
                                     const dct_view* resid_grad, const dct_view* resid_mask, int f32_mask, int dtype,
@@ -1619,7 +1473,7 @@ extern "C" int dct_enet_conv_bwd_in(const dct_view* raw, const float* w, const d
   if (bn_raw && (!stats_partial || !stats_rows || stats_capacity_rows < 1)) return DCT_ERR_BAD_ARG;
   return enet_conv_impl(raw, w, nullptr, tf, y, d, transposed, ws_out, ws_tap, ws_in, resid_grad, resid_mask, f32_mask, dtype,
                         bn_raw ? stats_partial : nullptr, bn_raw ? stats_capacity_rows : 0, bn_raw ? stats_rows : nullptr, stream,
-                        bn_raw, bn_scale, bn_shift, bn_slope, bn_act, bn_mean, bn_invstd, nullptr, nullptr, bin);
+                        bn_raw, bn_scale, bn_shift, bn_slope, bn_act, bn_mean, bn_invstd, bin);
 }
 
 extern "C" size_t dct_enet_reduce_workspace_bytes(int channels) {
@@ -1627,28 +1481,13 @@ extern "C" size_t dct_enet_reduce_workspace_bytes(int channels) {
 }
 
 
-// fin (nullable; mode + everything but partial / blocks / C / count filled in): the finalize of these sums rides in the launch's last
-// block where a ticket can be had -> *fused = true; otherwise the caller launches the finalize kernel as before
-static int enet_reduce_launch(const RedP& p0, int dtype, void* workspace, size_t workspace_bytes, hipStream_t st, int& blocks_out,
-                              const FinU* fin = nullptr, double count = 0.0, bool* fused = nullptr) {
+static int enet_reduce_launch(const RedP& p0, int dtype, void* workspace, size_t workspace_bytes, hipStream_t st, int& blocks_out) {
   RedP p = p0;
-  p.fin.mode = 0; p.fin.ticket = nullptr;
-  if (fused) *fused = false;
   const long long P = (long long)p.x.n * p.x.h * p.x.w;
   int ppb;
   const int blocks = red_plan(P, p.x.c, ppb);
   if (!workspace || workspace_bytes < (size_t)blocks * p.x.c * 3 * sizeof(double)) return DCT_ERR_WORKSPACE;
   p.ppb = ppb;
-  if (fin && fused) {
-    int* ticket = enet_next_ticket(st);
-    if (ticket) {
-      p.fin = *fin; p.fin.ticket = ticket;
-      if (p.fin.mode == 1) { p.fin.f.partial = (const double*)workspace; p.fin.f.blocks = blocks; p.fin.f.C = p.x.c; p.fin.f.count = count; }
-      else if (p.fin.mode == 2) { p.fin.b.partial = (const double*)workspace; p.fin.b.blocks = blocks; p.fin.b.C = p.x.c; p.fin.b.count = count; }
-      else { p.fin.s.partial = (const double*)workspace; p.fin.s.blocks = blocks; p.fin.s.C = p.x.c; }
-      *fused = true;
-    }
-  }
   // 8-channel vector path: every view it reads has 8-aligned strides and a 16-byte (T) / 32-byte (fp32) aligned base
   auto v8 = [&](const View& v, int f32) {
     const int esz = (f32 || dtype == DCT_F32) ? 4 : 2;
@@ -1693,13 +1532,8 @@ extern "C" int dct_enet_bn_fwd_stats_rows(const dct_view* raw, const float* gamm
     RedP p; p.x = to_view(raw); p.g = p.x; p.m = p.x;
     p.scale = p.shift = p.slope = p.mean = p.invstd = nullptr;
     p.act = 0; p.has_mask = 0; p.kind = 0; p.ppb = 0; p.fm = f32_mask & 1; p.partial = nullptr;
-    FinU u;
-    u.mode = 1; u.ticket = nullptr;
-    u.f = FinP{nullptr, 0, 0, 0.0, gamma, beta, eps, momentum, running_mean, running_var, 1, scale, shift, save_mean, save_invstd, save_var};
-    bool fused = false;
-    const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks, &u, (double)raw->n * raw->h * raw->w, &fused);
+    const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
     if (rc != DCT_OK) return rc;
-    if (fused) return dct_check_launch();
   }
   const double count = (double)raw->n * raw->h * raw->w;
   const FinP fp = {(const double*)workspace, blocks, raw->c, count, gamma, beta, eps, momentum, running_mean, running_var, training ? 1 : 0,
@@ -1737,16 +1571,13 @@ static int enet_bn_bwd_impl(const dct_view* raw, const dct_view* g, const dct_vi
   p.act = act; p.kind = 1; p.ppb = 0; p.fm = f32_mask; p.partial = nullptr;
   hipStream_t st = (hipStream_t)stream;
   int blocks = 0;
-  bool finalized = partial_rows < 0;    // < 0: dct_enet_conv_bnbwd_stats_fin has finalized already (c1c2 and the parameter gradients are set)
+  const bool finalized = partial_rows < 0;    // (apply only: c1c2 and the parameter gradients are set)
   const double count = (double)raw->n * raw->h * raw->w;
   if (partial_rows > 0) {         // the data-gradient convolution that produced g wrote the partial rows (dct_enet_conv_bnbwd_stats)
     if (!workspace || workspace_bytes < (size_t)partial_rows * raw->c * 3 * sizeof(double)) return DCT_ERR_WORKSPACE;
     blocks = partial_rows;
   } else if (!finalized) {
-    FinU u;
-    u.mode = 2; u.ticket = nullptr;
-    u.b = BFinP{nullptr, 0, 0, 0.0, training ? 1 : 0, dgamma, dbeta, act == 2 ? dslope : nullptr, c1c2, c1c2 + raw->c};
-    const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks, &u, count, &finalized);
+    const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
     if (rc != DCT_OK) return rc;
   }
   const long long total = (long long)raw->n * raw->h * raw->w * raw->c;
@@ -1776,7 +1607,7 @@ extern "C" int dct_enet_bn_bwd_sums(const dct_view* raw, const dct_view* g, cons
                                     const float* mean, const float* invstd,
                                     float* dgamma, float* dbeta, float* dslope, float* c1c2, int training,
                                     int f32_mask, int dtype, void* workspace, size_t workspace_bytes, int partial_rows, dct_stream stream) {
-  if (partial_rows < 0) return DCT_OK;        // (finalized by the producing convolution already)
+  if (partial_rows < 0) return DCT_ERR_BAD_ARG;
   return enet_bn_bwd_impl(raw, g, g_mask, scale, shift, slope, act, mean, invstd, dgamma, dbeta, dslope, c1c2, training, nullptr, f32_mask,
                           dtype, workspace, workspace_bytes, partial_rows, stream, true, false);
 }
@@ -1802,13 +1633,8 @@ extern "C" int dct_enet_channel_sum(const dct_view* x, float* out, int f32_mask,
   p.act = 0; p.has_mask = 0; p.kind = 0; p.ppb = 0; p.fm = f32_mask & 1; p.partial = nullptr;
   hipStream_t st = (hipStream_t)stream;
   int blocks = 0;
-  FinU u;
-  u.mode = 3; u.ticket = nullptr;
-  u.s = SFinP{nullptr, 0, 0, out};
-  bool fused = false;
-  const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks, &u, 0.0, &fused);
+  const int rc = enet_reduce_launch(p, dtype, workspace, workspace_bytes, st, blocks);
   if (rc != DCT_OK) return rc;
-  if (fused) return dct_check_launch();
   const SFinP sp = {(const double*)workspace, blocks, x->c, out};
   enet_launch<SumFinK>(DCT_PROF_OTHER, dim3(1), dim3(g_enet_fold_threads), 0, st, sp);
   return dct_check_launch();

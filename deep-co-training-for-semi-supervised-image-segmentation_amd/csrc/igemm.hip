@@ -1342,10 +1342,6 @@ static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
 
 void dct_split_dw_db_launch(const float* partial, float* scratch, float* dw, float* db, int cout, int inner, int blocks, int accumulate, hipStream_t st);   // reduce.hip
 size_t dct_split_dw_db_scratch(int cout, int inner);
-// igemm4.hip
-size_t dct_igemm4_workspace(int images, int Ho, int Wo, int Cin, int N);
-int dct_igemm4_launch(const void* params, int images, void* workspace, size_t workspace_bytes, hipStream_t st);
-extern int g_tune_igemm4, g_tune_igemm4_min_blocks, g_tune_igemm4_ablate, g_tune_igemm4_blocks;
 
 void dct_relu_bits_launch(const void* y_bf16, unsigned char* bits, long long chunks, hipStream_t st) {
   DCT_LAUNCH(DCT_PROF_POINTWISE, relu_bits_kernel, dim3(div_up(chunks, 256)), dim3(256), 0, st, (const bf16_t*)y_bf16, bits, chunks);
@@ -1361,8 +1357,6 @@ extern "C" size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* 
   size_t need = pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
   const PlanP pp = make_plan_p(x, y, d, dtype, N);
   if (pp.use && pp.splits > 1) need = std::max(need, (size_t)pp.splits * M * N * sizeof(float));
-  if (dtype == DCT_BF16 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dil == 1 && !d->scatter2x2)
-    need = std::max(need, dct_igemm4_workspace(y->n, Ho, Wo, x->c, N));
   if (d->stem_x) need = std::max(need, (size_t)y->n * ((Ho + 7) / 8) * ((Wo + 15) / 16) * 640 * sizeof(float) + dct_split_dw_db_scratch(64, 9));
   return need;
 }
@@ -1435,7 +1429,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   if (d->pool_only && (!d->pool_out || d->relu_bits_out)) return DCT_ERR_BAD_ARG;
   if (d->pool_codes && !d->pool_out) return DCT_ERR_BAD_ARG;
   if (d->pool_out) {
-    if (p.scatter || d->accumulate || ((uintptr_t)d->pool_out & 15) || ((uintptr_t)d->pool_codes & 7) || y->c % 8) return DCT_ERR_BAD_ARG;
+    if (p.scatter || d->accumulate || mask || d->mask_bits || ((uintptr_t)d->pool_out & 15) || ((uintptr_t)d->pool_codes & 7) || y->c % 8) return DCT_ERR_BAD_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
   const auto pool_after = [&]() -> int {   // the launch just issued did not pool its tile: the pooling kernel behind it
@@ -1454,7 +1448,6 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   p.cin_iters = x->c / pl.bk;
   p.partial = nullptr;
   p.staged = 0;
-  p.stamps = nullptr;
   p.x_bytes = ((long long)(x->n - 1) * x->sn + (long long)(x->h - 1) * x->sh + (long long)(x->w - 1) * x->sw + x->c) * esz;
   p.w_bytes = (long long)p.N * d->R * d->S * x->c * esz;
   if (pl.v2 && pl.splits == 1 && !d->accumulate) {
@@ -1469,32 +1462,6 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     const size_t need = (size_t)pl.splits * p.M * p.N * sizeof(float);
     if (!workspace || workspace_bytes < need) return DCT_ERR_WORKSPACE;
     p.partial = (float*)workspace;
-  }
-  if (pl.v2 && g_tune_igemm_halo && (!bias || !((uintptr_t)bias & 15)) && d->R == 3 && d->S == 3 && d->stride == 1 &&
-      d->dil == 1 && !p.scatter && !d->stem_x) {
-    // one-block-per-CU ping-pong tile (igemm4.hip): 256 pixels x 128 channels, eight waves of 64 x 64
-    const bool y16 = !((uintptr_t)y->ptr & 15) && y->sw % 8 == 0 && y->sh % 8 == 0 && y->sn % 8 == 0 && y->c % 8 == 0 &&
-                     (long long)y->n * y->sn < (1ll << 31);
-    const bool m16 = !mask || (!((uintptr_t)mask->ptr & 15) && mask->sw % 8 == 0 && mask->sh % 8 == 0 && mask->sn % 8 == 0 &&
-                               p.mask_channels % 8 == 0 && (long long)mask->n * mask->sn < (1ll << 31));
-    const bool x32 = (long long)x->n * x->sn < (1ll << 31) && 128ll * 9 * x->c * 2 < (1ll << 32);
-    if (y16 && m16 && x32) {
-      IgemmParams q = p;
-      q.partial = nullptr;
-      const int took = dct_igemm4_launch(&q, y->n, workspace, workspace_bytes, st);
-      if (took) DCT_PLAN_NOTE("igemm4 (one block per CU, 256 px x 128 ch)%s", took == 2 ? " split" : "");
-      if (took == 1) { const int rp = pool_after(); return rp != DCT_OK ? rp : dct_check_launch(); }
-      if (took == 2) {
-        q.partial = (float*)workspace;
-        const long long work = (long long)p.M * (p.N / 4);
-        const size_t per = (size_t)p.M * p.N * sizeof(float);
-        DCT_LAUNCH(DCT_PROF_IGEMM, (splitk_epilogue_kernel<bf16_t>), dim3(div_up(work, 256)), dim3(256), 0, st, q,
-                   (int)(dct_igemm4_workspace(y->n, p.Ho, p.Wo, p.Cin, p.N) / per));
-        bits_after();
-        const int rp = pool_after();
-        return rp != DCT_OK ? rp : dct_check_launch();
-      }
-    }
   }
   if (pl.v2 && pl.splits == 1 && g_tune_igemm_halo && (!bias || !((uintptr_t)bias & 15)) && d->R == 3 && d->S == 3 && d->stride == 1 &&
       d->dil == 1 && !p.scatter) {
@@ -1564,7 +1531,7 @@ int dct_tune_set_wgrad(int knob, int value);  // wgrad.hip
 extern int g_enet_wgrad_max_blocks;           // enet.hip
 extern int g_enet_mfma;                       // enet.hip
 extern int g_stem_dgrad_mfma;                 // pointwise.hip
-extern int g_enet_mwgrad_waves, g_enet_fuse_finalize;
+extern int g_enet_mwgrad_waves;
 
 extern "C" int dct_tune_set(int knob, int value) {
   switch (knob) {
@@ -1578,15 +1545,10 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_ENET_MFMA: if (value < 0 || value > 3) return DCT_ERR_BAD_ARG; g_enet_mfma = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_SPLIT: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
-    case DCT_TUNE_ENET_FUSE_FINALIZE: g_enet_fuse_finalize = value ? 1 : 0; return DCT_OK;
-    case DCT_TUNE_IGEMM4: g_tune_igemm4 = value ? 1 : 0; return DCT_OK;
-    case DCT_TUNE_IGEMM4_MIN_BLOCKS: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm4_min_blocks = value; return DCT_OK;
-    case 1000: g_tune_igemm4_ablate = value; return DCT_OK;      // diagnostic builds only
     case 1005: g_tune_igemm_pool = value ? 1 : 0; return DCT_OK;
     case 1008: g_stem_dgrad_mfma = value ? 1 : 0; return DCT_OK;
     case 1002: g_tune_igemm_split_max_tiles = value; return DCT_OK;     // planner studies (tools/bench_conv.py --ab-knob)
     case 1003: g_tune_igemm_split_min_kiters = value; return DCT_OK;
-    case 1001: if (value < 0) return DCT_ERR_BAD_ARG; g_tune_igemm4_blocks = value; return DCT_OK;      // diagnostic: persistent blocks per launch
     case DCT_TUNE_ENET_WGRAD_BLOCKS: if (value < 1 || value > 1024) return DCT_ERR_BAD_ARG; g_enet_wgrad_max_blocks = value; return DCT_OK;
     default: return dct_tune_set_wgrad(knob, value);
   }

@@ -1,5 +1,5 @@
-// Pieces shared by the implicit-GEMM convolution kernels (igemm.hip: per-tap / shared-halo / packed-rows tiles; igemm4.hip: the
-// one-block-per-CU ping-pong tile): the kernel parameter block, the LDS-staged row epilogue, and the inline-asm LDS read helpers.
+// Pieces of the implicit-GEMM convolution kernels (igemm.hip: per-tap / shared-halo / packed-rows tiles): the kernel parameter
+// block, the LDS-staged row epilogue, and the inline-asm LDS read helpers.
 #pragma once
 #include "dct_common.h"
 
@@ -21,7 +21,6 @@ struct IgemmParams {
   int kiters, kiters_per_split, cin_iters;
   int cout;  // real Cout (N/4 in scatter mode)
   int staged;  // v2: LDS-staged epilogue with 16-byte row stores (host-checked alignment / 32-bit offsets)
-  unsigned long long* stamps;   // igemm4 diagnostic builds: per-wave cycle sums
   long long x_bytes, w_bytes;   // lean loops: bytes from x / w to the end of the view / packed weights (buffer descriptor ranges)
   char* pool_y;                 // optional (shared-halo kernel): dense [n][Hp][Wp][cout] 2x2 ceil-mode max pooling of y, from the staged tile
   unsigned char* pool_codes;    // ... and its routing codes (dct_maxpool2x2_fwd_codes), nullable

@@ -281,7 +281,14 @@ class FlatGradSync(object):
         if self._fused_ready and (model_index is None or model_index in self._fused_ready):
             # not every small model produced gradients this step: exchange the ready ones one by one (same result, more launches)
             ready, self._fused_ready = self._fused_ready, []
-            self._fused_events = {}          # (each per-model collective below is launched on the calling stream, as begin() would)
+            events, self._fused_events = self._fused_events, {}
+            # every ready model's collective is launched HERE, on the calling stream, while model i's backward pass ran on the
+            # stream begin(i) was called on: the calling stream waits for each of those passes first (the event begin(i) recorded)
+            if self._arena is not None and self._arena.is_cuda:
+                cur = torch.cuda.current_stream(self._arena.device)
+                for i in ready:
+                    if i in events:
+                        cur.wait_event(events[i])
             for i in ready:
                 flat = self.segmentators[i].torchnet.flat_params
                 self._pending.append(self._start(i, flat, 0, flat.gflat.numel()))

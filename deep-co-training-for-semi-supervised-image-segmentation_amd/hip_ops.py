@@ -177,7 +177,7 @@ def conv2d(x, w_packed, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0,
         want = (y.shape[0], (y.shape[1] + 1) // 2, (y.shape[2] + 1) // 2, y.shape[3])
         assert tuple(pool_out.shape) == want and pool_out.is_contiguous() and pool_out.dtype == y.dtype, "pool_out: dense ceil-mode half of y"
         assert pool_codes is None or (pool_codes.dtype == torch.uint8 and pool_codes.is_contiguous() and tuple(pool_codes.shape) == want)
-        assert not accumulate and not scatter2x2
+        assert not accumulate and not scatter2x2 and mask is None and mask_bits is None, "pool_out is a forward-pass feature"
     else:
         assert pool_codes is None and not pool_only
     d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu, scatter2x2, accumulate, mask_channels, mask_scale,
@@ -349,7 +349,17 @@ def maxpool_bwd(x, dy, dx, relu_mask=False, scale=1.0, codes=None, skip=None):
     if codes is not None and skip is not None:
         assert codes.dtype == torch.uint8 and codes.is_contiguous() and tuple(codes.shape) == tuple(dy.shape)
         vs = view(skip)
-        call("dct_maxpool2x2_bwd_codes_skip", ptr(codes), C.byref(vdy), C.byref(vs), C.byref(vdx), int(relu_mask), float(scale), _dt(dy), stream())
+        rc = _lib.load().dct_maxpool2x2_bwd_codes_skip(ptr(codes), C.byref(vdy), C.byref(vs), C.byref(vdx), int(relu_mask), float(scale),
+                                                       _dt(dy), stream())
+        if rc == _lib.ERR_UNSUPPORTED:
+            # views the 16-byte kernel cannot take (channel counts / slice offsets off the vector width): the sum formed in memory,
+            # as before the fusion -- bilinear backward (which has a scalar form) into a buffer, + dy, then the plain un-pooling
+            total = bilinear_bwd(skip, torch.empty_like(dy))
+            total += dy
+            vt = view(total)
+            call("dct_maxpool2x2_bwd_codes", ptr(codes), C.byref(vt), C.byref(vdx), int(relu_mask), float(scale), _dt(dy), stream())
+            return dx
+        _lib.check(rc, "dct_maxpool2x2_bwd_codes_skip")
         return dx
     assert skip is None
     if codes is not None:
@@ -618,12 +628,10 @@ def enet_conv(x, w, bias, tf, y, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, tra
     return y
 
 
-def enet_conv_stats(x, w, bias, tf, y, stats, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, transposed=False, ws=(0, 0, 0), compute=None,
-                    fin=None):
+def enet_conv_stats(x, w, bias, tf, y, stats, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0, transposed=False, ws=(0, 0, 0), compute=None):
     """enet_conv with the consumer BatchNorm's partial sums written by the convolution's epilogue into ``stats`` (float64,
     >= tiles * C * 3 elements, tiles = ceil(pixels / 32)).  -> number of partial rows written, 0 when the call did not take the
-    MFMA form (the statistics then need the usual reduction).  With ``fin`` -> (rows, finalized): finalized = the launch's last
-    block has also run the BatchNorm's finalize (no `enet_bn_fwd_stats` call needed)."""
+    MFMA form (the statistics then need the usual reduction)."""
     d = conv_desc(R, S, stride, dil, pad_h, pad_w)
     vx, vy = view(x), view(y)
     keep, tfp = _tfp(tf)
@@ -632,15 +640,6 @@ def enet_conv_stats(x, w, bias, tf, y, stats, *, R, S, stride=1, dil=1, pad_h=0,
         dt = DTYPE_OF[compute]
     rows = C.c_int(0)
     cap = stats.numel() // (3 * y.shape[3])
-    if fin is not None:
-        # fin = (gamma, beta, eps, momentum, scale, shift, mean, invstd, save_var): the BatchNorm's finalize rides in the launch
-        gamma, beta, eps, momentum, scale, shift, mean, invstd, save_var = fin
-        f = _lib.EnetBnFin(ptr(gamma), ptr(beta), float(eps), float(momentum), None, None, 1, ptr(scale), ptr(shift), ptr(mean),
-                           ptr(invstd), ptr(save_var))
-        done = C.c_int(0)
-        call("dct_enet_conv_stats_fin", C.byref(vx), ptr(w), ptr(bias), tfp, C.byref(vy), C.byref(d), int(transposed),
-             int(ws[0]), int(ws[1]), int(ws[2]), fm, dt, ptr(stats), int(cap), C.byref(rows), C.byref(f), C.byref(done), stream())
-        return int(rows.value), bool(done.value)
     call("dct_enet_conv_stats", C.byref(vx), ptr(w), ptr(bias), tfp, C.byref(vy), C.byref(d), int(transposed),
          int(ws[0]), int(ws[1]), int(ws[2]), fm, dt, ptr(stats), int(cap), C.byref(rows), stream())
     return int(rows.value)
@@ -662,7 +661,7 @@ def enet_bn_fwd_stats(raw, gamma, beta, eps, momentum, running_mean, running_var
 
 
 def enet_conv_bnbwd_stats(x, w, y, stats, rec_raw, rec_tf, rec_mean, rec_invstd, *, R, S, stride=1, dil=1, pad_h=0, pad_w=0,
-                          transposed=False, ws=(0, 0, 0), compute=None, fin=None):
+                          transposed=False, ws=(0, 0, 0), compute=None):
     """Data-gradient convolution y = dgrad(x) (enet_conv without bias / transform / residual) whose epilogue also writes the
     BatchNorm-backward partial sums of the layer that produced y's tensor (raw output ``rec_raw``, consumer transform ``rec_tf``,
     saved statistics) into ``stats`` (float64, >= tiles * C * 3).  -> partial rows written (0: the usual reduction is needed)."""
@@ -674,15 +673,6 @@ def enet_conv_bnbwd_stats(x, w, y, stats, rec_raw, rec_tf, rec_mean, rec_invstd,
     act = rec_tf.mode if rec_tf.mode in (2, 3) else 0
     rows = C.c_int(0)
     cap = stats.numel() // (3 * y.shape[3])
-    if fin is not None:
-        # fin = (dgamma, dbeta, dslope, c1c2, training): the BatchNorm-backward finalize rides in the launch -> (rows, finalized)
-        dgamma, dbeta, dslope, c1c2, training = fin
-        f = _lib.EnetBnBwdFin(ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(c1c2), int(training))
-        done = C.c_int(0)
-        call("dct_enet_conv_bnbwd_stats_fin", C.byref(vx), ptr(w), C.byref(vy), C.byref(d), int(transposed), int(ws[0]), int(ws[1]),
-             int(ws[2]), fm, dt, C.byref(vr), ptr(rec_tf.scale), ptr(rec_tf.shift), ptr(rec_tf.slope), int(act), ptr(rec_mean),
-             ptr(rec_invstd), ptr(stats), int(cap), C.byref(rows), C.byref(f), C.byref(done), stream())
-        return int(rows.value), bool(done.value)
     call("dct_enet_conv_bnbwd_stats", C.byref(vx), ptr(w), C.byref(vy), C.byref(d), int(transposed), int(ws[0]), int(ws[1]), int(ws[2]),
          fm, dt, C.byref(vr), ptr(rec_tf.scale), ptr(rec_tf.shift), ptr(rec_tf.slope), int(act), ptr(rec_mean), ptr(rec_invstd),
          ptr(stats), int(cap), C.byref(rows), stream())
@@ -694,7 +684,7 @@ def enet_bn_bwd(raw, g, g_mask, tf, mean, invstd, dgamma, dbeta, dslope, c1c2, d
     vm = view(g_mask) if g_mask is not None else None
     act = tf.mode if tf.mode in (2, 3) else 0
     dt, fm = _mixed(raw, g, g_mask, draw)
-    if partial is not None and partial_rows != 0:         # rows written by enet_conv_bnbwd_stats: fold + apply only (< 0: apply only)
+    if partial is not None and partial_rows != 0:         # rows written by enet_conv_bnbwd_stats: fold + apply only
         call("dct_enet_bn_bwd_rows", C.byref(vr), C.byref(vg), None,
              ptr(tf.scale), ptr(tf.shift), ptr(tf.slope), int(act), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(dslope),
              ptr(c1c2), int(training), C.byref(vd), fm, dt, ptr(partial), partial.numel() * partial.element_size(), int(partial_rows),
@@ -708,10 +698,7 @@ def enet_bn_bwd(raw, g, g_mask, tf, mean, invstd, dgamma, dbeta, dslope, c1c2, d
 
 
 def enet_bn_bwd_sums(raw, g, g_mask, tf, mean, invstd, dgamma, dbeta, dslope, c1c2, training=True, partial=None, partial_rows=0):
-    """The sums half of `enet_bn_bwd`: parameter gradients (+=) and the apply pass's two means (c1c2).  partial_rows < 0: the
-    producing convolution has finalized already -- nothing to launch."""
-    if partial_rows < 0:
-        return
+    """The sums half of `enet_bn_bwd`: parameter gradients (+=) and the apply pass's two means (c1c2)."""
     vr, vg = view(raw), view(g)
     vm = view(g_mask) if g_mask is not None else None
     act = tf.mode if tf.mode in (2, 3) else 0

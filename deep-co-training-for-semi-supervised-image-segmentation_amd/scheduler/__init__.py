@@ -67,7 +67,8 @@ class ConstantScheduler(_EpochScheduler):
 
 
 class RampDownScheduler(_EpochScheduler):
-    """``max_value`` at epoch 0, ``min_val`` from ``cutoff`` on, max * (1 - ramp) + min in between (:96-116)."""
+    """``max_value`` at epoch 0, ``min_val`` from ``cutoff`` on, max - max * ramp + min in between (:96-116; the reference's order of
+    operations, so that the values agree to the last bit for any ``max_value``)."""
 
     def __init__(self, max_epoch, max_value, ramp_mult, min_val, cutoff):
         super().__init__()
@@ -86,4 +87,4 @@ class RampDownScheduler(_EpochScheduler):
             return max_val
         if epoch >= cutoff:
             return min_val
-        return max_val * (1.0 - _gaussian_ramp(epoch / cutoff, mult)) + min_val
+        return max_val - max_val * _gaussian_ramp(epoch / cutoff, mult) + min_val

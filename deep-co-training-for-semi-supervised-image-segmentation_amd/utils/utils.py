@@ -109,16 +109,25 @@ _EXHAUSTED = object()
 
 # ---- nested dictionaries --------------------------------------------------------------------------
 def _coerce_like(old: Any, new: Any) -> Any:
-    """``new`` in the type ``old`` has; strings (command-line overrides) are read as Python literals first"""
-    if isinstance(new, str) and not isinstance(old, str):
+    """``new`` in the type ``old`` has, as the reference's leaf rule does it (utils/utils.py:345-349): bool / list defaults read a
+    string override as a Python literal first (here without `eval`), every other type is the plain constructor call on the value
+    AS GIVEN -- so 'max_epoch=0.5' against an int default stays the string '0.5' (int('0.5') raises) instead of silently
+    becoming 0 -- and whatever fails to convert is kept as given.  One deliberate difference: 'true' / 'false' in any case are
+    read as the booleans (the reference keeps the string 'false', which is truthy)."""
+    kind = type(old)
+    if kind in (bool, list):
+        if not isinstance(new, str):
+            return new                                   # (the reference's eval() of a non-string raises: kept as given)
+        if kind is bool and new.strip().lower() in ("true", "false"):
+            return new.strip().lower() == "true"
         try:
-            new = ast.literal_eval(new)
-        except (ValueError, SyntaxError):
-            pass
-    if old is None or isinstance(new, type(old)):
+            return kind(ast.literal_eval(new))
+        except (ValueError, SyntaxError, TypeError):
+            return new
+    if old is None:
         return new
     try:
-        return type(old)(new)
+        return kind(new)
     except (TypeError, ValueError):
         return new
 

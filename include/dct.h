@@ -88,9 +88,10 @@ typedef struct dct_conv_desc {
   /* 2x2 / stride 2 / ceil-mode max pooling of y in the same call (nn.MaxPool2d behind the conv + ReLU of a UNet encoder block,
    * arch/network.py:120-130): pool_out (nullable) is a DENSE NHWC tensor [n][(h+1)/2][(w+1)/2][c] of y's type; pool_codes
    * (nullable) the routing codes of dct_maxpool2x2_fwd_codes, one byte per pooled element.  The shared-halo kernel pools its
-   * staged output tile before the tile leaves LDS (y is still written in full: the skip connection reads it, but the pool no
-   * longer re-reads it from memory); every other path launches the pooling kernel behind the conv.  Results are those of
-   * dct_conv2d followed by dct_maxpool2x2_fwd[_codes], bit for bit.  Not with scatter2x2 / accumulate. */
+   * staged output tile before the tile leaves LDS (the pool no longer re-reads y from memory; y itself is still written unless
+   * pool_only says nobody reads it); every other path launches the pooling kernel behind the conv.  Results are those of
+   * dct_conv2d followed by dct_maxpool2x2_fwd[_codes], bit for bit.  Not with scatter2x2 / accumulate, and not with mask /
+   * mask_bits (a forward-pass feature: the staged tile is pooled before the gates of a data gradient would be applied). */
   void* pool_out;
   uint8_t* pool_codes;
   /* pool_only != 0 (with pool_out): the caller consumes only the pooled tensor -- y must still be a valid buffer, but its contents
@@ -458,44 +459,17 @@ enum { DCT_TUNE_IGEMM_SPLIT = 1,   /* >= 1: force the split-K factor; -1 (defaul
        DCT_TUNE_ENET_MFMA = 26,              /* bf16 / f16 Enet: bit 0 = MFMA form of the convolutions with >= 16 input channels,
                                                 bit 1 = of the weight gradients; 3 (default), 0 = the fp32 VALU kernels */
        DCT_TUNE_ENET_MWGRAD_WAVES = 28,      /* >= 64 (default 2048): waves an MFMA weight-gradient launch aims for */
-       DCT_TUNE_ENET_FUSE_FINALIZE = 34,     /* 1: Enet BatchNorm / bias-sum finalizes ride in the producing launch's last block (measured slower:
-                                                csrc/enet.hip g_enet_fuse_finalize); 0 (default): one-block launches of their own */
-       DCT_TUNE_IGEMM4 = 35,                 /* 1: 3x3 stride-1 bf16 layers on the persistent one-block-per-CU ping-pong tile (csrc/igemm4.hip); 0 (default): igemm.hip tiles -- level on the step */
-       DCT_TUNE_IGEMM4_MIN_BLOCKS = 37,      /* default 96: fewest blocks for which it is taken (1: whatever the layer, the tests' setting) */
        DCT_TUNE_LEAN = 38 };                 /* bit mask (default 15: all set) of the instruction-lean loop forms, each bit-identical to
                                                 the plain form it replaces (0 = the plain forms, the tests' reference): bit 0 = filter-row weight gradient,
                                                 bit 1 = packed-rows conv kernel, bit 2 = per-tap weight gradient, bit 3 = per-tap conv kernel */
 /* (Knob numbers are stable across rounds; the gaps are A/B switches of variants that were measured slower and removed with their
  *  kernels -- DESIGN.md 4.1 / 4.2: register-staged bf16 kernels, 4-wave tiles, scattered epilogue stores, the 32x32x16 shared-halo
  *  form, XCD-aware tile orders, the weight-ring and four-fat-wave shared-halo tiles, one / four wave groups and per-tap reads in the
- *  filter-row weight gradient, the scalar Enet reductions, the channel-owner BatchNorm, the vector BatchNorm-backward apply -- and planner constants whose
+ *  filter-row weight gradient, the scalar Enet reductions, the channel-owner BatchNorm, the vector BatchNorm-backward apply, the Enet finalizes riding in their
+ *  producers' last blocks (34), the one-block-per-CU ping-pong conv tile (35, 37) -- and planner constants whose
  *  sweeps are on file: profiles/r03_knob_sweeps.txt.) */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
-
-/* The same two launches with the BatchNorm's one-block "finalize" (statistics -> scale / shift / saved statistics; backward sums ->
- * parameter gradients and the apply pass's two means) riding in the producing launch's LAST block (csrc/enet.hip
- * last_block_arrived): one launch less per BatchNorm on the chain.  *finalized = 1 when that happened -- then skip
- * dct_enet_bn_fwd_stats_rows, resp. call dct_enet_bn_bwd_rows with partial_rows = -1 (apply only); 0: proceed as after the plain call.
- * (dct_enet_bn_fwd_stats / dct_enet_bn_bwd / dct_enet_channel_sum fuse their own reduction + finalize the same way internally.) */
-typedef struct dct_enet_bn_fin {
-  const float* gamma; const float* beta; float eps, momentum;
-  float* running_mean; float* running_var;      /* nullable: deferred running statistics */
-  int32_t training;                              /* must be 1 */
-  float* scale; float* shift; float* save_mean; float* save_invstd; float* save_var;
-} dct_enet_bn_fin;
-typedef struct dct_enet_bn_bwd_fin { float* dgamma; float* dbeta; float* dslope; float* c1c2; int32_t training; } dct_enet_bn_bwd_fin;
-int dct_enet_conv_stats_fin(const dct_view* x, const float* w, const float* bias, const dct_enet_tf* tf,
-                            const dct_view* y, const dct_conv_desc* d, int transposed,
-                            int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
-                            double* stats_partial, int stats_capacity_rows, int* stats_rows,
-                            const dct_enet_bn_fin* fin, int* finalized, dct_stream stream);
-int dct_enet_conv_bnbwd_stats_fin(const dct_view* x, const float* w, const dct_view* y, const dct_conv_desc* d, int transposed,
-                                  int ws_out, int ws_tap, int ws_in, int f32_mask, int dtype,
-                                  const dct_view* bn_raw, const float* bn_scale, const float* bn_shift, const float* bn_slope,
-                                  int bn_act, const float* bn_mean, const float* bn_invstd,
-                                  double* stats_partial, int stats_capacity_rows, int* stats_rows,
-                                  const dct_enet_bn_bwd_fin* fin, int* finalized, dct_stream stream);
 
 /* "De-normalise on load": a data-gradient convolution whose input is the BatchNorm-backward result of the layer in front of it
  * computes that result where it would load it -- raw = that layer's fp32 output, tf = its scale / shift / slope (mode != 0),

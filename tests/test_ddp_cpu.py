@@ -238,16 +238,22 @@ def test_two_rank_gloo_small_models_share_one_collective_and_one_adversarial_pai
     np.testing.assert_allclose(a0["g"][1].numpy(), want.numpy(), rtol=1e-6)
 
 
-@pytest.mark.timeout(900)
-def test_bench_launches_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) must start its two ranks itself and leave ONE JSON line with
-    n_gpus = 2 as the last line of its output: --dry-launch runs that path on CPU (gloo, oracle-injected networks)."""
-    import json
+def _dry_bench(extra, timeout=850):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "2"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "1", "--warmup", "0"],
-                       env=env, capture_output=True, text=True, timeout=850)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "1", "--warmup", "0"] + extra,
+                          env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) must start its two ranks itself and leave ONE JSON line with
+    n_gpus = 2 as the last line of its output: --dry-launch runs that path on CPU (gloo, oracle-injected networks) through the
+    SAME `bench.measure()` the MI355X run uses -- warm-up, timed regions and every leg behind them (the per-launch event leg
+    included, with a CPU stand-in for the profiler) -- and counts the collectives each rank issues: the sequences must agree."""
+    import json
+    r = _dry_bench([])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -255,3 +261,15 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak"
     assert line["config"]["parallelism"] == "dp2" and line["value"] > 0
     assert all(v == v for v in line["losses_last_step"]["sup"])
+    col = line["collectives"]
+    assert col["same_sequence_on_every_rank"] and col["per_rank"][0] == col["per_rank"][1] > 0 and col["event_leg_ran"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_rank_conditional_step_leg_is_caught():
+    """The round-4 defect -- a leg behind the timed region that runs steps (hence gradient all-reduces) on rank 0 only while the
+    other ranks go on to the barrier -- re-introduced through a self-test switch: the launch must fail (gloo's collective
+    timeout), not print a line.  This is what makes the test above a test of the post-timed control flow."""
+    r = _dry_bench(["--dry-timeout", "20", "--dry-break-rank0-leg"], timeout=550)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]

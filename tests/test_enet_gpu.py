@@ -272,45 +272,6 @@ def test_enet_backward_leaves_on_a_side_stream_are_bit_identical():
     del keep
 
 
-def test_enet_finalize_in_the_last_block_matches_the_one_block_launches():
-    """Knob 34 (DCT_TUNE_ENET_FUSE_FINALIZE): the BatchNorm / bias-sum finalizes riding in their producers' last blocks give the
-    logits, statistics and gradients of the separate one-block launches up to the rounding of a different fold grouping (the rows
-    are folded by 256 instead of 1024 threads: same values, another association of the double sums), run after run."""
-    from dct_amd import _lib, hip_ops as K
-    C = 2
-    net = _hip_net(_oracle_net(C, 51), C, torch.bfloat16).train()
-    net.flat_params.ensure()
-    g = torch.Generator().manual_seed(12)
-    x = torch.rand(8, 1, 104, 96, generator=g).to(DEV)
-    dl = torch.randn(8, 104, 96, C, generator=g).to(DEV).to(torch.bfloat16)
-    lib = _lib.load()
-
-    def run():
-        lp, tape = net.plan_forward(x, True, defer_running=True)
-        buf = torch.zeros(net.flat_params.total, dtype=torch.float32, device=DEV)
-        dx = net.plan_backward(tape, dl, need_dx=True, need_dw=True, grad_buffer=buf)
-        torch.cuda.synchronize()
-        return lp.clone(), buf, dx.clone()
-
-    outs = {}
-    for knob in (0, 1):
-        assert lib.dct_tune_set(34, knob) == 0
-        try:
-            outs[knob] = [run() for _ in range(3)]
-        finally:
-            lib.dct_tune_set(34, 0)
-    for k in (0, 1):                              # either mode is deterministic
-        for r in outs[k][1:]:
-            for a, b in zip(outs[k][0], r):
-                assert torch.equal(a, b), f"knob {k}: run-to-run difference"
-    for a, b, what in zip(outs[0][0], outs[1][0], ("logits", "gradients", "dx")):
-        err = (a.float() - b.float()).abs().max().item()
-        scale = b.float().abs().max().item()
-        assert err <= 2e-3 * scale, f"{what}: {err:.3e} vs scale {scale:.3e}"
-    rel = (outs[0][0][1] - outs[1][0][1]).norm().item() / outs[1][0][1].norm().item()
-    assert rel < 1e-3, rel
-
-
 @pytest.mark.parametrize("need_dw", [True, False])
 def test_enet_denormalise_on_load_is_bit_identical(need_dw):
     """Data-gradient convolutions computing the BatchNorm-backward result of their input on load (K.enet_conv_bwd_in) give bit for

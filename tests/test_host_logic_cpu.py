@@ -243,6 +243,13 @@ def test_registry_and_dict_merge():
     assert out["Trainer"] == {"max_epoch": 3, "device": "cuda:0"} and out["Arch"] == {"name": "unet", "num_classes": 4}
     assert out["StartTraining"]["train_jsd"] is True and out["New"] == {"k": 1}
     assert dict_merge({"a": 1}, None, True) == {"a": 1} and dict_merge({"a": 1}, {"a": 2}) is None
+    # the reference's leaf rule (utils/utils.py:345-349): a value that does not convert is kept AS GIVEN -- '0.5' against an int
+    # default stays the string (int('0.5') raises), it does not become 0; bool defaults read 'false' / 'True' in any case
+    out = dict_merge({"max_epoch": 300, "lr": 1e-3, "flag": True, "axes": [1, 2], "name": "enet", "none": None},
+                     {"max_epoch": "0.5", "lr": "0.01", "flag": "false", "axes": "[1, 2, 3]", "name": 7, "none": "x"}, True)
+    assert out == {"max_epoch": "0.5", "lr": 0.01, "flag": False, "axes": [1, 2, 3], "name": "7", "none": "x"}
+    assert dict_merge({"flag": False, "n": 3}, {"flag": "TRUE", "n": 4.0}, True) == {"flag": True, "n": 4}
+    assert dict_merge({"flag": False}, {"flag": "no_such_name"}, True) == {"flag": "no_such_name"}
     # the trainer's use: per-model report dictionaries merged leaf by leaf (cotraining_totalloss._report_dict)
     assert dict_merge({"S0": {"DSC1": 0.5}}, {"S0": {"DSC": 0.25}}, True) == {"S0": {"DSC1": 0.5, "DSC": 0.25}}
 

@@ -497,73 +497,6 @@ def test_conv2d_per_tap_lean_form_is_bit_identical(ops, B, Cin, H, W, Cout, k, p
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "lean per-tap kernel differs from the plain form"
 
 
-_I4_DEFAULT = 0      # the kernel is an alternative tile family (level with igemm.hip on the cfg2 step): off unless asked for
-
-# one-block-per-CU ping-pong kernel (csrc/igemm4.hip): persistent blocks, 256-pixel rectangles x 128 channels, counted vmcnt + raw barriers.
-# Against F.conv2d, and bit for bit against the shared-halo kernel where both accumulate (slice, tap, 32-channel half) on
-# v_mfma_f32_16x16x32_bf16 (patch-kernel shapes); a repeat-launch race screen because its synchronisation is hand-placed.
-_I4_CASES = [
-    (4, 64, 130, 130, 128, 0),      # 16 x 16 patches, one channel slice (no halo prefetch), ragged right / bottom edge
-    (5, 128, 122, 90, 128, 2),      # data-gradient form: halo outside the image reads the zero page; two slices
-    (3, 192, 96, 96, 256, 0),       # three slices, two channel tiles
-    (16, 256, 59, 59, 256, 0),      # row-packed geometry (whole-width tiles), four slices
-    (16, 512, 27, 27, 512, 0),      # small image, eight slices, 192 blocks -> split over channel slices (fp32 slabs)
-    (16, 256, 18, 16, 256, 2),      # data-gradient form on a small image
-    (2, 64, 40, 300, 128, 0),       # wide, short image
-]
-
-
-@pytest.mark.parametrize("B,Cin,H,W,Cout,pad", _I4_CASES)
-def test_conv2d_pingpong_kernel(ops, B, Cin, H, W, Cout, pad):
-    from dct_amd import _lib
-    lib = _lib.load()
-    lib.dct_tune_set(35, 1)
-    lib.dct_tune_set(37, 1)          # take the kernel whatever the block count
-    try:
-        _shared_halo_case(ops, B, Cin, H, W, Cout, pad)
-    finally:
-        lib.dct_tune_set(35, _I4_DEFAULT)
-        lib.dct_tune_set(37, 96)
-
-
-@pytest.mark.parametrize("B,Cin,H,W,Cout,pad", _I4_CASES[:4])
-def test_conv2d_pingpong_kernel_is_bit_identical_and_race_free(ops, B, Cin, H, W, Cout, pad):
-    from dct_amd import _lib
-    lib = _lib.load()
-    dtype = torch.bfloat16
-    g = torch.Generator().manual_seed(14)
-    x = to_dev(q(torch.randn(B, Cin, H, W, generator=g), dtype), dtype)
-    w = kmajor(q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9), dtype), dtype)
-    b = torch.randn(Cout, generator=g).to(DEV)
-    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
-    mask = to_dev(q(torch.randn(B, Cout, Ho, Wo, generator=g), dtype), dtype)
-
-    def run():
-        y = torch.empty(B, Ho, Wo, Cout, dtype=dtype, device=DEV)
-        ops.conv2d(x, w, b, y, pad_h=pad, pad_w=pad, relu=True)
-        z = torch.ones(B, Ho, Wo, Cout, dtype=dtype, device=DEV)
-        ops.conv2d(x, w, None, z, pad_h=pad, pad_w=pad, mask=mask, mask_scale=2.0, accumulate=True)
-        return y, z
-    try:
-        lib.dct_tune_set(37, 1)
-        lib.dct_tune_set(35, 0)
-        lib.dct_tune_set(10, 0)          # reference: shared-halo patch kernel or the per-tap kernel
-        y0, z0 = run()
-        lib.dct_tune_set(35, 1)
-        y1, z1 = run()
-        if H >= 90:                      # the patch kernel accumulates in the same order on the same MFMA: every bit agrees
-            assert torch.equal(y1, y0) and torch.equal(z1, z0)
-        else:
-            assert (y1.float() - y0.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, y0.float().abs().max().item())
-        for _ in range(100):             # 200 launches: a missed wait or an early read shows as run-to-run differences
-            y2, z2 = run()
-            assert torch.equal(y2, y1) and torch.equal(z2, z1)
-    finally:
-        lib.dct_tune_set(35, _I4_DEFAULT)
-        lib.dct_tune_set(37, 96)
-        lib.dct_tune_set(10, _PACKED_DEFAULT)
-
-
 def _pack_bits(t_nhwc):
     """ReLU-gate bits of a dense NHWC tensor as the kernels lay them out: byte (pixel, c // 8), bit c % 8."""
     pos = (t_nhwc.float() > 0).to(torch.int32)
