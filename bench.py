@@ -94,8 +94,9 @@ def pmc_traffic(config):
 
 
 def pmc_mfma_busy(config):
-    """MFMA-pipe busy share per kernel class (newest committed profiles/r*_<config>_pmc_mfma_busy.txt) and the in-kernel shader clock
-    (profiles/r03_in_kernel_clock.txt): counter evidence of EARLIER rocprofv3 --pmc passes of this command; None when absent."""
+    """MFMA-pipe busy share per kernel class from the newest committed profiles/r*_<config>_pmc_mfma_busy.txt: counter evidence of an
+    EARLIER rocprofv3 --pmc pass of this command (tools/pmc_mfma.py); None when absent.  (The shader clock is measured by the run
+    itself: `shader_clock_ghz_during_the_step`.)"""
     import glob
     out = {}
     try:
@@ -103,15 +104,10 @@ def pmc_mfma_busy(config):
         with open(path) as f:
             for line in f:
                 t = line.split()
-                if len(t) >= 4 and t[2].endswith("%"):
+                if len(t) >= 3 and t[2].endswith("%"):
                     out[t[0]] = float(t[2].rstrip("%")) / 100.0
-        clocks = []
-        with open(os.path.join(ROOT, "profiles", "r03_in_kernel_clock.txt")) as f:
-            for line in f:
-                if "in-kernel shader clock" in line and "zeros 0%" in line:
-                    clocks.append(float(line.split("clock:")[1].split("GHz")[0]))
-        return {"mfma_pipe_busy_share_of_simd_cycles": out, "in_kernel_clock_ghz_dense_inputs": clocks,
-                "source": f"{os.path.relpath(path, ROOT)}, profiles/r03_in_kernel_clock.txt (committed rocprofv3 --pmc passes of this command)"}
+        return {"mfma_pipe_busy_share_of_simd_cycles": out,
+                "source": f"{os.path.relpath(path, ROOT)} (committed rocprofv3 --pmc pass of this command)"}
     except Exception:
         return None
 
@@ -235,6 +231,20 @@ class HipLegs:
     def scalar(self, v):
         return torch.tensor([v], dtype=torch.float64, device=self.device)
 
+    def clock_begin(self, seconds: float):
+        """One sleeping wave on a stream of its own for `seconds`: shader-clock cycles over reference ticks of its life
+        (include/dct.h dct_clock_probe) = the clock the chip holds while whatever is launched next runs."""
+        self._clk_out = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self._clk_stream = torch.cuda.Stream(device=self.device)
+        ticks = max(1, min(int(seconds * 1e8), 100_000_000))
+        self._lib.check(self._lib.load().dct_clock_probe(self._clk_out.data_ptr(), ticks, self._clk_stream.cuda_stream), "dct_clock_probe")
+
+    def clock_end(self):
+        self._clk_stream.synchronize()
+        cyc, ref = (int(v) for v in self._clk_out.tolist())
+        return {"ghz": 0.1 * cyc / ref if ref else None, "window_ms": ref / 1e5,
+                "how": "one sleeping wave beside the replayed step: d(s_memtime) / d(s_memrealtime) x 100 MHz over its life"}
+
     def prof_begin(self, record: bool):
         self._lib.prof_read(reset=True)
         self._lib.prof_enable(bool(record))
@@ -254,6 +264,12 @@ class DryLegs:
 
     def scalar(self, v):
         return torch.tensor([v], dtype=torch.float64)
+
+    def clock_begin(self, seconds: float):
+        pass
+
+    def clock_end(self):
+        return None
 
     def prof_begin(self, record: bool):
         self._on = bool(record)
@@ -299,7 +315,7 @@ def measure(args, tr, one_step, legs, rank, world, ddp_on, meters_leg=None, oper
             t_rep = float(tt.item())
         regions.append(t_rep)
     res = {"regions": regions, "elapsed": sorted(regions)[len(regions) // 2], "out": out, "exchange": None, "meters_ms": None,
-           "operand_stats": None, "prof": None}
+           "operand_stats": None, "prof": None, "clock": None}
     if ddp_on:
         ex = legs.scalar(tr.grad_sync.exposed_ms(reset=True) / (args.steps * reps))
         dist.all_reduce(ex, op=dist.ReduceOp.MAX)
@@ -310,6 +326,18 @@ def measure(args, tr, one_step, legs, rank, world, ddp_on, meters_leg=None, oper
                            "mode": "captured graph segments around the eager all-reduces" if graphs is not None and graphs.captures
                            else "eager launches, bucketed all-reduce from inside the backward pass"}
     base = args.warmup + args.steps * reps
+    # The shader clock UNDER this load: the K steps once more (every rank: their all-reduces must meet) with one sleeping probe wave
+    # beside them on rank 0, alive for ~80 % of the time the K steps take (the back-to-back single-layer loops of round 3's clock
+    # study are power-capped to 1.77 GHz; the step is not).
+    if not args.no_clock_probe:
+        if rank == 0:
+            legs.clock_begin(0.8 * res["elapsed"])
+        for i in range(args.steps):
+            one_step(base + i)
+        legs.sync()
+        if rank == 0:
+            res["clock"] = legs.clock_end()
+        base += args.steps
     # The step with the in-step meters on (SURVEY.md 8d asks for it separately).  `world == 1` is the same on every rank.
     if meters_leg is not None and world == 1:
         res["meters_ms"] = meters_leg(base)
@@ -410,6 +438,7 @@ def main():
                     help="extra (untimed) training steps before the warm-up: the timed network is then that many Adam steps old "
                          "(operand statistics of a trained net; profiles/r03_cfg2_after_300_steps.json)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--no-clock-probe", action="store_true", help="do not sample the shader clock beside the replayed step")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight gradients on a second stream per model (eager only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
     ap.add_argument("--single-stream", action="store_true",
@@ -547,6 +576,7 @@ def main():
                 operand_leg=operand_leg, enter_event_leg=enter_event_leg)
     regions, elapsed, out = m["regions"], m["elapsed"], m["out"]
     exchange, meters_ms, operand_stats, prof = m["exchange"], m["meters_ms"], m["operand_stats"], m["prof"]
+    clock = m["clock"]
     losses = dict(sup=[float(s) for s in out["sup"]], jsd=float(out["jsd"]))
     assert all(v == v for v in losses["sup"]) and losses["jsd"] == losses["jsd"], "NaN loss in the timed region"
 
@@ -621,6 +651,8 @@ def main():
                                "frac": (flops["igemm"] + flops["wgrad"]) / (ms_per_step * 1e-3) / 1e12 / peak},
                 # counter evidence of an EARLIER run, read from the committed profile files (not measured by this run)
                 "archived_counters": pmc_mfma_busy(args.config),
+                # measured by THIS run, beside the replayed (captured) step
+                "shader_clock_ghz_during_the_step": clock,
             }
         elif prof is not None:
             # Enet: HBM bound.  Algorithmic bytes = conv in+out activation elements x 2 B (bf16) x 3 (fwd, dgrad, wgrad)

@@ -160,6 +160,7 @@ SIGNATURES = {
     "dct_tune_set": (_i, [_i, _i]),
     "dct_prof_enable": (_i, [_i]),
     "dct_prof_read": (_i, [_P, _P, _i]),
+    "dct_clock_probe": (_i, [_P, C.c_uint64, _P]),
 }
 
 _lib = None

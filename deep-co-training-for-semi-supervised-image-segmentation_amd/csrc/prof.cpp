@@ -62,6 +62,25 @@ extern "C" int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, 
   return DCT_OK;
 }
 
+// Shader-clock probe (bench.py: the clock the chip holds WHILE the captured step runs): one wave reads the shader-clock counter
+// (s_memtime) and the constant 100 MHz reference counter (s_memrealtime) when it starts, sleeps in short naps until `ref_ticks`
+// reference ticks have passed, and reads both again: out[0] = shader cycles, out[1] = reference ticks -> GHz = 0.1 * out[0] / out[1].
+// One wave that is asleep almost all of the time: it takes one wave slot of one SIMD and a few issue cycles per microsecond.
+__global__ void dct_clock_probe_kernel(unsigned long long* out, unsigned long long ref_ticks) {
+  unsigned long long c0, r0, c1, r1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0) :: "memory");
+  do {
+    __builtin_amdgcn_s_sleep(32);
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1) :: "memory");
+  } while (r1 - r0 < ref_ticks);
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+extern "C" int dct_clock_probe(unsigned long long* out2, unsigned long long ref_ticks, dct_stream stream) {
+  if (!out2 || ref_ticks == 0 || ref_ticks > 100000000ull) return DCT_ERR_BAD_ARG;      // at most one second
+  hipLaunchKernelGGL(dct_clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out2, ref_ticks);
+  return hipGetLastError() == hipSuccess ? DCT_OK : DCT_ERR_LAUNCH;
+}
+
 extern "C" int dct_version(void) { return 100; }
 
 extern "C" const char* dct_status_string(int status) {

@@ -19,8 +19,9 @@
 #include <type_traits>
 
 // bit mask of the instruction-lean loop forms (dct_tune_set(DCT_TUNE_LEAN, ...); all bit-identical to the forms they replace):
-// bit 0 = filter-row weight gradient, bit 2 = per-tap weight gradient (this file), bit 1 = packed-rows conv kernel, bit 3 = per-tap conv kernel (igemm.hip)
-int g_tune_lean = 15;
+// bit 0 = filter-row weight gradient, bit 2 = per-tap weight gradient (this file), bit 1 = packed-rows conv kernel, bit 3 = per-tap conv kernel (igemm.hip),
+// bit 4 (with bit 0) = the filter-row loop skips the sub-steps of a K-step that hold no dy pixel
+int g_tune_lean = 31;
 
 namespace {
 
@@ -594,6 +595,7 @@ struct Wgrad3Params {
   int segs_per_row, nseg, seg_per_chunk;
   int pitch, nr, units_per_image;     // pitch > 0: narrow images -- a K-step packs nr image rows at a pitch of Wp + 2 rows
   int direct, accumulate, with_bias;
+  int skip_empty;                     // LEAN: multiply only the 16-row sub-steps of a K-step that hold dy pixels
   float* bias;
   long long slab_stride;
   long long p_bytes, q_bytes;         // LEAN: bytes from P / Q to the end of the views (buffer descriptor ranges, < 2^31)
@@ -713,6 +715,10 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
     rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qb, 0, (int)(pr.q_bytes - (long long)q0 * 2), 0x00020000);
   }
   const int lrowP = lane / CPRP, lrowQ = lane / CPRQ;
+  // LEAN: 16-row sub-steps of the step staged last whose dy rows hold pixels (1..4).  The rows behind them are staged as zeros,
+  // so their MFMAs (and bias sums) add exact zeros: the loop skips them -- a row tail of 20 pixels (84-pixel rows: 64 + 20) or
+  // a packed step of 48 rows (one 46-pixel row + gap) costs two / three sub-steps instead of four.  Bit-identical.
+  int sub_staged = 4;
   auto stage = [&](char* buf) {
     if constexpr (LEAN) {
       const unsigned cP = offP, cQ = offQ;
@@ -721,6 +727,7 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
       if (NARROW) {
         const int nrows = min(pr.nr, p.Hp - s_y);
         lim = nrows * pr.pitch; full = nrows == pr.nr;
+        sub_staged = pr.skip_empty ? (lim + 13) >> 4 : 4;       // dy rows 0 .. nrows * pitch - 3
         s_y += pr.nr;
         offP += (unsigned)(pr.nr * (int)p.psH * 2); offQ += (unsigned)(pr.nr * (int)p.qsH * 2);
         if (s_y >= p.Hp) {
@@ -730,6 +737,7 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
         }
       } else {
         lim = min(64, p.Wp - s_x); full = lim == 64;
+        sub_staged = pr.skip_empty ? (lim + 15) >> 4 : 4;
         s_x += 64;
         offP += (unsigned)(128 * psW); offQ += (unsigned)(128 * qsW);
         if (s_x >= p.Wp) {
@@ -806,6 +814,7 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   if (gbeg < gend) stage(smem);
   __syncthreads();
   int cur = 0;
+  int nsub = sub_staged;             // sub-steps of the step about to be multiplied
   int pbase[TP], qbase[3][TQ];
   {
     const int g = lane >> 4, li = lane & 15, lq = li >> 2, lpp = li & 3, lh = g >> 1;
@@ -932,11 +941,19 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
             if constexpr (QR == 3) tr_issue_o<(KK) * Q_KK + 2 * Q_HI>(qa[s][j], fb[set][s][j][QR - 1]);             \
           }                                                                                                         \
       }
+      // (nsub is wave-uniform: scalar branches)
       DCT_W3_ISSUE(0, 0)
-      DCT_W3_ISSUE(1, 1) lgkm_wait<NRD>(); compute(set0);
-      DCT_W3_ISSUE(0, 2) lgkm_wait<NRD>(); compute(set1);
-      DCT_W3_ISSUE(1, 3) lgkm_wait<NRD>(); compute(set0);
-      lgkm_wait<0>(); compute(set1);
+      if (nsub > 1) { DCT_W3_ISSUE(1, 1) lgkm_wait<NRD>(); } else { lgkm_wait<0>(); }
+      compute(set0);
+      if (nsub > 1) {
+        if (nsub > 2) { DCT_W3_ISSUE(0, 2) lgkm_wait<NRD>(); } else { lgkm_wait<0>(); }
+        compute(set1);
+        if (nsub > 2) {
+          if (nsub > 3) { DCT_W3_ISSUE(1, 3) lgkm_wait<NRD>(); } else { lgkm_wait<0>(); }
+          compute(set0);
+          if (nsub > 3) { lgkm_wait<0>(); compute(set1); }
+        }
+      }
 #undef DCT_W3_ISSUE
     } else {
     auto issue = [&](int set, int kk) {
@@ -967,6 +984,7 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
     { const unsigned long long t = w3_stamp(); st_bar += t - st_t0; st_t0 = t; }
 #endif
     cur ^= 1;
+    nsub = sub_staged;
   }
 #ifdef DCT_W3_STAMPS
   if (pr.stamps && lane == 0 && blockIdx.x < 4096) {
@@ -1114,11 +1132,18 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
     int segs = 1, pitch = 0, nr = 1;
     double fill;
     long long units;
-    if (Wp > 64) { segs = (Wp + 63) / 64; fill = (double)Wp / (segs * 64.0); units = (long long)p->h * segs; }
-    else {
+    // the lean loop multiplies only the 16-row sub-steps of a step that hold dy pixels: the fill is counted in those
+    const bool skips = (g_tune_lean & 17) == 17 && d->pad_h == 0 && d->pad_w == 0;
+    if (Wp > 64) {
+      segs = (Wp + 63) / 64; units = (long long)p->h * segs;
+      const int tail = Wp - 64 * (segs - 1);
+      fill = skips ? (double)Wp / (16.0 * (4 * (segs - 1) + (tail + 15) / 16)) : (double)Wp / (segs * 64.0);
+    } else {
       pitch = Wp + 2; nr = 66 / pitch; if (nr < 1) nr = 1;
       const int steps = (p->h + nr - 1) / nr;
-      fill = (double)p->h * Wp / (steps * 64.0);
+      const int last = p->h - (steps - 1) * nr;                 // image rows of an image's last step
+      const double subs = skips ? (steps - 1) * (double)((nr * pitch + 13) / 16) + (last * pitch + 13) / 16 : steps * 4.0;
+      fill = (double)p->h * Wp / (subs * 16.0);
       units = steps;
     }
     if (fill >= g_tune_wgrad_rows_fill * 0.01 && (long long)p->h * p->sh < (1ll << 29) && (long long)q->h * q->sh < (1ll << 29)) {
@@ -1263,6 +1288,7 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float
     pr.pitch = pl.pitch; pr.nr = pl.nr; pr.units_per_image = pl.units;
     pr.direct = pl.direct; pr.accumulate = d->accumulate;
     pr.bias = db; pr.with_bias = db ? 1 : 0; pr.slab_stride = slab_stride;
+    pr.skip_empty = (g_tune_lean & 16) ? 1 : 0;
     pr.p_bytes = ((long long)(p->n - 1) * p->sn + (long long)(p->h - 1) * p->sh + (long long)(p->w - 1) * p->sw + p->c) * 2;
     pr.q_bytes = ((long long)(q->n - 1) * q->sn + (long long)(q->h - 1) * q->sh + (long long)(q->w - 1) * q->sw + q->c) * 2;
     pr.stamps = g_w3_stamps;

@@ -459,9 +459,10 @@ enum { DCT_TUNE_IGEMM_SPLIT = 1,   /* >= 1: force the split-K factor; -1 (defaul
        DCT_TUNE_ENET_MFMA = 26,              /* bf16 / f16 Enet: bit 0 = MFMA form of the convolutions with >= 16 input channels,
                                                 bit 1 = of the weight gradients; 3 (default), 0 = the fp32 VALU kernels */
        DCT_TUNE_ENET_MWGRAD_WAVES = 28,      /* >= 64 (default 2048): waves an MFMA weight-gradient launch aims for */
-       DCT_TUNE_LEAN = 38 };                 /* bit mask (default 15: all set) of the instruction-lean loop forms, each bit-identical to
+       DCT_TUNE_LEAN = 38 };                 /* bit mask (default 31: all set) of the instruction-lean loop forms, each bit-identical to
                                                 the plain form it replaces (0 = the plain forms, the tests' reference): bit 0 = filter-row weight gradient,
-                                                bit 1 = packed-rows conv kernel, bit 2 = per-tap weight gradient, bit 3 = per-tap conv kernel */
+                                                bit 1 = packed-rows conv kernel, bit 2 = per-tap weight gradient, bit 3 = per-tap conv kernel, bit 4 (with bit 0, round 5) =
+                                                the filter-row loop skips the 16-row sub-steps of a K-step that hold no dy pixel (exact zeros) */
 /* (Knob numbers are stable across rounds; the gaps are A/B switches of variants that were measured slower and removed with their
  *  kernels -- DESIGN.md 4.1 / 4.2: register-staged bf16 kernels, 4-wave tiles, scattered epilogue stores, the 32x32x16 shared-halo
  *  form, XCD-aware tile orders, the weight-ring and four-fat-wave shared-halo tiles, one / four wave groups and per-tap reads in the
@@ -470,6 +471,11 @@ enum { DCT_TUNE_IGEMM_SPLIT = 1,   /* >= 1: force the split-K factor; -1 (defaul
  *  sweeps are on file: profiles/r03_knob_sweeps.txt.) */
 int dct_tune_set(int knob, int value);
 int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
+/* Shader-clock probe: ONE wave on `stream` that sleeps until ref_ticks ticks of the constant 100 MHz reference counter have passed
+ * and leaves out2[0] = shader-clock cycles (s_memtime), out2[1] = reference ticks (s_memrealtime) of its life: the clock the chip
+ * held meanwhile is 0.1 GHz * out2[0] / out2[1].  Launched on a stream of its own beside the captured step, it samples the clock
+ * UNDER that load (bench.py `roofline.shader_clock_ghz_during_the_step`).  out2: two device uint64.  ref_ticks <= 1e8 (one second). */
+int dct_clock_probe(unsigned long long* out2, unsigned long long ref_ticks, dct_stream stream);
 
 /* "De-normalise on load": a data-gradient convolution whose input is the BatchNorm-backward result of the layer in front of it
  * computes that result where it would load it -- raw = that layer's fp32 output, tf = its scale / shift / slope (mode != 0),

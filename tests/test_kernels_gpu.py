@@ -3,6 +3,7 @@ PyTorch fp32 CPU computation of the same op, and against the oracle for the loss
 fp32 mode is the parity path (tight tolerance); bf16 mode is compared against the same
 math on bf16-rounded inputs (tolerance = bf16 output rounding + accumulation order)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -147,7 +148,10 @@ def test_conv2d_3x3_shared_halo_is_reproducible(ops, B, Cin, H, W, Cout, pad):
 
 
 _PACKED_DEFAULT = 1
-_LEAN_DEFAULT = 15   # DCT_TUNE_LEAN default (csrc/wgrad.hip g_tune_lean)
+_LEAN_DEFAULT = 31   # DCT_TUNE_LEAN default (csrc/wgrad.hip g_tune_lean)
+# repeat launches of the race screens: 200 when a kernel's synchronisation was touched (DCT_LONG_TESTS=1), 50 in the default run,
+# which has to stay inside the driver's budget as tests are added
+_RACE_LAUNCHES = 200 if os.environ.get("DCT_LONG_TESTS") else 50
 
 
 def _shared_halo_case(ops, B, Cin, H, W, Cout, pad):
@@ -234,10 +238,16 @@ def test_conv2d_packed_rows_lean_form_is_bit_identical(ops, B, Cin, H, W, Cout, 
     (8, 256, 27, 27, 128, 0),       # filter-row kernel, narrow images: packed rows at pitch 27, last step of an image partial
     (16, 1024, 11, 11, 128, 0),     # per-tap kernel (step fill under the filter-row threshold): one wave per K-step decodes the pixels
     (3, 128, 70, 101, 128, 1),      # padding: the filter-row kernel keeps its plain form, the per-tap kernel's bounds go through the table
+    # round 5: the lean filter-row loop skips the 16-row sub-steps of a K-step that hold no dy pixel (they were staged as zeros)
+    (4, 64, 88, 88, 64, 0),         # wide rows of 86 = 64 + 22: the tail step multiplies two sub-steps of four (the UNet's enc1a)
+    (4, 128, 48, 48, 128, 0),       # narrow rows of 46 at pitch 48, one per step: three sub-steps (enc2a)
+    (3, 128, 30, 20, 64, 0),        # three packed rows of 18 per step (58 LDS rows: four sub-steps), an image's last step holds ONE row: two
+    (2, 64, 50, 35, 64, 0),         # rows of 33 at pitch 35: three sub-steps, the third with one live row
 ])
 def test_conv2d_wgrad_lean_forms_are_bit_identical(ops, B, Cin, H, W, Cout, pad):
     """Weight gradients with DCT_TUNE_LEAN = 0 (plain loops) and 15 (lean loops): dW bit for bit; the bias gradient to fp32 rounding
-    (the lean filter-row kernel sums it with v_dot2c_f32_bf16, two pixels per instruction)."""
+    (the lean filter-row kernel sums it with v_dot2c_f32_bf16, two pixels per instruction).  The filter-row kernel is forced for
+    every 3x3 shape (knob 9: its fill threshold), so that both forms run the same kernel whatever the planner would choose."""
     from dct_amd import _lib
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(23)
@@ -246,8 +256,11 @@ def test_conv2d_wgrad_lean_forms_are_bit_identical(ops, B, Cin, H, W, Cout, pad)
     dy = to_dev(q(torch.randn(B, Cout, Ho, Wo, generator=g), dtype), dtype)
     lib = _lib.load()
     outs = {}
+    force_rows = (B, Cin, H, W) in ((4, 64, 88, 88), (4, 128, 48, 48), (3, 128, 30, 20), (2, 64, 50, 35))
     try:
-        for form in (0, 15, 15):
+        if force_rows:
+            assert lib.dct_tune_set(9, 1) == 0
+        for form in (0, 31, 31):
             assert lib.dct_tune_set(38, form) == 0
             dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=DEV)
             db = torch.full((Cout,), float("nan"), device=DEV)
@@ -256,7 +269,8 @@ def test_conv2d_wgrad_lean_forms_are_bit_identical(ops, B, Cin, H, W, Cout, pad)
             outs.setdefault(form, []).append((dw, db))
     finally:
         lib.dct_tune_set(38, _LEAN_DEFAULT)
-    (dw0, db0), (dw1, db1), (dw2, db2) = outs[0][0], outs[15][0], outs[15][1]
+        lib.dct_tune_set(9, 70)
+    (dw0, db0), (dw1, db1), (dw2, db2) = outs[0][0], outs[31][0], outs[31][1]
     assert torch.equal(dw0, dw1), "lean weight gradient differs from the plain form"
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2), "lean form does not reproduce itself"
     assert (db0 - db1).abs().max().item() <= 2e-6 * max(1.0, db0.abs().max().item()) * math.sqrt(B * Ho * Wo)
@@ -410,7 +424,7 @@ def test_conv2d_fused_epilogues_race_screen(ops, B, Ha, Wa):
     assert lib.dct_tune_set(19, 1) == 0
     try:
         first = None
-        for it in range(200):
+        for it in range(_RACE_LAUNCHES):
             y = torch.empty(B, Ha, Wa, C, device=DEV, dtype=dtype)
             pooled = torch.full((B, (Ha + 1) // 2, (Wa + 1) // 2, C), float("nan"), device=DEV, dtype=dtype)
             codes = torch.full(pooled.shape, 255, device=DEV, dtype=torch.uint8)
@@ -447,7 +461,7 @@ def test_conv2d_wgrad_lean_forms_race_screen(ops, B, Cin, H, W, Cout, pad):
     Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
     dy = to_dev(q(torch.randn(B, Cout, Ho, Wo, generator=g), dtype), dtype)
     first = None
-    for it in range(200):
+    for it in range(_RACE_LAUNCHES):
         dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=DEV)
         db = torch.full((Cout,), float("nan"), device=DEV)
         ops.conv2d_wgrad(dy, x, dw, pad_h=pad, pad_w=pad, accumulate=False, db=db)
