@@ -254,8 +254,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = LEAN ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
   const int wn = wave / WAVES_M, wm = wave % WAVES_M;
-  // (an XCD-aware 1-D tile order -- each XCD a contiguous range of (split, channel tile, pixel tile) -- measured level on the step: removed)
-  const int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+  int bxi, byi, bzi;
+  if (!xcd_remap(p, bxi, byi, bzi)) return;
   const int m0 = bxi * BM, n0 = byi * BN;
   const int srow = wave * 8 + (lane >> 3);                 // staging row within a pass
   const int schunk = (lane & 7) ^ ((srow >> 1) & 7);       // source chunk for this lane's LDS slot
@@ -880,8 +880,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave / NWM, wm = wave % NWM;
-  const int img = blockIdx.x / tiles_per_img, ty = blockIdx.x - img * tiles_per_img;
-  const int y0 = ty * PR, n0 = blockIdx.y * BN;
+  int bxi, byi, bzi;
+  if (!xcd_remap(p, bxi, byi, bzi)) return;
+  const int img = bxi / tiles_per_img, ty = bxi - img * tiles_per_img;
+  const int y0 = ty * PR, n0 = byi * BN;
   const int pitch = p.Wo + 2, hrows = (PR + 2) * pitch;
   const long long Ktot = 9ll * p.Cin;
   const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
   const int aswz = (l31 >> 1) & 7;
 
   const int nch = p.Cin / 64;
-  const int cbeg = blockIdx.z * chunks_per_split, cend = min(nch, cbeg + chunks_per_split);
+  const int cbeg = bzi * chunks_per_split, cend = min(nch, cbeg + chunks_per_split);
   if constexpr (LEAN) {
     // LDS byte addresses of this wave's first halo / weight piece in stage 0 (pieces of one kind are NW KiB apart)
     const unsigned ldsA = smem_l + wave * 1024, ldsB = smem_l + 2 * A_BYTES + wave * 1024;
@@ -1072,7 +1074,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
       }
     __syncthreads();
     constexpr int NCH4 = BM * CPR4 / (NW * 64);
-    float* slab = p.partial + (long long)blockIdx.z * p.M * p.N + n0;
+    float* slab = p.partial + (long long)bzi * p.M * p.N + n0;
 #pragma unroll
     for (int t = 0; t < NCH4; ++t) {
       const int id = t * (NW * 64) + tid;
@@ -1306,8 +1308,20 @@ static void launch_v3p_k(const IgemmParams& p, const PlanP& pp, dim3 grid, hipSt
   }
   DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3p_kernel<128, 4, 2, LEAN>), grid, dim3(512), lds, st, p, pp.PR, pp.tiles_per_img, pp.cps);
 }
-static void launch_v3p(const IgemmParams& p, const PlanP& pp, int images, hipStream_t st) {
-  const dim3 grid((unsigned)(images * pp.tiles_per_img), p.N / 128, pp.splits);
+// dct_tune_set(DCT_TUNE_IGEMM_XCD): 0 = natural 3-D grids; 1 = the per-tap and packed-rows kernels deal their blocks XCD by XCD
+// (xcd_remap) on layers whose packed weights outweigh their activations; 2 = on every layer they run
+int g_tune_igemm_xcd = 1;
+static dim3 xcd_grid(IgemmParams& p, dim3 grid) {
+  p.xcd_total = 0; p.xcd_gx = p.xcd_gy = 1;
+  const long long total = (long long)grid.x * grid.y * grid.z;
+  const bool heavy = p.w_bytes > p.x_bytes;
+  if (g_tune_igemm_xcd == 0 || (g_tune_igemm_xcd == 1 && !heavy) || total < 16 || total > (1 << 24)) return grid;
+  p.xcd_gx = (int)grid.x; p.xcd_gy = (int)grid.y; p.xcd_total = (int)total;
+  return dim3((unsigned)(((total + 7) / 8) * 8), 1, 1);
+}
+static void launch_v3p(const IgemmParams& p0, const PlanP& pp, int images, hipStream_t st) {
+  IgemmParams p = p0;
+  const dim3 grid = xcd_grid(p, dim3((unsigned)(images * pp.tiles_per_img), p.N / 128, pp.splits));
   // lean loop: buffer descriptors need the activations and the packed weights under 2 GiB each
   if ((g_tune_lean & 2) && p.x_bytes < (1ll << 31) && p.w_bytes < (1ll << 31)) launch_v3p_k<true>(p, pp, grid, st);
   else launch_v3p_k<false>(p, pp, grid, st);
@@ -1318,9 +1332,12 @@ static void launch_v3p(const IgemmParams& p, const PlanP& pp, int images, hipStr
 }
 
 template <typename T>
-static int launch(const IgemmParams& p, const Plan& pl, hipStream_t st) {
+static int launch(const IgemmParams& p0, const Plan& pl, hipStream_t st) {
+  IgemmParams p = p0;
   dim3 grid(div_up(p.M, pl.bm), p.N / pl.bn, pl.splits);
+  p.xcd_total = 0; p.xcd_gx = p.xcd_gy = 1;
   if (pl.v2) {
+    grid = xcd_grid(p, grid);
     if (pl.bn == 128) {
       if (pl.bounds) launch_v2<128, 128, 4, 2, true>(p, grid, st); else launch_v2<128, 128, 4, 2, false>(p, grid, st);
     } else {
@@ -1419,6 +1436,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     p.bits_out = d->relu_bits_out;
   }
   p.stem_x = nullptr; p.stem_slab = nullptr;
+  p.xcd_total = 0; p.xcd_gx = p.xcd_gy = 1;
   if (d->stem_x) {
     if (!d->stem_dw || !d->stem_db || ((uintptr_t)d->stem_x & 3)) return DCT_ERR_BAD_ARG;
     if (dtype != DCT_BF16 || y->c != 64 || x->c != 64 || d->R != 3 || d->S != 3 || d->stride != 1 || d->dil != 1 || p.scatter || d->accumulate ||
@@ -1545,6 +1563,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_ENET_MFMA: if (value < 0 || value > 3) return DCT_ERR_BAD_ARG; g_enet_mfma = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_SPLIT: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
+    case DCT_TUNE_IGEMM_XCD: if (value < 0 || value > 2) return DCT_ERR_BAD_ARG; g_tune_igemm_xcd = value; return DCT_OK;
     case 1005: g_tune_igemm_pool = value ? 1 : 0; return DCT_OK;
     case 1008: g_stem_dgrad_mfma = value ? 1 : 0; return DCT_OK;
     case 1002: g_tune_igemm_split_max_tiles = value; return DCT_OK;     // planner studies (tools/bench_conv.py --ab-knob)

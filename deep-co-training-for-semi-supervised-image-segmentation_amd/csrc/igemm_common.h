@@ -26,6 +26,8 @@ struct IgemmParams {
   unsigned char* pool_codes;    // ... and its routing codes (dct_maxpool2x2_fwd_codes), nullable
   int Hp, Wp;
   int pool_only;                // with pool_y: y itself is not wanted (no row stores)
+  int xcd_gx, xcd_gy, xcd_total;  // per-tap / packed-rows kernels, weights-heavy layers: 1-D launch of 8 * ceil(total / 8) blocks re-dealt so that
+                                // each XCD owns a contiguous range of the (pixel tile fastest, channel tile, split) order -- xcd_total = 0: off
   const float* stem_x;          // optional (64-channel shared-halo data gradient): the stem's input image, dense [n][Ho + 2][Wo + 2]; the block then
   float* stem_slab;             // leaves its [64][10] partial of the stem's weight (taps 0..8) / bias (9) gradient here and does not store y
 };
@@ -177,6 +179,22 @@ __device__ __forceinline__ void staged_pool_out(const IgemmParams& p, const char
       *reinterpret_cast<uint2*>(p.pool_codes + o) = cd.w;
     }
   }
+}
+
+// Block -> (pixel tile, channel tile, split) for the weights-heavy deep levels.  The hardware deals consecutive workgroups of a
+// launch over the 8 XCDs (L2 slices); with the natural 3-D grid every XCD therefore walks ALL channel tiles and fetches every
+// weight of the layer into its own L2 (8 x 18.9 MB for the centre's 1024 -> 1024 convolution).  Here XCD j takes the j-th eighth of
+// the order (pixel tile fastest), i.e. a few (channel tile, split) slices with all their pixel tiles: each weight is fetched by one
+// XCD, the (much smaller) activations by all.  Returns false for the padding blocks of the 1-D launch.
+__device__ __forceinline__ bool xcd_remap(const IgemmParams& p, int& bx, int& by, int& bz) {
+  if (p.xcd_total == 0) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; return true; }
+  const int L = blockIdx.x, per = (p.xcd_total + 7) >> 3;
+  const int logical = (L & 7) * per + (L >> 3);
+  if (logical >= p.xcd_total) return false;
+  bx = logical % p.xcd_gx;
+  const int rest = logical / p.xcd_gx;
+  by = rest % p.xcd_gy; bz = rest / p.xcd_gy;
+  return true;
 }
 
 // max(v, 0) as ONE instruction: from fmaxf() hipcc emits a canonicalising v_max_f32 v, v, v in front of the real one (signalling-NaN

@@ -1141,9 +1141,10 @@ static bool make_wplan(const dct_view* p, const dct_view* q, const dct_conv_desc
     } else {
       pitch = Wp + 2; nr = 66 / pitch; if (nr < 1) nr = 1;
       const int steps = (p->h + nr - 1) / nr;
-      const int last = p->h - (steps - 1) * nr;                 // image rows of an image's last step
-      const double subs = skips ? (steps - 1) * (double)((nr * pitch + 13) / 16) + (last * pitch + 13) / 16 : steps * 4.0;
-      fill = (double)p->h * Wp / (subs * 16.0);
+      // (narrow images keep the whole-step count: what the skipping saves there is an image's LAST step, and on the layers that
+      //  would newly qualify -- cen_a, cen_b, enc4a: one pixel chunk, direct -- the per-tap kernel measured 6-11 % faster:
+      //  profiles/r05_wgrad3_substep_skip_ab.txt)
+      fill = (double)p->h * Wp / (steps * 64.0);
       units = steps;
     }
     if (fill >= g_tune_wgrad_rows_fill * 0.01 && (long long)p->h * p->sh < (1ll << 29) && (long long)q->h * q->sh < (1ll << 29)) {

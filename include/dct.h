@@ -459,6 +459,8 @@ enum { DCT_TUNE_IGEMM_SPLIT = 1,   /* >= 1: force the split-K factor; -1 (defaul
        DCT_TUNE_ENET_MFMA = 26,              /* bf16 / f16 Enet: bit 0 = MFMA form of the convolutions with >= 16 input channels,
                                                 bit 1 = of the weight gradients; 3 (default), 0 = the fp32 VALU kernels */
        DCT_TUNE_ENET_MWGRAD_WAVES = 28,      /* >= 64 (default 2048): waves an MFMA weight-gradient launch aims for */
+       DCT_TUNE_IGEMM_XCD = 39,              /* 1 (default): the per-tap and packed-rows conv kernels deal the blocks of a weights-heavy layer XCD by XCD
+                                                (each weight is fetched into ONE L2 slice); 0: natural 3-D grids; 2: on every layer */
        DCT_TUNE_LEAN = 38 };                 /* bit mask (default 31: all set) of the instruction-lean loop forms, each bit-identical to
                                                 the plain form it replaces (0 = the plain forms, the tests' reference): bit 0 = filter-row weight gradient,
                                                 bit 1 = packed-rows conv kernel, bit 2 = per-tap weight gradient, bit 3 = per-tap conv kernel, bit 4 (with bit 0, round 5) =

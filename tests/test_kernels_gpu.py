@@ -234,7 +234,7 @@ def test_conv2d_packed_rows_lean_form_is_bit_identical(ops, B, Cin, H, W, Cout, 
 
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout,pad", [
-    (4, 64, 130, 132, 64, 0),       # filter-row kernel, wide images: runs of 64 pixels, ragged row tail (130 = 2 x 64 + 2)
+    (4, 64, 130, 132, 64, 0),       # filter-row kernel, wide images: runs of 64 pixels, ragged row tail (130 = 2 x 64 + 2: one sub-step)
     (8, 256, 27, 27, 128, 0),       # filter-row kernel, narrow images: packed rows at pitch 27, last step of an image partial
     (16, 1024, 11, 11, 128, 0),     # per-tap kernel (step fill under the filter-row threshold): one wave per K-step decodes the pixels
     (3, 128, 70, 101, 128, 1),      # padding: the filter-row kernel keeps its plain form, the per-tap kernel's bounds go through the table
@@ -256,7 +256,7 @@ def test_conv2d_wgrad_lean_forms_are_bit_identical(ops, B, Cin, H, W, Cout, pad)
     dy = to_dev(q(torch.randn(B, Cout, Ho, Wo, generator=g), dtype), dtype)
     lib = _lib.load()
     outs = {}
-    force_rows = (B, Cin, H, W) in ((4, 64, 88, 88), (4, 128, 48, 48), (3, 128, 30, 20), (2, 64, 50, 35))
+    force_rows = (B, Cin, H, W) in ((4, 64, 130, 132), (4, 64, 88, 88), (4, 128, 48, 48), (3, 128, 30, 20), (2, 64, 50, 35))
     try:
         if force_rows:
             assert lib.dct_tune_set(9, 1) == 0
@@ -509,6 +509,41 @@ def test_conv2d_per_tap_lean_form_is_bit_identical(ops, B, Cin, H, W, Cout, k, p
         lib.dct_tune_set(7, 1)
     assert not torch.isnan(outs[0].float()).any()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "lean per-tap kernel differs from the plain form"
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,pad,halo", [
+    (16, 1024, 11, 11, 1024, 0, 1),   # the centre's second convolution: per-tap kernel, 88 tiles x 5 splits (fp32 slabs + fold)
+    (16, 1024, 9, 9, 512, 2, 1),      # its data-gradient form: packed-rows kernel split over channel slices
+    (16, 512, 16, 16, 512, 0, 1),     # packed rows, unsplit, staged epilogue
+    (5, 128, 30, 46, 128, 0, 0),      # per-tap kernel on a mid-size image, a block count that is not a multiple of eight
+    (3, 64, 40, 44, 64, 1, 0),        # 256 x 64 per-tap tile with bounds
+])
+def test_conv2d_xcd_block_order_is_bit_identical(ops, B, Cin, H, W, Cout, pad, halo):
+    """DCT_TUNE_IGEMM_XCD: the per-tap and packed-rows kernels launched as a 1-D grid whose blocks are re-dealt XCD by XCD (2: on
+    every layer) give the natural grid's output bit for bit -- same tiles, same K order; only which block computes which tile moves.
+    The padding blocks of the 1-D launch (total not a multiple of eight) must leave nothing behind."""
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(41)
+    x = to_dev(q(torch.randn(B, Cin, H, W, generator=g), dtype), dtype)
+    w = kmajor(q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9), dtype), dtype)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    lib = _lib.load()
+    outs = []
+    try:
+        lib.dct_tune_set(7, halo)
+        for mode in (0, 2, 2):
+            assert lib.dct_tune_set(39, mode) == 0
+            y = torch.full((B, Ho + 1, Wo, Cout), float("nan"), dtype=dtype, device=DEV)     # one guard row behind every image
+            ops.conv2d(x, w, b, y[:, :Ho], pad_h=pad, pad_w=pad, relu=True)
+            outs.append(y)
+    finally:
+        lib.dct_tune_set(39, 1)
+        lib.dct_tune_set(7, 1)
+    assert not torch.isnan(outs[0][:, :Ho].float()).any() and torch.isnan(outs[1][:, Ho].float()).all()
+    assert torch.equal(outs[0][:, :Ho].view(torch.int16), outs[1][:, :Ho].view(torch.int16)), "XCD-dealt launch differs from the natural grid"
+    assert torch.equal(outs[1][:, :Ho].view(torch.int16), outs[2][:, :Ho].view(torch.int16))
 
 
 def _pack_bits(t_nhwc):
