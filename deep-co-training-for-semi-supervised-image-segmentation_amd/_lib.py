@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
                 ("accumulate", C.c_int32), ("mask_channels", C.c_int32), ("mask_scale", C.c_float),
                 ("mask_bits", C.c_void_p), ("relu_bits_out", C.c_void_p), ("pool_out", C.c_void_p), ("pool_codes", C.c_void_p),
                 ("pool_only", C.c_int32), ("stem_x", C.c_void_p), ("stem_dw", C.c_void_p), ("stem_db", C.c_void_p),
-                ("stem_accumulate", C.c_int32)]
+                ("stem_accumulate", C.c_int32), ("unpool_codes", C.c_void_p), ("unpool_h", C.c_int32), ("unpool_w", C.c_int32)]
 
 
 class EnetTf(C.Structure):
@@ -45,9 +45,11 @@ class EnetBwdIn(C.Structure):
 
 def conv_desc(R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=0, scatter2x2=0, accumulate=0,
               mask_channels=0, mask_scale=1.0, mask_bits=None, relu_bits_out=None, pool_out=None, pool_codes=None,
-              pool_only=False, stem=None) -> ConvDesc:
-    """``stem``: (x fp32 dense [N,H+2,W+2,1], dw [64,9], db [64], accumulate) -- dct_conv_desc.stem_*"""
+              pool_only=False, stem=None, unpool=None) -> ConvDesc:
+    """``stem``: (x fp32 dense [N,H+2,W+2,1], dw [64,9], db [64], accumulate) -- dct_conv_desc.stem_*;
+    ``unpool``: (codes uint8 dense [N,(H+1)//2,(W+1)//2,C], H, W) -- dct_conv_desc.unpool_*"""
     sx, sdw, sdb, sacc = stem if stem is not None else (None, None, None, False)
+    ucodes, uh, uw = unpool if unpool is not None else (None, 0, 0)
     return ConvDesc(R, S, stride, dil, pad_h, pad_w, int(relu), int(scatter2x2), int(accumulate),
                     int(mask_channels), float(mask_scale),
                     mask_bits.data_ptr() if mask_bits is not None else None,
@@ -55,7 +57,8 @@ def conv_desc(R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=0, scatter2x2=0,
                     pool_out.data_ptr() if pool_out is not None else None,
                     pool_codes.data_ptr() if pool_codes is not None else None, int(bool(pool_only)),
                     sx.data_ptr() if sx is not None else None, sdw.data_ptr() if sdw is not None else None,
-                    sdb.data_ptr() if sdb is not None else None, int(bool(sacc)))
+                    sdb.data_ptr() if sdb is not None else None, int(bool(sacc)),
+                    ucodes.data_ptr() if ucodes is not None else None, int(uh), int(uw))
 
 
 def view(t: torch.Tensor) -> View:

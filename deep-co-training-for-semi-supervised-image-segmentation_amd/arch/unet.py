@@ -203,6 +203,8 @@ class UNet(nn.Module):
         self.pool_only = True                # ... whose full-resolution output is then not stored at all (nobody else reads it)
         self.fuse_stem_wgrad = True          # the stem's weight gradient from the epilogue of the data gradient that produces its dy (not stored then)
         self.fuse_skip_grad = True           # the skip connections' bilinear backward gathered by the un-pooling instead of summed in memory
+        self.unpool_on_load = True           # levels 1-3: the un-pooled gradient of an encoder block is never written -- its two consumers expand
+                                             # {pooled gradient + routing codes} while they stage (dct_conv_desc.unpool_codes)
         self._wgrad_stream = None
 
     # ------------------------------------------------------------------------------ weights
@@ -492,25 +494,44 @@ class UNet(nn.Module):
 
         stem_fused = [False]
 
-        def conv_bwd(conv, x_in, dy, dx_out, mask=None, mask_channels=0, mask_scale=1.0, accumulate=False, stem=None):
+        def conv_bwd(conv, x_in, dy, dx_out, mask=None, mask_channels=0, mask_scale=1.0, accumulate=False, stem=None, unpool=None):
             """dy: grad wrt the conv's pre-activation output (already ReLU-masked).  ``stem``: (x, dw, db, accumulate) -- try to take
-            the stem's weight gradient from this data gradient's output tile (dx_out is then not written; stem_fused[0] tells)."""
+            the stem's weight gradient from this data gradient's output tile (dx_out is then not written; stem_fused[0] tells).
+            ``unpool`` = (codes, H, W): dy is the gradient at the POOLED tensor; the kernels expand it to the un-pooled gradient while
+            they stage where they can, else it is un-pooled into a buffer here, once, for whoever still needs it."""
+            def materialised():
+                codes, uh, uw = unpool
+                full = torch.empty(dy.shape[0], uh, uw, dy.shape[3], dtype=dt, device=dev)
+                return K.maxpool_bwd(None, dy, full, relu_mask=True, scale=1.0, codes=codes)
             if need_dw:
                 with on_side(dy, x_in):
                     if dt == torch.bfloat16:     # bias gradient rides along in the weight-gradient launch
-                        K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=gacc, db=self._gb(conv))
+                        try:
+                            K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=gacc, db=self._gb(conv), unpool=unpool)
+                        except K.UnpoolOnLoadUnsupported:
+                            dy, unpool = materialised(), None
+                            K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=gacc, db=self._gb(conv))
                     else:
+                        if unpool is not None:
+                            dy, unpool = materialised(), None
                         K.conv2d_wgrad(dy, x_in, self._gw(conv), accumulate=gacc)
                         K.bias_grad(dy, self._gb(conv), accumulate=gacc)
             if dx_out is not None:
                 mb = gate_bits.get(id(mask)) if mask is not None else None
                 if stem is not None and mb is not None:
                     try:
-                        K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, pad_h=2, pad_w=2, mask=mask, mask_bits=mb, stem=stem)
+                        K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, pad_h=2, pad_w=2, mask=mask, mask_bits=mb, stem=stem, unpool=unpool)
                         stem_fused[0] = True
                         return dx_out
                     except K.StemFusionUnsupported:
-                        pass
+                        pass                     # (the stem's weight gradient then runs as its own launch)
+                if unpool is not None:
+                    try:
+                        K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, pad_h=2, pad_w=2, mask=mask, mask_channels=mask_channels,
+                                 mask_scale=mask_scale, accumulate=accumulate, mask_bits=mb, unpool=unpool)
+                        return dx_out
+                    except K.UnpoolOnLoadUnsupported:
+                        dy, unpool = materialised(), None
                 K.conv2d(dy, P[id(conv)]["dgrad"], None, dx_out, pad_h=2, pad_w=2, mask=mask,
                          mask_channels=mask_channels, mask_scale=mask_scale, accumulate=accumulate, mask_bits=mb)
             return dx_out
@@ -551,11 +572,15 @@ class UNet(nn.Module):
         dp: Dict[int, torch.Tensor] = {}
         skip_g: Dict[int, torch.Tensor] = {}
         skip_fused = bool(self.fuse_skip_grad and all(A.get(f"pc{k}") is not None for k in (1, 2, 3, 4)))
+        # Levels whose un-pooled gradient is expanded on load (no un-pooling launch to gather the skip gradient in): the bilinear
+        # backward of the skip connection is written to dp and the next block's data gradient accumulates onto it.
+        up_levels = {k for k in (1, 2, 3) if self.unpool_on_load and dt == torch.bfloat16 and A.get(f"pc{k}") is not None and
+                     isinstance(A[f"d{k}"], _ShapeOf) and self._debug is None}
         for lvl, co in ((2, 64), (3, 128), (4, 256)):
             ca, _, cb, _, ct = self._roles[f"enc{lvl}"]
             ea, eb = A[f"e{lvl}a"], A[f"e{lvl}b"]
             p = A[f"p{lvl - 1}"]
-            if skip_fused:
+            if skip_fused and (lvl - 1) not in up_levels:
                 skip_g[lvl - 1] = dcat[..., co:]          # gathered by level (lvl - 1)'s un-pooling (K.maxpool_bwd(..., skip=))
             else:
                 dp[lvl - 1] = K.bilinear_bwd(dcat[..., co:], new_like(p))
@@ -587,17 +612,22 @@ class UNet(nn.Module):
         for lvl in (4, 3, 2, 1):
             ca, _, cb, _ = self._roles[f"dec{lvl}"]
             a, d = A[f"a{lvl}"], A[f"d{lvl}"]
-            dd = K.maxpool_bwd(d, dp[lvl], new_like(d), relu_mask=True, scale=ds if lvl == 4 else 1.0, codes=A.get(f"pc{lvl}"),
-                               skip=skip_g.get(lvl))
+            unpool = None
+            if lvl in up_levels:
+                dd, unpool = dp[lvl], (A[f"pc{lvl}"], d.shape[1], d.shape[2])      # the pooled gradient stands for the un-pooled one
+            else:
+                dd = K.maxpool_bwd(d, dp[lvl], new_like(d), relu_mask=True, scale=ds if lvl == 4 else 1.0, codes=A.get(f"pc{lvl}"),
+                                   skip=skip_g.get(lvl))
             stem = None
             if (lvl == 1 and need_dw and not need_dx and self.fuse_stem_wgrad and dt == torch.bfloat16 and side is None and
                     A["bn"].get("a1") is None and self._debug is None):
                 stem = (A["x"], self._gw(ca), self._gb(ca), gacc)       # the stem's dy has no other reader: see dct_conv_desc.stem_x
-            da = bn_back(f"a{lvl}", conv_bwd(cb, a, dd, new_like(a), mask=a, stem=stem))
+            da = bn_back(f"a{lvl}", conv_bwd(cb, a, dd, new_like(a), mask=a, stem=stem, unpool=unpool))
             if lvl > 1:
-                if skip_fused:
+                summed = not skip_fused or (lvl - 1) in up_levels          # dp[lvl - 1] already holds the skip connection's share
+                if not summed:
                     dp[lvl - 1] = new_like(A[f"p{lvl - 1}"])
-                conv_bwd(ca, A[f"p{lvl - 1}"], da, dp[lvl - 1], accumulate=not skip_fused)
+                conv_bwd(ca, A[f"p{lvl - 1}"], da, dp[lvl - 1], accumulate=summed)
             else:
                 c0 = ca
                 if need_dw and not stem_fused[0]:

@@ -68,6 +68,26 @@ __device__ __forceinline__ float block_sum_256(float v, float* smem4) {
   return smem4[0] + smem4[1] + smem4[2] + smem4[3];
 }
 
+// ---- un-pooling on load (round 5) -------------------------------------------------------------------------------------------------
+// The gradient at a max-pooled tensor and the pooling's routing codes (dct_maxpool2x2_fwd_codes: bits 0-1 = window position of
+// the first maximum, bit 2 = its ReLU gate, bit 3 = no maximum) ARE the un-pooled gradient, at 3 bytes per window and channel
+// instead of 8 -- three of its four positions are zero by construction.  The consumers of an encoder block's un-pooled gradient
+// (the block's data gradient and weight gradient) expand {eight pooled bf16 + their eight codes} into the 16-byte chunk of window
+// position `pos` while they stage: the same values dct_maxpool2x2_bwd_codes(relu_mask = 1, scale = 1) would have written.
+// Per 32-bit pair of elements: the two code bytes move into the 16-bit lanes (v_perm_b32), "== pos | 4" becomes 0 / 0xFFFF
+// (packed min / sub on the XORed codes), one AND.
+__device__ __forceinline__ uint4 dct_unpool_chunk8(uint4 g, uint2 codes, unsigned pos) {
+  const unsigned key = (pos | 4u) * 0x01010101u;
+  const unsigned c0 = (codes.x & 0x0F0F0F0Fu) ^ key, c1 = (codes.y & 0x0F0F0F0Fu) ^ key;       // zero byte <=> routed here and gate open
+  unsigned m[4];
+  const unsigned z[4] = {__builtin_amdgcn_perm(0u, c0, 0x0c010c00u), __builtin_amdgcn_perm(0u, c0, 0x0c030c02u),
+                         __builtin_amdgcn_perm(0u, c1, 0x0c010c00u), __builtin_amdgcn_perm(0u, c1, 0x0c030c02u)};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    asm("v_pk_min_u16 %0, %1, %2\n\tv_pk_sub_u16 %0, %0, %2" : "=&v"(m[k]) : "v"(z[k]), "v"(0x00010001u));       // 0 -> 0xFFFF, else 0
+  return make_uint4(g.x & m[0], g.y & m[1], g.z & m[2], g.w & m[3]);
+}
+
 // ---- profiling hooks (prof.cpp) -------------------------------------------------------------
 void dct_prof_begin(int cls, hipStream_t s);
 void dct_prof_end(int cls, hipStream_t s);

@@ -571,7 +571,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
 // Variants of this tile that were measured and removed: a four-slot ring of 32-channel weight half-stages with
 // counted vmcnt and raw barriers (-15 %: twice the barriers for the same MFMAs), four waves of 64 x 64 instead of eight of
 // 32 x 64 (-8 %), three unrolled taps per loop trip (-13 %), an XCD-aware tile order (level), amdgpu_waves_per_eu(4) (-1 %).
-template <int BN, int NWM, int NWN, int ABUFS>
+// UNPOOL (round 5): the input is an encoder block's un-pooled gradient that nobody has written: x = the gradient at the pooled tensor,
+// up_codes = the pooling's routing codes.  The 10 x 18 halo of a slice is 5 x 9 whole windows (patches start at multiples of
+// (8, 16) and the data gradient's padding is 2: even coordinates); an item = one window x 8 channels -- 16 bytes of gradient and 8
+// code bytes through registers, four 16-byte LDS writes -- takes the place of the halo's LDS-DMA pieces.  A window outside the pooled
+// tensor stages zeros (the data gradient's padding).  8.6 KB per halo instead of 22.5 KB, and the 130 MB un-pooled tensor of the
+// first level (with its producer launch) is gone.
+template <int BN, int NWM, int NWN, int ABUFS, bool UNPOOL>
 __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, int tiles_x, int tiles_y) {
   constexpr int NW = NWM * NWN;
   constexpr int TH = 8, TW = 16, BM = TH * TW, HW = TW + 2, HROWS = (TH + 2) * HW;   // 180 halo rows of 128 B
@@ -618,6 +624,49 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
       if (piece < APIECES) {
         const char* src = aoff[i] >= 0 ? reinterpret_cast<const char*>(xb + aoff[i] + c0) : zero;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + piece * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // UNPOOL: this thread's windows of the halo.  The pooled gradient is DENSE (host-checked), so the element offset of an item's eight
+  // gradients is also the byte offset of its eight codes: one register per item (-1: no item, -2: an item that stages zeros).
+  constexpr int UITEMS = UNPOOL ? (45 * 8 + NW * 64 - 1) / (NW * 64) : 1;
+  int ugoff[UITEMS];
+  uint4 ug[UITEMS];
+  uint2 uc[UITEMS];
+  if constexpr (UNPOOL) {
+#pragma unroll
+    for (int i = 0; i < UITEMS; ++i) {
+      const int id = tid + i * NW * 64;
+      const int w = id >> 3, wy = w / 9, wx = w - wy * 9;
+      ugoff[i] = -1;
+      if (id < 45 * 8) {
+        const int py = (y0 - p.pad_h) / 2 + wy, px = (x0 - p.pad_w) / 2 + wx;       // (exact: even numerators)
+        ugoff[i] = ((unsigned)py < (unsigned)p.up_Hp && (unsigned)px < (unsigned)p.up_Wp)
+                       ? (int)(((long long)(img * p.up_Hp + py) * p.up_Wp + px) * p.Cin + (id & 7) * 8) : -2;
+      }
+    }
+  }
+  auto unpool_load = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < UITEMS; ++i) {
+      ug[i] = make_uint4(0u, 0u, 0u, 0u); uc[i] = make_uint2(0x08080808u, 0x08080808u);       // code 8: routed nowhere
+      if (ugoff[i] >= 0) {
+        ug[i] = *reinterpret_cast<const uint4*>(xb + ugoff[i] + c0);
+        uc[i] = *reinterpret_cast<const uint2*>(p.up_codes + ugoff[i] + c0);
+      }
+    }
+  };
+  auto unpool_store = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < UITEMS; ++i) {
+      if (ugoff[i] == -1) continue;
+      const int id = tid + i * NW * 64;
+      const int w = id >> 3, c8 = id & 7, wy = w / 9, wx = w - wy * 9;
+      const int row0 = (2 * wy) * HW + 2 * wx;                   // halo row of the window's first position
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = row0 + (k >> 1) * HW + (k & 1);
+        *reinterpret_cast<uint4*>(buf + row * 128 + ((c8 ^ ((row >> 1) & 7)) * 16)) = dct_unpool_chunk8(ug[i], uc[i], (unsigned)k);
       }
     }
   };
@@ -672,10 +721,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
       }
     }
   }
-  stageA(Abuf, 0);
+  if constexpr (UNPOOL) unpool_load(0); else stageA(Abuf, 0);
   stageB(Bbuf, 0, 0);
   float* biasL = reinterpret_cast<float*>(smem + ABUFS * A_BYTES + 2 * B_BYTES);   // bias -> LDS now: no memory round trip in the epilogue
   if (tid < BN) biasL[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+  if constexpr (UNPOOL) unpool_store(Abuf);
   __syncthreads();
   // Fragment addresses with as little vector ALU work as the layout allows.  Weights: a lane's two sub-step addresses are
   // constants of the lane (+ the stage, a scalar); the wave's 16-row blocks are reached through the read's immediate offset.
@@ -691,7 +741,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
       const int sx = t % 3, rr = t / 3;
       if (t < 8) stageB(Bbuf + (bb ^ 1) * B_BYTES, t + 1, c * 64);
       else if (c + 1 < nch) stageB(Bbuf + (bb ^ 1) * B_BYTES, 0, (c + 1) * 64);
-      if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
+      if constexpr (UNPOOL) {
+        // the next slice's windows: loads in flight over taps 3..8, expanded into the free halo stage in front of the slice's last barrier
+        if (ABUFS == 2 && t == 3 && c + 1 < nch) unpool_load((c + 1) * 64);
+      } else {
+        if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
+      }
       const unsigned wa0 = Wb0 + bb * B_BYTES, wa1 = wa0 ^ 64u;
       unsigned rho_t = rho0;
       asm volatile("" : "+v"(rho_t));                        // recompute the tap's two addresses here (6 VALU) instead of keeping hoisted ones in registers
@@ -718,6 +773,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
 #pragma unroll
           for (int j = 0; j < PXB; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k2][i], b[k2][j], acc[i][j], 0, 0, 0);
+      }
+      if constexpr (UNPOOL) {
+        if (ABUFS == 2 && t == 8 && c + 1 < nch) unpool_store(Abuf + (ab ^ 1) * A_BYTES);
       }
       __syncthreads();
       bb ^= 1;
@@ -1244,17 +1302,22 @@ static void launch_v2(const IgemmParams& p, dim3 grid, hipStream_t st) {
   else launch_v2_k<BM, BN, WM, WN, BOUNDS, false>(p, grid, st);
 }
 
-template <int BN, int NWN, int ABUFS>
-static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images, hipStream_t st) {
+template <int BN, int NWN, int ABUFS, bool UNPOOL>
+static void launch_v3u(const IgemmParams& p, int tiles_x, int tiles_y, int images, hipStream_t st) {
   constexpr size_t lds = ABUFS * (size_t)(23 * 1024) + 2 * (size_t)BN * 128 + (size_t)BN * 4;   // halo stage(s), two weight stages, bias
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3m_kernel<BN, 4, NWN, ABUFS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3m_kernel<BN, 4, NWN, ABUFS, UNPOOL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const dim3 grid((unsigned)(images * tiles_y * tiles_x), p.N / BN, 1);
-  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 4, NWN, ABUFS>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
+  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 4, NWN, ABUFS, UNPOOL>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
+}
+template <int BN, int NWN, int ABUFS>
+static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images, hipStream_t st) {
+  if (p.up_codes) launch_v3u<BN, NWN, ABUFS, true>(p, tiles_x, tiles_y, images, st);
+  else launch_v3u<BN, NWN, ABUFS, false>(p, tiles_x, tiles_y, images, st);
 }
 
 // Packed-rows shared-halo kernel (igemm3p_kernel) for small images: geometry and split over channel slices.
@@ -1311,17 +1374,21 @@ static void launch_v3p_k(const IgemmParams& p, const PlanP& pp, dim3 grid, hipSt
 // dct_tune_set(DCT_TUNE_IGEMM_XCD): 0 = natural 3-D grids; 1 = the per-tap and packed-rows kernels deal their blocks XCD by XCD
 // (xcd_remap) on layers whose packed weights outweigh their activations; 2 = on every layer they run
 int g_tune_igemm_xcd = 1;
-static dim3 xcd_grid(IgemmParams& p, dim3 grid) {
+static dim3 xcd_grid(IgemmParams& p, dim3 grid, bool per_tap) {
   p.xcd_total = 0; p.xcd_gx = p.xcd_gy = 1;
   const long long total = (long long)grid.x * grid.y * grid.z;
-  const bool heavy = p.w_bytes > p.x_bytes;
-  if (g_tune_igemm_xcd == 0 || (g_tune_igemm_xcd == 1 && !heavy) || total < 16 || total > (1 << 24)) return grid;
+  // measured per layer (profiles/r05_xcd_block_order_ab.txt): the per-tap kernel gains where the weights outweigh the activations
+  // (the centre's 1024 -> 1024 convolution 53 -> 42 us, its transposed convolution 17.3 -> 15.7); the packed-rows kernel LOSES 2-10 %
+  // on the same layers (its XCDs then stream eight different weight slices at once instead of sharing one through the memory-side
+  // cache), so it takes the order only when forced (2: the bit-identity test)
+  const bool want = g_tune_igemm_xcd == 2 || (g_tune_igemm_xcd == 1 && per_tap && p.w_bytes > p.x_bytes);
+  if (!want || total < 16 || total > (1 << 24)) return grid;
   p.xcd_gx = (int)grid.x; p.xcd_gy = (int)grid.y; p.xcd_total = (int)total;
   return dim3((unsigned)(((total + 7) / 8) * 8), 1, 1);
 }
 static void launch_v3p(const IgemmParams& p0, const PlanP& pp, int images, hipStream_t st) {
   IgemmParams p = p0;
-  const dim3 grid = xcd_grid(p, dim3((unsigned)(images * pp.tiles_per_img), p.N / 128, pp.splits));
+  const dim3 grid = xcd_grid(p, dim3((unsigned)(images * pp.tiles_per_img), p.N / 128, pp.splits), false);
   // lean loop: buffer descriptors need the activations and the packed weights under 2 GiB each
   if ((g_tune_lean & 2) && p.x_bytes < (1ll << 31) && p.w_bytes < (1ll << 31)) launch_v3p_k<true>(p, pp, grid, st);
   else launch_v3p_k<false>(p, pp, grid, st);
@@ -1337,7 +1404,7 @@ static int launch(const IgemmParams& p0, const Plan& pl, hipStream_t st) {
   dim3 grid(div_up(p.M, pl.bm), p.N / pl.bn, pl.splits);
   p.xcd_total = 0; p.xcd_gx = p.xcd_gy = 1;
   if (pl.v2) {
-    grid = xcd_grid(p, grid);
+    grid = xcd_grid(p, grid, true);
     if (pl.bn == 128) {
       if (pl.bounds) launch_v2<128, 128, 4, 2, true>(p, grid, st); else launch_v2<128, 128, 4, 2, false>(p, grid, st);
     } else {
@@ -1364,8 +1431,17 @@ void dct_relu_bits_launch(const void* y_bf16, unsigned char* bits, long long chu
   DCT_LAUNCH(DCT_PROF_POINTWISE, relu_bits_kernel, dim3(div_up(chunks, 256)), dim3(256), 0, st, (const bf16_t*)y_bf16, bits, chunks);
 }
 
-extern "C" size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype) {
-  if (!x || !y || !d) return 0;
+// the view the convolution arithmetic runs on: x itself, or (d->unpool_codes) the un-pooled tensor x stands for
+static dct_view conv_input_extent(const dct_view* x, const dct_conv_desc* d) {
+  dct_view v = *x;
+  if (d->unpool_codes) { v.h = d->unpool_h; v.w = d->unpool_w; }
+  return v;
+}
+
+extern "C" size_t dct_conv2d_workspace_bytes(const dct_view* x0, const dct_view* y, const dct_conv_desc* d, int dtype) {
+  if (!x0 || !y || !d) return 0;
+  const dct_view xe = conv_input_extent(x0, d);
+  const dct_view* x = &xe;
   const int Ho = d->scatter2x2 ? y->h / 2 : y->h, Wo = d->scatter2x2 ? y->w / 2 : y->w;
   const int M = y->n * Ho * Wo;
   const int N = d->scatter2x2 ? 4 * y->c : y->c;
@@ -1378,10 +1454,20 @@ extern "C" size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* 
   return need;
 }
 
-extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* bias, const dct_view* mask,
+extern "C" int dct_conv2d(const dct_view* x0, const void* w_packed, const float* bias, const dct_view* mask,
                           const dct_view* y, const dct_conv_desc* d, int dtype,
                           void* workspace, size_t workspace_bytes, dct_stream stream) {
-  if (!view_ok(x) || !view_ok(y) || !w_packed || !d) return DCT_ERR_BAD_ARG;
+  if (!view_ok(x0) || !view_ok(y) || !w_packed || !d) return DCT_ERR_BAD_ARG;
+  if (d->unpool_codes) {
+    // x0 is the gradient at the pooled tensor; the convolution runs on the un-pooled extent (strides stay x0's: the kernel indexes windows)
+    if (d->unpool_h < 1 || d->unpool_w < 1 || x0->h != (d->unpool_h + 1) / 2 || x0->w != (d->unpool_w + 1) / 2) return DCT_ERR_BAD_ARG;
+    if (dtype != DCT_BF16 || d->R != 3 || d->S != 3 || d->stride != 1 || d->dil != 1 || d->scatter2x2 || d->pad_h != 2 || d->pad_w != 2 ||
+        x0->c % 64 || ((uintptr_t)d->unpool_codes & 7) || x0->sw != x0->c || x0->sh != (long long)x0->w * x0->c ||
+        x0->sn != (long long)x0->h * x0->w * x0->c || (long long)x0->n * x0->sn >= (1ll << 31))
+      return DCT_ERR_UNSUPPORTED;
+  }
+  const dct_view xe = conv_input_extent(x0, d);
+  const dct_view* x = &xe;
   if (dtype != DCT_F32 && dtype != DCT_BF16) return DCT_ERR_BAD_ARG;
   if (d->R < 1 || d->S < 1 || d->stride < 1 || d->dil < 1) return DCT_ERR_BAD_ARG;
   if (x->n != y->n) return DCT_ERR_BAD_ARG;
@@ -1437,6 +1523,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
   }
   p.stem_x = nullptr; p.stem_slab = nullptr;
   p.xcd_total = 0; p.xcd_gx = p.xcd_gy = 1;
+  p.up_codes = d->unpool_codes; p.up_Hp = x0->h; p.up_Wp = x0->w;
   if (d->stem_x) {
     if (!d->stem_dw || !d->stem_db || ((uintptr_t)d->stem_x & 3)) return DCT_ERR_BAD_ARG;
     if (dtype != DCT_BF16 || y->c != 64 || x->c != 64 || d->R != 3 || d->S != 3 || d->stride != 1 || d->dil != 1 || p.scatter || d->accumulate ||
@@ -1516,6 +1603,7 @@ extern "C" int dct_conv2d(const dct_view* x, const void* w_packed, const float* 
     }
   }
   if (d->stem_x) return DCT_ERR_UNSUPPORTED;      // only the shared-halo 64-channel tile can take the stem along
+  if (d->unpool_codes) return DCT_ERR_UNSUPPORTED;      // only the shared-halo kernels expand a pooled gradient while they stage (the caller un-pools first)
   if (pl.v2 && (!bias || !((uintptr_t)bias & 15))) {
     const PlanP pp = make_plan_p(x, y, d, dtype, p.N);
     if (pp.use) {

@@ -28,6 +28,8 @@ struct IgemmParams {
   int pool_only;                // with pool_y: y itself is not wanted (no row stores)
   int xcd_gx, xcd_gy, xcd_total;  // per-tap / packed-rows kernels, weights-heavy layers: 1-D launch of 8 * ceil(total / 8) blocks re-dealt so that
                                 // each XCD owns a contiguous range of the (pixel tile fastest, channel tile, split) order -- xcd_total = 0: off
+  const unsigned char* up_codes;  // optional (shared-halo kernels, round 5): x is the gradient at a 2x2 max-POOLED tensor [n][up_Hp][up_Wp][Cin] (strides
+  int up_Hp, up_Wp;               // xsN / xsH / xsW) and up_codes its dense routing codes; the kernel stages the un-pooled gradient [n][Hi][Wi][Cin] from them
   const float* stem_x;          // optional (64-channel shared-halo data gradient): the stem's input image, dense [n][Ho + 2][Wo + 2]; the block then
   float* stem_slab;             // leaves its [64][10] partial of the stem's weight (taps 0..8) / bias (9) gradient here and does not store y
 };

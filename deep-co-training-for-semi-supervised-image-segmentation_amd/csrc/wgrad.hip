@@ -596,6 +596,8 @@ struct Wgrad3Params {
   int pitch, nr, units_per_image;     // pitch > 0: narrow images -- a K-step packs nr image rows at a pitch of Wp + 2 rows
   int direct, accumulate, with_bias;
   int skip_empty;                     // LEAN: multiply only the 16-row sub-steps of a K-step that hold dy pixels
+  const unsigned char* up_codes;      // UNPOOL: P is the DENSE gradient at the pooled tensor [n][up_Hp][up_Wp][Cp], up_codes its routing codes; w.Hp / w.Wp
+  int up_Hp, up_Wp;                   // stay the extent of the un-pooled tensor the reduction runs over
   float* bias;
   long long slab_stride;
   long long p_bytes, q_bytes;         // LEAN: bytes from P / Q to the end of the views (buffer descriptor ranges, < 2^31)
@@ -622,8 +624,14 @@ template <int RB> __device__ __forceinline__ int swz3(int k) {       // in 16-B 
 // QSHIFT: the x fragments of a row's three taps come from ONE 12-pixel window per lane (three transposing reads) -- tap 2 is the
 // window moved by one dword, tap 1 four v_alignbit_b32 -- instead of three separate 8-pixel reads: 5 instead of 8 fragment reads per
 // sub-step (0.83 KiB of LDS per MFMA instead of 1.33; the kernel is LDS-bandwidth bound).  Same MFMA operands bit for bit.
-template <int BP, int BQ, int NW, bool NARROW, int G, bool QSHIFT, bool LEAN>
+// UNPOOL (round 5; LEAN, one image row per K-step): the dy operand is an encoder block's un-pooled gradient, expanded while it is
+// staged from the gradient at the pooled tensor and the pooling's routing codes (dct_common.h dct_unpool_chunk8).  A K-step's 64
+// pixels of image row y are 32 windows of pooled row y / 2; a thread of the group owns one window x 8 channels: 16 + 8 bytes through
+// registers (issued with the step's LDS-DMA pieces, one K-step ahead), two 16-byte LDS writes in front of the step's barrier -- the
+// positions (y % 2, 0) and (y % 2, 1) of the window; windows past the row's end write zeros.  The x strip is staged as before.
+template <int BP, int BQ, int NW, bool NARROW, int G, bool QSHIFT, bool LEAN, bool UNPOOL = false>
 __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
+  static_assert(!UNPOOL || (LEAN && BP == 64 && NW == 4), "UNPOOL: lean loop, 64-channel dy tile, 256 threads per group");
   const WgradParams& p = pr.w;
   constexpr int RBP = BP * 2, RBQ = BQ * 2;
   constexpr int CPRP = RBP / 16, CPRQ = RBQ / 16, RPIP = 64 / CPRP, RPIQ = 64 / CPRQ;
@@ -719,8 +727,26 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
   // so their MFMAs (and bias sums) add exact zeros: the loop skips them -- a row tail of 20 pixels (84-pixel rows: 64 + 20) or
   // a packed step of 48 rows (one 46-pixel row + gap) costs two / three sub-steps instead of four.  Bit-identical.
   int sub_staged = 4;
+  // UNPOOL: the thread's window of a step (j = thread of the group / 8) and its 8-channel chunk
+  const int utg = wave * 64 + lane, uj = utg >> 3, uc8 = utg & 7;
+  const int uoff = uj * p.Cp + p0 + uc8 * 8;                                      // elements (= code bytes) from the step's first window
+  const int udst = (2 * uj) * RBP + ((uc8 ^ swz3<RBP>(2 * uj)) * 16);            // LDS bytes of the window's first pixel row in a dy tile (the second: + RBP)
+  uint4 ug = make_uint4(0u, 0u, 0u, 0u);
+  uint2 ucd = make_uint2(0u, 0u);
+  unsigned upos = 0;                 // window position of the staged step's first pixel column: 2 * (y % 2)
   auto stage = [&](char* buf) {
     if constexpr (LEAN) {
+      if constexpr (UNPOOL) {
+        // the step's windows: pooled row s_y / 2, from column s_x / 2 on; pixels 2 j, 2 j + 1 of the step lie in window j
+        const int lim_px = NARROW ? p.Wp : min(64, p.Wp - s_x);
+        const int base = ((s_n * pr.up_Hp + (s_y >> 1)) * pr.up_Wp + (s_x >> 1)) * p.Cp;
+        upos = (unsigned)(s_y & 1) * 2u;
+        ug = make_uint4(0u, 0u, 0u, 0u); ucd = make_uint2(0x08080808u, 0x08080808u);       // code 8: routed nowhere -> zeros
+        if (2 * uj < lim_px) {
+          ug = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.P) + base + uoff);
+          ucd = *reinterpret_cast<const uint2*>(pr.up_codes + base + uoff);
+        }
+      }
       const unsigned cP = offP, cQ = offQ;
       int lim;                    // LDS rows of this step that hold pixels (dy; the x strip has two more on wide images)
       bool full;
@@ -755,7 +781,7 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
           if (!live[i]) continue;
-          if (i < NPCP / NW) buf_lds16(rsP, buf + ldst[i], loff[i], cP);
+          if (i < NPCP / NW) { if constexpr (!UNPOOL) buf_lds16(rsP, buf + ldst[i], loff[i], cP); }
           else buf_lds16(rsQ, buf + ldst[i], loff[i], cQ);
         }
       } else {
@@ -765,8 +791,10 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
           if (!live[i]) continue;
           const int piece = wave + i * NW;
           if (i < NPCP / NW) {
+            if constexpr (!UNPOOL) {
             const int v = lrowP < lim - piece * RPIP ? loff[i] : (int)0x80000000u;
             buf_lds16(rsP, buf + ldst[i], v, cP);
+            }
           } else {
             const int v = lrowQ < limQ - (piece - NPCP) * RPIQ ? loff[i] : (int)0x80000000u;
             buf_lds16(rsQ, buf + ldst[i], v, cQ);
@@ -811,7 +839,15 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][i][j][e] = 0.f;
 
-  if (gbeg < gend) stage(smem);
+  // UNPOOL: the staged step's two pixel rows of this thread's window into the dy tile of `buf`
+  auto unpool_store = [&](char* buf) {
+    *reinterpret_cast<uint4*>(buf + udst) = dct_unpool_chunk8(ug, ucd, upos);
+    *reinterpret_cast<uint4*>(buf + udst + RBP) = dct_unpool_chunk8(ug, ucd, upos + 1u);
+  };
+  if (gbeg < gend) {
+    stage(smem);
+    if constexpr (UNPOOL) unpool_store(smem);
+  }
   __syncthreads();
   int cur = 0;
   int nsub = sub_staged;             // sub-steps of the step about to be multiplied
@@ -979,6 +1015,9 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
 #ifdef DCT_W3_STAMPS
     { const unsigned long long t = w3_stamp(); st_comp += t - st_t0; st_t0 = t; }
 #endif
+    if constexpr (UNPOOL) {
+      if (gi + 1 < gend) unpool_store(smem + (cur ^ 1) * STAGE);
+    }
     __syncthreads();
 #ifdef DCT_W3_STAMPS
     { const unsigned long long t = w3_stamp(); st_bar += t - st_t0; st_t0 = t; }
@@ -1203,24 +1242,33 @@ static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
   if ((g_tune_lean & 4) && pr.p_bytes < (1ll << 31) && pr.q_bytes < (1ll << 31)) launch_w2_k<BP, BQ, NW, true>(pr, grid, st);
   else launch_w2_k<BP, BQ, NW, false>(pr, grid, st);
 }
-template <int BP, int BQ, int NW, bool NARROW, int G, bool QSHIFT, bool LEAN>
+template <int BP, int BQ, int NW, bool NARROW, int G, bool QSHIFT, bool LEAN, bool UNPOOL = false>
 static void launch_w3_q(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
   constexpr size_t lds = G * 2 * (64 * (size_t)BP * 2 + 72 * (size_t)BQ * 2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT, LEAN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT, LEAN, UNPOOL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT, LEAN>), dim3(grid), dim3(G * NW * 64), lds, st, pr);
+  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT, LEAN, UNPOOL>), dim3(grid), dim3(G * NW * 64), lds, st, pr);
+}
+// lean form of the filter-row kernel: no padding, views under 2 GiB (buffer descriptors)
+static bool w3_lean(const Wgrad3Params& pr) {
+  return (g_tune_lean & 1) && pr.w.pad_h == 0 && pr.w.pad_w == 0 && pr.p_bytes < (1ll << 31) && pr.q_bytes < (1ll << 31);
 }
 static void launch_w3(const Wgrad3Params& pr, const WPlan& pl, hipStream_t st) {
   const unsigned grid = wgrid(pl, 3);
+  if (pr.up_codes) {        // (the caller has checked: lean form, one image row per K-step)
+    if (pr.pitch > 0) launch_w3_q<64, 64, 4, true, 2, true, true, true>(pr, grid, st);
+    else launch_w3_q<64, 64, 4, false, 2, true, true, true>(pr, grid, st);
+    return;
+  }
   // the planner only picks 64 x 64 tiles for this kernel; always two wave groups per block (half the fp32 slabs at the same waves
   // per CU: +4 % on the step; one group and four groups measured behind) and the three taps' x fragments from ONE 12-pixel window
   // per lane (QSHIFT: 5 transposing reads per sub-step instead of 8, +5-6.5 % on the twelve layers that take this kernel)
   // LEAN (the staging as buffer loads with constant lane offsets; bit-identical): layers without padding whose views stay under 2 GiB
-  const bool lean = (g_tune_lean & 1) && pr.w.pad_h == 0 && pr.w.pad_w == 0 && pr.p_bytes < (1ll << 31) && pr.q_bytes < (1ll << 31);
+  const bool lean = w3_lean(pr);
   if (pr.pitch > 0) {
     if (lean) launch_w3_q<64, 64, 4, true, 2, true, true>(pr, grid, st); else launch_w3_q<64, 64, 4, true, 2, true, false>(pr, grid, st);
   } else {
@@ -1241,10 +1289,23 @@ static void launch_w2(const Wgrad2Params& pr, const WPlan& pl, hipStream_t st) {
 unsigned long long* g_w3_stamps = nullptr;    // diagnostic builds only
 extern "C" int dct_debug_w3_stamps(void* buf) { g_w3_stamps = (unsigned long long*)buf; return 0; }
 
-extern "C" size_t dct_conv2d_wgrad_workspace_bytes(const dct_view* p, const dct_view* q, const dct_conv_desc* d, int dtype) {
-  if (!p || !q || !d) return 0;
+// the view the reduction runs over: p itself, or (d->unpool_codes) the dense un-pooled tensor p stands for
+static dct_view wgrad_p_extent(const dct_view* p, const dct_conv_desc* d) {
+  dct_view v = *p;
+  if (d->unpool_codes) {
+    v.h = d->unpool_h; v.w = d->unpool_w;
+    v.sw = v.c; v.sh = (long long)v.w * v.c; v.sn = (long long)v.h * v.w * v.c;
+  }
+  return v;
+}
+
+extern "C" size_t dct_conv2d_wgrad_workspace_bytes(const dct_view* p0, const dct_view* q, const dct_conv_desc* d, int dtype) {
+  if (!p0 || !q || !d) return 0;
+  const dct_view pe = wgrad_p_extent(p0, d);
+  const dct_view* p = &pe;
   WPlan pl;
   if (!make_wplan(p, q, d, dtype, pl)) return 0;
+  if (d->unpool_codes && !(pl.v3 && (pl.pitch == 0 || pl.nr == 1))) return 0;
   return pl.direct ? 16 : (size_t)pl.slabs * ((size_t)p->c * q->c * d->R * d->S + p->c) * sizeof(float);
 }
 
@@ -1253,10 +1314,19 @@ extern "C" int dct_conv2d_wgrad(const dct_view* p, const dct_view* q, float* dw,
   return dct_conv2d_wgrad_bias(p, q, dw, nullptr, d, dtype, workspace, workspace_bytes, stream);
 }
 
-extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float* dw, float* db, const dct_conv_desc* d, int dtype,
+extern "C" int dct_conv2d_wgrad_bias(const dct_view* p0, const dct_view* q, float* dw, float* db, const dct_conv_desc* d, int dtype,
                                      void* workspace, size_t workspace_bytes, dct_stream stream) {
-  if (!view_ok(p) || !view_ok(q) || !dw || !d) return DCT_ERR_BAD_ARG;
+  if (!view_ok(p0) || !view_ok(q) || !dw || !d) return DCT_ERR_BAD_ARG;
   if (dtype != DCT_F32 && dtype != DCT_BF16) return DCT_ERR_BAD_ARG;
+  if (d->unpool_codes) {
+    // p0 is the DENSE gradient at the pooled tensor; the reduction runs over the un-pooled extent, expanded while the kernel stages
+    if (d->unpool_h < 1 || d->unpool_w < 1 || p0->h != (d->unpool_h + 1) / 2 || p0->w != (d->unpool_w + 1) / 2) return DCT_ERR_BAD_ARG;
+    if (dtype != DCT_BF16 || d->R != 3 || d->S != 3 || d->stride != 1 || d->dil != 1 || d->pad_h || d->pad_w || ((uintptr_t)d->unpool_codes & 7) ||
+        p0->sw != p0->c || p0->sh != (long long)p0->w * p0->c || p0->sn != (long long)p0->h * p0->w * p0->c || !(g_tune_lean & 1))
+      return DCT_ERR_UNSUPPORTED;
+  }
+  const dct_view pe = wgrad_p_extent(p0, d);
+  const dct_view* p = &pe;
   if (p->n != q->n) return DCT_ERR_BAD_ARG;
   {
     const int eh = (q->h + 2 * d->pad_h - d->dil * (d->R - 1) - 1) / d->stride + 1;
@@ -1290,10 +1360,17 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float
     pr.direct = pl.direct; pr.accumulate = d->accumulate;
     pr.bias = db; pr.with_bias = db ? 1 : 0; pr.slab_stride = slab_stride;
     pr.skip_empty = (g_tune_lean & 16) ? 1 : 0;
+    pr.up_codes = d->unpool_codes; pr.up_Hp = p0->h; pr.up_Wp = p0->w;
     pr.p_bytes = ((long long)(p->n - 1) * p->sn + (long long)(p->h - 1) * p->sh + (long long)(p->w - 1) * p->sw + p->c) * 2;
     pr.q_bytes = ((long long)(q->n - 1) * q->sn + (long long)(q->h - 1) * q->sh + (long long)(q->w - 1) * q->sw + q->c) * 2;
     pr.stamps = g_w3_stamps;
+    if (d->unpool_codes) {
+      pr.w.P = (const char*)p0->ptr;
+      if (!w3_lean(pr) || !(pl.pitch == 0 || pl.nr == 1)) return DCT_ERR_UNSUPPORTED;      // (nothing has been launched)
+    }
     launch_w3(pr, pl, st);
+  } else if (d->unpool_codes) {
+    return DCT_ERR_UNSUPPORTED;          // only the filter-row kernel expands a pooled gradient while it stages
   } else if (pl.v2) {
     Wgrad2Params pr;
     pr.w = wp;

@@ -161,10 +161,26 @@ class StemFusionUnsupported(RuntimeError):
     """conv2d(..., stem=...) on a layer whose kernel cannot take the stem's weight gradient along (the caller runs the two launches instead)."""
 
 
+class UnpoolOnLoadUnsupported(RuntimeError):
+    """conv2d / conv2d_wgrad(..., unpool=...) on a layer whose kernel cannot expand the pooled gradient while it stages (nothing was
+    launched: the caller un-pools into a buffer with `maxpool_bwd` and calls again without ``unpool``)."""
+
+
+def _check_unpool(unpool, pooled):
+    codes, H, W = unpool
+    want = (pooled.shape[0], (H + 1) // 2, (W + 1) // 2, pooled.shape[3])
+    assert tuple(pooled.shape) == want and pooled.is_contiguous(), "unpool: the input is the DENSE gradient at the pooled tensor"
+    assert codes.dtype == torch.uint8 and codes.is_contiguous() and tuple(codes.shape) == want, "unpool: dense routing codes of the pooling"
+
+
 def conv2d(x, w_packed, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, relu=False, mask=None,
            mask_channels=0, mask_scale=1.0, accumulate=False, scatter2x2=False, mask_bits=None, relu_bits_out=None,
-           pool_out=None, pool_codes=None, pool_only=False, stem=None):
+           pool_out=None, pool_codes=None, pool_only=False, stem=None, unpool=None):
     """y (NHWC view, written in place) = epilogue(conv(x, w_packed)); see include/dct.h dct_conv2d.
+
+    ``unpool`` = (codes, H, W): x is the gradient at a max-pooled tensor and the convolution runs on its un-pooled [N,H,W,C] form, which
+    the kernel expands from (x, codes) while it stages (dct_conv_desc.unpool_*); raises ``UnpoolOnLoadUnsupported`` (nothing launched)
+    when the layer does not take a kernel that can.
 
     ``relu_bits_out`` (uint8 [N,H,W,C/8], dense y): the launch also leaves the ReLU-gate bits of y there (`relu_bits_like`);
     ``mask_bits``: such bits of ``mask`` -- the data gradient then reads 1/16 of the bytes where its epilogue can.
@@ -180,8 +196,10 @@ def conv2d(x, w_packed, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0,
         assert not accumulate and not scatter2x2 and mask is None and mask_bits is None, "pool_out is a forward-pass feature"
     else:
         assert pool_codes is None and not pool_only
+    if unpool is not None:
+        _check_unpool(unpool, x)
     d = conv_desc(R, S, stride, dil, pad_h, pad_w, relu, scatter2x2, accumulate, mask_channels, mask_scale,
-                  _bits_ok(mask_bits, mask), _bits_ok(relu_bits_out, y), pool_out, pool_codes, pool_only, stem)
+                  _bits_ok(mask_bits, mask), _bits_ok(relu_bits_out, y), pool_out, pool_codes, pool_only, stem, unpool)
     if stem is not None:
         sx, sdw, sdb, _ = stem
         assert sx.dtype == torch.float32 and sx.is_contiguous() and sx.numel() == y.shape[0] * (y.shape[1] + 2) * (y.shape[2] + 2)
@@ -199,26 +217,43 @@ def conv2d(x, w_packed, bias, y, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0,
             raise StemFusionUnsupported()
         _lib.check(rc, "dct_conv2d")
         return y
+    if unpool is not None:
+        rc = getattr(lib, "dct_conv2d")(C.byref(vx), ptr(w_packed), ptr(bias), C.byref(vm) if vm is not None else None,
+                                        C.byref(vy), C.byref(d), dt, ptr(ws), ws.numel(), stream())
+        if rc == _lib.ERR_UNSUPPORTED:
+            raise UnpoolOnLoadUnsupported()
+        _lib.check(rc, "dct_conv2d")
+        return y
     call("dct_conv2d", C.byref(vx), ptr(w_packed), ptr(bias), C.byref(vm) if vm is not None else None,
          C.byref(vy), C.byref(d), dt, ptr(ws), ws.numel(), stream())
     return y
 
 
-def conv2d_wgrad(p, q, dw, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, accumulate=False, db=None):
+def conv2d_wgrad(p, q, dw, *, R=3, S=3, stride=1, dil=1, pad_h=0, pad_w=0, accumulate=False, db=None, unpool=None):
     """dw[p.c][R][S][q.c] (fp32, dense) (+)= sum_m p[m] (x) q[shifted m]; with ``db`` (bf16 only) also
-    db[p.c] (+)= sum_m p[m] in the same launch."""
-    d = conv_desc(R, S, stride, dil, pad_h, pad_w, accumulate=accumulate)
+    db[p.c] (+)= sum_m p[m] in the same launch.  ``unpool`` = (codes, H, W): p is the gradient at a max-pooled tensor, expanded to its
+    un-pooled [N,H,W,C] form while the kernel stages (dct_conv_desc.unpool_*); ``UnpoolOnLoadUnsupported`` when the layer's kernel cannot."""
+    if unpool is not None:
+        _check_unpool(unpool, p)
+    d = conv_desc(R, S, stride, dil, pad_h, pad_w, accumulate=accumulate, unpool=unpool)
     vp, vq = view(p), view(q)
     lib = _lib.load()
     dt = _dt(p)
     need = lib.dct_conv2d_wgrad_workspace_bytes(C.byref(vp), C.byref(vq), C.byref(d), dt)
     if need == 0:
+        if unpool is not None:
+            raise UnpoolOnLoadUnsupported()
         raise RuntimeError("dct_amd: conv2d_wgrad unsupported shape")
     ws = _ws(need, p.device)
-    if db is not None:
-        call("dct_conv2d_wgrad_bias", C.byref(vp), C.byref(vq), ptr(dw), ptr(db), C.byref(d), dt, ptr(ws), ws.numel(), stream())
-    else:
-        call("dct_conv2d_wgrad", C.byref(vp), C.byref(vq), ptr(dw), C.byref(d), dt, ptr(ws), ws.numel(), stream())
+    name = "dct_conv2d_wgrad_bias" if db is not None else "dct_conv2d_wgrad"
+    args = (C.byref(vp), C.byref(vq), ptr(dw)) + ((ptr(db),) if db is not None else ()) + (C.byref(d), dt, ptr(ws), ws.numel(), stream())
+    if unpool is not None:
+        rc = getattr(lib, name)(*args)
+        if rc == _lib.ERR_UNSUPPORTED:
+            raise UnpoolOnLoadUnsupported()
+        _lib.check(rc, name)
+        return dw
+    call(name, *args)
     return dw
 
 

@@ -109,6 +109,16 @@ typedef struct dct_conv_desc {
   float* stem_dw;
   float* stem_db;
   int32_t stem_accumulate;
+  /* Un-pooling on load (round 5; the backward pass of a UNet encoder block, network.py:120-130: ... Conv2d, ReLU, MaxPool2d).  The gradient at the
+   * block's full-resolution output is maxpool-backward of the gradient at the pooled tensor: three of four positions are zero and the
+   * fourth is a copy, so it need not exist in memory.  With unpool_codes (nullable; the DENSE routing codes of dct_maxpool2x2_fwd_codes,
+   * [n][(unpool_h + 1) / 2][(unpool_w + 1) / 2][c]) the input view (dct_conv2d: x; dct_conv2d_wgrad: p) is the gradient AT THE POOLED
+   * tensor and the kernel expands it to the [n][unpool_h][unpool_w][c] tensor dct_maxpool2x2_bwd_codes(relu_mask = 1, scale = 1) would
+   * have written while it stages -- bit for bit the result of that launch followed by the plain call.  bf16, 3x3 stride 1; dct_conv2d:
+   * the data-gradient form (padding 2) on the shared-halo kernel; DCT_ERR_UNSUPPORTED (nothing launched) where the layer takes another
+   * kernel: the caller then un-pools into a buffer and calls again without the codes. */
+  const uint8_t* unpool_codes;
+  int32_t unpool_h, unpool_w;
 } dct_conv_desc;
 
 size_t dct_conv2d_workspace_bytes(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype);

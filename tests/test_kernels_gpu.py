@@ -546,6 +546,110 @@ def test_conv2d_xcd_block_order_is_bit_identical(ops, B, Cin, H, W, Cout, pad, h
     assert torch.equal(outs[1][:, :Ho].view(torch.int16), outs[2][:, :Ho].view(torch.int16))
 
 
+def _pooled_gradient_case(B, C, H, W, seed):
+    """A ReLU'd activation d [B,H,W,C], its 2x2 ceil-mode pooling codes, and a random gradient at the pooled tensor (bf16, dense)."""
+    from dct_amd import hip_ops as K
+    g = torch.Generator().manual_seed(seed)
+    d = torch.relu(torch.randn(B, H, W, C, generator=g)).to(DEV).to(torch.bfloat16)
+    Hp, Wp = (H + 1) // 2, (W + 1) // 2
+    pooled = torch.empty(B, Hp, Wp, C, dtype=torch.bfloat16, device=DEV)
+    codes = torch.empty(B, Hp, Wp, C, dtype=torch.uint8, device=DEV)
+    K.maxpool_fwd(d, pooled, codes=codes)
+    dp = torch.randn(B, Hp, Wp, C, generator=g).to(DEV).to(torch.bfloat16)
+    dd = K.maxpool_bwd(None, dp, torch.empty(B, H, W, C, dtype=torch.bfloat16, device=DEV), relu_mask=True, scale=1.0, codes=codes)
+    return dp, codes, dd
+
+
+@pytest.mark.parametrize("B,C,H,W,Cout", [
+    (4, 64, 60, 76, 64),        # the first level's form: 64 -> 64 channels, one channel slice, four waves (two windows per thread)
+    (3, 128, 58, 44, 128),      # 128-channel tiles, two channel slices: the second slice's windows are fetched during taps 3..8
+    (2, 256, 57, 57, 256),      # odd extents: ceil-mode windows that reach past the tensor, four slices
+    (5, 64, 33, 95, 128),       # 64 -> 128 channels (128-channel tile, single slice), ragged patches on both edges
+])
+def test_conv2d_data_gradient_unpools_on_load_bit_identical(ops, B, C, H, W, Cout):
+    """dct_conv_desc.unpool_codes: the data-gradient convolution of {gradient at the pooled tensor, routing codes} against the same
+    convolution of the un-pooled gradient written by dct_maxpool2x2_bwd_codes first -- every output bit, with the ReLU-gate bits of the
+    consumer and with accumulation."""
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    dp, codes, dd = _pooled_gradient_case(B, C, H, W, 51)
+    g = torch.Generator().manual_seed(52)
+    w = kmajor(q(torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(C * 9), dtype), dtype)
+    act = to_dev(q(torch.randn(B, Cout, H + 2, W + 2, generator=g), dtype), dtype)       # the layer input whose ReLU gates the data gradient
+    bits = _pack_bits(act)
+    old = to_dev(q(torch.randn(B, Cout, H + 2, W + 2, generator=g), dtype), dtype)
+    lib = _lib.load()
+    try:
+        lib.dct_tune_set(19, 1)          # shared-halo kernel whatever the block count
+        outs = []
+        for unpool in (None, (codes, H, W)):
+            src = dd if unpool is None else dp
+            y = torch.full((B, H + 2, W + 2, Cout), float("nan"), dtype=dtype, device=DEV)
+            ops.conv2d(src, w, None, y, pad_h=2, pad_w=2, mask=act, mask_bits=bits, unpool=unpool)
+            z = old.clone()
+            ops.conv2d(src, w, None, z, pad_h=2, pad_w=2, accumulate=True, unpool=unpool)
+            outs.append((y, z))
+    finally:
+        lib.dct_tune_set(19, 400)
+    assert not torch.isnan(outs[0][0].float()).any() and outs[0][0].float().abs().max().item() > 0
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)), "masked data gradient differs"
+    assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16)), "accumulated data gradient differs"
+
+
+def test_conv2d_unpool_on_load_is_refused_where_no_kernel_can():
+    """A layer that does not take the shared-halo kernel (too few blocks here) must refuse -- before launching anything -- so that the
+    caller can un-pool into a buffer: hip_ops raises UnpoolOnLoadUnsupported and leaves y untouched."""
+    from dct_amd import hip_ops as K
+    dtype = torch.bfloat16
+    dp, codes, dd = _pooled_gradient_case(1, 128, 20, 20, 53)
+    w = kmajor(q(torch.randn(128, 128, 3, 3, generator=torch.Generator().manual_seed(54)) / 34.0, dtype), dtype)
+    y = torch.full((1, 22, 22, 128), 7.0, dtype=dtype, device=DEV)
+    with pytest.raises(K.UnpoolOnLoadUnsupported):
+        K.conv2d(dp, w, None, y, pad_h=2, pad_w=2, unpool=(codes, 20, 20))
+    torch.cuda.synchronize()
+    assert (y == 7.0).all()
+    dw = torch.zeros(128, 3, 3, 128, device=DEV)
+    a = torch.randn(1, 34, 32, 128, device=DEV).to(dtype)
+    dp2, codes2, _ = _pooled_gradient_case(1, 128, 32, 30, 55)       # rows of 30 pixels: two image rows per K-step -- not expanded on load
+    with pytest.raises(K.UnpoolOnLoadUnsupported):
+        K.conv2d_wgrad(dp2, a, dw, unpool=(codes2, 32, 30))
+    torch.cuda.synchronize()
+    assert (dw == 0).all()
+
+
+@pytest.mark.parametrize("B,C,H,W,Cq", [
+    (4, 64, 60, 140, 64),       # wide rows: 140 = 64 + 64 + 12 pixels per row, a one-sub-step tail
+    (3, 128, 41, 122, 64),      # odd height (the last pooled row has one image row), two dy channel tiles
+    (2, 256, 57, 57, 128),      # one whole row per K-step (pitch 59), odd width: the last window holds one pixel
+    (6, 64, 44, 40, 192),       # rows of 40 at pitch 42
+])
+def test_conv2d_wgrad_unpools_on_load_bit_identical(ops, B, C, H, W, Cq):
+    """dct_conv_desc.unpool_codes on the weight gradient: dy = {gradient at the pooled tensor, routing codes}, expanded by the
+    filter-row kernel while it stages, against the un-pooled gradient read from memory: dW and db bit for bit (same kernel, same
+    K order, same operands), writing and accumulating."""
+    from dct_amd import _lib
+    dtype = torch.bfloat16
+    dp, codes, dd = _pooled_gradient_case(B, C, H, W, 56)
+    x = torch.randn(B, H + 2, W + 2, Cq, generator=torch.Generator().manual_seed(57)).to(DEV).to(dtype)
+    lib = _lib.load()
+    outs = []
+    try:
+        lib.dct_tune_set(9, 1)           # filter-row kernel whatever the fill
+        for unpool in (None, (codes, H, W)):
+            src = dd if unpool is None else dp
+            dw = torch.full((C, 3, 3, Cq), float("nan"), device=DEV)
+            db = torch.full((C,), float("nan"), device=DEV)
+            ops.conv2d_wgrad(src, x, dw, accumulate=False, db=db, unpool=unpool)
+            dw2, db2 = torch.ones_like(dw), torch.ones_like(db)
+            ops.conv2d_wgrad(src, x, dw2, accumulate=True, db=db2, unpool=unpool)
+            outs.append((dw, db, dw2, db2))
+    finally:
+        lib.dct_tune_set(9, 70)
+    assert torch.isfinite(outs[0][0]).all() and outs[0][0].abs().max().item() > 0
+    for a, b, what in zip(outs[0], outs[1], ("dW", "db", "dW accumulated", "db accumulated")):
+        assert torch.equal(a, b), what
+
+
 def _pack_bits(t_nhwc):
     """ReLU-gate bits of a dense NHWC tensor as the kernels lay them out: byte (pixel, c // 8), bit c % 8."""
     pos = (t_nhwc.float() > 0).to(torch.int32)

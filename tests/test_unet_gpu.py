@@ -231,6 +231,7 @@ def test_unet_skip_gradient_gathered_by_the_unpooling(dtype, tol):
     for flag in (False, True):
         net = _hip_net(onet, C, dtype, p=0.5).train()
         net.fuse_skip_grad = flag
+        net.unpool_on_load = False          # (levels 1-3 would otherwise sum their skip gradient in memory whatever the flag)
         net.fuse_stem_wgrad = False
         net.dropout_seed = 99
         xd = x.clone().requires_grad_(True)
@@ -244,6 +245,30 @@ def test_unet_skip_gradient_gathered_by_the_unpooling(dtype, tol):
         assert _rel2(b.cpu().numpy(), a.cpu().numpy()) <= tol, (k, _rel2(b.cpu().numpy(), a.cpu().numpy()))
         changed += int(not torch.equal(a, b))
     assert k and (dtype == torch.float32 or changed > 0)
+
+
+@pytest.mark.parametrize("B,H,W,need_dx", [(2, 200, 216, True), (6, 256, 256, False)])
+def test_unet_unpooled_gradients_expanded_on_load_are_bit_identical(B, H, W, need_dx):
+    """Levels 1-3 of the encoder never write their un-pooled gradient (UNet.unpool_on_load): the block's data gradient and weight
+    gradient expand {pooled gradient + routing codes} while they stage.  Against the same plan with the un-pooling launch in front of
+    them (both with the skip gradient summed in memory, so that the pooled gradients are the same numbers): every gradient bit for bit
+    -- whichever kernels take the expansion and whichever fall back to un-pooling into a buffer (the small levels of the first case)."""
+    C = 4
+    onet = _oracle_net(C, 23, p=0.5).train()
+    x = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(48)).to(DEV)
+    gl = torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(49)).to(DEV)
+    outs = []
+    for flag in (False, True):
+        net = _hip_net(onet, C, torch.bfloat16, p=0.5).train()
+        net.unpool_on_load, net.fuse_skip_grad = flag, False
+        net.dropout_seed = 77
+        _, tape = net.plan_forward(x, True)
+        dx = net.plan_backward(tape, gl, need_dx=need_dx, need_dw=True, overwrite=True)
+        torch.cuda.synchronize()
+        outs.append(([dx.clone()] if need_dx else []) + [net.flat_params.gflat.clone()])
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and a.abs().max().item() > 0
+        assert torch.equal(a, b)
 
 
 def test_unet_rejects_small_and_cpu_inputs():
