@@ -112,11 +112,11 @@ def pmc_mfma_busy(config):
         return None
 
 
-def make_trainer(cfg, dtype, device, rank, world, grad_sync_factory, n_batches=4):
+def make_trainer(cfg, dtype, device, rank, world, grad_sync_factory, n_batches=4, data="blob"):
     from dct_amd.loss import get_loss_fn
     from dct_amd.models import Segmentator
     from dct_amd.trainer import CoTrainer
-    from helpers import FakeLoader, blob_batches
+    from helpers import FakeLoader, batches, blob_batches
     S, C, H = cfg["S"], cfg["C"], cfg["H"]
     torch.manual_seed(1234)        # identical initial weights on every rank
     segs = [Segmentator({"name": cfg["arch"], "num_classes": C, "compute_dtype": dtype},
@@ -126,7 +126,9 @@ def make_trainer(cfg, dtype, device, rank, world, grad_sync_factory, n_batches=4
     def dev_batches(seed, B):
         # blob-structured slices (tests/helpers.py): the nets learn them, so the timed steps run on the operand statistics
         # of a network that is training (i.i.d. random labels drive it to the trivial uniform predictor)
-        return [[[b[0][0].to(device), b[0][1].to(device)], None, b[2]] for b in blob_batches(seed, n_batches, B, H, C)]
+        # --data iid: the inputs SURVEY.md 8d prescribes (torch.rand images in [0, 1), torch.randint labels, seeded)
+        make = batches if data == "iid" else blob_batches
+        return [[[b[0][0].to(device), b[0][1].to(device)], None, b[2]] for b in make(seed, n_batches, B, H, C)]
 
     base = 1234 + 1000 * rank      # reference default seed (config/ACDC_config_cotraing.yaml:79) + rank
     lab = [FakeLoader(dev_batches(base + 1 + i, cfg["B_l"]), cfg["B_l"]) for i in range(S)]
@@ -438,6 +440,9 @@ def main():
                     help="extra (untimed) training steps before the warm-up: the timed network is then that many Adam steps old "
                          "(operand statistics of a trained net; profiles/r03_cfg2_after_300_steps.json)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--data", default="blob", choices=["blob", "iid"],
+                    help="synthetic inputs: blob-structured slices the nets learn (default: the timed network then carries a training net's "
+                         "operand statistics), or iid = torch.rand images + torch.randint labels as SURVEY.md 8d words it")
     ap.add_argument("--no-clock-probe", action="store_true", help="do not sample the shader clock beside the replayed step")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight gradients on a second stream per model (eager only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
@@ -495,7 +500,7 @@ def main():
     for kv in args.tune:
         k, v = kv.split("=")
         _lib.check(_lib.load().dct_tune_set(int(k), int(v)), f"dct_tune_set({kv})")
-    tr, lab, unl = make_trainer(cfg, dtype, device, rank, 2 if (args.force_ddp and world == 1) else world, sync_factory)
+    tr, lab, unl = make_trainer(cfg, dtype, device, rank, 2 if (args.force_ddp and world == 1) else world, sync_factory, data=args.data)
     for kv in args.attr:
         k, v = kv.split("=")
         assert hasattr(tr, k), k
@@ -504,7 +509,7 @@ def main():
         k, v = kv.split("=")
         for seg in tr.segmentators:
             assert hasattr(seg.torchnet, k), k
-            setattr(seg.torchnet, k, bool(int(v)))
+            setattr(seg.torchnet, k, bool(int(v)) if isinstance(getattr(seg.torchnet, k), bool) else int(v))
     S = cfg["S"]
     nb = len(unl)
     tr.model_streams = not args.single_stream
@@ -594,8 +599,9 @@ def main():
                           "reported": "median"},
         "config": {"workload": f"{args.config}: {cfg['desc']}", "imgs_per_step_per_gpu": imgs_per_step,
                    "global_batch": f"{cfg['B_l'] * world}+{cfg['B_u'] * world}", "parallelism": f"dp{world}",
-                   "weights": "random init (xavier_normal), reference architecture; trained for the setup + warm-up steps on "
-                              "blob-structured synthetic slices (tests/helpers.py::blob_batches)",
+                   "inputs": "blob-structured synthetic slices (tests/helpers.py::blob_batches)" if args.data == "blob"
+                   else "iid: torch.rand images in [0, 1), torch.randint labels (tests/helpers.py::batches; SURVEY.md 8d)",
+                   "weights": "random init (xavier_normal), reference architecture; trained for the setup + warm-up steps on these inputs",
                    "adam_steps_before_the_timed_region": SETUP_STEPS + args.train_steps + args.warmup},
         "losses_last_step": losses,
     }

@@ -203,6 +203,9 @@ class UNet(nn.Module):
         self.pool_only = True                # ... whose full-resolution output is then not stored at all (nobody else reads it)
         self.fuse_stem_wgrad = True          # the stem's weight gradient from the epilogue of the data gradient that produces its dy (not stored then)
         self.fuse_skip_grad = True           # the skip connections' bilinear backward gathered by the un-pooling instead of summed in memory
+        self.unpool_max_level = 1            # the deepest level that does.  Measured on the captured cfg2 step (profiles/r05_unpool_on_load_per_level.txt): level 1
+                                             # alone is level in time (-0.4 GB of writes, -0.8 GB of reads per step); with levels 2-3 the step is 1.2 % SLOWER --
+                                             # the expansion's ~40 vector instructions per thread and K-step land in the filter-row weight gradient's issue-bound loop
         self.unpool_on_load = True           # levels 1-3: the un-pooled gradient of an encoder block is never written -- its two consumers expand
                                              # {pooled gradient + routing codes} while they stage (dct_conv_desc.unpool_codes)
         self._wgrad_stream = None
@@ -574,7 +577,7 @@ class UNet(nn.Module):
         skip_fused = bool(self.fuse_skip_grad and all(A.get(f"pc{k}") is not None for k in (1, 2, 3, 4)))
         # Levels whose un-pooled gradient is expanded on load (no un-pooling launch to gather the skip gradient in): the bilinear
         # backward of the skip connection is written to dp and the next block's data gradient accumulates onto it.
-        up_levels = {k for k in (1, 2, 3) if self.unpool_on_load and dt == torch.bfloat16 and A.get(f"pc{k}") is not None and
+        up_levels = {k for k in (1, 2, 3) if self.unpool_on_load and k <= int(self.unpool_max_level) and dt == torch.bfloat16 and A.get(f"pc{k}") is not None and
                      isinstance(A[f"d{k}"], _ShapeOf) and self._debug is None}
         for lvl, co in ((2, 64), (3, 128), (4, 256)):
             ca, _, cb, _, ct = self._roles[f"enc{lvl}"]

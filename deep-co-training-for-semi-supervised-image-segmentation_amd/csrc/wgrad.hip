@@ -757,7 +757,7 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
         s_y += pr.nr;
         offP += (unsigned)(pr.nr * (int)p.psH * 2); offQ += (unsigned)(pr.nr * (int)p.qsH * 2);
         if (s_y >= p.Hp) {
-          s_y = 0;
+          s_y = 0; ++s_n;
           offP += (unsigned)(((int)p.psN - pr.units_per_image * pr.nr * (int)p.psH) * 2);
           offQ += (unsigned)(((int)p.qsN - pr.units_per_image * pr.nr * (int)p.qsH) * 2);
         }
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(G * NW * 64) void wgrad3_kernel(Wgrad3Params pr) {
           offP += (unsigned)(((int)p.psH - pr.segs_per_row * 64 * psW) * 2);
           offQ += (unsigned)(((int)p.qsH - pr.segs_per_row * 64 * qsW) * 2);
           if (++s_y == p.Hp) {
-            s_y = 0;
+            s_y = 0; ++s_n;
             offP += (unsigned)(((int)p.psN - p.Hp * (int)p.psH) * 2);
             offQ += (unsigned)(((int)p.qsN - p.Hp * (int)p.qsH) * 2);
           }

@@ -260,7 +260,7 @@ def test_unet_unpooled_gradients_expanded_on_load_are_bit_identical(B, H, W, nee
     outs = []
     for flag in (False, True):
         net = _hip_net(onet, C, torch.bfloat16, p=0.5).train()
-        net.unpool_on_load, net.fuse_skip_grad = flag, False
+        net.unpool_on_load, net.unpool_max_level, net.fuse_skip_grad = flag, 3, False
         net.dropout_seed = 77
         _, tape = net.plan_forward(x, True)
         dx = net.plan_backward(tape, gl, need_dx=need_dx, need_dw=True, overwrite=True)
