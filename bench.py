@@ -42,6 +42,9 @@ CONFIGS = {
     # BASELINE configs[3] / [4]: the Enet configurations (HBM/launch bound; roofline leg reports HBM GB/s)
     "cfg4": dict(arch="enet", H=200, C=2, B_l=8, B_u=8, train_adv=True, S=2,
                  desc="2xEnet co-training (CE + JSD + FGSM), spinal-cord-GM-shaped 200x200 C=2, bs 8+8 per GPU"),
+    # "cfg4 ... arch enet as in script/GM/check.sh:12 (also report unet, valid at 200)"
+    "cfg4u": dict(arch="unet", H=200, C=2, B_l=8, B_u=8, train_adv=True, S=2,
+                  desc="2xUNet co-training (CE + JSD + FGSM), spinal-cord-GM-shaped 200x200 C=2, bs 8+8 per GPU"),
     "cfg5": dict(arch="enet", H=320, C=2, B_l=4, B_u=16, train_adv=True, S=3,
                  desc="3xEnet co-training (CE + JSD + FGSM), prostate-shaped 320x320 C=2, lab:unlab 1:4 (4+16 per GPU)"),
 }

@@ -23,9 +23,11 @@ def per_kernel(path, counter):
                    else "enet_conv" if "enet_conv_kernel" in name else "enet_reduce" if "enet_reduce" in name
                    else "enet_wgrad" if "enet_wgrad_kernel" in name else "enet_finalize" if "finalize_kernel" in name and "enet" in name
                    else "enet_bn_bwd_apply" if "enet_bn_bwd_apply" in name else "enet_tail" if "enet_tail" in name
-                   else "enet_wgrad_reduce" if "enet_wgrad_reduce" in name else None)
-            if key is None:
-                continue
+                   else "enet_wgrad_reduce" if "enet_wgrad_reduce" in name
+                   # round 5: the launches around the conv kernels too, so that bytes moved OUT of the conv families (un-pooling, folds) stay visible
+                   else "zz_folds" if ("wgrad_reduce" in name or "splitk_epilogue" in name or "slab_rows_fold" in name or "split_dw_db" in name)
+                   else "zz_pool_bilinear" if ("maxpool" in name or "bilinear" in name) else "zz_adam" if "adam_kernel" in name
+                   else "zz_other")
             a = agg.setdefault(key, [0, 0.0])
             a[0] += 1
             a[1] += float(r["Counter_Value"])
@@ -45,8 +47,11 @@ def main():
                   "write_bytes_per_launch": vw * 1024 / max(nw, 1)}
         out[k]["bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
     if launches_total:
-        tot = sum(v["bytes_per_launch"] * v["launches"] for k, v in out.items() if isinstance(v, dict))
-        out["all_listed_kernels"] = {"bytes_per_step": tot / launches_total, "steps_profiled": launches_total}
+        conv = sum(v["bytes_per_launch"] * v["launches"] for k, v in out.items() if isinstance(v, dict) and not k.startswith("zz_"))
+        rest = sum(v["bytes_per_launch"] * v["launches"] for k, v in out.items() if isinstance(v, dict) and k.startswith("zz_"))
+        out["all_listed_kernels"] = {"bytes_per_step": conv / launches_total, "steps_profiled": launches_total,
+                                     "what": "the conv / weight-gradient kernel families (the figure of rounds 1-4)"}
+        out["whole_step"] = {"bytes_per_step": (conv + rest) / launches_total, "what": "every launch of the step (zz_* = the launches around the conv kernels)"}
     print(json.dumps(out, indent=1))
 
 
