@@ -37,6 +37,9 @@ CONFIGS = {
     # name: arch, H, C, B_l, B_u, train_adv, S
     "cfg2": dict(arch="unet", H=256, C=4, B_l=8, B_u=8, train_adv=False, S=2,
                  desc="2xUNet co-training (CE + JSD), ACDC-shaped 256x256 C=4, bs 8+8 per GPU"),
+    # diagnostic (not a BASELINE config): ONE of cfg2's two networks, same batches -- what the second model's chain costs beside the first
+    "cfg2s1": dict(arch="unet", H=256, C=4, B_l=8, B_u=8, train_adv=False, S=1,
+                   desc="diagnostic: ONE UNet of cfg2 (CE + the degenerate one-model JSD), 256x256 C=4, bs 8+8"),
     "cfg3": dict(arch="unet", H=256, C=4, B_l=8, B_u=8, train_adv=True, S=2,
                  desc="2xUNet co-training (CE + JSD + FGSM eps .03), 256x256 C=4, bs 8+8 per GPU"),
     # BASELINE configs[3] / [4]: the Enet configurations (HBM/launch bound; roofline leg reports HBM GB/s)

@@ -68,6 +68,33 @@ __device__ __forceinline__ float block_sum_256(float v, float* smem4) {
   return smem4[0] + smem4[1] + smem4[2] + smem4[3];
 }
 
+// ---- streaming stores (round 5) -------------------------------------------------------------------------------------------------
+// A 16-byte store of an activation / gradient tensor that nobody reads before hundreds of megabytes of other traffic have gone through
+// the memory-side cache.  tools/probe_store_bw: with the default policy a 132 MB fill whose lines are not resident runs at 3.1 TB/s
+// behind a stream of reads (the rate of every write-only stream of the step in rounds 1-4, and the reason a written byte was priced at
+// two read ones), with the non-temporal policy at 5.4 TB/s.  DCT_NT_STORES = 0 builds the default-policy form (A/B).
+#ifndef DCT_NT_STORES
+#define DCT_NT_STORES 1
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned dct_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned dct_u32x2;
+template <typename V> __device__ __forceinline__ void dct_store16_stream(void* p, const V& v) {
+  static_assert(sizeof(V) == 16, "16-byte vector");
+#if DCT_NT_STORES
+  __builtin_nontemporal_store(__builtin_bit_cast(dct_u32x4, v), reinterpret_cast<dct_u32x4*>(p));
+#else
+  *reinterpret_cast<dct_u32x4*>(p) = __builtin_bit_cast(dct_u32x4, v);
+#endif
+}
+template <typename V> __device__ __forceinline__ void dct_store8_stream(void* p, const V& v) {
+  static_assert(sizeof(V) == 8, "8-byte vector");
+#if DCT_NT_STORES
+  __builtin_nontemporal_store(__builtin_bit_cast(dct_u32x2, v), reinterpret_cast<dct_u32x2*>(p));
+#else
+  *reinterpret_cast<dct_u32x2*>(p) = __builtin_bit_cast(dct_u32x2, v);
+#endif
+}
+
 // ---- un-pooling on load (round 5) -------------------------------------------------------------------------------------------------
 // The gradient at a max-pooled tensor and the pooling's routing codes (dct_maxpool2x2_fwd_codes: bits 0-1 = window position of
 // the first maximum, bit 2 = its ReLU gate, bit 3 = no maximum) ARE the un-pooled gradient, at 3 bytes per window and channel

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm2_kernel(IgemmPar
       bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * (BN * 2) + ((cc ^ (row & (CPR - 1))) * 16));
       if (p.mask_bits) chunk_gate_bits(v, mb[t], p.mask_scale);
       else if (use_mask[t]) chunk_gate_act(v, mk[t], p.mask_scale);
-      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yoff[t]) = v;
+      dct_store16_stream(reinterpret_cast<bf16_t*>(p.y) + yoff[t], v);
       if (p.bits_out) p.bits_out[(unsigned long long)yoff[t] >> 3] = (unsigned char)relu_bits8(v);
     }
     return;

@@ -136,7 +136,7 @@ __device__ __forceinline__ void staged_rows_out(const IgemmParams& p, const char
       asm volatile("" ::: "memory");
       chunk_add(v, old[t]);
     }
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co) = v;
+    dct_store16_stream(reinterpret_cast<bf16_t*>(p.y) + yo[t] + co, v);
     if (p.bits_out) p.bits_out[(unsigned)(yo[t] + co) >> 3] = (unsigned char)relu_bits8(v);
   }
 }
@@ -173,12 +173,12 @@ __device__ __forceinline__ void staged_pool_out(const IgemmParams& p, const char
     bf16x8 out;
 #pragma unroll
     for (int i = 0; i < 8; ++i) out[i] = (bf16_t)m[i];
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.pool_y) + o) = out;
+    dct_store16_stream(reinterpret_cast<bf16_t*>(p.pool_y) + o, out);
     if (p.pool_codes) {
       union { unsigned char b[8]; uint2 w; } cd;
 #pragma unroll
       for (int i = 0; i < 8; ++i) cd.b[i] = (unsigned char)(arg[i] | (m[i] > 0.f ? 4 : 0));
-      *reinterpret_cast<uint2*>(p.pool_codes + o) = cd.w;
+      dct_store8_stream(p.pool_codes + o, cd.w);
     }
   }
 }

@@ -17,7 +17,7 @@ template <> struct VecIO<bf16_t, 8> {
     bf16x8 t;
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
-    *reinterpret_cast<bf16x8*>(p) = t;
+    dct_store16_stream(p, t);
   }
 };
 template <> struct VecIO<float, 4> {
@@ -26,7 +26,7 @@ template <> struct VecIO<float, 4> {
     v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
   }
   __device__ static void store(float* p, const float* v) {
-    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    dct_store16_stream(p, f32x4{v[0], v[1], v[2], v[3]});
   }
 };
 template <typename T> struct VecIO<T, 1> {

@@ -154,6 +154,7 @@ def test_unet_gate_bits_and_pool_codes_leave_every_gradient_bit_identical():
     for flag in (False, True):
         net = _hip_net(onet, C, torch.bfloat16, p=0.5).train()
         net.relu_bits = net.pool_codes = flag
+        net.unpool_on_load = False          # (needs the codes: it would change the flow of one arm only)
         net.fuse_skip_grad = False      # (needs the codes; it changes the rounding of an intermediate: its own test below)
         net.dropout_seed = 99
         xd = x.clone().requires_grad_(True)
@@ -180,6 +181,7 @@ def test_unet_pooling_in_the_conv_call_leaves_everything_bit_identical(dtype):
             net = _hip_net(onet, C, dtype, p=0.5)
             net = net.train() if train else net.eval()
             net.fuse_pool = flag                # (with it, pool_only: the encoder blocks' full-resolution outputs are not stored)
+            net.unpool_on_load = False          # (follows pool_only: it would sum the skip gradient in memory in one arm only)
             net.dropout_seed = 99
             xd = x.clone().requires_grad_(True)
             y = net(xd)
