@@ -203,11 +203,13 @@ class UNet(nn.Module):
         self.pool_only = True                # ... whose full-resolution output is then not stored at all (nobody else reads it)
         self.fuse_stem_wgrad = True          # the stem's weight gradient from the epilogue of the data gradient that produces its dy (not stored then)
         self.fuse_skip_grad = True           # the skip connections' bilinear backward gathered by the un-pooling instead of summed in memory
-        self.unpool_max_level = 1            # the deepest level that does.  Measured on the captured cfg2 step (profiles/r05_unpool_on_load_per_level.txt): level 1
-                                             # alone is level in time (-0.4 GB of writes, -0.8 GB of reads per step); with levels 2-3 the step is 1.2 % SLOWER --
-                                             # the expansion's ~40 vector instructions per thread and K-step land in the filter-row weight gradient's issue-bound loop
-        self.unpool_on_load = True           # levels 1-3: the un-pooled gradient of an encoder block is never written -- its two consumers expand
-                                             # {pooled gradient + routing codes} while they stage (dct_conv_desc.unpool_codes)
+        self.unpool_max_level = 3            # the deepest level that does
+        self.unpool_on_load = False          # levels 1..unpool_max_level: the un-pooled gradient of an encoder block is never written -- its two consumers
+                                             # expand {pooled gradient + routing codes} while they stage (dct_conv_desc.unpool_codes).  Built, bit-identical,
+                                             # and OFF: on the captured cfg2 step level 1 alone is 0.5 % slower and levels 1-3 are 1.2 % slower than the
+                                             # un-pooling launches (profiles/r05_unpool_on_load_per_level.txt, r05_knob_sweep.txt) although 0.3 GB of
+                                             # writes and 0.7 GB of reads per step are gone: the expansion's ~40 vector instructions per thread and
+                                             # K-step land in the filter-row weight gradient's issue-bound loop (+10 % on that kernel)
         self._wgrad_stream = None
 
     # ------------------------------------------------------------------------------ weights

@@ -1330,7 +1330,10 @@ int g_tune_igemm_packed_split = 160;   // packed kernel: layers with fewer block
                                        // (+0.9 / +2.1 / +1.3 % on the step against 400); round 4, after the instruction diet: 160-200 are 1.7 % ahead of
                                        // 100 on the step (5.52 -> 5.43 ms, three alternating graph-mode runs each; 260: 5.45) -- cen_a, enc4a and enc4b
                                        // (128 blocks each) now run as 256
-int g_tune_igemm_packed_fill = 76;     // percent: least fill of the packed 128-pixel tiles
+int g_tune_igemm_packed_fill = 50;     // percent: least fill of the packed 128-pixel tiles.  76 until round 5 (the isolated-layer optimum of round 1); on the
+                                       // captured cfg2 step 60 / 50 / 40 are 1.0 / 1.25 / 1.2 % ahead of 76 (two alternating rounds on one box,
+                                       // profiles/r05_knob_sweep.txt): the centre's second convolution (81-pixel images: 63 %), enc3a / enc2a / enc2b and
+                                       // enc3b's data gradient (69-75 %) leave the per-tap kernel, which re-reads its input once per tap
 static PlanP make_plan_p(const dct_view* x, const dct_view* y, const dct_conv_desc* d, int dtype, int N) {
   PlanP pp = {0, 0, 0, 1, 0};
   if (!g_tune_igemm_halo || !g_tune_igemm_packed || dtype != DCT_BF16 || d->R != 3 || d->S != 3 || d->stride != 1 || d->dil != 1 ||

@@ -465,7 +465,7 @@ enum { DCT_TUNE_IGEMM_SPLIT = 1,   /* >= 1: force the split-K factor; -1 (defaul
        DCT_TUNE_IGEMM_HALO_MIN_BLOCKS = 19,  /* default 400: fewest blocks for which the shared-halo patch kernel is taken */
        DCT_TUNE_IGEMM_HALO_COVER = 20,       /* percent (default 75): least image cover of its 8 x 16 patches */
        DCT_TUNE_IGEMM_PACKED_SPLIT = 23,     /* default 160: packed-rows kernel splits layers with fewer blocks over channel slices */
-       DCT_TUNE_IGEMM_PACKED_FILL = 24,      /* percent (default 76): least fill of the packed-rows kernel's 128-pixel tiles */
+       DCT_TUNE_IGEMM_PACKED_FILL = 24,      /* percent (default 50; 76 until round 5): least fill of the packed-rows kernel's 128-pixel tiles */
        DCT_TUNE_ENET_MFMA = 26,              /* bf16 / f16 Enet: bit 0 = MFMA form of the convolutions with >= 16 input channels,
                                                 bit 1 = of the weight gradients; 3 (default), 0 = the fp32 VALU kernels */
        DCT_TUNE_ENET_MWGRAD_WAVES = 28,      /* >= 64 (default 2048): waves an MFMA weight-gradient launch aims for */

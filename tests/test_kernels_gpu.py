@@ -227,7 +227,7 @@ def test_conv2d_packed_rows_lean_form_is_bit_identical(ops, B, Cin, H, W, Cout, 
             assert torch.equal(y.view(torch.int16), first.view(torch.int16))
     finally:
         lib.dct_tune_set(38, _LEAN_DEFAULT)
-        lib.dct_tune_set(24, 76)
+        lib.dct_tune_set(24, 50)
         lib.dct_tune_set(10, _PACKED_DEFAULT)
     assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16)), "lean form differs from the plain form"
     assert not torch.isnan(first.float()).any()
