@@ -733,6 +733,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
   // the second sub-step is the first with address bit 6 flipped, the second column block is HW rows further.
   const unsigned Wb0 = smem_l + ABUFS * A_BYTES + (wn * WTN + l15) * 128 + ((kq ^ aswz) * 16);
                                                              // (second sub-step: chunk (4 + kq) ^ aswz = the first address with bit 6 flipped)
+  // Round 5: a wave whose two patch rows both lie below the image (the last patch row of a 57-row image holds ONE image row: three of the
+  // four pixel waves have nothing) keeps staging and the barriers but issues no fragment reads and no MFMAs -- its accumulators are never
+  // stored.  2-9 % of the matrix and LDS work of the layers whose height is not a multiple of 8, off the resources the co-resident
+  // block and the other model's kernels share.  Bit-identical.
+  const bool wave_live = y0 + PXB * wm < p.Ho;
   int ab = 0, bb = 0;
   for (int c = 0; c < nch; ++c) {
     const unsigned Xs = smem_l + ab * A_BYTES;                // scalar
@@ -747,6 +752,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
       } else {
         if (ABUFS == 2 && t == 0 && c + 1 < nch) stageA(Abuf + (ab ^ 1) * A_BYTES, (c + 1) * 64);
       }
+      if (wave_live) {
       const unsigned wa0 = Wb0 + bb * B_BYTES, wa1 = wa0 ^ 64u;
       unsigned rho_t = rho0;
       asm volatile("" : "+v"(rho_t));                        // recompute the tap's two addresses here (6 VALU) instead of keeping hoisted ones in registers
@@ -773,6 +779,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3m_kernel(IgemmParams p, 
 #pragma unroll
           for (int j = 0; j < PXB; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k2][i], b[k2][j], acc[i][j], 0, 0, 0);
+      }
       }
       if constexpr (UNPOOL) {
         if (ABUFS == 2 && t == 8 && c + 1 < nch) unpool_store(Abuf + (ab ^ 1) * A_BYTES);
@@ -1027,6 +1034,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
     const unsigned Wl0 = smem_l + 2 * A_BYTES + (wn * WTN + l31) * 128 + ((half ^ aswz) * 16);
     int ab = 0, bb = 0;
     const int nsteps = 9 * (cend - cbeg);
+    // Round 5: a wave whose 32 pixel slots all lie past the tile's PR * Wo pixels (two rows of 46 pixels fill 92 of 128 slots: the
+    // fourth pixel wave has nothing) stages and keeps the barriers but issues no fragment reads and no MFMAs.  Bit-identical.
+    const bool wave_live = wm * 32 < PR * p.Wo;
     int t = 0, tapoff = 0, scol = 0;                            // tap index, r * pitch + s, s
 #pragma unroll 1
     for (int k = 0; k < nsteps; ++k) {
@@ -1036,6 +1046,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
         stB(bb ^ 1, wo);
       }
       if (t == 0 && k + 9 < nsteps) stA(ab ^ 1, xo + 128u);
+      if (wave_live) {
       const int rho = rho0 + tapoff;
       const unsigned Wl = Wl0 + bb * B_BYTES;
       const unsigned Xl = smem_l + ab * A_BYTES + rho * 128 + ((half ^ ((rho >> 1) & 7)) * 16);
@@ -1056,6 +1067,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void igemm3p_kernel(IgemmParams p, 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][i], b[set], acc[i], 0, 0, 0);
+      }
       }
       __syncthreads();
       bb ^= 1;
