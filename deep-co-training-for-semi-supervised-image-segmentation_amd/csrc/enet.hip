@@ -473,7 +473,10 @@ __device__ __forceinline__ void pix3u(unsigned pix, int h, int w, int& n, int& y
 // LDS, are added in wave order, and each wave stores 8 of the 32 pixel rows.  The producer's BatchNorm + activation sits in LDS
 // as (scale, shift, negative-side slope) per input channel -- identity (1, 0, 1) without a transform, slope 0 for ReLU, 1 for the
 // affine form -- so applying it is branch-free.
-constexpr int MC_W = 4;            // waves per block = K-split factor
+#ifndef DCT_MC_W
+#define DCT_MC_W 4
+#endif
+constexpr int MC_W = DCT_MC_W;     // waves per block = K-split factor (8: the round-5 A/B build, profiles/r05_enet_k_split_8_waves_ab.txt)
 constexpr int MC_E = 16 / MC_W;    // accumulators (pixel rows per half-wave) a wave stores after the fold
 __device__ __forceinline__ int mc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }      // MFMA 32x32 D layout: row of accumulator e
 constexpr int MC_U = 1;            // K-steps of one wave whose loads are issued together.  3 is the fastest ALONE (3x3 32->32: 6.6 us)
@@ -1413,7 +1416,7 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
       if (ok) { p.stats = stats_partial; *stats_rows = (int)ptiles; }
     }
     int nt = 1;
-    if (ntiles >= 4 && ptiles >= 2048) nt = 4;
+    if (MC_W <= 4 && ntiles >= 4 && ptiles >= 2048) nt = 4;
     else if (ntiles >= 2 && ptiles * ((ntiles + 1) / 2) >= 2048) nt = 2;
     const int ngroups = (ntiles + nt - 1) / nt;
     if (ptiles * ngroups > 0x7fffffffLL) return DCT_ERR_UNSUPPORTED;
@@ -1421,7 +1424,7 @@ static int enet_conv_impl(const dct_view* x, const float* w, const float* bias, 
     p.ngroups = ngroups;
     if (nt == 1) ENET_T(dtype, (enet_launch<MconvK<T, 1>>(DCT_PROF_OTHER, dim3(gridm), dim3(64 * MC_W), 0, st0, p)));
     else if (nt == 2) ENET_T(dtype, (enet_launch<MconvK<T, 2>>(DCT_PROF_OTHER, dim3(gridm), dim3(64 * MC_W), 0, st0, p)));
-    else ENET_T(dtype, (enet_launch<MconvK<T, 4>>(DCT_PROF_OTHER, dim3(gridm), dim3(64 * MC_W), 0, st0, p)));
+    else if constexpr (MC_W <= 4) ENET_T(dtype, (enet_launch<MconvK<T, 4>>(DCT_PROF_OTHER, dim3(gridm), dim3(64 * MC_W), 0, st0, p)));
     return dct_check_launch();
   }
   if (bin) return DCT_ERR_UNSUPPORTED;        // (the VALU kernel has no de-normalise-on-load form: the caller materialises draw)
