@@ -449,6 +449,8 @@ def main():
     ap.add_argument("--data", default="blob", choices=["blob", "iid"],
                     help="synthetic inputs: blob-structured slices the nets learn (default: the timed network then carries a training net's "
                          "operand statistics), or iid = torch.rand images + torch.randint labels as SURVEY.md 8d words it")
+    ap.add_argument("--allow-nan", action="store_true",
+                    help="diagnostic runs that skip kernel families (--tune 1100=MASK: garbage results, timing only): do not insist on finite losses")
     ap.add_argument("--no-clock-probe", action="store_true", help="do not sample the shader clock beside the replayed step")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight gradients on a second stream per model (eager only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
@@ -589,7 +591,7 @@ def main():
     exchange, meters_ms, operand_stats, prof = m["exchange"], m["meters_ms"], m["operand_stats"], m["prof"]
     clock = m["clock"]
     losses = dict(sup=[float(s) for s in out["sup"]], jsd=float(out["jsd"]))
-    assert all(v == v for v in losses["sup"]) and losses["jsd"] == losses["jsd"], "NaN loss in the timed region"
+    assert args.allow_nan or (all(v == v for v in losses["sup"]) and losses["jsd"] == losses["jsd"]), "NaN loss in the timed region"
 
     ms_per_step = 1e3 * elapsed / args.steps
     imgs_per_step = S * cfg["B_l"] + cfg["B_u"]

@@ -123,8 +123,20 @@ extern int g_dct_prof_on;
 extern thread_local char g_dct_last_plan[200];
 #define DCT_PLAN_NOTE(...) snprintf(g_dct_last_plan, sizeof(g_dct_last_plan), __VA_ARGS__)
 
+// Diagnostic (tools/ablate_step.py): launches of a kernel family can be SKIPPED -- results are garbage, timing tells what the family
+// costs the captured step (its serialized time minus what the other chain's kernels hide).  dct_tune_set(1100, mask); 0 = nothing skipped.
+extern int g_dct_skip_families;
+enum { DCT_FAM_IGEMM2 = 1, DCT_FAM_IGEMM3M = 2, DCT_FAM_IGEMM3P = 4, DCT_FAM_WGRAD2 = 8, DCT_FAM_WGRAD3 = 16, DCT_FAM_FOLDS = 32,
+       DCT_FAM_ADAM = 64, DCT_FAM_POINTWISE = 128 };
+#define DCT_LAUNCH_FAM(fam, cls, kernel, grid, block, shmem, stream, ...)              \
+  do {                                                                                 \
+    if (g_dct_skip_families & (fam)) break;                                            \
+    DCT_LAUNCH(cls, kernel, grid, block, shmem, stream, __VA_ARGS__);                  \
+  } while (0)
+
 #define DCT_LAUNCH(cls, kernel, grid, block, shmem, stream, ...)                       \
   do {                                                                                 \
+    if (((cls) == DCT_PROF_POINTWISE && (g_dct_skip_families & 128)) || ((cls) == DCT_PROF_ADAM && (g_dct_skip_families & 64))) break; \
     if (g_dct_prof_on) dct_prof_begin((cls), (stream));                                \
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);               \
     if (g_dct_prof_on) dct_prof_end((cls), (stream));                                  \

@@ -1304,7 +1304,7 @@ static void launch_v2_k(const IgemmParams& p, dim3 grid, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm2_kernel<BM, BN, WM, WN, BOUNDS, LEAN>), grid, dim3(WM * WN * 64), lds, st, p);
+  DCT_LAUNCH_FAM(DCT_FAM_IGEMM2, DCT_PROF_IGEMM, (igemm2_kernel<BM, BN, WM, WN, BOUNDS, LEAN>), grid, dim3(WM * WN * 64), lds, st, p);
 }
 template <int BM, int BN, int WM, int WN, bool BOUNDS>
 static void launch_v2(const IgemmParams& p, dim3 grid, hipStream_t st) {
@@ -1324,7 +1324,7 @@ static void launch_v3u(const IgemmParams& p, int tiles_x, int tiles_y, int image
     attr_set = true;
   }
   const dim3 grid((unsigned)(images * tiles_y * tiles_x), p.N / BN, 1);
-  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3m_kernel<BN, 4, NWN, ABUFS, UNPOOL>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
+  DCT_LAUNCH_FAM(DCT_FAM_IGEMM3M, DCT_PROF_IGEMM, (igemm3m_kernel<BN, 4, NWN, ABUFS, UNPOOL>), grid, dim3(4 * NWN * 64), lds, st, p, tiles_x, tiles_y);
 }
 template <int BN, int NWN, int ABUFS>
 static void launch_v3(const IgemmParams& p, int tiles_x, int tiles_y, int images, hipStream_t st) {
@@ -1384,7 +1384,7 @@ static void launch_v3p_k(const IgemmParams& p, const PlanP& pp, dim3 grid, hipSt
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_IGEMM, (igemm3p_kernel<128, 4, 2, LEAN>), grid, dim3(512), lds, st, p, pp.PR, pp.tiles_per_img, pp.cps);
+  DCT_LAUNCH_FAM(DCT_FAM_IGEMM3P, DCT_PROF_IGEMM, (igemm3p_kernel<128, 4, 2, LEAN>), grid, dim3(512), lds, st, p, pp.PR, pp.tiles_per_img, pp.cps);
 }
 // dct_tune_set(DCT_TUNE_IGEMM_XCD): 0 = natural 3-D grids; 1 = the per-tap and packed-rows kernels deal their blocks XCD by XCD
 // (xcd_remap) on layers whose packed weights outweigh their activations; 2 = on every layer they run
@@ -1409,7 +1409,7 @@ static void launch_v3p(const IgemmParams& p0, const PlanP& pp, int images, hipSt
   else launch_v3p_k<false>(p, pp, grid, st);
   if (pp.splits > 1) {
     const long long work = (long long)p.M * (p.N / 4);
-    DCT_LAUNCH(DCT_PROF_IGEMM, (splitk_epilogue_kernel<bf16_t>), dim3(div_up(work, 256)), dim3(256), 0, st, p, pp.splits);
+    DCT_LAUNCH_FAM(DCT_FAM_FOLDS, DCT_PROF_IGEMM, (splitk_epilogue_kernel<bf16_t>), dim3(div_up(work, 256)), dim3(256), 0, st, p, pp.splits);
   }
 }
 
@@ -1432,7 +1432,7 @@ static int launch(const IgemmParams& p0, const Plan& pl, hipStream_t st) {
   }
   if (pl.splits > 1) {
     const long long work = (long long)p.M * (p.N / 4);
-    DCT_LAUNCH(DCT_PROF_IGEMM, (splitk_epilogue_kernel<T>), dim3(div_up(work, 256)), dim3(256), 0, st, p, pl.splits);
+    DCT_LAUNCH_FAM(DCT_FAM_FOLDS, DCT_PROF_IGEMM, (splitk_epilogue_kernel<T>), dim3(div_up(work, 256)), dim3(256), 0, st, p, pl.splits);
   }
   return dct_check_launch();
 }
@@ -1667,6 +1667,7 @@ extern "C" int dct_tune_set(int knob, int value) {
     case DCT_TUNE_IGEMM_PACKED_SPLIT: if (value < 1) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_split = value; return DCT_OK;
     case DCT_TUNE_IGEMM_PACKED_FILL: if (value < 1 || value > 100) return DCT_ERR_BAD_ARG; g_tune_igemm_packed_fill = value; return DCT_OK;
     case DCT_TUNE_IGEMM_XCD: if (value < 0 || value > 2) return DCT_ERR_BAD_ARG; g_tune_igemm_xcd = value; return DCT_OK;
+    case 1100: g_dct_skip_families = value; return DCT_OK;      // diagnostic: skip kernel families (tools/ablate_step.py)
     case 1005: g_tune_igemm_pool = value ? 1 : 0; return DCT_OK;
     case 1008: g_stem_dgrad_mfma = value ? 1 : 0; return DCT_OK;
     case 1002: g_tune_igemm_split_max_tiles = value; return DCT_OK;     // planner studies (tools/bench_conv.py --ab-knob)

@@ -6,6 +6,7 @@
 #include "dct_common.h"
 
 int g_dct_prof_on = 0;
+int g_dct_skip_families = 0;      // diagnostic: dct_common.h DCT_LAUNCH_FAM
 
 // Diagnostic: which kernel / grid the planner chose for the last dct_conv2d / dct_conv2d_wgrad call of this thread
 // (tools/bench_conv.py --plan prints it per layer).  Not part of the ABI contract.

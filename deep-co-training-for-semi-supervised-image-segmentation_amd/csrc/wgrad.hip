@@ -1235,7 +1235,7 @@ static void launch_w2_k(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ, NW, LEAN>), dim3(grid), dim3(NW * 64), lds, st, pr);
+  DCT_LAUNCH_FAM(DCT_FAM_WGRAD2, DCT_PROF_WGRAD, (wgrad2_kernel<BP, BQ, NW, LEAN>), dim3(grid), dim3(NW * 64), lds, st, pr);
 }
 template <int BP, int BQ, int NW>
 static void launch_w2_t(const Wgrad2Params& pr, unsigned grid, hipStream_t st) {
@@ -1251,7 +1251,7 @@ static void launch_w3_q(const Wgrad3Params& pr, unsigned grid, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  DCT_LAUNCH(DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT, LEAN, UNPOOL>), dim3(grid), dim3(G * NW * 64), lds, st, pr);
+  DCT_LAUNCH_FAM(DCT_FAM_WGRAD3, DCT_PROF_WGRAD, (wgrad3_kernel<BP, BQ, NW, NARROW, G, QSHIFT, LEAN, UNPOOL>), dim3(grid), dim3(G * NW * 64), lds, st, pr);
 }
 // lean form of the filter-row kernel: no padding, views under 2 GiB (buffer descriptors)
 static bool w3_lean(const Wgrad3Params& pr) {
@@ -1388,7 +1388,7 @@ extern "C" int dct_conv2d_wgrad_bias(const dct_view* p0, const dct_view* q, floa
                 pl.direct ? ", direct" : "");
   if (!pl.direct) {
     const long long n4b = db ? p->c / 4 : 0;
-    DCT_LAUNCH(DCT_PROF_WGRAD, wgrad_reduce_kernel, dim3(div_up(E / 4 + n4b, 256)), dim3(256), 0, st,
+    DCT_LAUNCH_FAM(DCT_FAM_FOLDS, DCT_PROF_WGRAD, wgrad_reduce_kernel, dim3(div_up(E / 4 + n4b, 256)), dim3(256), 0, st,
                (const float*)workspace, dw, db, E / 4, n4b, slab_stride, pl.slabs, d->accumulate);
   }
   return dct_check_launch();

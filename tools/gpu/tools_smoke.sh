@@ -24,5 +24,8 @@ t probe_buffer_lds   bash -c '/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w t
 t isa_loop_mix       bash -c 'cd deep-co-training-for-semi-supervised-image-segmentation_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S wgrad.hip -o /tmp/wgrad_smoke.s 2>/dev/null; cd ../.. && python tools/isa_loop_mix.py /tmp/wgrad_smoke.s wgrad3_kernelILi64ELi64ELi4ELb0ELi2ELb1ELb1'
 t pmc_kernel_mix     bash -c 'export TMPDIR=/tmp; rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -d '$O'/pm -o p --output-format csv -- python3 tools/bench_conv.py --batch 4 --reps 2 --only dec3b > /dev/null 2>&1; python tools/pmc_kernel_mix.py $(find '$O'/pm -name "*counter_collection.csv" | head -1); python tools/trace_alone.py $(find '$O'/pm -name "*kernel_trace.csv" | head -1); python tools/trace_runs.py $(find '$O'/pm -name "*kernel_trace.csv" | head -1) 2 | tail -5'
 t power_clock        bash tools/gpu/power_clock.sh cfg2 60
+t bench_unpool       python tools/bench_unpool.py --reps 3 --batch 4
+t bench_grouped      python tools/bench_grouped.py --reps 3
+t probe_store_bw     bash -c '/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/probe_store_bw/probe.hip -o tools/probe_store_bw/probe.bin && tools/probe_store_bw/probe.bin | tail -5'
 for f in $O/*.log; do echo "==> $f"; tail -n 3 "$f"; done | grep -E "==>|Error|error|Traceback" | tail -n 60
 cat $O/summary.txt
