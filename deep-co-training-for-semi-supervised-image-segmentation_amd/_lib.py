@@ -125,6 +125,7 @@ SIGNATURES = {
     "dct_kl_map_bwd": (_i, [_P, _P, _P, _P, _i64, _i, _f, _P]),
     "dct_jsd_logits_fwd": (_i, [_P, _i, _i64, _i, _P, _P, _sz, _P]),
     "dct_jsd_logits_bwd": (_i, [_P, _i, _i64, _i, _P, _f, _P, _i, _P]),
+    "dct_jsd_logits_step": (_i, [_P, _i, _i64, _i, _P, _P, _P, _f, _P, _i, _P, _sz, _P]),
     "dct_kl_logits_fwd": (_i, [_P, _P, _i64, _i, _f, _P, _P, _sz, _P]),
     "dct_kl_logits_bwd": (_i, [_P, _P, _i64, _i, _f, _P, _f, _P, _i, _P]),
     "dct_argmax": (_i, [_P, _P, _i64, _i, _P]),
@@ -164,6 +165,7 @@ SIGNATURES = {
     "dct_prof_enable": (_i, [_i]),
     "dct_prof_read": (_i, [_P, _P, _i]),
     "dct_clock_probe": (_i, [_P, C.c_uint64, _P]),
+    "dct_stamp": (_i, [_P, C.c_uint32, _P]),
 }
 
 _lib = None

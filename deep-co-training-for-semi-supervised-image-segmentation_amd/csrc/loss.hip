@@ -253,6 +253,60 @@ __global__ __launch_bounds__(256) void jsd_bwd_kernel(PtrPack pk, int S, long lo
   }
 }
 
+// The co-training step's whole JSD section in ONE pass over the logits (round 5): mean-JSD partial sums (jsd_fwd_kernel<C, true>'s, on its
+// grid: same pixels per thread, same order -> the same block partials), the S softmax maps the step returns (softmax_fwd_kernel's) and the S
+// logit gradients (jsd_bwd_kernel<C, true>'s arithmetic).  Five launches became two (this + the finalize) in the one stretch of the step where
+// nothing else runs: both models' forward passes have just joined (tools/phase_stamps.py).  Bit-identical to the separate launches.
+template <int C, int SMAX>
+__global__ __launch_bounds__(256) void jsd_step_kernel(PtrPack pk, PtrPack probs, int S, long long P, const float* gscale, float gmul, int acc,
+                                                        int want_grad, float* partial) {
+  const float invS = 1.f / (float)S;
+  const float g = (gscale ? gscale[0] : 1.f) * gmul / (float)P;
+  float sum = 0.f;
+  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < P; pix += (long long)gridDim.x * 256) {
+    float p[SMAX][C], mean[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) mean[c] = 0.f;
+    float hsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+      if (s < S) {
+        float x[C];
+        load_px<C>(pk.in[s], pix, x);
+        softmax_px<C>(x, p[s]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) mean[c] += p[s][c];
+        hsum += entropy_px<C>(p[s]);
+        if (probs.out[s]) store_px<C>(probs.out[s], pix, p[s], false);
+      }
+    }
+    float dm[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) mean[c] *= invS;
+    sum += entropy_px<C>(mean) - hsum * invS;
+    if (want_grad) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) dm[c] = dent(mean[c]);
+#pragma unroll
+      for (int s = 0; s < SMAX; ++s) {
+        if (s < S) {
+          float d[C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) d[c] = invS * (dm[c] - dent(p[s][c]));
+          float dot = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) dot += d[c] * p[s][c];
+          float o[C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) o[c] = g * p[s][c] * (d[c] - dot);
+          store_px<C>(pk.out[s], pix, o, acc);
+        }
+      }
+    }
+  }
+  block_partial2(sum, 0.f, partial);
+}
+
 // ---- KL(y || p) -----------------------------------------------------------------------------------
 template <int C, bool FROM_LOGITS>
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* pin, const float* yin, long long P, float eps, float* map, float* partial) {
@@ -539,6 +593,23 @@ extern "C" int dct_jsd_logits_bwd(const float* const* logits, int S, int64_t pix
   hipStream_t st = (hipStream_t)stream;
   if (S <= 4) { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_bwd_kernel<C, true, 4>), dim3(wide_grid(pixels)), dim3(256), 0, st, pk, S, (long long)pixels, (const float*)nullptr, gscale, gmul, accumulate)); }
   else { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_bwd_kernel<C, true, MAXS>), dim3(wide_grid(pixels)), dim3(256), 0, st, pk, S, (long long)pixels, (const float*)nullptr, gscale, gmul, accumulate)); }
+  return dct_check_launch();
+}
+
+extern "C" int dct_jsd_logits_step(const float* const* logits, int S, int64_t pixels, int C_, float* out1, float* const* probs,
+                                   const float* gscale, float gmul, float* const* dlogits, int accumulate,
+                                   void* workspace, size_t workspace_bytes, dct_stream stream) {
+  PtrPack pk, pp;
+  if (!fill_pack(pk, logits, dlogits, S) || !out1 || pixels < 1) return DCT_ERR_BAD_ARG;
+  for (int s = 0; s < MAXS; ++s) { pp.in[s] = nullptr; pp.out[s] = (probs && s < S) ? probs[s] : nullptr; }
+  if (!dlogits) { for (int s = 0; s < MAXS; ++s) pk.out[s] = nullptr; }
+  if (!ws_ok(workspace, workspace_bytes)) return DCT_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = grid_for(pixels);       // dct_jsd_logits_fwd's grid: the block partials, hence the mean, come out bit for bit
+  const int want = dlogits ? 1 : 0;
+  if (S <= 4) { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_step_kernel<C, 4>), dim3(grid), dim3(256), 0, st, pk, pp, S, (long long)pixels, gscale, gmul, accumulate, want, (float*)workspace)); }
+  else { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_step_kernel<C, MAXS>), dim3(grid), dim3(256), 0, st, pk, pp, S, (long long)pixels, gscale, gmul, accumulate, want, (float*)workspace)); }
+  DCT_LAUNCH(DCT_PROF_LOSS, finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, (int)grid, out1, 0, (float)pixels, 0);
   return dct_check_launch();
 }
 

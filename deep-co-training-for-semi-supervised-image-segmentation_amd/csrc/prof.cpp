@@ -82,6 +82,24 @@ extern "C" int dct_clock_probe(unsigned long long* out2, unsigned long long ref_
   return hipGetLastError() == hipSuccess ? DCT_OK : DCT_ERR_LAUNCH;
 }
 
+// Phase stamp (tools/phase_stamps.py): a one-thread kernel that leaves the 100 MHz reference counter at `slot` -- queued on a model's
+// stream between the phases of the step (it is an ordinary kernel node: it replays with the captured graph), it dates the phases of the
+// REAL schedule, which a tracing profiler serialises.
+// slot[0] counts the stamps of this site, slot[1 + n % ring] holds the n-th: a replayed graph (fixed addresses) leaves a timeline of its last
+// `ring` replays, so the steps can be dated while they are PIPELINED (no host synchronisation between replays).
+__global__ void dct_stamp_kernel(unsigned long long* slot, unsigned ring) {
+  unsigned long long r;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) :: "memory");
+  const unsigned long long n = slot[0];
+  slot[1 + n % ring] = r;
+  slot[0] = n + 1;
+}
+extern "C" int dct_stamp(unsigned long long* slot, unsigned ring, dct_stream stream) {
+  if (!slot || ring < 1) return DCT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dct_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot, ring);
+  return hipGetLastError() == hipSuccess ? DCT_OK : DCT_ERR_LAUNCH;
+}
+
 extern "C" int dct_version(void) { return 100; }
 
 extern "C" const char* dct_status_string(int status) {

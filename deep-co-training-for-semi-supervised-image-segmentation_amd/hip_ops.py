@@ -535,6 +535,20 @@ def jsd_logits_bwd(logits: List[torch.Tensor], C_, dlogits: List[torch.Tensor], 
     return dlogits
 
 
+def jsd_logits_step(logits: List[torch.Tensor], C_, dlogits: List[torch.Tensor] = None, want_probs: bool = True, gscale=None, gmul=1.0,
+                    accumulate=False):
+    """-> (mean JSD [1], [softmax(logits_s)] or None): `jsd_logits_fwd`, the S `softmax_fwd` maps and `jsd_logits_bwd` into ``dlogits`` (None:
+    no gradients) as ONE pass over the logits + the finalize -- bit for bit what the separate launches give (dct_jsd_logits_step)."""
+    dev = logits[0].device
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = _loss_ws(dev)
+    probs = [torch.empty_like(lp) for lp in logits] if want_probs else None
+    call("dct_jsd_logits_step", _ptr_array(logits), len(logits), logits[0].numel() // C_, C_, ptr(out),
+         _ptr_array(probs) if probs is not None else None, ptr(gscale), float(gmul),
+         _ptr_array(dlogits) if dlogits is not None else None, int(accumulate), ptr(ws), ws.numel(), stream())
+    return out, probs
+
+
 def kl_logits_fwd(p_logits, y_logits, C_, eps=1e-10):
     out = torch.empty(1, dtype=torch.float32, device=p_logits.device)
     ws = _loss_ws(out.device)

@@ -365,6 +365,19 @@ class CoTrainer(Trainer):
                 net.plan_backward(tape, dl, need_dx=False, need_dw=True, grad_buffer=buf)
         return fp, bufs
 
+    # Diagnostic (tools/phase_stamps.py): with ``self.phase_stamps`` = a zeroed int64 device tensor [S, 4, 1 + PHASE_RING], one-thread stamp
+    # launches date the phases of the step on each model's stream (site k = 0 forward starts, 1 forward + loss done, 2 backward done,
+    # 3 optimizer done) into a ring per site.  They are kernel nodes: a captured step replays them, so pipelined replays leave a timeline.
+    phase_stamps = None
+    PHASE_RING = 64
+
+    def _stamp(self, model: int, k: int):
+        buf = self.phase_stamps
+        if buf is None:
+            return
+        from .. import _lib
+        _lib.check(_lib.load().dct_stamp(buf[model, k].data_ptr(), self.PHASE_RING, torch.cuda.current_stream(self.device).cuda_stream), "dct_stamp")
+
     def _finish_step(self, backward_calls, streams=None):
         """zero_grad (after the forwards, :245) -> backward (:246-247) -> [gradient all-reduce] -> step (:248).
         ``backward_calls``: list of (model index or None, callable).  With data parallelism each
@@ -381,6 +394,8 @@ class CoTrainer(Trainer):
         for idx, call in backward_calls:
             with on(idx):
                 call()
+                if idx is not None:
+                    self._stamp(idx, 2)
                 if self.grad_sync is not None and idx is not None and idx not in self._pass_pending:
                     self._sched.call(lambda idx=idx: self.grad_sync.begin(idx))
         if self._pass_pending:
@@ -427,6 +442,7 @@ class CoTrainer(Trainer):
                     if flat is not None and flat.grads_attached():
                         flat.gflat.mul_(unscale)
                 seg.optimizer.step()
+                self._stamp(i, 3)
 
     def _run_step_generic(self, lab, unl, train_jsd, train_adv, adv_choice) -> dict:
         S = len(self.segmentators)
@@ -514,6 +530,7 @@ class CoTrainer(Trainer):
         full = []                                                              # fuse: (tape, logits, dlogits) of the joint pass
         for i in range(S):                                                     # :208-218
             with on(i):
+                self._stamp(i, 0)
                 img, gt = lab[i]
                 B_l = img.shape[0]
                 if fuse:
@@ -530,6 +547,7 @@ class CoTrainer(Trainer):
                 K.ce_bwd(lp, t, C, out[1:2], dl_out, gmul=gs, ignore_index=ignore)
                 sup.append(out[0])
                 preds.append(_nchw(lp))
+                self._stamp(i, 1)
         jsd, unlab_probs = 0, []
         if train_jsd:                                                          # :219-227
             if fuse:
@@ -546,10 +564,11 @@ class CoTrainer(Trainer):
                         dl_outs.append(torch.empty_like(lp_u))
             joined_after_forwards = True
             join()                                  # the JSD couples all S models: main stream, then fork again
-            jsd = K.jsd_logits_fwd(lps, C)[0]
-            unlab_probs = [_nchw(K.softmax_fwd(lp, C)) for lp in lps]
+            # value, the S softmax maps and the S logit gradients in ONE pass over the logits (dct_jsd_logits_step: bit for bit the five separate launches)
+            jsd1, probs = K.jsd_logits_step(lps, C, dl_outs if lam_cot != 0.0 else None, True, **g_cot)
+            jsd = jsd1[0]
+            unlab_probs = [_nchw(p_) for p_ in probs]
             if lam_cot != 0.0:
-                K.jsd_logits_bwd(lps, C, dl_outs, **g_cot)
                 if not fuse:
                     for i in range(S):
                         passes[i].append((utapes[i], dl_outs[i]))
@@ -778,10 +797,10 @@ class CoTrainer(Trainer):
         jq = free[0]
         sched.wait([(jq, st) for st in free[1:]])
         with sched.on(jq):
-            jsd = K.jsd_logits_fwd(lps, C)[0]
-            unlab_probs = [_nchw(K.softmax_fwd(lp, C)) for lp in lps]
-            if lam_cot != 0.0:
-                K.jsd_logits_bwd(lps, C, dl_outs, **g_cot)
+            # value, the S softmax maps and the S logit gradients in ONE pass over the logits (dct_jsd_logits_step: bit for bit the five separate launches)
+            jsd1, probs = K.jsd_logits_step(lps, C, dl_outs if lam_cot != 0.0 else None, True, **g_cot)
+            jsd = jsd1[0]
+            unlab_probs = [_nchw(p_) for p_ in probs]
         sched.wait([(st, jq) for st in free[1:]])
         for i in range(S):
             with sched.on(lab_q[i]):
@@ -865,10 +884,10 @@ class CoTrainer(Trainer):
         lps = [unl_out[i][0] for i in range(S)]
         dl_outs = [torch.empty_like(lp) for lp in lps]
         with sched.on(q_unl):                                                  # :219-227
-            jsd = K.jsd_logits_fwd(lps, C)[0]
-            unlab_probs = [_nchw(K.softmax_fwd(lp, C)) for lp in lps]
-            if lam_cot != 0.0:
-                K.jsd_logits_bwd(lps, C, dl_outs, **g_cot)
+            # value, the S softmax maps and the S logit gradients in ONE pass over the logits (dct_jsd_logits_step: bit for bit the five separate launches)
+            jsd1, probs = K.jsd_logits_step(lps, C, dl_outs if lam_cot != 0.0 else None, True, **g_cot)
+            jsd = jsd1[0]
+            unlab_probs = [_nchw(p_) for p_ in probs]
 
         def backward_group(members):
             # what does not record (zero fill of the pass buffers, the cast of the loss gradients) goes first
@@ -974,11 +993,11 @@ class CoTrainer(Trainer):
         with sched.on(qj):
             lps = [full[i][1][B_l:] for i in range(2)]
             dl_outs = [full[i][2][B_l:] for i in range(2)]
-            jsd = K.jsd_logits_fwd(lps, C)[0]
-            unlab_probs = [_nchw(K.softmax_fwd(lp, C)) for lp in lps]
-            if lam_cot != 0.0:
-                K.jsd_logits_bwd(lps, C, dl_outs, **g_cot)
-            else:
+            # value, the S softmax maps and the S logit gradients in ONE pass over the logits (dct_jsd_logits_step: bit for bit the five separate launches)
+            jsd1, probs = K.jsd_logits_step(lps, C, dl_outs if lam_cot != 0.0 else None, True, **g_cot)
+            jsd = jsd1[0]
+            unlab_probs = [_nchw(p_) for p_ in probs]
+            if lam_cot == 0.0:
                 for d in dl_outs:
                     d.zero_()
         jsd_done = sched.record(qj)

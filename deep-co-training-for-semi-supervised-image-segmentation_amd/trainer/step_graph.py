@@ -128,11 +128,16 @@ class StepGraphCache(object):
             first = True
         else:
             first = False
-        for (s_img, s_gt), (img, gt) in zip(cap.lab, lab):
-            s_img.copy_(img, non_blocking=True)
-            s_gt.copy_(gt, non_blocking=True)
-        if cap.unl is not None:
-            cap.unl[0].copy_(unl[0], non_blocking=True)
+        # The mini-batches into the static input buffers: ONE multi-tensor copy per dtype instead of 2 S + 1 launches -- the replays are
+        # pipelined, and whatever is queued between two graph launches sits on the critical path (tools/phase_stamps.py: 60 us between
+        # one step's last optimizer and the next step's first kernel, with five copies and three result clones in it)
+        dsts = [t for pair in cap.lab for t in pair] + ([cap.unl[0]] if cap.unl is not None else [])
+        srcs = [t for pair in lab for t in pair] + ([unl[0]] if cap.unl is not None else [])
+        try:
+            torch._foreach_copy_(dsts, srcs, non_blocking=True)
+        except (RuntimeError, TypeError, AttributeError):
+            for d, s_ in zip(dsts, srcs):
+                d.copy_(s_, non_blocking=True)
         if cap.program is not None:            # one graph per stream segment, launched on the segments' own streams
             cap.program.replay()
         else:
@@ -147,11 +152,15 @@ class StepGraphCache(object):
             for (obj, name), d in zip(self._counters(), cap.counters):
                 setattr(obj, name, getattr(obj, name) + d)
         o = cap.out
-        # the small results are copied out (callers may keep them across steps); the prediction maps are the
-        # graph's static buffers, valid until the next step
-        return dict(sup=[s.clone() for s in o["sup"]],
-                    jsd=o["jsd"].clone() if torch.is_tensor(o["jsd"]) else o["jsd"],
-                    adv=o["adv"].clone() if torch.is_tensor(o["adv"]) else o["adv"],
+        # the small results are copied out (callers may keep them across steps) -- as ONE stacked tensor: one launch between two replays
+        # instead of one per scalar; the prediction maps are the graph's static buffers, valid until the next step
+        scalars = list(o["sup"]) + [o[k] for k in ("jsd", "adv") if torch.is_tensor(o[k])]
+        vals = torch.stack([v.reshape(()) for v in scalars])
+        n = len(o["sup"])
+        rest = iter(vals[n:])
+        return dict(sup=[vals[i] for i in range(n)],
+                    jsd=next(rest) if torch.is_tensor(o["jsd"]) else o["jsd"],
+                    adv=next(rest) if torch.is_tensor(o["adv"]) else o["adv"],
                     preds=o["preds"], unlab_probs=o["unlab_probs"])
 
     def _capture(self, sig, lab, unl, train_jsd, train_adv, adv_choice, lam_dev) -> Optional[_Captured]:

@@ -269,6 +269,12 @@ int dct_jsd_logits_fwd(const float* const* logits, int S, int64_t pixels, int C,
                        void* workspace, size_t workspace_bytes, dct_stream stream);
 int dct_jsd_logits_bwd(const float* const* logits, int S, int64_t pixels, int C, const float* gscale,
                        float gmul, float* const* dlogits, int accumulate, dct_stream stream);
+/* The step's whole JSD section in one pass (round 5): out1[0] = mean JSD (dct_jsd_logits_fwd's value, bit for bit), probs[s] (nullable array /
+ * entries) = softmax of logits[s] (dct_softmax_fwd), dlogits[s] (nullable array: no gradients) (=|+=) the gradient dct_jsd_logits_bwd writes.
+ * Two launches instead of five between the join of the S forward passes and the fork of the S backward passes (cotraining_totalloss.py:219-227). */
+int dct_jsd_logits_step(const float* const* logits, int S, int64_t pixels, int C, float* out1, float* const* probs,
+                        const float* gscale, float gmul, float* const* dlogits, int accumulate,
+                        void* workspace, size_t workspace_bytes, dct_stream stream);
 /* out[0] = mean_pix sum_c y*(log(y+eps)-log(p+eps)), p = softmax(p_logits), y = softmax(y_logits) */
 int dct_kl_logits_fwd(const float* p_logits, const float* y_logits, int64_t pixels, int C, float eps,
                       float* out1, void* workspace, size_t workspace_bytes, dct_stream stream);
@@ -488,6 +494,10 @@ int dct_prof_read(double* ms_per_class, int64_t* launches_per_class, int reset);
  * held meanwhile is 0.1 GHz * out2[0] / out2[1].  Launched on a stream of its own beside the captured step, it samples the clock
  * UNDER that load (bench.py `roofline.shader_clock_ghz_during_the_step`).  out2: two device uint64.  ref_ticks <= 1e8 (one second). */
 int dct_clock_probe(unsigned long long* out2, unsigned long long ref_ticks, dct_stream stream);
+/* Phase stamp: a one-thread launch on `stream` that appends the 100 MHz reference counter (s_memrealtime) to a ring: slot[0] counts the site's
+ * stamps, slot[1 + n % ring] holds the n-th (device uint64[1 + ring], zeroed by the caller).  Diagnostic: queued between the phases of a step, it
+ * dates them in the real, pipelined schedule of the replayed graph (CoTrainer.phase_stamps, tools/phase_stamps.py). */
+int dct_stamp(unsigned long long* slot, unsigned ring, dct_stream stream);
 
 /* "De-normalise on load": a data-gradient convolution whose input is the BatchNorm-backward result of the layer in front of it
  * computes that result where it would load it -- raw = that layer's fp32 output, tf = its scale / shift / slope (mode != 0),

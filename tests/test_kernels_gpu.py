@@ -652,6 +652,29 @@ def test_conv2d_wgrad_unpools_on_load_bit_identical(ops, B, C, H, W, Cq):
         assert torch.equal(a, b), what
 
 
+@pytest.mark.parametrize("S,C,accumulate", [(2, 4, False), (3, 2, True), (6, 4, False)])
+def test_jsd_step_in_one_pass_is_bit_identical(ops, S, C, accumulate):
+    """dct_jsd_logits_step (mean JSD + the S softmax maps + the S logit gradients in one pass) against dct_jsd_logits_fwd, dct_softmax_fwd
+    and dct_jsd_logits_bwd: every output bit -- the value because the pass keeps the forward kernel's grid and summation order."""
+    g = torch.Generator().manual_seed(61)
+    P = 3 * 97 * 101
+    logits = [torch.randn(P, C, generator=g).to(DEV) for _ in range(S)]
+    gscale = torch.tensor([0.37], device=DEV)
+    old = [torch.randn(P, C, generator=g).to(DEV) for _ in range(S)]
+    want_v = ops.jsd_logits_fwd(logits, C)
+    want_p = [ops.softmax_fwd(lp, C) for lp in logits]
+    want_g = ops.jsd_logits_bwd(logits, C, [o.clone() for o in old], gscale=gscale, gmul=4.0, accumulate=accumulate)
+    got_g = [o.clone() for o in old]
+    got_v, got_p = ops.jsd_logits_step(logits, C, got_g, True, gscale=gscale, gmul=4.0, accumulate=accumulate)
+    assert torch.equal(got_v, want_v) and float(got_v) > 0
+    for a, b in zip(got_p, want_p):
+        assert torch.equal(a, b)
+    for a, b in zip(got_g, want_g):
+        assert torch.equal(a, b)
+    v2, p2 = ops.jsd_logits_step(logits, C, None, False)          # value only
+    assert torch.equal(v2, want_v) and p2 is None
+
+
 def _pack_bits(t_nhwc):
     """ReLU-gate bits of a dense NHWC tensor as the kernels lay them out: byte (pixel, c // 8), bit c % 8."""
     pos = (t_nhwc.float() > 0).to(torch.int32)
