@@ -1223,6 +1223,17 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmParams p, int
   IgemmParams q = p;
   q.partial = nullptr;
   epilogue_store4<T>(q, n, oy, ox, c, v);
+  if constexpr (sizeof(T) == 2) {
+    if (p.bits_out) {
+      // ReLU-gate bits of the rounded output (relu_bits_kernel's test, which used to be a launch of its own behind every split layer):
+      // this thread's four channels are half a byte, its neighbour (the other half of the same pixel's 8-channel group) supplies the rest
+      unsigned nib = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) nib |= ((float)(bf16_t)v[e] > 0.f ? 1u : 0u) << e;
+      const unsigned other = __shfl_xor(nib, 1, 64);
+      if ((c & 4) == 0) p.bits_out[(unsigned long long)(n * p.ysN + oy * p.ysH + ox * p.ysW + c) >> 3] = (unsigned char)(nib | (other << 4));
+    }
+  }
 }
 
 // ReLU-gate bits of a dense bf16 tensor (the paths whose epilogue does not leave them behind: split-K, unstaged stores)
@@ -1634,7 +1645,6 @@ extern "C" int dct_conv2d(const dct_view* x0, const void* w_packed, const float*
         { const int rp = pool_after(); if (rp != DCT_OK) return rp; }
         DCT_PLAN_NOTE("igemm3p packed rows (%d rows of %d px per 128-px tile): %d x %d blocks x %d channel-slice splits", pp.PR, p.Wo,
                       y->n * pp.tiles_per_img, p.N / 128, pp.splits);
-        if (pp.splits > 1) bits_after();
         return dct_check_launch();
       }
     }
@@ -1642,7 +1652,7 @@ extern "C" int dct_conv2d(const dct_view* x0, const void* w_packed, const float*
   const int rc = dtype == DCT_BF16 ? launch<bf16_t>(p, pl, st) : launch<float>(p, pl, st);
   DCT_PLAN_NOTE("%s per-tap %d x %d tile%s: %lld tiles x %d splits, %d K-steps each%s", pl.v2 ? "igemm2" : "igemm", pl.bm, pl.bn,
                 pl.bounds ? " (bounds)" : "", pl.tiles, pl.splits, pl.kiters_per_split, p.staged ? ", staged epilogue" : "");
-  if (rc == DCT_OK && !p.staged) bits_after();
+  if (rc == DCT_OK && !p.staged && pl.splits == 1) bits_after();      // (a split layer's fold writes the bits itself)
   if (rc == DCT_OK) { const int rp = pool_after(); if (rp != DCT_OK) return rp; }
   return rc == DCT_OK ? dct_check_launch() : rc;
 }
