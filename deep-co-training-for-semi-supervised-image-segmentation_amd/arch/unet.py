@@ -203,6 +203,9 @@ class UNet(nn.Module):
         self.pool_only = True                # ... whose full-resolution output is then not stored at all (nobody else reads it)
         self.fuse_stem_wgrad = True          # the stem's weight gradient from the epilogue of the data gradient that produces its dy (not stored then)
         self.fuse_skip_grad = True           # the skip connections' bilinear backward gathered by the un-pooling instead of summed in memory
+        self.late_packs = True               # the transposed weight packs (first reader: the centre's up-convolution) are launched behind the encoder,
+                                             # beside the other chain's kernels, instead of in front of the stem where nothing else runs
+        self._pending_packs = None
         self.unpool_max_level = 3            # the deepest level that does
         self.unpool_on_load = False          # levels 1..unpool_max_level: the un-pooled gradient of an encoder block is never written -- its two consumers
                                              # expand {pooled gradient + routing codes} while they stage (dct_conv_desc.unpool_codes).  Built, bit-identical,
@@ -237,8 +240,9 @@ class UNet(nn.Module):
     def _gb(self, conv: _ConvP) -> torch.Tensor:
         return self.flat_params.grad_dense(self._pidx[id(conv.bias)])
 
-    def _ensure_packs(self):
-        """(Re)build compute-dtype weight packs when the fp32 masters changed."""
+    def _ensure_packs(self, late: bool = False):
+        """(Re)build compute-dtype weight packs when the fp32 masters changed.  ``late``: the batched transposing launch is left
+        pending for `_run_forward`, which issues it in front of the packs' first reader (`_flush_packs`)."""
         fp = self.flat_params
         if fp.ensure():
             self._shadow_fresh = False
@@ -282,8 +286,15 @@ class UNet(nn.Module):
         if self._pack_table is None or self._pack_table[0] != tkey:
             self._pack_table = (tkey,) + K.pack_jobs_table(jobs, dev)
         _, table, njobs, tiles, edge = self._pack_table
-        K.pack_weights_batched(table, njobs, tiles, dt, edge)
+        self._pending_packs = (table, njobs, tiles, dt, edge)
+        if not late:
+            self._flush_packs()
         self._pack_key = key
+
+    def _flush_packs(self):
+        job, self._pending_packs = self._pending_packs, None
+        if job is not None:
+            K.pack_weights_batched(*job)
 
     # ------------------------------------------------------------------------------ forward
     def _check_input(self, x: torch.Tensor):
@@ -300,7 +311,7 @@ class UNet(nn.Module):
     def plan_forward(self, x: torch.Tensor, save: bool = True):
         """-> (logits, tape): logits physical NHWC fp32 [B,H,W,C]; tape feeds plan_backward (None if not save)."""
         self._check_input(x)
-        self._ensure_packs()
+        self._ensure_packs(late=bool(self.late_packs))
         return self._run_forward(x, save)
 
     supports_grad_overwrite = True
@@ -431,6 +442,7 @@ class UNet(nn.Module):
             A[f"a{lvl}"], A[f"d{lvl}"], A[f"p{lvl}"], A[f"pc{lvl}"] = a, dd, p, codes
             src = p
         # center
+        self._flush_packs()                  # first reader of a transposed pack: the centre's up-convolution below
         ca, bna, cb, bnb, ct = self._roles["center"]
         c1 = conv3(src, ca, new(h - 2, w - 2, 1024), bna, "c1", gate=True)
         c2 = conv3(c1, cb, new(h - 4, w - 4, 1024), bnb, "c2")
@@ -567,6 +579,8 @@ class UNet(nn.Module):
         df = K.bilinear_bwd(dlogits, torch.empty(B, fh, fw, C, dtype=torch.float32, device=dev))
         e1b, e1a = A["e1b"], A["e1a"]
         de1b = new_like(e1b)
+        # (the classifier's weight gradient is a leaf, but launched later -- behind enc1's gradients, out of the stretch where nothing else runs --
+        # the step is 0.3 % SLOWER: profiles/r05_dead_zone_ab.txt)
         K.head_bwd(e1b, df, self._w(self.final), de1b,
                    self._gw(self.final) if need_dw else None, self._gb(self.final) if need_dw else None,
                    relu_mask=True, accumulate=gacc)

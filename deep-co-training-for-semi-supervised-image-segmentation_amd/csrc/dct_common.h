@@ -115,6 +115,19 @@ __device__ __forceinline__ uint4 dct_unpool_chunk8(uint4 g, uint2 codes, unsigne
   return make_uint4(g.x & m[0], g.y & m[1], g.z & m[2], g.w & m[3]);
 }
 
+// ReLU-gate bits of eight 16-bit floats (bf16 or fp16, four packed pairs): bit i = element i > 0.  Sign-magnitude: positive <=> the pattern is > 0
+// as a signed 16-bit integer (NaN patterns would count as positive: the callers' values have been through a ReLU).  Packed max / min turn each
+// half into 0 / 1, three shift-ors interleave the four words, one more folds the high halves in: 13 vector instructions against the ~24 of eight
+// compare + select + or (the stem's forward kernel is bound by vector issue).  Bits 8.. of the result are junk: store it as a byte.
+__device__ __forceinline__ unsigned dct_positive_bits8(dct_u32x4 w) {
+  unsigned t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    asm("v_pk_max_i16 %0, %1, %2\n\tv_pk_min_u16 %0, %0, %3" : "=&v"(t[k]) : "v"(w[k]), "v"(0u), "v"(0x00010001u));
+  const unsigned u = t[0] | (t[1] << 2) | (t[2] << 4) | (t[3] << 6);
+  return u | (u >> 15);
+}
+
 // ---- profiling hooks (prof.cpp) -------------------------------------------------------------
 void dct_prof_begin(int cls, hipStream_t s);
 void dct_prof_end(int cls, hipStream_t s);

@@ -21,22 +21,28 @@ template <int C> __device__ __forceinline__ void load_px(const float* p, long lo
     for (int c = 0; c < C; ++c) v[c] = p[pix * C + c];
   }
 }
-template <int C> __device__ __forceinline__ void store_px(float* p, long long pix, const float v[C], bool acc) {
-  if (acc) {
-    float o[C];
-    load_px<C>(p, pix, o);
-    float t[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) t[c] = v[c] + o[c];
-    store_px<C>(p, pix, t, false);
-    return;
-  }
+template <int C> __device__ __forceinline__ void store_px_plain(float* p, long long pix, const float v[C]) {
   if constexpr (C == 4) *reinterpret_cast<f32x4*>(p + pix * 4) = f32x4{v[0], v[1], v[2], v[3]};
   else if constexpr (C == 2) *reinterpret_cast<f32x2*>(p + pix * 2) = f32x2{v[0], v[1]};
   else {
 #pragma unroll
     for (int c = 0; c < C; ++c) p[pix * C + c] = v[c];
   }
+}
+// (not written as a call of itself with acc = false: a recursive function is not inlined, and every caller then passed its pixel through scratch
+// memory to a real call -- round 5, seen in the ISA of every kernel of this file that stores through it)
+template <int C> __device__ __forceinline__ void store_px(float* p, long long pix, const float v[C], bool acc) {
+  if (acc) {
+#pragma clang fp contract(off)    // the value is rounded before it is added, whatever expression the caller formed it from (as when this was a call)
+    float o[C];
+    load_px<C>(p, pix, o);
+    float t[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) t[c] = v[c] + o[c];
+    store_px_plain<C>(p, pix, t);
+    return;
+  }
+  store_px_plain<C>(p, pix, v);
 }
 template <int C> __device__ __forceinline__ float softmax_px(const float x[C], float p[C]) {
   float m = x[0];
@@ -258,48 +264,74 @@ __global__ __launch_bounds__(256) void jsd_bwd_kernel(PtrPack pk, int S, long lo
 // logit gradients (jsd_bwd_kernel<C, true>'s arithmetic).  Five launches became two (this + the finalize) in the one stretch of the step where
 // nothing else runs: both models' forward passes have just joined (tools/phase_stamps.py).  Bit-identical to the separate launches.
 template <int C, int SMAX>
-__global__ __launch_bounds__(256) void jsd_step_kernel(PtrPack pk, PtrPack probs, int S, long long P, const float* gscale, float gmul, int acc,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void jsd_step_kernel(PtrPack pk, PtrPack probs, int S, long long P, const float* gscale, float gmul, int acc,
                                                         int want_grad, float* partial) {
   const float invS = 1.f / (float)S;
   const float g = (gscale ? gscale[0] : 1.f) * gmul / (float)P;
   float sum = 0.f;
-  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < P; pix += (long long)gridDim.x * 256) {
-    float p[SMAX][C], mean[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) mean[c] = 0.f;
-    float hsum = 0.f;
+  // Two of the thread's pixels per trip (two-model case), every load of both (logits and the gradients to add to) issued before the first store: with 1024 blocks
+  // a thread walks 2+ pixels and the launch sits where nothing else runs -- the trip used to be six dependent memory round trips per pixel.
+  // Per pixel the arithmetic and its order are those of the separate kernels; the thread's pixels are summed in the same order.
+  constexpr int NP = SMAX <= 2 ? 2 : 1;       // (two pixels of four or eight models do not fit the register file)
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long pix0 = (long long)blockIdx.x * 256 + threadIdx.x; pix0 < P; pix0 += NP * stride) {
+    const bool two = NP == 2 && pix0 + stride < P;
+    float x[NP][SMAX][C], old[NP][SMAX][C];
 #pragma unroll
     for (int s = 0; s < SMAX; ++s) {
       if (s < S) {
-        float x[C];
-        load_px<C>(pk.in[s], pix, x);
-        softmax_px<C>(x, p[s]);
-#pragma unroll
-        for (int c = 0; c < C; ++c) mean[c] += p[s][c];
-        hsum += entropy_px<C>(p[s]);
-        if (probs.out[s]) store_px<C>(probs.out[s], pix, p[s], false);
+        load_px<C>(pk.in[s], pix0, x[0][s]);
+        if constexpr (NP == 2) { if (two) load_px<C>(pk.in[s], pix0 + stride, x[NP - 1][s]); }
+        if (want_grad && acc) {
+          load_px<C>(pk.out[s], pix0, old[0][s]);
+          if constexpr (NP == 2) { if (two) load_px<C>(pk.out[s], pix0 + stride, old[NP - 1][s]); }
+        }
       }
     }
-    float dm[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) mean[c] *= invS;
-    sum += entropy_px<C>(mean) - hsum * invS;
-    if (want_grad) {
+    for (int h = 0; h < NP; ++h) {
+      if (h == 1 && !two) continue;
+      const long long pix = pix0 + h * stride;
+      float p[SMAX][C], mean[C];
 #pragma unroll
-      for (int c = 0; c < C; ++c) dm[c] = dent(mean[c]);
+      for (int c = 0; c < C; ++c) mean[c] = 0.f;
+      float hsum = 0.f;
 #pragma unroll
       for (int s = 0; s < SMAX; ++s) {
         if (s < S) {
-          float d[C];
+          softmax_px<C>(x[h][s], p[s]);
 #pragma unroll
-          for (int c = 0; c < C; ++c) d[c] = invS * (dm[c] - dent(p[s][c]));
-          float dot = 0.f;
+          for (int c = 0; c < C; ++c) mean[c] += p[s][c];
+          hsum += entropy_px<C>(p[s]);
+          if (probs.out[s]) store_px<C>(probs.out[s], pix, p[s], false);
+        }
+      }
+      float dm[C];
 #pragma unroll
-          for (int c = 0; c < C; ++c) dot += d[c] * p[s][c];
-          float o[C];
+      for (int c = 0; c < C; ++c) mean[c] *= invS;
+      sum += entropy_px<C>(mean) - hsum * invS;
+      if (want_grad) {
 #pragma unroll
-          for (int c = 0; c < C; ++c) o[c] = g * p[s][c] * (d[c] - dot);
-          store_px<C>(pk.out[s], pix, o, acc);
+        for (int c = 0; c < C; ++c) dm[c] = dent(mean[c]);
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {
+          if (s < S) {
+            float d[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) d[c] = invS * (dm[c] - dent(p[s][c]));
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) dot += d[c] * p[s][c];
+            float o[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[c] = g * p[s][c] * (d[c] - dot);
+            if (acc) {
+#pragma clang fp contract(off)    // store_px's accumulate: round, then add
+#pragma unroll
+              for (int c = 0; c < C; ++c) o[c] = o[c] + old[h][s][c];
+            }
+            store_px<C>(pk.out[s], pix, o, false);
+          }
         }
       }
     }
@@ -607,7 +639,8 @@ extern "C" int dct_jsd_logits_step(const float* const* logits, int S, int64_t pi
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = grid_for(pixels);       // dct_jsd_logits_fwd's grid: the block partials, hence the mean, come out bit for bit
   const int want = dlogits ? 1 : 0;
-  if (S <= 4) { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_step_kernel<C, 4>), dim3(grid), dim3(256), 0, st, pk, pp, S, (long long)pixels, gscale, gmul, accumulate, want, (float*)workspace)); }
+  if (S <= 2) { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_step_kernel<C, 2>), dim3(grid), dim3(256), 0, st, pk, pp, S, (long long)pixels, gscale, gmul, accumulate, want, (float*)workspace)); }
+  else if (S <= 4) { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_step_kernel<C, 4>), dim3(grid), dim3(256), 0, st, pk, pp, S, (long long)pixels, gscale, gmul, accumulate, want, (float*)workspace)); }
   else { DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, (jsd_step_kernel<C, MAXS>), dim3(grid), dim3(256), 0, st, pk, pp, S, (long long)pixels, gscale, gmul, accumulate, want, (float*)workspace)); }
   DCT_LAUNCH(DCT_PROF_LOSS, finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, (int)grid, out1, 0, (float)pixels, 0);
   return dct_check_launch();

@@ -240,31 +240,41 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(View x, const float* w, c
     for (int i = 0; i < VEC && id.cv * VEC + i < g.cout; ++i) yp[i] = from_f32<T>(out[i]);
 }
 
-// 3x3, stride 1, dilation 1, cout a multiple of VEC: one thread per (row, 4 adjacent output pixels, VEC-channel
-// slice).  The 3x6 input window and the slice's 9xVEC weights sit in registers, so a pixel costs its 9xVEC FMAs
-// plus a quarter of the address arithmetic; per channel the taps accumulate in the same order as stem_fwd_kernel.
-template <typename T, int VEC>
+// 3x3, stride 1, dilation 1, cout a multiple of VEC: one thread per (row, PX adjacent output pixels, VEC-channel slice).  The 3 x (PX + 2) input
+// window and the slice's 9xVEC weights sit in registers; per channel the taps accumulate in the same order as stem_fwd_kernel.
+// The kernel writes 132 MB per network and step and reads next to nothing, but it was VECTOR-ISSUE bound (round 5, from its ISA: 1041 vector
+// instructions per thread for 288 FMAs -- a wave64 instruction occupies its SIMD for four cycles, and this library is built without packed-FP32
+// instructions): 64-bit multiply-adds for the address of every one of the 18 window loads, their range predicates, and the weights' LDS reads
+// per four pixels.  Now: one 64-bit window base per thread and 32-bit offsets from it, unpredicated loads for threads whose window lies inside
+// the image (all but the last of a row with valid padding), eight pixels per thread.
+// (Measured and dropped: a thread's pixels EIGHT apart, so that a wave's store instruction writes 1 KB of one row instead of eight 128-byte
+// pieces 512 bytes apart: 39.0 -> 52.8 us -- tools/probe_store_bw: the two patterns fill at the same 6.7 TB/s; the per-pixel windows cost it.)
+template <typename T, int VEC, int PX>
 __global__ __launch_bounds__(256) void stem_fwd3x3_kernel(View x, const float* w, const float* bias, View y, StemGeom g,
                                                           unsigned char* __restrict__ bits) {
   extern __shared__ float sw[];  // [9][cout], then bias[cout]
   for (int i = threadIdx.x; i < g.cout * 9; i += 256) { const int c = i / 9, t = i - c * 9; sw[t * g.cout + c] = w[i]; }
   for (int i = threadIdx.x; i < g.cout; i += 256) sw[g.cout * 9 + i] = bias ? bias[i] : 0.f;
   __syncthreads();
-  constexpr int PX = 4;
   const int cvecs = g.cout / VEC, wq = (y.w + PX - 1) / PX;
   const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, y.n, y.h, wq, cvecs);
   if (!id.ok) return;
   const int x0 = id.x * PX;
-  const float* xp = reinterpret_cast<const float*>(x.ptr) + (long long)id.n * x.sn;
+  const int iy0 = id.y - g.pad_h, ix0 = x0 - g.pad_w;
+  const int xsh = (int)x.sh, xsw = (int)x.sw;                  // (the host checked that a 3-row window's offsets fit 32 bits)
+  const float* win = reinterpret_cast<const float*>(x.ptr) + ((long long)id.n * x.sn + (long long)iy0 * x.sh + (long long)ix0 * x.sw);
   float xin[3][PX + 2];
+  if (iy0 >= 0 && iy0 + 2 < x.h && ix0 >= 0 && ix0 + PX + 1 < x.w) {
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int iy = id.y + r - g.pad_h;
-    const bool rok = (unsigned)iy < (unsigned)x.h;
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int j = 0; j < PX + 2; ++j) {
-      const int ix = x0 + j - g.pad_w;
-      xin[r][j] = (rok && (unsigned)ix < (unsigned)x.w) ? xp[iy * x.sh + ix * x.sw] : 0.f;
+      for (int j = 0; j < PX + 2; ++j) xin[r][j] = win[r * xsh + j * xsw];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const bool rok = (unsigned)(iy0 + r) < (unsigned)x.h;
+#pragma unroll
+      for (int j = 0; j < PX + 2; ++j) xin[r][j] = (rok && (unsigned)(ix0 + j) < (unsigned)x.w) ? win[r * xsh + j * xsw] : 0.f;
     }
   }
   float wv[9][VEC], bv[VEC];
@@ -276,9 +286,12 @@ __global__ __launch_bounds__(256) void stem_fwd3x3_kernel(View x, const float* w
 #pragma unroll
   for (int i = 0; i < VEC; ++i) bv[i] = swc[9 * g.cout + i];
   T* yp = reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, x0) + id.cv * VEC;
+  const int ysw = (int)y.sw;
+  unsigned char* bp = bits ? bits + ((((long long)id.n * y.h + id.y) * y.w + x0) * cvecs + id.cv) : nullptr;
+  const int np = min(PX, y.w - x0);
 #pragma unroll
   for (int p = 0; p < PX; ++p) {
-    if (x0 + p >= y.w) break;
+    if (p >= np) break;
     float out[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) out[i] = 0.f;
@@ -293,14 +306,15 @@ __global__ __launch_bounds__(256) void stem_fwd3x3_kernel(View x, const float* w
       out[i] += bv[i];
       if (g.relu) out[i] = fmaxf(out[i], 0.f);
     }
-    VecIO<T, VEC>::store(yp + p * y.sw, out);
     if constexpr (VEC == 8) {
-      if (bits) {        // ReLU-gate bits of the ROUNDED outputs (dense y: one byte per pixel and slice), for the consumer's data gradient
-        unsigned b = 0;
+      typename vec8_of<T>::type pk;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) b |= (to_f32((T)out[i]) > 0.f ? 1u : 0u) << i;
-        bits[(((long long)id.n * y.h + id.y) * y.w + x0 + p) * cvecs + id.cv] = (unsigned char)b;
-      }
+      for (int i = 0; i < VEC; ++i) pk[i] = (T)out[i];
+      dct_store16_stream(yp + p * ysw, pk);
+      // ReLU-gate bits of the ROUNDED outputs (dense y: one byte per pixel and slice), for the consumer's data gradient
+      if (bp) bp[p * cvecs] = (unsigned char)dct_positive_bits8(__builtin_bit_cast(dct_u32x4, pk));
+    } else {
+      VecIO<T, VEC>::store(yp + p * ysw, out);
     }
   }
 }
@@ -433,6 +447,40 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(View x, const float* w, c
   }
   float* yp = reinterpret_cast<float*>(y.ptr) + voff(y, id.n, id.y, id.x);
   for (int o = 0; o < cout; ++o) yp[o] = acc[o] + sw[cout * cin + o];
+}
+// The same with cin / VEC lanes per pixel (a power of two): a pixel's channels are ONE coalesced read instead of a thread's serial walk over them, and
+// the launch has cin / VEC times the threads -- the forward pass's tail runs where nothing else does (tools/phase_stamps.py), 113 k pixels are
+// 1.7 waves per SIMD.  Partial dot products folded by a butterfly; lane o of the group stores class o.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void head_fwd_lanes_kernel(View x, const float* w, const float* bias, View y, int lanes_log2) {
+  extern __shared__ float sw[];  // [cout][cin] + bias
+  const int cin = x.c, cout = y.c;
+  for (int i = threadIdx.x; i < cout * cin; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < cout; i += 256) sw[cout * cin + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int L = 1 << lanes_log2, sub = (int)threadIdx.x & (L - 1);
+  const PixIdx id = decode(((long long)blockIdx.x * 256 + threadIdx.x) >> lanes_log2, x.n, x.h, x.w, 1);
+  float acc[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+  if (id.ok) {
+    float v[VEC];
+    VecIO<T, VEC>::load(reinterpret_cast<const T*>(x.ptr) + voff(x, id.n, id.y, id.x) + sub * VEC, v);
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < cout)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[o] = fmaf(v[i], sw[o * cin + sub * VEC + i], acc[o]);
+  }
+  for (int m = 1; m < L; m <<= 1)
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < cout) acc[o] += __shfl_xor(acc[o], m);
+  if (!id.ok || sub >= cout) return;
+  float r = acc[0];
+#pragma unroll
+  for (int o = 1; o < 8; ++o) r = sub == o ? acc[o] : r;
+  reinterpret_cast<float*>(y.ptr)[voff(y, id.n, id.y, id.x) + sub] = r + sw[cout * cin + sub];
 }
 // dx[pix][ci] = sum_co dy[pix][co]*w[co][ci]  (* x>0 when relu_mask); thread per (pixel, VEC slice)
 template <typename T, int VEC>
@@ -649,6 +697,56 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(View dy, View dx, flo
   VecIO<T, VEC>::store(op, acc);
 }
 
+// The same gather with L lanes per dx pixel (the rows of the candidate window dealt over them, partial sums folded by a butterfly): for a
+// steep up-sampling -- the classifier's logits, 84 x 84 -> 256 x 256: ~10 x 10 candidates, ~38 loads per dx pixel -- on a tensor too small to fill
+// the chip with one thread per pixel (113 k threads walking their windows one load after the other: 21.8 us between the JSD join and the first
+// MFMA kernel of the backward pass, where nothing else runs).
+template <typename T, int VEC, int L>
+__global__ __launch_bounds__(256) void bilinear_bwd_split_kernel(View dy, View dx, float sh, float sw, int accumulate) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int sub = (int)(threadIdx.x & (L - 1));
+  const PixIdx id = decode(t / L, dx.n, dx.h, dx.w, dx.c / VEC);      // a group's lanes are all in or all out (256 % L == 0)
+  auto range = [](int i, float scale, int out_size, int& lo, int& hi) {
+    lo = max(0, (int)floorf((float)(i - 1) / scale) - 1);
+    hi = min(out_size - 1, (int)ceilf((float)(i + 1) / scale) + 1);
+  };
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  if (id.ok) {
+    int jlo, jhi, klo, khi;
+    range(id.y, sh, dy.h, jlo, jhi);
+    range(id.x, sw, dy.w, klo, khi);
+    for (int j = jlo + sub; j <= jhi; j += L) {
+      const Lerp ly = lerp_of(j, sh, dx.h);
+      if (ly.i0 != id.y && ly.i1 != id.y) continue;
+      const float wy = (ly.i0 == id.y ? ly.w0 : 0.f) + (ly.i1 == id.y ? ly.w1 : 0.f);
+      for (int k = klo; k <= khi; ++k) {
+        const Lerp lx = lerp_of(k, sw, dx.w);
+        if (lx.i0 != id.x && lx.i1 != id.x) continue;
+        const float wx = (lx.i0 == id.x ? lx.w0 : 0.f) + (lx.i1 == id.x ? lx.w1 : 0.f);
+        float g[VEC];
+        VecIO<T, VEC>::load(reinterpret_cast<const T*>(dy.ptr) + voff(dy, id.n, j, k) + id.cv * VEC, g);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(g[i], wy * wx, acc[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < L; m <<= 1)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], m);
+  if (!id.ok || sub) return;
+  T* op = reinterpret_cast<T*>(dx.ptr) + voff(dx, id.n, id.y, id.x) + id.cv * VEC;
+  if (accumulate) {
+    float old[VEC];
+    VecIO<T, VEC>::load(op, old);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] += old[i];
+  }
+  VecIO<T, VEC>::store(op, acc);
+}
+
 // Un-pooling with the skip connection's gradient gathered on the way (dct_maxpool2x2_bwd_codes_skip): the pooled tensor p feeds the next
 // encoder block AND, bilinearly resized, the decoder's concatenation, so its gradient is dp = (data gradient of the next block) + (bilinear
 // backward of the concatenation's gradient).  The sum used to be formed in memory (the bilinear backward wrote dp, the data gradient
@@ -855,8 +953,10 @@ extern "C" int dct_conv_cin1_fwd(const dct_view* x, const float* w, const float*
     if (!vec_ok(y, 1, sizeof(T)) || (y->sw % VEC) || (y->sh % VEC) || (y->sn % VEC) || ((uintptr_t)y->ptr % 16)) return DCT_ERR_UNSUPPORTED;
     const long long total = (long long)y->n * y->h * y->w * ((y->c + VEC - 1) / VEC);
     if (d->R == 3 && d->S == 3 && d->stride == 1 && d->dil == 1 && y->c % VEC == 0) {
-      const long long quads = (long long)y->n * y->h * ((y->w + 3) / 4) * (y->c / VEC);
-      DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_fwd3x3_kernel<T, VEC>), dim3(div_up(quads, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), g,
+      constexpr int PX = 8;
+      if (3 * x->sh + (PX + 2) * x->sw > 0x7fffffffll || (long long)PX * y->sw > 0x7fffffffll) return DCT_ERR_UNSUPPORTED;
+      const long long groups = (long long)y->n * y->h * ((y->w + PX - 1) / PX) * (y->c / VEC);
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (stem_fwd3x3_kernel<T, VEC, PX>), dim3(div_up(groups, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), g,
                  VEC == 8 ? bits : nullptr);
       bits_done = VEC == 8;
     } else if (d->R == 3 && d->S == 3)
@@ -900,7 +1000,13 @@ extern "C" int dct_conv1x1_head_fwd(const dct_view* x, const float* w, const flo
   DISPATCH_T(dtype, {
     if (!vec_ok(x, VEC, sizeof(T))) return DCT_ERR_UNSUPPORTED;
     const long long total = (long long)x->n * x->h * x->w;
-    DCT_LAUNCH(DCT_PROF_POINTWISE, (head_fwd_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y));
+    const int lanes = x->c / VEC;
+    int lg = 0;
+    while ((1 << lg) < lanes) ++lg;
+    if (x->c % VEC == 0 && (1 << lg) == lanes && lanes >= 2 && lanes <= 64 && lanes >= y->c)
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (head_fwd_lanes_kernel<T, VEC>), dim3(div_up(total * lanes, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y), lg);
+    else
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (head_fwd_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), sh, st, to_view(x), w, bias, to_view(y));
   });
   return dct_check_launch();
 }
@@ -1018,7 +1124,11 @@ extern "C" int dct_bilinear_bwd(const dct_view* dy, const dct_view* dx, int dtyp
   const float sh = ac_scale(dx->h, dy->h), sw = ac_scale(dx->w, dy->w);
   DISPATCH_T(dtype_dy, {
     const long long px = (long long)dx->n * dx->h * dx->w;
-    if (vec_ok(dx, VEC, sizeof(T)) && vec_ok(dy, VEC, sizeof(T)))
+    const bool vec = vec_ok(dx, VEC, sizeof(T)) && vec_ok(dy, VEC, sizeof(T));
+    // steep up-sampling on a small tensor (the classifier's logits): eight lanes per dx pixel
+    if (vec && sh > 0.f && sw > 0.f && sh < 0.5f && sw < 0.5f && px * (dx->c / VEC) < 262144)
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (bilinear_bwd_split_kernel<T, VEC, 8>), dim3(div_up(px * (dx->c / VEC) * 8, 256)), dim3(256), 0, st, to_view(dy), to_view(dx), sh, sw, accumulate);
+    else if (vec)
       DCT_LAUNCH(DCT_PROF_POINTWISE, (bilinear_bwd_kernel<T, VEC>), dim3(div_up(px * (dx->c / VEC), 256)), dim3(256), 0, st, to_view(dy), to_view(dx), sh, sw, accumulate);
     else
       DCT_LAUNCH(DCT_PROF_POINTWISE, (bilinear_bwd_kernel<T, 1>), dim3(div_up(px * dx->c, 256)), dim3(256), 0, st, to_view(dy), to_view(dx), sh, sw, accumulate);

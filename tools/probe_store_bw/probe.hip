@@ -39,6 +39,36 @@ __global__ __launch_bounds__(256) void fill_span(uint4* dst, long long n16, unsi
   const long long b0 = (long long)blockIdx.x * per_block16;
   for (int i = threadIdx.x; i < per_block16 && b0 + i < n16; i += 256) st16<MODE>(dst + b0 + i, v);
 }
+// the stem's pattern: a wave owns 4 KiB; each of its four store instructions writes eight 128-byte pieces 512 bytes apart (lane = piece * 8 + sub)
+template <int MODE>
+__global__ __launch_bounds__(256) void fill_pieces(uint4* dst, long long n16, unsigned seed) {
+  const uint4 v = make_uint4(seed, seed + 1, seed + 2, seed + 3);
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63, piece = lane >> 3, sub = lane & 7;
+  const long long waves = (long long)gridDim.x * 4;
+  for (long long w = wave; w * 256 < n16; w += waves) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const long long i = w * 256 + piece * 32 + p * 8 + sub;
+      if (i < n16) st16<MODE>(dst + i, v);
+    }
+  }
+}
+// ... and the contiguous form with the same four stores per thread (1 KiB per instruction, a wave's 4 KiB in order)
+template <int MODE>
+__global__ __launch_bounds__(256) void fill_rows4(uint4* dst, long long n16, unsigned seed) {
+  const uint4 v = make_uint4(seed, seed + 1, seed + 2, seed + 3);
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const long long waves = (long long)gridDim.x * 4;
+  for (long long w = wave; w * 256 < n16; w += waves) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const long long i = w * 256 + p * 64 + lane;
+      if (i < n16) st16<MODE>(dst + i, v);
+    }
+  }
+}
 __global__ __launch_bounds__(256) void read_sum(const uint4* src, long long n16, unsigned* out) {
   unsigned acc = 0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) { const uint4 v = src[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
@@ -113,6 +143,16 @@ int main() {
       printf("%-44s %10.1f %10.2f\n", "fill 132 MB " label " behind a 600 MB fill", t - tw, bytes / (t - tw) / 1e6);           \
     }
     COLD(0, "default") COLD(1, "nt") COLD(2, "sc0 sc1") COLD(3, "sc1") COLD(4, "sc0") COLD(5, "sc0 sc1 nt") COLD(6, "sc1 nt")
+#define COLDK(KERNEL, label)                                                                                                   \
+    {                                                                                                                          \
+      double t = time_us([&] {                                                                                                 \
+        hipLaunchKernelGGL(read_sum, dim3(4096), dim3(256), 0, 0, big, (600ll << 20) / 16, out);                               \
+        hipLaunchKernelGGL(KERNEL, dim3(8448), dim3(256), 0, 0, buf, n16, 7u);                                                \
+      }, 10);                                                                                                                  \
+      printf("%-44s %10.1f %10.2f\n", label " behind a 600 MB read", t - tr, bytes / (t - tr) / 1e6);                          \
+    }
+    // round 5: does it matter how a wave's stores land?  (8448 blocks = one 4 KiB span per wave over 132 MB)
+    COLDK(fill_rows4<1>, "rows of 1 KiB, nt") COLDK(fill_pieces<1>, "8 x 128 B pieces, nt") COLDK(fill_rows4<0>, "rows of 1 KiB, default") COLDK(fill_pieces<0>, "8 x 128 B pieces, default")
     // ... and a cold READ of 132 MB for comparison
     {
       double t = time_us([&] {
