@@ -60,11 +60,7 @@ __device__ __forceinline__ unsigned pk_positive_mask(unsigned d) {
 // gradient of the layer it feeds needs (1/16 of the bytes of the activation itself).  Bits above 7 of the result are junk: callers
 // store the low byte.
 __device__ __forceinline__ unsigned relu_bits8(const bf16x8& v) {
-  Chunk8 c; c.v = v;
-  // dword k holds elements 2k (low half) and 2k + 1: gates at bit 0 and bit 16; the shifted sum puts element 2k at bit 2k and
-  // element 2k + 1 at bit 16 + 2k
-  const unsigned r = pk_positive01(c.d[0]) + (pk_positive01(c.d[1]) << 2) + (pk_positive01(c.d[2]) << 4) + (pk_positive01(c.d[3]) << 6);
-  return r | (r >> 15);
+  return dct_positive_bits8(__builtin_bit_cast(dct_u32x4, v));       // dct_common.h (shared with the stem's forward kernel)
 }
 // v = gate bit ? v * scale : 0 (the ReLU / dropout backward of the producer), gates as one byte
 __device__ __forceinline__ void chunk_gate_bits(bf16x8& v, unsigned bits, float scale) {

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void jsd_bwd_kernel(PtrPack pk, int S, long lo
 // logit gradients (jsd_bwd_kernel<C, true>'s arithmetic).  Five launches became two (this + the finalize) in the one stretch of the step where
 // nothing else runs: both models' forward passes have just joined (tools/phase_stamps.py).  Bit-identical to the separate launches.
 template <int C, int SMAX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void jsd_step_kernel(PtrPack pk, PtrPack probs, int S, long long P, const float* gscale, float gmul, int acc,
+__global__ __launch_bounds__(256) void jsd_step_kernel(PtrPack pk, PtrPack probs, int S, long long P, const float* gscale, float gmul, int acc,
                                                         int want_grad, float* partial) {
   const float invS = 1.f / (float)S;
   const float g = (gscale ? gscale[0] : 1.f) * gmul / (float)P;

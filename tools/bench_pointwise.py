@@ -60,6 +60,20 @@ def main():
         rows.append((f"maxpool_fwd {c}x{h}", timeit(lambda: K.maxpool_fwd(x, yp), args.reps), (x.numel() + yp.numel()) * 2))
         rows.append((f"maxpool_bwd {c}x{h}", timeit(lambda: K.maxpool_bwd(x, dyp, dx, relu_mask=True), args.reps),
                      (2 * x.numel() + yp.numel()) * 2))
+    # the step's own un-pooling: routed by the pooling codes, the skip connection's bilinear backward gathered on the way (cat res per level)
+    for (c, h), cres in zip(((64, 252), (128, 122), (256, 57), (512, 25)), (88, 48, 28, 18)):
+        x = torch.randn(B, h, h, c, device=DEV, generator=g).to(dt)
+        hp = (h + 1) // 2
+        yp = torch.empty(B, hp, hp, c, device=DEV, dtype=dt)
+        codes = torch.empty(B, hp, hp, c, device=DEV, dtype=torch.uint8)
+        K.maxpool_fwd(x, yp, codes=codes)
+        dyp = torch.randn(B, hp, hp, c, device=DEV, generator=g).to(dt)
+        dcat = torch.randn(B, cres, cres, 2 * c, device=DEV, generator=g).to(dt)
+        dx = torch.empty_like(x)
+        rows.append((f"unpool+skip {c}x{h}", timeit(lambda: K.maxpool_bwd(None, dyp, dx, relu_mask=True, codes=codes, skip=dcat[..., c:]), args.reps),
+                     (x.numel() + yp.numel() + dcat.numel() // 2) * 2 + codes.numel()))
+        cat = torch.empty(B, cres, cres, 2 * c, device=DEV, dtype=dt)
+        rows.append((f"skip resize {c}x{hp}->{cres}", timeit(lambda: K.bilinear_fwd(yp, cat[..., c:]), args.reps), (yp.numel() + cat.numel() // 2) * 2))
     for name, t, nbytes in rows:
         print(f"{name:20s} {t * 1e6:8.1f} us  {nbytes / t / 1e9:8.1f} GB/s")
 
