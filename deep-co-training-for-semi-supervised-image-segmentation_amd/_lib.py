@@ -87,6 +87,8 @@ SIGNATURES = {
     "dct_conv2d_wgrad_bias": (_i, [_VP, _VP, _P, _P, _DP, _i, _P, _sz, _P]),
     "dct_bias_grad": (_i, [_VP, _P, _i, _i, _P, _sz, _P]),
     "dct_bias_grad_workspace_bytes": (_sz, [_VP]),
+    "dct_bias_grad_batched": (_i, [_P, _P, _i, _i, _i, _P, _sz, _P]),
+    "dct_bias_grad_batched_workspace_bytes": (_sz, [_P, _i]),
     "dct_pack_weight": (_i, [_P, _P, _i, _i, _i, _i, _i, _i, _P]),
     "dct_pack_weights_batched": (_i, [_P, _i, _i, _i, _P]),
     "dct_pack_weights_batched64": (_i, [_P, _i, _i, _P]),
@@ -108,13 +110,14 @@ SIGNATURES = {
     "dct_bilinear_fwd": (_i, [_VP, _VP, _i, _i, _P]),
     "dct_bilinear_bwd": (_i, [_VP, _VP, _i, _i, _i, _P]),
     "dct_dropout_fwd": (_i, [_VP, _VP, _P, _f, _u64, _u64, _i, _P]),
-    "dct_dropout_fwd_dev": (_i, [_VP, _VP, _P, _f, _u64, _P, _i, _P]),
+    "dct_dropout_fwd_dev": (_i, [_VP, _VP, _P, _f, _u64, _P, _i, _i, _P]),
     "dct_dropout_apply": (_i, [_VP, _VP, _P, _f, _i, _P]),
     "dct_relu_bwd": (_i, [_VP, _VP, _VP, _f, _i, _P]),
     "dct_cast": (_i, [_VP, _VP, _i, _i, _P]),
     "dct_loss_workspace_bytes": (_sz, [_i64]),
     "dct_ce_fwd": (_i, [_P, _P, _i64, _i, _i, _P, _P, _sz, _P]),
     "dct_ce_bwd": (_i, [_P, _P, _i64, _i, _i, _P, _P, _f, _P, _i, _P]),
+    "dct_ce_step": (_i, [_P, _P, _i64, _i, _i, _P, _P, _f, _P, _i, _P, _sz, _P]),
     "dct_softmax_fwd": (_i, [_P, _P, _i64, _i, _P]),
     "dct_softmax_bwd": (_i, [_P, _P, _P, _i64, _i, _i, _P]),
     "dct_entropy_fwd": (_i, [_P, _P, _i64, _i, _P]),

@@ -117,6 +117,35 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, const 
   }
 }
 
+// The step's cross-entropy pair in two launches instead of three (round 5: every small launch on a model's chain costs the step ~3 us): the backward
+// kernel folds the forward kernel's block partials itself -- every block, in finalize_kernel's order, so the count (and the loss block 0 writes)
+// come out bit for bit -- before it writes the logit gradients.
+template <int C>
+__global__ __launch_bounds__(256) void ce_bwd_fin_kernel(const float* logits, const long long* tgt, long long P, int ignore, const float* partial,
+                                                          int blocks, float* out2, const float* gscale, float gmul, float* dl, int acc) {
+  __shared__ float sa[256], sb[256];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < blocks; i += 256) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+  sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  const float count = sb[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { out2[0] = sa[0] / count; out2[1] = count; }
+  const float g = (gscale ? gscale[0] : 1.f) * gmul / count;
+  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < P; pix += (long long)gridDim.x * 256) {
+    const long long t = tgt[pix];
+    float x[C], p[C], d[C];
+    load_px<C>(logits, pix, x);
+    softmax_px<C>(x, p);
+#pragma unroll
+    for (int c = 0; c < C; ++c) d[c] = (t == ignore) ? 0.f : g * (p[c] - (t == c ? 1.f : 0.f));
+    store_px<C>(dl, pix, d, acc);
+  }
+}
+
 // ---- softmax / entropy (module API) -------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* logits, float* probs, long long P) {
@@ -551,6 +580,18 @@ extern "C" int dct_ce_bwd(const float* logits, const int64_t* targets, int64_t p
   if (!logits || !targets || !count || !dlogits || pixels < 1) return DCT_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, ce_bwd_kernel<C>, dim3(wide_grid(pixels)), dim3(256), 0, st, logits, (const long long*)targets, (long long)pixels, ignore_index, count, gscale, gmul, dlogits, accumulate));
+  return dct_check_launch();
+}
+extern "C" int dct_ce_step(const float* logits, const int64_t* targets, int64_t pixels, int C_, int ignore_index, float* out2,
+                           const float* gscale, float gmul, float* dlogits, int accumulate, void* workspace, size_t workspace_bytes,
+                           dct_stream stream) {
+  if (!logits || !targets || !out2 || !dlogits || pixels < 1) return DCT_ERR_BAD_ARG;
+  if (!ws_ok(workspace, workspace_bytes)) return DCT_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = grid_for(pixels);       // dct_ce_fwd's grid: the same block partials
+  DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, ce_fwd_kernel<C>, dim3(grid), dim3(256), 0, st, logits, (const long long*)targets, (long long)pixels, ignore_index, (float*)workspace));
+  DISPATCH_C(C_, DCT_LAUNCH(DCT_PROF_LOSS, ce_bwd_fin_kernel<C>, dim3(wide_grid(pixels)), dim3(256), 0, st, logits, (const long long*)targets, (long long)pixels, ignore_index,
+                            (const float*)workspace, (int)grid, out2, gscale, gmul, dlogits, accumulate));
   return dct_check_launch();
 }
 extern "C" int dct_softmax_fwd(const float* logits, float* probs, int64_t pixels, int C_, dct_stream stream) {

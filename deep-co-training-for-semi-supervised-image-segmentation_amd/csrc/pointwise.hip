@@ -827,14 +827,20 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned 
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 // thread per 4 consecutive channels of a pixel
-// calls (nullable): device-resident call counter; the Philox offset is then calls[0] << 40 (what the host passes as
-// `offset` otherwise), so a captured HIP graph draws a fresh mask on every replay.
-__global__ void dropout_advance_kernel(unsigned long long* calls) { calls[0] += 1ull; }
+// calls (nullable): device-resident call counter in TWO 64-bit words that successive launches use in turn.  This launch reads calls[parity] = n, is
+// call number n + 1 -- the Philox offset is that << 40 (what the host passes as `offset` otherwise), so a captured HIP graph draws a fresh mask on
+// every replay -- and its first thread stores n + 1 to calls[parity ^ 1], the word no block of this launch reads; the next launch comes with the
+// other parity.  (Until round 5 a one-thread kernel in front did the increment: two launches per dropout site on every model's chain, where a small
+// launch costs the step ~3 us.  One word + a last-block ticket was tried first: 5000 same-address atomics per launch cost 60 us.)
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(View x, View y, unsigned char* mask_out, const unsigned char* mask_in,
                                                        float p, unsigned long long seed, unsigned long long offset,
-                                                       const unsigned long long* calls) {
-  if (calls) offset = calls[0] << 40;
+                                                       unsigned long long* calls, int parity) {
+  if (calls) {
+    const unsigned long long call = calls[parity] + 1ull;
+    offset = call << 40;
+    if (blockIdx.x == 0 && threadIdx.x == 0) calls[parity ^ 1] = call;
+  }
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const PixIdx id = decode(idx, x.n, x.h, x.w, x.c / 4);
   if (!id.ok) return;
@@ -1137,16 +1143,15 @@ extern "C" int dct_bilinear_bwd(const dct_view* dy, const dct_view* dx, int dtyp
 }
 
 static int dropout_impl(const dct_view* x, const dct_view* y, uint8_t* mask_out, const uint8_t* mask_in, float p,
-                        uint64_t seed, uint64_t offset, int dtype, dct_stream stream, uint64_t* calls = nullptr) {
+                        uint64_t seed, uint64_t offset, int dtype, dct_stream stream, uint64_t* calls = nullptr, int parity = 0) {
   if (!view_ok(x) || !view_ok(y) || !same_nhw(x, y) || x->c != y->c || p < 0.f || p >= 1.f) return DCT_ERR_BAD_ARG;
   if (x->c % 4) return DCT_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const long long total = (long long)x->n * x->h * x->w * (x->c / 4);
-  if (calls) DCT_LAUNCH(DCT_PROF_POINTWISE, dropout_advance_kernel, dim3(1), dim3(1), 0, st, (unsigned long long*)calls);
   DISPATCH_T(dtype, {
     DCT_LAUNCH(DCT_PROF_POINTWISE, dropout_kernel<T>, dim3(div_up(total, 256)), dim3(256), 0, st, to_view(x), to_view(y),
                (unsigned char*)mask_out, (const unsigned char*)mask_in, p, (unsigned long long)seed, (unsigned long long)offset,
-               (const unsigned long long*)calls);
+               (unsigned long long*)calls, parity & 1);
   });
   return dct_check_launch();
 }
@@ -1155,9 +1160,9 @@ extern "C" int dct_dropout_fwd(const dct_view* x, const dct_view* y, uint8_t* ma
   return dropout_impl(x, y, mask_out, nullptr, p, seed, offset, dtype, stream);
 }
 extern "C" int dct_dropout_fwd_dev(const dct_view* x, const dct_view* y, uint8_t* mask_out, float p,
-                                   uint64_t seed, uint64_t* calls, int dtype, dct_stream stream) {
-  if (!calls || ((uintptr_t)calls & 7)) return DCT_ERR_BAD_ARG;
-  return dropout_impl(x, y, mask_out, nullptr, p, seed, 0, dtype, stream, calls);
+                                   uint64_t seed, uint64_t* calls, int parity, int dtype, dct_stream stream) {
+  if (!calls || ((uintptr_t)calls & 7) || (parity & ~1)) return DCT_ERR_BAD_ARG;
+  return dropout_impl(x, y, mask_out, nullptr, p, seed, 0, dtype, stream, calls, parity);
 }
 extern "C" int dct_dropout_apply(const dct_view* x, const dct_view* y, const uint8_t* mask, float p, int dtype,
                                  dct_stream stream) {

@@ -48,7 +48,7 @@ static inline int view_linear(const dct_view* v) {
 // ------------------------------------------------------------------------------- bias grad
 // partial[blk][c] = sum over the block's pixels of dy[pix][c]
 template <typename T>
-__global__ __launch_bounds__(256) void bias_partial_kernel(View dy, float* partial, int ppb, int linear) {
+__device__ __forceinline__ void bias_partial_body(const View& dy, float* partial, int ppb, int linear, int blk) {
   constexpr int VEC = Vec<T>::N;
   __shared__ float red[256 * VEC];
   const int C = dy.c;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void bias_partial_kernel(View dy, float* parti
   const int rows = 256 / CV;
   const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
   const long long P = (long long)dy.n * dy.h * dy.w;
-  const long long pbeg = (long long)blockIdx.x * ppb, pend = min(P, pbeg + ppb);
+  const long long pbeg = (long long)blk * ppb, pend = min(P, pbeg + ppb);
   const T* base = reinterpret_cast<const T*>(dy.ptr) + cv * VEC;
   float acc[VEC];
 #pragma unroll
@@ -83,8 +83,25 @@ __global__ __launch_bounds__(256) void bias_partial_kernel(View dy, float* parti
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += red[r * C + c];
-    partial[(long long)blockIdx.x * C + c] = s;
+    partial[(long long)blk * C + c] = s;
   }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bias_partial_kernel(View dy, float* partial, int ppb, int linear) {
+  bias_partial_body<T>(dy, partial, ppb, linear, (int)blockIdx.x);
+}
+// Several bias gradients in one launch pair (dct_bias_grad_batched: a UNet's four up-convolutions -- 2 x 4 launches of ~5 us on each model's chain
+// became 2): job k owns the blocks [blk0, blk0 + blocks) of the partial kernel and [red0, red0 + ceil(c / 16)) of the fold; per job the arithmetic
+// and its order are those of the single call.
+constexpr int kBiasJobs = 8;
+struct BiasJob { View dy; float* partial; float* db; int ppb, linear, blk0, blocks, red0, pad; };
+struct BiasJobs { BiasJob j[kBiasJobs]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256) void bias_partial_batched_kernel(BiasJobs js) {
+  int k = 0;
+  for (int i = 1; i < js.n; ++i) k = (int)blockIdx.x >= js.j[i].blk0 ? i : k;
+  const BiasJob& jb = js.j[k];
+  bias_partial_body<T>(jb.dy, jb.partial, jb.ppb, jb.linear, (int)blockIdx.x - jb.blk0);
 }
 
 // out[i] (=|+=) sum_b partial[b][i]; 16 outputs per block, 16 strided partial sums each, folded in
@@ -108,6 +125,17 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partia
   const int i = blockIdx.x * 16 + (threadIdx.x & 15);
   const float t = fold16(partial, i, n, blocks, red);
   if (threadIdx.x < 16 && i < n) out[i] = accumulate ? out[i] + t : t;
+}
+
+__global__ __launch_bounds__(256) void partial_reduce_batched_kernel(BiasJobs js, int accumulate) {
+  __shared__ float red[256];
+  int k = 0;
+  for (int i = 1; i < js.n; ++i) k = (int)blockIdx.x >= js.j[i].red0 ? i : k;
+  const BiasJob& jb = js.j[k];
+  const int n = jb.dy.c;
+  const int i = ((int)blockIdx.x - jb.red0) * 16 + (threadIdx.x & 15);
+  const float t = fold16(jb.partial, i, n, jb.blocks, red);
+  if (threadIdx.x < 16 && i < n) jb.db[i] = accumulate ? jb.db[i] + t : t;
 }
 
 static int bias_plan(const dct_view* dy, int vec, int& ppb) {
@@ -478,6 +506,48 @@ extern "C" int dct_bias_grad(const dct_view* dy, float* db, int accumulate, int 
   else DCT_LAUNCH(DCT_PROF_POINTWISE, bias_partial_kernel<float>, dim3(blocks), dim3(256), 0, st, v, (float*)workspace, ppb, lin);
   DCT_LAUNCH(DCT_PROF_POINTWISE, partial_reduce_kernel, dim3(div_up(dy->c, 16)), dim3(256), 0, st,
              (const float*)workspace, db, dy->c, blocks, accumulate);
+  return dct_check_launch();
+}
+
+extern "C" size_t dct_bias_grad_batched_workspace_bytes(const dct_view* dys, int n) {
+  size_t t = 0;
+  for (int k = 0; dys && k < n; ++k) t += dct_bias_grad_workspace_bytes(dys + k);
+  return t;
+}
+
+extern "C" int dct_bias_grad_batched(const dct_view* dys, float* const* dbs, int n, int accumulate, int dtype,
+                                     void* workspace, size_t workspace_bytes, dct_stream stream) {
+  if (!dys || !dbs || n < 1) return DCT_ERR_BAD_ARG;
+  if (n > kBiasJobs) return DCT_ERR_UNSUPPORTED;
+  if (dtype != DCT_F32 && dtype != DCT_BF16) return DCT_ERR_BAD_ARG;
+  const int vec = dtype == DCT_BF16 ? 8 : 4;
+  BiasJobs js;
+  js.n = n;
+  int blk = 0, red = 0;
+  size_t off = 0;
+  for (int k = 0; k < n; ++k) {
+    const dct_view* dy = dys + k;
+    if (!view_ok(dy) || !dbs[k]) return DCT_ERR_BAD_ARG;
+    if (dy->c % vec) return DCT_ERR_UNSUPPORTED;
+    const int cv = dy->c / vec;
+    if (cv > 256 || 256 % cv) return DCT_ERR_UNSUPPORTED;
+    if (((uintptr_t)dy->ptr % 16) || (dy->sw % vec) || (dy->sh % vec) || (dy->sn % vec)) return DCT_ERR_UNSUPPORTED;
+    BiasJob& jb = js.j[k];
+    jb.dy = to_view(dy);
+    jb.blocks = bias_plan(dy, vec, jb.ppb);
+    jb.linear = view_linear(dy);
+    jb.blk0 = blk; jb.red0 = red; jb.pad = 0;
+    jb.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + off);
+    jb.db = dbs[k];
+    blk += jb.blocks;
+    red += div_up(dy->c, 16);
+    off += (size_t)jb.blocks * dy->c * sizeof(float);
+  }
+  if (!workspace || workspace_bytes < off) return DCT_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DCT_BF16) DCT_LAUNCH(DCT_PROF_POINTWISE, bias_partial_batched_kernel<bf16_t>, dim3(blk), dim3(256), 0, st, js);
+  else DCT_LAUNCH(DCT_PROF_POINTWISE, bias_partial_batched_kernel<float>, dim3(blk), dim3(256), 0, st, js);
+  DCT_LAUNCH(DCT_PROF_POINTWISE, partial_reduce_batched_kernel, dim3(red), dim3(256), 0, st, js, accumulate);
   return dct_check_launch();
 }
 

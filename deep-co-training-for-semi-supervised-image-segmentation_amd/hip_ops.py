@@ -265,6 +265,19 @@ def bias_grad(dy, db, accumulate=False):
     return db
 
 
+def bias_grad_batched(dys, dbs, accumulate=False):
+    """db_k (+)= column sums of dy_k for up to eight (dy, db) pairs of one dtype in ONE launch pair (dct_bias_grad_batched)."""
+    n = len(dys)
+    if n == 1:
+        return bias_grad(dys[0], dbs[0], accumulate)
+    assert 1 < n <= 8 and len(dbs) == n and all(d.dtype == dys[0].dtype for d in dys)
+    views = (_lib.View * n)(*[view(d) for d in dys])
+    ptrs = (C.c_void_p * n)(*[int(b.data_ptr()) for b in dbs])
+    need = _lib.load().dct_bias_grad_batched_workspace_bytes(views, n)
+    ws = _ws(need, dys[0].device)
+    call("dct_bias_grad_batched", views, ptrs, n, int(accumulate), _dt(dys[0]), ptr(ws), ws.numel(), stream())
+
+
 def pack_weight(src_f32, dst, P, T, Q, transpose=False, flip_taps=False):
     call("dct_pack_weight", ptr(src_f32), ptr(dst), P, T, Q, int(transpose), int(flip_taps), _dt(dst), stream())
     return dst
@@ -418,12 +431,14 @@ def bilinear_bwd(dy, dx, accumulate=False):
     return dx
 
 
-def dropout_fwd(x, y, p, seed, offset, mask_out=None, calls_dev=None):
-    """``calls_dev`` (int64[1] device tensor): the call counter lives on the device (incremented in stream order,
-    offset = counter << 40) and ``offset`` is ignored -- the graph-replayable form."""
+def dropout_fwd(x, y, p, seed, offset, mask_out=None, calls_dev=None, parity=0):
+    """``calls_dev`` (int64[2] device tensor): the call counter lives on the device -- the launch reads word ``parity``, is call number that + 1
+    (offset = number << 40; ``offset`` is ignored) and stores the number to the other word; the caller alternates ``parity`` from call to call.
+    The graph-replayable form."""
     vx, vy = view(x), view(y)
     if calls_dev is not None:
-        call("dct_dropout_fwd_dev", C.byref(vx), C.byref(vy), ptr(mask_out), float(p), int(seed), ptr(calls_dev), _dt(x), stream())
+        assert calls_dev.dtype == torch.int64 and calls_dev.numel() >= 2
+        call("dct_dropout_fwd_dev", C.byref(vx), C.byref(vy), ptr(mask_out), float(p), int(seed), ptr(calls_dev), int(parity), _dt(x), stream())
         return y
     call("dct_dropout_fwd", C.byref(vx), C.byref(vy), ptr(mask_out), float(p), int(seed), int(offset), _dt(x), stream())
     return y
@@ -470,6 +485,16 @@ def ce_bwd(logits_pc, targets, C_, count, dlogits, gscale=None, gmul=1.0, ignore
     call("dct_ce_bwd", ptr(logits_pc), ptr(targets), logits_pc.numel() // C_, C_, int(ignore_index), ptr(count),
          ptr(gscale), float(gmul), ptr(dlogits), int(accumulate), stream())
     return dlogits
+
+
+def ce_step(logits_pc, targets, C_, dlogits, gscale=None, gmul=1.0, ignore_index=255, accumulate=False):
+    """ce_fwd + ce_bwd of the same logits in two launches instead of three (dct_ce_step; bit for bit the two calls).  Returns the device
+    tensor [2] = (mean loss, count); ``dlogits`` is written (added to)."""
+    out = torch.empty(2, dtype=torch.float32, device=logits_pc.device)
+    ws = _loss_ws(logits_pc.device)
+    call("dct_ce_step", ptr(logits_pc), ptr(targets), logits_pc.numel() // C_, C_, int(ignore_index), ptr(out), ptr(gscale), float(gmul),
+         ptr(dlogits), int(accumulate), ptr(ws), ws.numel(), stream())
+    return out
 
 
 def softmax_fwd(logits_pc, C_):

@@ -543,8 +543,7 @@ class CoTrainer(Trainer):
                     dl_out = torch.empty_like(lp)
                     passes[i].append((tape, dl_out))
                 t = gt.reshape(-1)
-                out = K.ce_fwd(lp, t, C, ignore)
-                K.ce_bwd(lp, t, C, out[1:2], dl_out, gmul=gs, ignore_index=ignore)
+                out = K.ce_step(lp, t, C, dl_out, gmul=gs, ignore_index=ignore)       # loss value + count and the logit gradient: two launches
                 sup.append(out[0])
                 preds.append(_nchw(lp))
                 self._stamp(i, 1)
@@ -778,8 +777,7 @@ class CoTrainer(Trainer):
                 lp, tape = nets[i].plan_forward(img, True, defer_running=True)
                 dl = torch.empty_like(lp)
                 t = gt.reshape(-1)
-                out = K.ce_fwd(lp, t, C, ignore)
-                K.ce_bwd(lp, t, C, out[1:2], dl, gmul=gs, ignore_index=ignore)
+                out = K.ce_step(lp, t, C, dl, gmul=gs, ignore_index=ignore)       # loss value + count and the logit gradient: two launches
                 sup.append(out[0])
                 preds.append(_nchw(lp))
                 lab_pass.append((tape, dl))
@@ -876,8 +874,7 @@ class CoTrainer(Trainer):
                 lp, gt = lab_out[i][0], lab[i][1]
                 dl = torch.empty_like(lp)
                 t = gt.reshape(-1)
-                out = K.ce_fwd(lp, t, C, ignore)
-                K.ce_bwd(lp, t, C, out[1:2], dl, gmul=gs, ignore_index=ignore)
+                out = K.ce_step(lp, t, C, dl, gmul=gs, ignore_index=ignore)       # loss value + count and the logit gradient: two launches
                 sup.append(out[0])
                 preds.append(_nchw(lp))
                 dls.append(dl)
@@ -971,8 +968,7 @@ class CoTrainer(Trainer):
                 dl_all = torch.empty_like(lp_all)
                 full[i] = (tape, lp_all, dl_all)
                 lp, t = lp_all[:B_l], gt.reshape(-1)
-                out = K.ce_fwd(lp, t, C, ignore)
-                K.ce_bwd(lp, t, C, out[1:2], dl_all[:B_l], gmul=gs, ignore_index=ignore)
+                out = K.ce_step(lp, t, C, dl_all[:B_l], gmul=gs, ignore_index=ignore)       # loss value + count and the logit gradient: two launches
                 sup[i] = out[0]
                 preds[i] = _nchw(lp)
             fwd_done[i] = sched.record(q_of[i])
@@ -1028,9 +1024,9 @@ class CoTrainer(Trainer):
         if x.shape[0] > gt.shape[0]:
             pseudo = K.argmax(lp, C)
             t = torch.cat((t, pseudo[t.numel():]))
-        out = K.ce_fwd(lp, t, C, ignore)
         # only the sign of the input gradient is used: the (power-of-two) scale keeps it out of half's subnormals
-        dl = K.ce_bwd(lp, t, C, out[1:2], torch.empty_like(lp), gmul=getattr(self, "_loss_scale", 1.0), ignore_index=ignore)
+        dl = torch.empty_like(lp)
+        K.ce_step(lp, t, C, dl, gmul=getattr(self, "_loss_scale", 1.0), ignore_index=ignore)
         gx = net.plan_backward(tape, dl, need_dx=True, need_dw=False)
         x_adv, noise = K.fgsm_step(x.detach().contiguous(), gx.contiguous(), eps)
         return x_adv, noise, lp, tape

@@ -249,6 +249,9 @@ class StepGraphCache(object):
                     seg.torchnet.wgrad_side_stream = s
         cap.graph = graph
         cap.counters = [getattr(o, n) - b for (o, n), b in zip(self._counters(), before)]
+        for (o, n), d in zip(self._counters(), cap.counters):
+            if n == "_drop_calls" and d % 2:       # the device counter's two words are used in turn (dct_dropout_fwd_dev): replays must stay in turn
+                raise RuntimeError("dct_amd: a captured step must hold an even number of dropout launches per network")
         # a re-allocation during the capture (first gradient buffer, moments) would have changed the signature
         if self._signature(lab, unl, train_jsd, train_adv, adv_choice, self._lam_host) != sig:
             raise RuntimeError("dct_amd: weights / gradients / Adam moments were (re)allocated while the step was being "

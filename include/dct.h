@@ -142,6 +142,12 @@ int dct_conv2d_wgrad_bias(const dct_view* p, const dct_view* q, float* dw, float
 int dct_bias_grad(const dct_view* dy, float* db, int accumulate, int dtype,
                   void* workspace, size_t workspace_bytes, dct_stream stream);
 size_t dct_bias_grad_workspace_bytes(const dct_view* dy);
+/* n (<= 8) bias gradients in one launch pair: dbs[k][c] (+)= sum over pixels of dys[k][.., c]; per job the sums and their order are those of
+ * dct_bias_grad.  (A UNet's four up-convolutions: nn.ConvTranspose2d's bias gradient is the column sum of the OTHER operand of its weight-gradient
+ * GEMM, so it cannot ride along there; four launch pairs of ~5 us each sat on every model's backward chain.) */
+int dct_bias_grad_batched(const dct_view* dys, float* const* dbs, int n, int accumulate, int dtype,
+                          void* workspace, size_t workspace_bytes, dct_stream stream);
+size_t dct_bias_grad_batched_workspace_bytes(const dct_view* dys, int n);
 
 /* Repack fp32 master weights src[P][T][Q] (T taps) into `dtype`:
  *   transpose == 0: straight cast copy;
@@ -217,11 +223,12 @@ int dct_bilinear_bwd(const dct_view* dy, const dct_view* dx, int dtype_dy, int d
  * index); y = keep ? x/(1-p) : 0.  mask_out (uint8, nullable, dense NHWC) receives the keep mask. */
 int dct_dropout_fwd(const dct_view* x, const dct_view* y, uint8_t* mask_out, float p,
                     uint64_t seed, uint64_t offset, int dtype, dct_stream stream);
-/* Same, with the call counter in device memory: *calls += 1 (stream-ordered), then offset = *calls << 40.
- * Nothing in the launch depends on a per-step host value, so a captured HIP graph of the training step
- * draws a fresh mask on every replay. */
+/* Same, with the call counter in device memory: calls = TWO 64-bit words that successive launches use in turn.  The launch reads
+ * calls[parity] = n, is call number n + 1 (offset = that << 40) and stores n + 1 to calls[parity ^ 1]; the caller alternates `parity` (0, 1, 0, ...)
+ * from launch to launch, stream-ordered.  Nothing in the launch depends on a per-step host value, so a captured HIP graph of the training step
+ * draws a fresh mask on every replay -- provided a replay holds an EVEN number of launches per counter (a UNet forward pass has two sites). */
 int dct_dropout_fwd_dev(const dct_view* x, const dct_view* y, uint8_t* mask_out, float p,
-                        uint64_t seed, uint64_t* calls, int dtype, dct_stream stream);
+                        uint64_t seed, uint64_t* calls, int parity, int dtype, dct_stream stream);
 /* y = x * (mask_u8 ? 1/(1-p) : 0) with a caller-supplied dense mask (parity replay). */
 int dct_dropout_apply(const dct_view* x, const dct_view* y, const uint8_t* mask, float p, int dtype,
                       dct_stream stream);
@@ -248,6 +255,12 @@ int dct_ce_fwd(const float* logits, const int64_t* targets, int64_t pixels, int 
 int dct_ce_bwd(const float* logits, const int64_t* targets, int64_t pixels, int C, int ignore_index,
                const float* count, const float* gscale, float gmul, float* dlogits, int accumulate,
                dct_stream stream);
+/* dct_ce_fwd + dct_ce_bwd of the same logits in two launches instead of three: the backward kernel folds the forward kernel's block partials
+ * itself (every block, in the forward call's order: out2 and dlogits are bit for bit those of the two calls).  The co-training step's supervised
+ * term (cotraining_totalloss.py:211-216 + the loss.backward() of :247). */
+int dct_ce_step(const float* logits, const int64_t* targets, int64_t pixels, int C, int ignore_index, float* out2,
+                const float* gscale, float gmul, float* dlogits, int accumulate, void* workspace, size_t workspace_bytes,
+                dct_stream stream);
 int dct_softmax_fwd(const float* logits, float* probs, int64_t pixels, int C, dct_stream stream);
 /* dlogits (=|+=) p * (dprobs - sum_c dprobs*p) */
 int dct_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, int64_t pixels, int C,

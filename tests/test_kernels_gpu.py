@@ -652,6 +652,28 @@ def test_conv2d_wgrad_unpools_on_load_bit_identical(ops, B, C, H, W, Cq):
         assert torch.equal(a, b), what
 
 
+@pytest.mark.parametrize("C,accumulate,ignored", [(4, False, False), (2, True, True), (5, False, True)])
+def test_ce_step_is_bit_identical_to_forward_then_backward(ops, C, accumulate, ignored):
+    """dct_ce_step (the backward kernel folds the forward kernel's block partials itself) against dct_ce_fwd + dct_ce_bwd: loss, count and
+    every gradient bit."""
+    g = torch.Generator().manual_seed(71)
+    P = 5 * 131 * 67
+    logits = (3 * torch.randn(P, C, generator=g)).to(DEV)
+    t = torch.randint(0, C, (P,), generator=g)
+    if ignored:
+        t[torch.rand(P, generator=g) < 0.2] = 255
+    t = t.to(DEV)
+    gscale = torch.tensor([0.61], device=DEV)
+    old = torch.randn(P, C, generator=g).to(DEV)
+    want_o = ops.ce_fwd(logits, t, C, 255)
+    want_g = ops.ce_bwd(logits, t, C, want_o[1:2], old.clone(), gscale=gscale, gmul=8.0, ignore_index=255, accumulate=accumulate)
+    got_g = old.clone()
+    got_o = ops.ce_step(logits, t, C, got_g, gscale=gscale, gmul=8.0, ignore_index=255, accumulate=accumulate)
+    torch.cuda.synchronize()
+    assert torch.equal(got_o, want_o) and float(got_o[0]) > 0 and float(got_o[1]) == float((t != 255).sum())
+    assert torch.equal(got_g, want_g)
+
+
 @pytest.mark.parametrize("S,C,accumulate", [(2, 4, False), (3, 2, True), (6, 4, False)])
 def test_jsd_step_in_one_pass_is_bit_identical(ops, S, C, accumulate):
     """dct_jsd_logits_step (mean JSD + the S softmax maps + the S logit gradients in one pass) against dct_jsd_logits_fwd, dct_softmax_fwd
@@ -913,6 +935,30 @@ def test_bias_grad(ops, dtype, C):
     close(db.cpu(), old + dy.sum((0, 2, 3)), dtype, "bias grad", rtol16=2e-4)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_bias_grad_batched_is_bit_identical_to_single_calls(ops, dtype, accumulate):
+    """dct_bias_grad_batched (a UNet's four up-convolutions' bias gradients in one launch pair) against one dct_bias_grad per tensor: every
+    bit.  The tensors are channel slices of wider ones (the decoder's concatenations), of different sizes and channel counts."""
+    g = torch.Generator().manual_seed(17)
+    shapes = [(3, 44, 40, 64), (3, 24, 24, 128), (2, 14, 14, 256), (2, 9, 9, 512)]
+    dys, olds = [], []
+    for (B, H, W, Cc) in shapes:
+        wide = to_dev(q(torch.randn(B, 2 * Cc, H, W, generator=g), dtype), dtype)        # NHWC physical, [..., :Cc] is a strided slice
+        dys.append(wide[..., :Cc])
+        olds.append(torch.randn(Cc, generator=g).to(DEV))
+    want = [o.clone() for o in olds]
+    for dy, db in zip(dys, want):
+        ops.bias_grad(dy, db, accumulate=accumulate)
+    got = [o.clone() for o in olds]
+    ops.bias_grad_batched(dys, got, accumulate=accumulate)
+    torch.cuda.synchronize()
+    for a, b, dy, o in zip(got, want, dys, olds):
+        assert torch.equal(a, b)
+        ref = dy.float().sum((0, 1, 2)).cpu() + (o.cpu() if accumulate else 0)
+        close(a.cpu(), ref, dtype, "batched bias grad", rtol16=2e-4)
+
+
 # ------------------------------------------------------------------------------------ stem / head
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_stem_cin1(ops, dtype):
@@ -1088,6 +1134,21 @@ def test_dropout(ops, dtype):
     y3 = torch.empty_like(xd)
     ops.dropout_apply(xd, y3, mask, 0.5)
     assert torch.equal(y3, yd)
+
+
+def test_dropout_device_counter_advances_itself(ops):
+    """The graph-replayable form (dct_dropout_fwd_dev): launch k of a counter that starts at c draws the mask of offset (c + k) << 40 and leaves
+    c + k in the counter word the NEXT launch reads (the two words are used in turn) -- over 40 back-to-back launches of two sizes."""
+    for shape in ((1, 512, 3, 3), (2, 512, 25, 25)):
+        xd = to_dev(torch.rand(*shape) + 0.5, torch.bfloat16)
+        state = torch.tensor([6, 6], dtype=torch.int64, device=DEV)
+        got, want = torch.empty_like(xd), torch.empty_like(xd)
+        for k in range(1, 41):
+            ops.dropout_fwd(xd, got, 0.5, seed=99, offset=0, calls_dev=state, parity=(k - 1) & 1)
+            if k in (1, 2, 17, 40):
+                ops.dropout_fwd(xd, want, 0.5, seed=99, offset=(6 + k) << 40)
+                assert torch.equal(got, want), k
+        assert state.tolist() == [46, 45]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

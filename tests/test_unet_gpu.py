@@ -273,6 +273,32 @@ def test_unet_unpooled_gradients_expanded_on_load_are_bit_identical(B, H, W, nee
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_unet_launch_batching_is_bit_identical(dtype):
+    """Round 5's launch-order switches: the transposed weight packs launched behind the encoder (UNet.late_packs) and the four up-convolutions'
+    bias gradients in one launch pair (UNet.batch_bias_grads), against the round-4 order: logits and every gradient bit for bit, over two
+    optimizer-free passes (the second one re-uses the packs of the first)."""
+    C, B, H, W = 4, 2, 192, 180
+    onet = _oracle_net(C, 29, p=0.5).train()
+    x = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(58)).to(DEV)
+    gl = torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(59)).to(DEV)
+    outs = []
+    for flag in (False, True):
+        net = _hip_net(onet, C, dtype, p=0.5).train()
+        net.late_packs = net.batch_bias_grads = flag
+        net.dropout_seed = 78
+        got = []
+        for rep in range(2):
+            lp, tape = net.plan_forward(x, True)
+            net.plan_backward(tape, gl, need_dx=False, need_dw=True, overwrite=True)
+            torch.cuda.synchronize()
+            got += [lp.clone(), net.flat_params.gflat.clone()]
+        outs.append(got)
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and a.abs().max().item() > 0
+        assert torch.equal(a, b)
+
+
 def test_unet_rejects_small_and_cpu_inputs():
     from dct_amd.arch import get_arch
     net = get_arch("unet", {"num_classes": 4}).to(DEV)
