@@ -108,6 +108,7 @@ SIGNATURES = {
     "dct_maxpool2x2_bwd_codes": (_i, [_P, _VP, _VP, _i, _f, _i, _P]),
     "dct_maxpool2x2_bwd_codes_skip": (_i, [_P, _VP, _VP, _VP, _i, _f, _i, _P]),
     "dct_bilinear_fwd": (_i, [_VP, _VP, _i, _i, _P]),
+    "dct_bilinear_fwd_batched": (_i, [_P, _P, _i, _i, _P]),
     "dct_bilinear_bwd": (_i, [_VP, _VP, _i, _i, _i, _P]),
     "dct_dropout_fwd": (_i, [_VP, _VP, _P, _f, _u64, _u64, _i, _P]),
     "dct_dropout_fwd_dev": (_i, [_VP, _VP, _P, _f, _u64, _P, _i, _i, _P]),

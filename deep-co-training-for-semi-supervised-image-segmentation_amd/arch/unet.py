@@ -208,6 +208,7 @@ class UNet(nn.Module):
                                              # beside the other chain's kernels, instead of in front of the stem where nothing else runs
         self._pending_packs = None
         self.batch_bias_grads = True         # the four up-convolutions' bias gradients in one launch pair per gradient bucket
+        self.batch_skip_resize = True        # the four skip connections' bilinear resizes in one launch, in front of the centre
         self.unpool_max_level = 3            # the deepest level that does
         self.unpool_on_load = False          # levels 1..unpool_max_level: the un-pooled gradient of an encoder block is never written -- its two consumers
                                              # expand {pooled gradient + routing codes} while they stage (dct_conv_desc.unpool_codes).  Built, bit-identical,
@@ -447,14 +448,24 @@ class UNet(nn.Module):
             src = p
         # center
         self._flush_packs()                  # first reader of a transposed pack: the centre's up-convolution below
+        # The four skip connections' resizes (pooled tensor -> second half of the decoder level's concatenation) in ONE launch here, where all
+        # four pooled tensors exist, instead of one launch per decoder level (UNet.batch_skip_resize; dct_bilinear_fwd_batched)
+        cats = {}
+        if self.batch_skip_resize:
+            ch, cw = h, w
+            for lvl, co in ((4, 512), (3, 256), (2, 128), (1, 64)):
+                ch, cw = 2 * (ch - 4), 2 * (cw - 4)
+                cats[lvl] = new(ch, cw, 2 * co)
+            K.bilinear_fwd_batched([A[f"p{lvl}"] for lvl in (4, 3, 2, 1)], [cats[lvl][..., cats[lvl].shape[3] // 2:] for lvl in (4, 3, 2, 1)])
         ca, bna, cb, bnb, ct = self._roles["center"]
         c1 = conv3(src, ca, new(h - 2, w - 2, 1024), bna, "c1", gate=True)
         c2 = conv3(c1, cb, new(h - 4, w - 4, 1024), bnb, "c2")
         c2d = dropout(c2, 1)
         h, w = 2 * (h - 4), 2 * (w - 4)
-        cat = new(h, w, 1024)
+        cat = cats[4] if cats else new(h, w, 1024)
         K.conv2d(c2d, P[id(ct)]["fwd"], ct.bias, cat[..., :512], R=1, S=1, relu=True, scatter2x2=True)
-        K.bilinear_fwd(A["p4"], cat[..., 512:])
+        if not cats:
+            K.bilinear_fwd(A["p4"], cat[..., 512:])
         A["c1"], A["c2"], A["cat4"] = c1, c2d, cat
         # decoder ("enc")
         for lvl, feat, co in ((4, 512, 256), (3, 256, 128), (2, 128, 64)):
@@ -462,9 +473,10 @@ class UNet(nn.Module):
             ea = conv3(cat, ca, new(h - 2, w - 2, feat), bna, f"e{lvl}a", gate=True)
             eb = conv3(ea, cb, new(h - 4, w - 4, feat), bnb, f"e{lvl}b", gate=True)
             h, w = 2 * (h - 4), 2 * (w - 4)
-            cat = new(h, w, 2 * co)
+            cat = cats[lvl - 1] if cats else new(h, w, 2 * co)
             K.conv2d(eb, P[id(ct)]["fwd"], ct.bias, cat[..., :co], R=1, S=1, relu=True, scatter2x2=True)
-            K.bilinear_fwd(A[f"p{lvl - 1}"], cat[..., co:])
+            if not cats:
+                K.bilinear_fwd(A[f"p{lvl - 1}"], cat[..., co:])
             A[f"e{lvl}a"], A[f"e{lvl}b"], A[f"cat{lvl - 1}"] = ea, eb, cat
         ca, bna, cb, _ = self._roles["enc1"]
         e1a = conv3(cat, ca, new(h - 2, w - 2, 64), bna, "e1a", gate=True)

@@ -641,8 +641,8 @@ __device__ __forceinline__ Lerp lerp_of(int j, float scale, int in_size) {
   return r;
 }
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void bilinear_fwd_kernel(View x, View y, float sh, float sw) {
-  const PixIdx id = decode((long long)blockIdx.x * 256 + threadIdx.x, y.n, y.h, y.w, y.c / VEC);
+__device__ __forceinline__ void bilinear_fwd_body(const View& x, const View& y, float sh, float sw, long long idx) {
+  const PixIdx id = decode(idx, y.n, y.h, y.w, y.c / VEC);
   if (!id.ok) return;
   const Lerp ly = lerp_of(id.y, sh, x.h), lx = lerp_of(id.x, sw, x.w);
   const T* xp = reinterpret_cast<const T*>(x.ptr) + id.cv * VEC;
@@ -655,6 +655,22 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(View x, View y, float
   for (int i = 0; i < VEC; ++i)
     out[i] = ly.w0 * (lx.w0 * a[i] + lx.w1 * b[i]) + ly.w1 * (lx.w0 * c[i] + lx.w1 * d[i]);
   VecIO<T, VEC>::store(reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, id.x) + id.cv * VEC, out);
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(View x, View y, float sh, float sw) {
+  bilinear_fwd_body<T, VEC>(x, y, sh, sw, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+// Several resizes in one launch (dct_bilinear_fwd_batched: a UNet's four skip connections -- every pooled tensor exists once the encoder is through,
+// so the four launches of ~7 us on each model's decoder chain are one, in front of the centre): job k owns the blocks [blk0, next blk0).
+constexpr int kBilJobs = 8;
+struct BilJob { View x, y; float sh, sw; int blk0, pad; };
+struct BilJobs { BilJob j[kBilJobs]; int n; };
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bilinear_fwd_batched_kernel(BilJobs js) {
+  int k = 0;
+  for (int i = 1; i < js.n; ++i) k = (int)blockIdx.x >= js.j[i].blk0 ? i : k;
+  const BilJob& jb = js.j[k];
+  bilinear_fwd_body<T, VEC>(jb.x, jb.y, jb.sh, jb.sw, (long long)((int)blockIdx.x - jb.blk0) * 256 + threadIdx.x);
 }
 // gather backward: thread per (source pixel, VEC slice); candidate destination rows/cols are a
 // slightly widened analytic range and each is tested with the forward's exact index arithmetic.
@@ -1115,10 +1131,38 @@ extern "C" int dct_bilinear_fwd(const dct_view* x, const dct_view* y, int dtype_
   const float sh = ac_scale(x->h, y->h), sw = ac_scale(x->w, y->w);
   DISPATCH_T(dtype_in, {
     const long long px = (long long)y->n * y->h * y->w;
-    if (vec_ok(x, VEC, sizeof(T)) && vec_ok(y, VEC, sizeof(T)))
-      DCT_LAUNCH(DCT_PROF_POINTWISE, (bilinear_fwd_kernel<T, VEC>), dim3(div_up(px * (y->c / VEC), 256)), dim3(256), 0, st, to_view(x), to_view(y), sh, sw);
-    else
+    if (vec_ok(x, VEC, sizeof(T)) && vec_ok(y, VEC, sizeof(T))) {
+      // ONE kernel for the single and the batched call (a job table of one): two instantiations of the same source came out with different
+      // FMA contractions of the interpolation weights, i.e. results a last bit apart
+      BilJobs js;
+      js.n = 1;
+      js.j[0].x = to_view(x); js.j[0].y = to_view(y); js.j[0].sh = sh; js.j[0].sw = sw; js.j[0].blk0 = 0; js.j[0].pad = 0;
+      DCT_LAUNCH(DCT_PROF_POINTWISE, (bilinear_fwd_batched_kernel<T, VEC>), dim3(div_up(px * (y->c / VEC), 256)), dim3(256), 0, st, js);
+    } else
       DCT_LAUNCH(DCT_PROF_POINTWISE, (bilinear_fwd_kernel<T, 1>), dim3(div_up(px * y->c, 256)), dim3(256), 0, st, to_view(x), to_view(y), sh, sw);
+  });
+  return dct_check_launch();
+}
+extern "C" int dct_bilinear_fwd_batched(const dct_view* xs, const dct_view* ys, int n, int dtype, dct_stream stream) {
+  if (!xs || !ys || n < 1) return DCT_ERR_BAD_ARG;
+  if (n > kBilJobs) return DCT_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, {
+    BilJobs js;
+    js.n = n;
+    long long blk = 0;
+    for (int k = 0; k < n; ++k) {
+      const dct_view* x = xs + k; const dct_view* y = ys + k;
+      if (!view_ok(x) || !view_ok(y) || x->n != y->n || x->c != y->c) return DCT_ERR_BAD_ARG;
+      if (!vec_ok(x, VEC, sizeof(T)) || !vec_ok(y, VEC, sizeof(T))) return DCT_ERR_UNSUPPORTED;      // (the scalar form: one dct_bilinear_fwd per tensor)
+      BilJob& jb = js.j[k];
+      jb.x = to_view(x); jb.y = to_view(y);
+      jb.sh = ac_scale(x->h, y->h); jb.sw = ac_scale(x->w, y->w);
+      jb.blk0 = (int)blk; jb.pad = 0;
+      blk += div_up((long long)y->n * y->h * y->w * (y->c / VEC), 256);
+      if (blk > 0x7fffffffll) return DCT_ERR_UNSUPPORTED;
+    }
+    DCT_LAUNCH(DCT_PROF_POINTWISE, (bilinear_fwd_batched_kernel<T, VEC>), dim3((unsigned)blk), dim3(256), 0, st, js);
   });
   return dct_check_launch();
 }

@@ -215,6 +215,10 @@ int dct_maxpool2x2_bwd_codes_skip(const uint8_t* codes, const dct_view* dy, cons
  * slice of a concat buffer.  in/out dtypes given separately (the final resize reads/writes f32).
  * bwd is a gather (deterministic): dx[src] (+)= sum of dy[dst]*weight. */
 int dct_bilinear_fwd(const dct_view* x, const dct_view* y, int dtype_in, int dtype_out, dct_stream stream);
+/* n (<= 8) resizes of one dtype in ONE launch: ys[k] = dct_bilinear_fwd(xs[k]), bit for bit.  DCT_ERR_UNSUPPORTED for views off the 16-byte
+ * vector width (use one dct_bilinear_fwd per tensor).  (A UNet's four skip connections, network.py:216-223: every pooled tensor exists once the
+ * encoder is through.) */
+int dct_bilinear_fwd_batched(const dct_view* xs, const dct_view* ys, int n, int dtype, dct_stream stream);
 int dct_bilinear_bwd(const dct_view* dy, const dct_view* dx, int dtype_dy, int dtype_dx, int accumulate,
                      dct_stream stream);
 

@@ -1116,6 +1116,26 @@ def test_bilinear(ops, dtype, C, hin, win, hout, wout):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_bilinear_fwd_batched_is_bit_identical_to_single_calls(ops, dtype):
+    """dct_bilinear_fwd_batched (a UNet's four skip-connection resizes in one launch) against one dct_bilinear_fwd per tensor: every bit.
+    Destinations are channel slices of wider tensors (the decoder's concatenations); sizes shrink, grow and stay."""
+    g = torch.Generator().manual_seed(31)
+    cases = [(2, 64, 37, 41, 26, 30), (2, 128, 19, 19, 16, 16), (1, 256, 9, 11, 12, 12), (3, 64, 8, 8, 8, 8)]
+    xs, wides = [], []
+    for (B, Cc, hi, wi, ho, wo) in cases:
+        xs.append(to_dev(q(torch.randn(B, Cc, hi, wi, generator=g), dtype), dtype))
+        wides.append((B, ho, wo, 2 * Cc))
+    want = [torch.zeros(*w, dtype=dtype, device=DEV) for w in wides]
+    got = [torch.zeros(*w, dtype=dtype, device=DEV) for w in wides]
+    for x, y in zip(xs, want):
+        ops.bilinear_fwd(x, y[..., y.shape[3] // 2:])
+    ops.bilinear_fwd_batched(xs, [y[..., y.shape[3] // 2:] for y in got])
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert b.float().abs().max().item() > 0 and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_dropout(ops, dtype):
     x = q(torch.rand(2, 512, 25, 25) + 0.5, dtype)
     xd = to_dev(x, dtype)
