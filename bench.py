@@ -571,11 +571,12 @@ def main():
             return None
         net0 = tr.segmentators[0].torchnet
         keep_only, net0.pool_only = getattr(net0, "pool_only", False), False     # this pass wants every block's full-resolution output
+        keep_dp, net0.fuse_drop_pool = getattr(net0, "fuse_drop_pool", False), False   # ... the dropped fourth level included
         _, tape = net0.plan_forward(torch.cat((lab[0][0][0][0], unl[0][0][0]), dim=0), True)
         torch.cuda.synchronize()
-        net0.pool_only = keep_only
+        net0.pool_only, net0.fuse_drop_pool = keep_only, keep_dp
         keys = ["a1", "d1", "a2", "d2", "a3", "d3", "a4", "d4", "c1", "c2", "e4a", "e4b", "e3a", "e3b", "e2a", "e2b", "e1a", "e1b"]
-        stats = {"zero_fraction_of_bf16_activations": {k: round(float((tape[k] == 0).float().mean()), 4) for k in keys if k in tape},
+        stats = {"zero_fraction_of_bf16_activations": {k: round(float((tape[k] == 0).float().mean()), 4) for k in keys if k in tape and torch.is_tensor(tape[k])},
                  "note": "ReLU outputs (d4 / c2 include dropout p=0.5); ~0.5 is what a trained ReLU net carries"}
         del tape
         return stats

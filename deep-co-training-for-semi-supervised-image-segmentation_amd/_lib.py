@@ -112,6 +112,7 @@ SIGNATURES = {
     "dct_bilinear_bwd": (_i, [_VP, _VP, _i, _i, _i, _P]),
     "dct_dropout_fwd": (_i, [_VP, _VP, _P, _f, _u64, _u64, _i, _P]),
     "dct_dropout_fwd_dev": (_i, [_VP, _VP, _P, _f, _u64, _P, _i, _i, _P]),
+    "dct_dropout_maxpool2x2_fwd_codes": (_i, [_VP, _VP, _P, _f, _u64, _P, _i, _i, _P]),
     "dct_dropout_apply": (_i, [_VP, _VP, _P, _f, _i, _P]),
     "dct_relu_bwd": (_i, [_VP, _VP, _VP, _f, _i, _P]),
     "dct_cast": (_i, [_VP, _VP, _i, _i, _P]),

@@ -209,6 +209,7 @@ class UNet(nn.Module):
         self._pending_packs = None
         self.batch_bias_grads = True         # the four up-convolutions' bias gradients in one launch pair per gradient bucket
         self.batch_skip_resize = True        # the four skip connections' bilinear resizes in one launch, in front of the centre
+        self.fuse_drop_pool = True           # the fourth level's dropout + max-pool in one launch (the dropped tensor is never written)
         self.unpool_max_level = 3            # the deepest level that does
         self.unpool_on_load = False          # levels 1..unpool_max_level: the un-pooled gradient of an encoder block is never written -- its two consumers
                                              # expand {pooled gradient + routing codes} while they stage (dct_conv_desc.unpool_codes).  Built, bit-identical,
@@ -406,15 +407,21 @@ class UNet(nn.Module):
                 return src
             dst = torch.empty_like(src)
             m = torch.empty(src.shape, dtype=torch.uint8, device=dev) if masks_out is not None else None
-            if self._drop_state is None or self._drop_state.device != dev:
-                self._drop_state = torch.tensor([self._drop_calls, self._drop_calls], dtype=torch.int64, device=dev)
-                self._drop_parity = 0
-            self._drop_calls += 1       # the kernel advances the device copy in stream order (graph-replayable): word `parity` -> the other word
-            K.dropout_fwd(src, dst, self.dropout_p, self.dropout_seed, 0, mask_out=m, calls_dev=self._drop_state, parity=self._drop_parity)
-            self._drop_parity ^= 1      # (two sites per forward pass: a captured step holds an even number of launches, so its replays stay in turn)
+            state, parity = drop_turn()
+            K.dropout_fwd(src, dst, self.dropout_p, self.dropout_seed, 0, mask_out=m, calls_dev=state, parity=parity)
             if masks_out is not None:
                 masks_out.append(m)
             return dst
+
+        def drop_turn():
+            """-> (device call counter, the word this launch reads); the launch advances the device copy in stream order (graph-replayable)."""
+            if self._drop_state is None or self._drop_state.device != dev:
+                self._drop_state = torch.tensor([self._drop_calls, self._drop_calls], dtype=torch.int64, device=dev)
+                self._drop_parity = 0
+            self._drop_calls += 1
+            parity = self._drop_parity
+            self._drop_parity ^= 1      # (two sites per forward pass: a captured step holds an even number of launches, so its replays stay in turn)
+            return self._drop_state, parity
 
         # encoder ("dec" in the reference's naming)
         h, w = H, W
@@ -436,13 +443,21 @@ class UNet(nn.Module):
             # ... and alone: the backward pass routes by the codes and never reads the block's full-resolution output
             only = fuse and self.pool_only and (codes is not None or not save) and self._debug is None
             d = conv3(a, cb, new(h - 4, w - 4, width), pool_out=p if fuse else None, pool_codes=codes if fuse else None, pool_only=only)
-            dd = dropout(d, 0) if lvl == 4 else d
+            # the fourth level of a training pass: dropout and the pool behind it in one launch; the dropped tensor is never written
+            drop_pool = (lvl == 4 and not fuse and training and self.fuse_drop_pool and self.external_dropout_masks is None and masks_out is None
+                         and codes is not None and self._debug is None)
+            if drop_pool:
+                state, parity = drop_turn()
+                K.dropout_maxpool_fwd(d, p, codes, self.dropout_p, self.dropout_seed, state, parity)
+                d = dd = _ShapeOf(d)
+            else:
+                dd = dropout(d, 0) if lvl == 4 else d
             if only:
                 # nobody reads the block's full-resolution output again (the backward pass routes by the codes and needs its SHAPE):
                 # the buffer goes back to the allocator now instead of riding in the tape until the backward pass (130 MB at level 1)
                 d = dd = _ShapeOf(d)
             h, w = hp, wp
-            if not fuse:
+            if not fuse and not drop_pool:
                 K.maxpool_fwd(dd, p, codes=codes)
             A[f"a{lvl}"], A[f"d{lvl}"], A[f"p{lvl}"], A[f"pc{lvl}"] = a, dd, p, codes
             src = p

@@ -881,6 +881,54 @@ __global__ __launch_bounds__(256) void dropout_kernel(View x, View y, unsigned c
   }
 }
 
+// Dropout + the 2 x 2 max-pool behind it in ONE pass (dct_dropout_maxpool2x2_fwd_codes: the fourth encoder level of a training pass -- conv, ReLU,
+// dropout, pool): thread per (pooled pixel, VEC channels); every window element gets dropout_kernel's mask (same Philox counter: the element's index
+// in the dense [n][h][w][c / 4] walk), value and rounding, then maxpool_fwd_codes_kernel's scan.  The dropped full-resolution tensor is never
+// written (the backward pass routes by the codes); one launch and 2 x its bytes less on every model's chain.  Bit-identical to the two launches.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void dropout_maxpool_fwd_codes_kernel(View x, View y, unsigned char* __restrict__ codes, float p, unsigned long long seed,
+                                                                         unsigned long long* calls, int parity) {
+  const unsigned long long call = calls[parity] + 1ull;
+  const unsigned long long offset = call << 40;
+  if (blockIdx.x == 0 && threadIdx.x == 0) calls[parity ^ 1] = call;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const PixIdx id = decode(t, y.n, y.h, y.w, y.c / VEC);
+  if (!id.ok) return;
+  const float scale = 1.f / (1.f - p);
+  const int groups = x.c / 4;
+  float m[VEC];
+  int arg[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { m[i] = -INFINITY; arg[i] = 8; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int iy = 2 * id.y + (k >> 1), ix = 2 * id.x + (k & 1);
+    if (iy < x.h && ix < x.w) {
+      float v[VEC];
+      VecIO<T, VEC>::load(reinterpret_cast<const T*>(x.ptr) + voff(x, id.n, iy, ix) + id.cv * VEC, v);
+      const long long pix = ((long long)id.n * x.h + iy) * x.w + ix;
+#pragma unroll
+      for (int g4 = 0; g4 < VEC / 4; ++g4) {
+        unsigned r[4];
+        philox4x32_10(seed, offset + (unsigned long long)(pix * groups + id.cv * (VEC / 4) + g4), r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool keep = (float)(r[i] >> 8) * (1.0f / 16777216.0f) >= p;
+          const float d = to_f32(from_f32<T>(keep ? v[g4 * 4 + i] * scale : 0.f));          // the dropped tensor's stored value
+          if (d > m[g4 * 4 + i]) { m[g4 * 4 + i] = d; arg[g4 * 4 + i] = k; }
+        }
+      }
+    }
+  }
+  VecIO<T, VEC>::store(reinterpret_cast<T*>(y.ptr) + voff(y, id.n, id.y, id.x) + id.cv * VEC, m);
+  union { unsigned char b[VEC]; unsigned w[VEC / 4]; } cd;             // dense [n][h][w][c], same walk as `decode`
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) cd.b[i] = (unsigned char)(arg[i] | (m[i] > 0.f ? 4 : 0));
+  unsigned* cp = reinterpret_cast<unsigned*>(codes + t * VEC);
+  if constexpr (VEC == 8) *reinterpret_cast<uint2*>(cp) = make_uint2(cd.w[0], cd.w[1]);
+  else cp[0] = cd.w[0];
+}
+
 // ---- relu backward / cast --------------------------------------------------------------------
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(View g, View a, View y, float scale) {
@@ -1207,6 +1255,20 @@ extern "C" int dct_dropout_fwd_dev(const dct_view* x, const dct_view* y, uint8_t
                                    uint64_t seed, uint64_t* calls, int parity, int dtype, dct_stream stream) {
   if (!calls || ((uintptr_t)calls & 7) || (parity & ~1)) return DCT_ERR_BAD_ARG;
   return dropout_impl(x, y, mask_out, nullptr, p, seed, 0, dtype, stream, calls, parity);
+}
+extern "C" int dct_dropout_maxpool2x2_fwd_codes(const dct_view* x, const dct_view* y, uint8_t* codes, float p, uint64_t seed, uint64_t* calls,
+                                                int parity, int dtype, dct_stream stream) {
+  if (!view_ok(x) || !view_ok(y) || !codes || x->n != y->n || x->c != y->c || p < 0.f || p >= 1.f) return DCT_ERR_BAD_ARG;
+  if (y->h != (x->h + 1) / 2 || y->w != (x->w + 1) / 2) return DCT_ERR_BAD_ARG;
+  if (!calls || ((uintptr_t)calls & 7) || (parity & ~1)) return DCT_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, {
+    if (!vec_ok(x, VEC, sizeof(T)) || !vec_ok(y, VEC, sizeof(T)) || ((uintptr_t)codes % VEC)) return DCT_ERR_UNSUPPORTED;
+    const long long total = (long long)y->n * y->h * y->w * (y->c / VEC);
+    DCT_LAUNCH(DCT_PROF_POINTWISE, (dropout_maxpool_fwd_codes_kernel<T, VEC>), dim3(div_up(total, 256)), dim3(256), 0, st, to_view(x), to_view(y), codes, p,
+               (unsigned long long)seed, (unsigned long long*)calls, parity & 1);
+  });
+  return dct_check_launch();
 }
 extern "C" int dct_dropout_apply(const dct_view* x, const dct_view* y, const uint8_t* mask, float p, int dtype,
                                  dct_stream stream) {

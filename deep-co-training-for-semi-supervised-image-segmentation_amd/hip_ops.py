@@ -460,6 +460,16 @@ def dropout_fwd(x, y, p, seed, offset, mask_out=None, calls_dev=None, parity=0):
     return y
 
 
+def dropout_maxpool_fwd(x, y, codes, p, seed, calls_dev, parity):
+    """y, codes = maxpool_fwd(dropout_fwd(x, calls_dev=..., parity=...), codes=...) in one pass, without the dropped tensor
+    (dct_dropout_maxpool2x2_fwd_codes; bit for bit the two launches)."""
+    assert calls_dev.dtype == torch.int64 and calls_dev.numel() >= 2
+    assert codes.dtype == torch.uint8 and codes.is_contiguous() and tuple(codes.shape) == tuple(y.shape)
+    vx, vy = view(x), view(y)
+    call("dct_dropout_maxpool2x2_fwd_codes", C.byref(vx), C.byref(vy), ptr(codes), float(p), int(seed), ptr(calls_dev), int(parity), _dt(x), stream())
+    return y
+
+
 def dropout_apply(x, y, mask_u8, p):
     vx, vy = view(x), view(y)
     call("dct_dropout_apply", C.byref(vx), C.byref(vy), ptr(mask_u8), float(p), _dt(x), stream())

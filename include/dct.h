@@ -233,6 +233,11 @@ int dct_dropout_fwd(const dct_view* x, const dct_view* y, uint8_t* mask_out, flo
  * draws a fresh mask on every replay -- provided a replay holds an EVEN number of launches per counter (a UNet forward pass has two sites). */
 int dct_dropout_fwd_dev(const dct_view* x, const dct_view* y, uint8_t* mask_out, float p,
                         uint64_t seed, uint64_t* calls, int parity, int dtype, dct_stream stream);
+/* dct_dropout_fwd_dev followed by dct_maxpool2x2_fwd_codes in ONE pass: y = maxpool(dropout(x)) and its routing codes, bit for bit, without the
+ * dropped full-resolution tensor (the backward pass routes by the codes and the 1 / (1 - p) scale).  The fourth encoder level of a UNet's training
+ * pass (network.py:160-166: conv, ReLU, Dropout, MaxPool2d).  calls / parity as dct_dropout_fwd_dev. */
+int dct_dropout_maxpool2x2_fwd_codes(const dct_view* x, const dct_view* y, uint8_t* codes, float p, uint64_t seed, uint64_t* calls,
+                                     int parity, int dtype, dct_stream stream);
 /* y = x * (mask_u8 ? 1/(1-p) : 0) with a caller-supplied dense mask (parity replay). */
 int dct_dropout_apply(const dct_view* x, const dct_view* y, const uint8_t* mask, float p, int dtype,
                       dct_stream stream);

@@ -1172,6 +1172,28 @@ def test_dropout_device_counter_advances_itself(ops):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout_and_pool_in_one_pass_is_bit_identical(ops, dtype):
+    """dct_dropout_maxpool2x2_fwd_codes against dct_dropout_fwd_dev + dct_maxpool2x2_fwd_codes from the same counter: pooled values, routing codes
+    and the counter word the next launch reads -- odd sizes (ceil-mode edge windows), two successive calls."""
+    x = to_dev(q(torch.randn(2, 512, 25, 23), dtype), dtype)
+    hp, wp = 13, 12
+    for start in (0, 7):
+        s_a = torch.tensor([start, start], dtype=torch.int64, device=DEV)
+        s_b = s_a.clone()
+        for parity in (0, 1):
+            dropped = torch.empty_like(x)
+            ops.dropout_fwd(x, dropped, 0.5, seed=4242, offset=0, calls_dev=s_a, parity=parity)
+            want_p = torch.empty(2, hp, wp, 512, dtype=dtype, device=DEV)
+            want_c = torch.empty(2, hp, wp, 512, dtype=torch.uint8, device=DEV)
+            ops.maxpool_fwd(dropped, want_p, codes=want_c)
+            got_p, got_c = torch.empty_like(want_p), torch.empty_like(want_c)
+            ops.dropout_maxpool_fwd(x, got_p, got_c, 0.5, 4242, s_b, parity)
+            torch.cuda.synchronize()
+            assert torch.equal(got_p, want_p) and torch.equal(got_c, want_c) and got_p.float().abs().max().item() > 0
+            assert s_a.tolist() == s_b.tolist()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_relu_bwd_and_cast(ops, dtype):
     g = torch.Generator().manual_seed(12)
     a = q(torch.randn(2, 64, 9, 7, generator=g), dtype)

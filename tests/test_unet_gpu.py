@@ -277,7 +277,7 @@ def test_unet_unpooled_gradients_expanded_on_load_are_bit_identical(B, H, W, nee
 def test_unet_launch_batching_is_bit_identical(dtype):
     """Round 5's launch-order switches: the transposed weight packs launched behind the encoder (UNet.late_packs) and the four up-convolutions'
     bias gradients in one launch pair (UNet.batch_bias_grads), the four skip connections' resizes in one launch (UNet.batch_skip_resize),
-    against the round-4 order: logits and every gradient bit for bit, over two
+    the fourth level's dropout + max-pool in one launch (UNet.fuse_drop_pool), against the round-4 order: logits and every gradient bit for bit, over two
     optimizer-free passes (the second one re-uses the packs of the first)."""
     C, B, H, W = 4, 2, 192, 180
     onet = _oracle_net(C, 29, p=0.5).train()
@@ -286,7 +286,7 @@ def test_unet_launch_batching_is_bit_identical(dtype):
     outs = []
     for flag in (False, True):
         net = _hip_net(onet, C, dtype, p=0.5).train()
-        net.late_packs = net.batch_bias_grads = net.batch_skip_resize = flag
+        net.late_packs = net.batch_bias_grads = net.batch_skip_resize = net.fuse_drop_pool = flag
         net.dropout_seed = 78
         got = []
         for rep in range(2):
