@@ -63,6 +63,14 @@ def main():
         period = float((t0[1:] - t0[:-1]).mean())
         gap = float((t0[1:] - tl[:-1, :, 3].max(dim=1).values).mean())
         print(f"{args.config}, {mode}: mean over {tl.shape[0]} replays, microseconds from the step's first forward start")
+        if cfg["train_adv"]:
+            # the three-queue adversarial step (CoTrainer._run_step_adv_chain) stamps other sites: model a's queue / the adversarial chain + model b
+            rows = (("model a (its own queue)", ["forward starts", "forward + loss done", "backward done", "adversarial backward + optimizer done"]),
+                    ("model b + adversarial chain", ["forward starts", "adversarial batch ready", "adversarial forward of model a done", "backward + optimizer done (third queue)"]))
+            for m, (who, labels) in enumerate(rows):
+                print(f"  {who}: " + ";  ".join(f"{lb} {float(rel[m][k]):.1f}" for k, lb in enumerate(labels)))
+            print(f"  step period {period:.1f} us")
+            continue
         for k, nme in enumerate(names):
             print(f"  {nme:22s} " + "  ".join(f"model {m}: {float(rel[m][k]):8.1f}" for m in range(S)))
         print(f"  step period {period:.1f} us;  last optimizer done -> next step's first forward start: {gap:.1f} us")
