@@ -312,13 +312,19 @@ class UNet(nn.Module):
 
     # Autograd-free entry points of the execution plan (the fused trainer step drives them directly: no autograd
     # engine thread hop, and the whole step is a plain launch sequence that a HIP graph can capture).
-    def plan_forward(self, x: torch.Tensor, save: bool = True):
-        """-> (logits, tape): logits physical NHWC fp32 [B,H,W,C]; tape feeds plan_backward (None if not save)."""
+    def plan_forward(self, x: torch.Tensor, save: bool = True, keep_predrop: bool = False, reuse=None):
+        """-> (logits, tape): logits physical NHWC fp32 [B,H,W,C]; tape feeds plan_backward (None if not save).
+        ``keep_predrop``: a training pass also keeps the fourth encoder level's output in front of its dropout in the tape.  ``reuse``: the tape
+        of such a pass over THE SAME INPUT TENSOR with the same weights: everything in front of the first dropout -- the stem and the eight
+        encoder convolutions, half of a forward pass -- is the same computation and is taken from that tape (shared, read-only) instead of
+        run again; the pass starts at the fourth level's dropout with masks of its own.  (The FGSM generator's clean forward pass follows the
+        joint forward pass of the same network over the same batch: AEGenerator.py:27 behind cotraining_totalloss.py:208-227.)"""
         self._check_input(x)
         self._ensure_packs(late=bool(self.late_packs))
-        return self._run_forward(x, save)
+        return self._run_forward(x, save, keep_predrop=keep_predrop, reuse=reuse)
 
     supports_grad_overwrite = True
+    supports_forward_reuse = True        # plan_forward(keep_predrop=..., reuse=...)
 
     def plan_backward(self, tape, dlogits: torch.Tensor, need_dx: bool = False, need_dw: bool = True,
                       overwrite: bool = False):
@@ -355,7 +361,7 @@ class UNet(nn.Module):
         return self._wgrad_stream
 
     # The plan itself ------------------------------------------------------------------------
-    def _run_forward(self, x: torch.Tensor, save: bool):
+    def _run_forward(self, x: torch.Tensor, save: bool, keep_predrop: bool = False, reuse=None):
         dt, dev = self.compute_dtype, x.device
         B, _, H, W = x.shape
         P = self._packs
@@ -426,8 +432,36 @@ class UNet(nn.Module):
         # encoder ("dec" in the reference's naming)
         h, w = H, W
         src = xs
+        if reuse is not None:
+            # same input tensor, same weights (the packs' key), a training pass with the pre-dropout tensor kept: else run everything
+            ok = (training and not self.batchnorm and self.external_dropout_masks is None and masks_out is None and self._debug is None
+                  and reuse.get("d4pre") is not None and reuse.get("pack_key") == self._pack_key
+                  and reuse["x"].data_ptr() == xs.data_ptr() and reuse["x"].shape == xs.shape and all(reuse.get(f"pc{k}") is not None for k in (1, 2, 3)))
+            if not ok:
+                reuse = None
         for lvl, width in enumerate(_WIDTHS, start=1):
+            if reuse is not None and lvl < 4:
+                a, dd, p, codes = (reuse[f"{k}{lvl}"] for k in ("a", "d", "p", "pc"))
+                if id(a) in reuse["bits"]:
+                    bits[id(a)] = reuse["bits"][id(a)]
+                h, w = p.shape[1], p.shape[2]
+                A[f"a{lvl}"], A[f"d{lvl}"], A[f"p{lvl}"], A[f"pc{lvl}"] = a, dd, p, codes
+                src = p
+                continue
             ca, bna, cb, _ = self._roles[f"dec{lvl}"]
+            if reuse is not None:                # level 4: the two convolutions from the tape, dropout + pool with this pass's mask
+                a, d = reuse["a4"], reuse["d4pre"]
+                if id(a) in reuse["bits"]:
+                    bits[id(a)] = reuse["bits"][id(a)]
+                hp, wp = (h - 4 + 1) // 2, (w - 4 + 1) // 2
+                codes = torch.empty(B, hp, wp, width, dtype=torch.uint8, device=dev)
+                p = new(hp, wp, width)
+                state, parity = drop_turn()
+                K.dropout_maxpool_fwd(d, p, codes, self.dropout_p, self.dropout_seed, state, parity)
+                h, w = hp, wp
+                A[f"a{lvl}"], A[f"d{lvl}"], A[f"p{lvl}"], A[f"pc{lvl}"] = a, _ShapeOf(d), p, codes
+                src = p
+                continue
             a = new(h - 2, w - 2, width)
             if lvl == 1:
                 K.conv_cin1_fwd(xs, self._w(ca), ca.bias, a, relu=bna is None, relu_bits_out=want_bits(a, bna))
@@ -449,6 +483,8 @@ class UNet(nn.Module):
             if drop_pool:
                 state, parity = drop_turn()
                 K.dropout_maxpool_fwd(d, p, codes, self.dropout_p, self.dropout_seed, state, parity)
+                if keep_predrop and save:
+                    A["d4pre"], A["pack_key"] = d, self._pack_key        # for a later pass over the same input (plan_forward(reuse=...))
                 d = dd = _ShapeOf(d)
             else:
                 dd = dropout(d, 0) if lvl == 4 else d
