@@ -300,6 +300,34 @@ def test_unet_launch_batching_is_bit_identical(dtype):
         assert torch.equal(a, b)
 
 
+def test_unet_second_pass_over_the_same_input_reuses_the_encoder_bit_for_bit():
+    """plan_forward(reuse=tape of a pass over the same input tensor): the stem and the eight encoder convolutions in front of the first dropout come from
+    that tape.  Against a net that runs both passes in full (same weights, same dropout seed and counter): the second pass's logits, its input gradient
+    (the FGSM generator's use) and its weight gradients bit for bit; a different input tensor or changed weights fall back to the full pass."""
+    C, B, H, W = 4, 2, 192, 180
+    onet = _oracle_net(C, 31, p=0.5).train()
+    x = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(68)).to(DEV)
+    gl = torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(69)).to(DEV)
+    outs = []
+    for share in (False, True):
+        net = _hip_net(onet, C, torch.bfloat16, p=0.5).train()
+        net.dropout_seed = 79
+        lp1, t1 = net.plan_forward(x, True, keep_predrop=share)
+        lp2, t2 = net.plan_forward(x, True, reuse=t1 if share else None)
+        if share:
+            assert t2["a1"] is t1["a1"] and t2["p3"] is t1["p3"]          # (the encoder was not run again)
+        dx = net.plan_backward(t2, gl, need_dx=True, need_dw=True, overwrite=True)
+        torch.cuda.synchronize()
+        outs.append([lp1.clone(), lp2.clone(), dx.clone(), net.flat_params.gflat.clone()])
+        if share:
+            lp3, t3 = net.plan_forward(x.clone(), True, reuse=t1)             # another tensor: the full pass
+            assert t3["a1"] is not t1["a1"]
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and a.abs().max().item() > 0
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[0][0], outs[0][1])                             # (the two passes drew different masks)
+
+
 def test_unet_rejects_small_and_cpu_inputs():
     from dct_amd.arch import get_arch
     net = get_arch("unet", {"num_classes": 4}).to(DEV)
